@@ -1,0 +1,455 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE.
+
+Run in the build container only (needs /root/reference, never the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+
+It imports ``myrtlespeech`` from /root/reference/src (CPU PyTorch), feeds seeded
+inputs through the reference's own modules and stores inputs / weights /
+outputs as small ``.npz`` files.  Only data is written; no reference source.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference/src"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.dont_write_bytecode = True
+
+from myrtlespeech.loss.ctc_loss import CTCLoss  # noqa: E402
+from myrtlespeech.model.cnn import MaskConv1d, MaskConv2d, PaddingMode, Conv2dTo1d, Conv1dTo2d  # noqa: E402
+from myrtlespeech.model.deep_speech_1 import DeepSpeech1  # noqa: E402
+from myrtlespeech.model.deep_speech_2 import DeepSpeech2  # noqa: E402
+from myrtlespeech.model.fully_connected import FullyConnected  # noqa: E402
+from myrtlespeech.model.hard_lstm import HardLSTM  # noqa: E402
+from myrtlespeech.model.lookahead import Lookahead  # noqa: E402
+from myrtlespeech.model.rnn import RNN, RNNType  # noqa: E402
+from myrtlespeech.model.seq_len_wrapper import SeqLenWrapper  # noqa: E402
+from myrtlespeech.post_process.ctc_beam_decoder import CTCBeamDecoder  # noqa: E402
+from myrtlespeech.post_process.ctc_greedy_decoder import CTCGreedyDecoder  # noqa: E402
+
+from oracle.ds_oracle import toy_language_model  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, cfg, arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, cfg=np.array(json.dumps(cfg)), **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def sd_arrays(module, prefix="sd/"):
+    return {prefix + k: npy(v) for k, v in module.state_dict().items()}
+
+
+def ragged(list_of_lists):
+    flat = np.array([v for l in list_of_lists for v in l], dtype=np.int64)
+    lens = np.array([len(l) for l in list_of_lists], dtype=np.int64)
+    return flat, lens
+
+
+# ----------------------------------------------------------------------------- rnn
+def gen_rnn():
+    cases = [
+        # name, type, In, H, L, bidir, batch_first, fgb, T, N, lens, with_hx
+        ("rnn_lstm_bi2", RNNType.LSTM, 12, 16, 2, True, False, 1.0, 9, 4, [9, 7, 4, 2], False),
+        ("rnn_lstm_uni_hx_bf", RNNType.LSTM, 8, 8, 1, False, True, None, 7, 3, [7, 7, 3], True),
+        ("rnn_lstm_fast_h64", RNNType.LSTM, 40, 64, 1, True, False, 1.0, 12, 5, [12, 12, 9, 5, 1], False),
+        ("rnn_lstm_fast_h128_n33", RNNType.LSTM, 24, 128, 1, True, False, 1.0, 10, 33,
+         sorted([10] * 5 + list(range(1, 11)) * 2 + [6] * 8, reverse=True), True),
+        ("rnn_lstm_odd", RNNType.LSTM, 5, 3, 3, True, False, 0.5, 6, 2, [6, 5], True),
+        ("rnn_gru_bi2_hx", RNNType.GRU, 10, 8, 2, True, False, None, 8, 3, [8, 5, 1], True),
+        ("rnn_gru_uni", RNNType.GRU, 6, 12, 1, False, False, None, 5, 4, [5, 5, 4, 2], False),
+        ("rnn_tanh_bi", RNNType.BASIC_RNN, 7, 9, 2, True, True, None, 6, 3, [6, 4, 4], False),
+    ]
+    for (name, rt, In, H, L, bi, bf, fgb, T, N, lens, with_hx) in cases:
+        torch.manual_seed(hash(name) % 1000 if False else sum(map(ord, name)))
+        m = RNN(rt, In, H, num_layers=L, bidirectional=bi, forget_gate_bias=fgb, batch_first=bf).eval()
+        x = torch.randn(N, T, In) if bf else torch.randn(T, N, In)
+        D = 2 if bi else 1
+        hx = None
+        arrays = {}
+        if with_hx:
+            h0 = torch.randn(L * D, N, H) * 0.5
+            if rt == RNNType.LSTM:
+                c0 = torch.randn(L * D, N, H) * 0.5
+                hx = (h0, c0)
+                arrays["in/c0"] = npy(c0)
+            else:
+                hx = h0
+            arrays["in/h0"] = npy(h0)
+        lens_t = torch.tensor(lens, dtype=torch.int64)
+        (out, ol), hid = m((x.clone(), lens_t), hx)
+        arrays.update({"in/x": npy(x), "in/lens": npy(lens_t), "out/y": npy(out), "out/lens": npy(ol)})
+        if rt == RNNType.LSTM:
+            arrays["out/hn"], arrays["out/cn"] = npy(hid[0]), npy(hid[1])
+        else:
+            arrays["out/hn"] = npy(hid)
+        arrays.update(sd_arrays(m))
+        save(name, dict(rnn_type=int(rt), input_size=In, hidden_size=H, num_layers=L, bidirectional=bi,
+                        batch_first=bf, forget_gate_bias=fgb), arrays)
+
+
+def gen_hard_lstm():
+    for name, In, H, L, bi, bf, T, N in [("hard_lstm_bi", 6, 8, 2, True, False, 5, 3),
+                                         ("hard_lstm_uni_bf", 5, 4, 1, False, True, 6, 2)]:
+        torch.manual_seed(sum(map(ord, name)))
+        m = HardLSTM(In, H, num_layers=L, bidirectional=bi, batch_first=bf, forget_gate_bias=1.0).eval()
+        x = torch.randn(N, T, In) * 2 if bf else torch.randn(T, N, In) * 2
+        D = 2 if bi else 1
+        h0, c0 = torch.randn(L * D, N, H) * 0.5, torch.randn(L * D, N, H) * 0.5
+        lens_t = torch.tensor([T] * N, dtype=torch.int64)
+        (out, ol), hid = m((x.clone(), lens_t), (h0, c0))
+        arrays = {"in/x": npy(x), "in/lens": npy(lens_t), "in/h0": npy(h0), "in/c0": npy(c0), "out/y": npy(out),
+                  "out/hn": npy(hid[0]), "out/cn": npy(hid[1])}
+        arrays.update(sd_arrays(m))
+        save(name, dict(input_size=In, hidden_size=H, num_layers=L, bidirectional=bi, batch_first=bf,
+                        forget_gate_bias=1.0), arrays)
+
+
+# ----------------------------------------------------------------------------- conv
+def gen_conv():
+    cases2d = [
+        # name, Cin, Cout, k(f,t), s(f,t), same, F, T, N, lens
+        ("conv2d_same_s22", 1, 4, [5, 3], [2, 2], True, 9, 13, 3, [13, 8, 2]),
+        ("conv2d_same_s21", 3, 5, [3, 5], [2, 1], True, 8, 11, 2, [11, 6]),
+        ("conv2d_none_s12", 2, 3, [3, 4], [1, 2], False, 7, 15, 3, [15, 15, 9]),
+        ("conv2d_ds2_like", 1, 32, [41, 11], [2, 2], True, 80, 37, 2, [37, 21]),
+        ("conv2d_ds2_like2", 16, 32, [11, 11], [2, 1], True, 40, 19, 2, [19, 11]),
+    ]
+    for name, ci, co, k, s, same, Fd, T, N, lens in cases2d:
+        torch.manual_seed(sum(map(ord, name)))
+        m = MaskConv2d(ci, co, k, s, PaddingMode.SAME if same else PaddingMode.NONE).eval()
+        x = torch.randn(N, ci, Fd, T)
+        lens_t = torch.tensor(lens, dtype=torch.int64)
+        xin = x.clone()
+        y, ol = m((xin, lens_t))
+        arrays = {"in/x": npy(x), "in/lens": npy(lens_t), "out/y": npy(y), "out/lens": npy(ol),
+                  "out/x_after": npy(xin)}
+        arrays.update(sd_arrays(m))
+        save(name, dict(in_channels=ci, out_channels=co, kernel_size=k, stride=s, same=same), arrays)
+    cases1d = [
+        ("conv1d_same_s2", 6, 4, 5, 2, True, 17, 3, [17, 10, 3]),
+        ("conv1d_none_s1", 3, 7, 3, 1, False, 9, 2, [9, 5]),
+        ("conv1d_same_s3", 5, 33, 7, 3, True, 40, 2, [40, 22]),
+    ]
+    for name, ci, co, k, s, same, T, N, lens in cases1d:
+        torch.manual_seed(sum(map(ord, name)))
+        m = MaskConv1d(ci, co, k, s, PaddingMode.SAME if same else PaddingMode.NONE).eval()
+        x = torch.randn(N, ci, T)
+        lens_t = torch.tensor(lens, dtype=torch.int32)
+        xin = x.clone()
+        y, ol = m((xin, lens_t))
+        arrays = {"in/x": npy(x), "in/lens": npy(lens_t), "out/y": npy(y), "out/lens": npy(ol),
+                  "out/x_after": npy(xin)}
+        arrays.update(sd_arrays(m))
+        save(name, dict(in_channels=ci, out_channels=co, kernel_size=k, stride=s, same=same), arrays)
+
+
+# ----------------------------------------------------------------------------- fc / lookahead
+def gen_fc_lookahead():
+    torch.manual_seed(11)
+    m = FullyConnected(10, 7, 2, 12, torch.nn.Hardtanh(0.0, 20.0)).eval()
+    x = torch.randn(3, 5, 10) * 3
+    lens_t = torch.tensor([5, 4, 2])
+    y, ol = m((x, lens_t))
+    arrays = {"in/x": npy(x), "in/lens": npy(lens_t), "out/y": npy(y)}
+    arrays.update(sd_arrays(m))
+    save("fc_h2_hardtanh", dict(in_features=10, out_features=7, num_hidden_layers=2, hidden_size=12,
+                                act=[0.0, 20.0]), arrays)
+    torch.manual_seed(12)
+    m = FullyConnected(6, 4, 0, None, None).eval()
+    x = torch.randn(2, 3, 6)
+    y, _ = m((x, torch.tensor([3, 1])))
+    arrays = {"in/x": npy(x), "in/lens": np.array([3, 1]), "out/y": npy(y)}
+    arrays.update(sd_arrays(m))
+    save("fc_h0", dict(in_features=6, out_features=4, num_hidden_layers=0, hidden_size=None, act=None), arrays)
+    torch.manual_seed(13)
+    m = FullyConnected(9, 5, 1, 8, torch.nn.ReLU()).eval()
+    x = torch.randn(2, 4, 9)
+    y, _ = m((x, torch.tensor([4, 4])))
+    arrays = {"in/x": npy(x), "in/lens": np.array([4, 4]), "out/y": npy(y)}
+    arrays.update(sd_arrays(m))
+    save("fc_h1_relu", dict(in_features=9, out_features=5, num_hidden_layers=1, hidden_size=8, act="relu"), arrays)
+
+    torch.manual_seed(14)
+    m = Lookahead(6, 4).eval()
+    x = torch.randn(3, 6, 9)
+    y, _ = m((x, torch.tensor([9, 5, 2])))
+    arrays = {"in/x": npy(x), "in/lens": np.array([9, 5, 2]), "out/y": npy(y)}
+    arrays.update(sd_arrays(m))
+    save("lookahead_f6_c4", dict(in_features=6, context=4), arrays)
+    torch.manual_seed(15)
+    m = Lookahead(70, 20).eval()
+    x = torch.randn(2, 70, 33)
+    y, _ = m((x, torch.tensor([33, 20])))
+    arrays = {"in/x": npy(x), "in/lens": np.array([33, 20]), "out/y": npy(y)}
+    arrays.update(sd_arrays(m))
+    save("lookahead_f70_c20", dict(in_features=70, context=20), arrays)
+
+
+# ----------------------------------------------------------------------------- DS2 / DS1
+def act_wrap(lo, hi):
+    return SeqLenWrapper(torch.nn.Hardtanh(lo, hi), torch.nn.Identity())
+
+
+def gen_ds2():
+    # tiny bidirectional-LSTM DS2 (structure of builders/deep_speech_2.py:136-221)
+    torch.manual_seed(21)
+    cnn = torch.nn.Sequential(
+        MaskConv2d(1, 4, [5, 3], [2, 2], PaddingMode.SAME), act_wrap(0.0, 20.0),
+        MaskConv2d(4, 4, [3, 3], [2, 1], PaddingMode.SAME), act_wrap(0.0, 20.0),
+    )
+    rnn = RNN(RNNType.LSTM, 4 * 4, 16, num_layers=2, bidirectional=True, forget_gate_bias=1.0)
+    fc = FullyConnected(32, 11, 1, 24, torch.nn.Hardtanh(0.0, 20.0))
+    m = DeepSpeech2(cnn, rnn, None, fc).eval()
+    x = torch.randn(3, 1, 16, 40)
+    lens_t = torch.tensor([40, 29, 12], dtype=torch.int64)
+    (y, ol), hid = m((x.clone(), lens_t))
+    dec = CTCGreedyDecoder(10)(y, ol)
+    flat, dl = ragged(dec)
+    cfg = dict(convs=[dict(kind="conv2d", idx=0, in_channels=1, out_channels=4, kernel=[5, 3], stride=[2, 2],
+                           same=True, act=[0.0, 20.0]),
+                      dict(kind="conv2d", idx=2, in_channels=4, out_channels=4, kernel=[3, 3], stride=[2, 1],
+                           same=True, act=[0.0, 20.0])],
+               rnn=dict(kind=0, input=16, hidden=16, layers=2, bidirectional=True, forget_gate_bias=1.0),
+               lookahead=None, fc=dict(in_features=32, out_features=11, n_hidden=1, hidden=24, act=[0.0, 20.0]),
+               blank=10)
+    arrays = {"in/x": npy(x), "in/lens": npy(lens_t), "out/y": npy(y), "out/lens": npy(ol),
+              "out/hn": npy(hid[0]), "out/cn": npy(hid[1]), "out/greedy_flat": flat, "out/greedy_lens": dl}
+    arrays.update(sd_arrays(m))
+    save("ds2_tiny_bilstm", cfg, arrays)
+
+    # conv1d + unidirectional GRU + lookahead (shipped-config shape in miniature)
+    torch.manual_seed(22)
+    cnn = torch.nn.Sequential(
+        MaskConv2d(1, 3, [5, 3], [2, 2], PaddingMode.SAME), act_wrap(0.0, 20.0),
+        Conv2dTo1d(),
+        MaskConv1d(3 * 6, 10, 3, 1, PaddingMode.SAME), act_wrap(0.0, 20.0),
+        Conv1dTo2d(),
+    )
+    rnn = RNN(RNNType.GRU, 10, 12, num_layers=2, bidirectional=False)
+    la = torch.nn.Sequential(Lookahead(12, 5), SeqLenWrapper(torch.nn.Identity(), torch.nn.Identity()))
+    fc = FullyConnected(12, 7, 0, None, None)
+    m = DeepSpeech2(cnn, rnn, la, fc).eval()
+    x = torch.randn(2, 1, 12, 30)
+    lens_t = torch.tensor([30, 17], dtype=torch.int64)
+    h0 = torch.randn(2, 2, 12) * 0.3
+    (y, ol), hid = m((x.clone(), lens_t), h0)
+    cfg = dict(convs=[dict(kind="conv2d", idx=0, in_channels=1, out_channels=3, kernel=[5, 3], stride=[2, 2],
+                           same=True, act=[0.0, 20.0]),
+                      dict(kind="conv1d", idx=3, in_channels=18, out_channels=10, kernel=3, stride=1, same=True,
+                           act=[0.0, 20.0])],
+               rnn=dict(kind=1, input=10, hidden=12, layers=2, bidirectional=False, forget_gate_bias=None),
+               lookahead=dict(context=5, act=None),
+               fc=dict(in_features=12, out_features=7, n_hidden=0, hidden=None, act=None), blank=6)
+    arrays = {"in/x": npy(x), "in/lens": npy(lens_t), "in/h0": npy(h0), "out/y": npy(y), "out/lens": npy(ol),
+              "out/hn": npy(hid)}
+    arrays.update(sd_arrays(m))
+    save("ds2_tiny_gru_lookahead", cfg, arrays)
+
+
+def gen_ds1():
+    for hard in (False, True):
+        torch.manual_seed(31 + hard)
+        m = DeepSpeech1(input_features=5, input_channels=3, n_hidden=8, out_features=6, drop_prob=0.25,
+                        relu_clip=20.0, forget_gate_bias=1.0, hard_lstm=hard).eval()
+        x = torch.randn(3, 3, 5, 11)
+        lens_t = torch.tensor([11, 8, 5] if not hard else [11, 11, 11], dtype=torch.int64)
+        (y, ol), hid = m((x.clone(), lens_t))
+        arrays = {"in/x": npy(x), "in/lens": npy(lens_t), "out/y": npy(y), "out/lens": npy(ol),
+                  "out/hn": npy(hid[0]), "out/cn": npy(hid[1])}
+        arrays.update(sd_arrays(m))
+        save("ds1_tiny_hard" if hard else "ds1_tiny", dict(input_features=5, input_channels=3, n_hidden=8,
+                                                             out_features=6, relu_clip=20.0, hard_lstm=hard), arrays)
+
+
+# ----------------------------------------------------------------------------- CTC loss
+def gen_ctc_loss():
+    torch.manual_seed(41)
+    T, N, V = 14, 4, 6
+    x = torch.randn(T, N, V) * 2
+    x_lens = torch.tensor([14, 11, 7, 3], dtype=torch.int32)
+    tgt = [[1, 2, 2, 3], [4, 1], [0, 0, 1, 4, 2, 3, 1, 4], []]  # 3rd is impossible (8 + repeats > 7)
+    blank = 5
+    S = max(len(t) for t in tgt)
+    y = torch.zeros(N, S, dtype=torch.int32)
+    for n, t in enumerate(tgt):
+        y[n, :len(t)] = torch.tensor(t, dtype=torch.int32)
+    y_lens = torch.tensor([len(t) for t in tgt], dtype=torch.int32)
+    arrays = {"in/x": npy(x), "in/x_lens": npy(x_lens), "in/y": npy(y), "in/y_lens": npy(y_lens),
+              "in/y_flat": np.array([v for t in tgt for v in t], dtype=np.int32)}
+    for red in ("none", "mean", "sum"):
+        for zi in (False, True):
+            out = CTCLoss(blank=blank, reduction=red, zero_infinity=zi)((x, x_lens), (y, y_lens))
+            arrays[f"out/{red}_{int(zi)}"] = npy(out)
+    out = CTCLoss(blank=blank, reduction="none")((x, x_lens), (torch.tensor(arrays["in/y_flat"]), y_lens))
+    arrays["out/none_flat"] = npy(out)
+    save("ctc_loss_small", dict(blank=blank), arrays)
+
+    torch.manual_seed(42)
+    T, N, V = 60, 3, 29
+    x = torch.randn(T, N, V)
+    x_lens = torch.tensor([60, 45, 30], dtype=torch.int64)
+    y_lens = torch.tensor([20, 14, 9], dtype=torch.int64)
+    y = torch.randint(0, 28, (N, 20), dtype=torch.int64)
+    arrays = {"in/x": npy(x), "in/x_lens": npy(x_lens), "in/y": npy(y), "in/y_lens": npy(y_lens)}
+    for red in ("none", "mean", "sum"):
+        arrays[f"out/{red}_0"] = npy(CTCLoss(blank=28, reduction=red)((x, x_lens), (y, y_lens)))
+    save("ctc_loss_v29", dict(blank=28), arrays)
+
+
+# ----------------------------------------------------------------------------- decoders
+def gen_greedy():
+    torch.manual_seed(51)
+    T, N, V = 25, 5, 6
+    x = torch.randn(T, N, V)
+    x = (x * 2).round() / 2  # coarse grid -> many exact ties
+    lens = [25, 20, 13, 1, 0]
+    arrays = {"in/x": npy(x), "in/lens": np.array(lens, dtype=np.int16)}
+    for blank in (0, 3, 5):
+        dec = CTCGreedyDecoder(blank)(x, torch.tensor(lens, dtype=torch.int16))
+        arrays[f"out/flat_b{blank}"], arrays[f"out/lens_b{blank}"] = ragged(dec)
+    save("greedy_ties", dict(blanks=[0, 3, 5]), arrays)
+
+
+def gen_beam():
+    # the reference's two KATs (tests/post_process/test_ctc_beam_decoder.py:17-102)
+    x = torch.empty((2, 1, 2))
+    x[:, 0, 0] = torch.tensor([0.3, 0.3])
+    x[:, 0, 1] = torch.tensor([0.7, 0.7])
+    r = CTCBeamDecoder(blank_index=1, beam_width=2, prune_threshold=0.0)(x, torch.tensor([2], dtype=torch.int8))
+    assert r == [[0]]
+    arrays = {"kat2x2/x": npy(x), "kat2x2/out": np.array(r[0])}
+    al = dict(zip("deouw_ ", range(7)))
+    x = torch.empty((4, 1, 7))
+    x[:, 0, al["d"]] = torch.tensor([0.75, 0.05, 0.10, 0.01])
+    x[:, 0, al["e"]] = torch.tensor([0.05, 0.20, 0.20, 0.01])
+    x[:, 0, al["o"]] = torch.tensor([0.05, 0.30, 0.35, 0.01])
+    x[:, 0, al["u"]] = torch.tensor([0.05, 0.20, 0.10, 0.01])
+    x[:, 0, al["w"]] = torch.tensor([0.05, 0.00, 0.20, 0.01])
+    x[:, 0, al["_"]] = torch.tensor([0.00, 0.00, 0.10, 0.94])
+    x[:, 0, al[" "]] = torch.tensor([0.05, 0.05, 0.05, 0.01])
+    ln = torch.tensor([4], dtype=torch.int8)
+    arrays["katlm/x"] = npy(x)
+    r = CTCBeamDecoder(blank_index=al["_"], beam_width=20)(x, ln)
+    assert r == [[al[c] for c in "do"]]
+    arrays["katlm/out_nolm"] = np.array(r[0])
+    for target in ("dew", "due"):
+        tt = tuple(al[c] for c in target) + (al[" "],)
+        r = CTCBeamDecoder(blank_index=al["_"], beam_width=20, separator_index=al[" "],
+                           language_model=lambda w, tt=tt: 2.0 if w == tt else 0.0, lm_weight=10.0,
+                           word_weight=2.0)(x, ln)
+        assert r == [[al[c] for c in target + " "]]
+        arrays[f"katlm/out_{target}"] = np.array(r[0])
+    save("beam_kats", {}, arrays)
+
+    # seeded random tables (normalised probabilities)
+    torch.manual_seed(61)
+    arrays = {}
+    cases = []
+    T, N, V = 18, 4, 6
+    x = torch.softmax(torch.randn(T, N, V) * 2.0, dim=-1)
+    lens = torch.tensor([18, 12, 5, 0], dtype=torch.int32)
+    arrays["a/x"], arrays["a/lens"] = npy(x), npy(lens)
+    for ci, (blank, W, thr, sep, ww) in enumerate([(5, 1, 0.001, None, 1.0), (5, 3, 0.001, None, 1.0),
+                                                   (0, 8, 0.0, None, 1.0), (2, 4, 0.05, None, 1.0),
+                                                   (5, 4, 0.001, 0, 1.0), (5, 6, 0.01, 1, 2.5)]):
+        dec = CTCBeamDecoder(blank, W, thr, separator_index=sep, word_weight=ww)(x, lens)
+        arrays[f"a/out{ci}_flat"], arrays[f"a/out{ci}_lens"] = ragged(dec)
+        cases.append(dict(set="a", idx=ci, blank=blank, beam_width=W, prune=thr, sep=sep, word_weight=ww, lm=False))
+    # with the toy LM
+    for ci, (blank, W, thr, sep, ww, lw) in enumerate([(5, 4, 0.001, 0, 1.0, 1.0), (5, 8, 0.0, 2, 1.5, 0.7)]):
+        dec = CTCBeamDecoder(blank, W, thr, language_model=toy_language_model, lm_weight=lw, separator_index=sep,
+                             word_weight=ww)(x, lens)
+        arrays[f"a/outlm{ci}_flat"], arrays[f"a/outlm{ci}_lens"] = ragged(dec)
+        cases.append(dict(set="a", idx=f"lm{ci}", blank=blank, beam_width=W, prune=thr, sep=sep, word_weight=ww,
+                          lm=True, lm_weight=lw))
+    # peaky V=29 case, longer, beam 8 (the config-4 width) + one that underflows float32 to an empty beam
+    torch.manual_seed(62)
+    T, N, V = 120, 3, 29
+    x = torch.softmax(torch.randn(T, N, V) * 6.0, dim=-1)
+    lens = torch.tensor([120, 77, 31], dtype=torch.int64)
+    arrays["b/x"], arrays["b/lens"] = npy(x), npy(lens)
+    dec = CTCBeamDecoder(28, 8)(x, lens)
+    arrays["b/out0_flat"], arrays["b/out0_lens"] = ragged(dec)
+    cases.append(dict(set="b", idx=0, blank=28, beam_width=8, prune=0.001, sep=None, word_weight=1.0, lm=False))
+    dec = CTCBeamDecoder(28, 3, 0.02, separator_index=0, word_weight=1.0)(x, lens)
+    arrays["b/out1_flat"], arrays["b/out1_lens"] = ragged(dec)
+    cases.append(dict(set="b", idx=1, blank=28, beam_width=3, prune=0.02, sep=0, word_weight=1.0, lm=False))
+    torch.manual_seed(63)
+    T, N, V = 400, 2, 8
+    x = torch.softmax(torch.randn(T, N, V) * 0.3, dim=-1)  # flat -> best path prob ~ (1/8)^400 underflows
+    lens = torch.tensor([400, 60], dtype=torch.int64)
+    arrays["c/x"], arrays["c/lens"] = npy(x), npy(lens)
+    dec = CTCBeamDecoder(7, 4)(x, lens)
+    arrays["c/out0_flat"], arrays["c/out0_lens"] = ragged(dec)
+    cases.append(dict(set="c", idx=0, blank=7, beam_width=4, prune=0.001, sep=None, word_weight=1.0, lm=False))
+    save("beam_random", dict(cases=cases), arrays)
+
+
+# ----------------------------------------------------------------------------- config-2 summary
+def gen_ds2_cfg2_summary():
+    """Full-size DS2 (BASELINE.json configs[1]) on seeded synthetic input, reduced to
+    a sub-sampled logits grid + greedy transcripts so the fixture stays small.  The
+    test regenerates weights/inputs from the same seeds (weight checksums stored)."""
+    torch.manual_seed(0)
+    cnn = torch.nn.Sequential(
+        MaskConv2d(1, 32, [41, 11], [2, 2], PaddingMode.SAME), act_wrap(0.0, 20.0),
+        MaskConv2d(32, 32, [21, 11], [2, 1], PaddingMode.SAME), act_wrap(0.0, 20.0),
+    )
+    rnn = RNN(RNNType.LSTM, 640, 1024, num_layers=5, bidirectional=True, forget_gate_bias=1.0)
+    fc = FullyConnected(2048, 29, 1, 1024, torch.nn.Hardtanh(0.0, 20.0))
+    m = DeepSpeech2(cnn, rnn, None, fc).eval()
+    g = torch.Generator().manual_seed(1234)
+    N, T = 32, 1001
+    x = torch.randn(N, 1, 80, T, generator=g)
+    lens = torch.sort(torch.randint(501, 1002, (N,), generator=g), descending=True).values
+    lens[0] = T
+    import time
+    t0 = time.time()
+    (y, ol), hid = m((x.clone(), lens))
+    print(f"reference cfg2 forward: {time.time() - t0:.1f} s on {torch.get_num_threads()} threads")
+    dec = CTCGreedyDecoder(28)(y, ol)
+    flat, dl = ragged(dec)
+    chk = {k: float(v.double().abs().sum()) for k, v in m.state_dict().items()}
+    arrays = {"in/lens": npy(lens), "in/x_abs_sum": np.array(float(x.double().abs().sum())),
+              "out/lens": npy(ol), "out/y_sub": npy(y[::25, ::4, :]), "out/y_abs_mean": np.array(float(y.abs().mean())),
+              "out/hn_sub": npy(hid[0][:, ::8, ::64]), "out/cn_sub": npy(hid[1][:, ::8, ::64]),
+              "out/greedy_flat": flat, "out/greedy_lens": dl}
+    save("ds2_cfg2_summary", dict(weight_abs_sums=chk, seed_weights=0, seed_input=1234, N=N, T=T), arrays)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["rnn", "hard", "conv", "fc", "ds2", "ds1", "ctc", "greedy", "beam", "cfg2"]
+    if "rnn" in which:
+        gen_rnn()
+    if "hard" in which:
+        gen_hard_lstm()
+    if "conv" in which:
+        gen_conv()
+    if "fc" in which:
+        gen_fc_lookahead()
+    if "ds2" in which:
+        gen_ds2()
+    if "ds1" in which:
+        gen_ds1()
+    if "ctc" in which:
+        gen_ctc_loss()
+    if "greedy" in which:
+        gen_greedy()
+    if "beam" in which:
+        gen_beam()
+    if "cfg2" in which:
+        gen_ds2_cfg2_summary()

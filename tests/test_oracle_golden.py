@@ -1,0 +1,199 @@
+"""Pin the CPU oracle (oracle/ds_oracle.py) against the golden vectors produced by
+the reference itself (tests/golden/gen_golden.py) and the reference's own KATs.
+CPU only."""
+import numpy as np
+import pytest
+
+from oracle import ds_oracle as O
+from util import Golden, golden_names, unragged
+
+TOL = dict(rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", golden_names("rnn_"))
+def test_rnn(name):
+    g = Golden(name)
+    c = g.cfg
+    hx = None
+    if g.has("in/h0"):
+        hx = (g["in/h0"], g["in/c0"]) if c["rnn_type"] == 0 else g["in/h0"]
+    sd = {k[len("rnn."):]: v for k, v in g.sd().items()}
+    out, hid = O.rnn_forward(c["rnn_type"], g["in/x"], g["in/lens"], sd, c["hidden_size"], c["num_layers"],
+                             c["bidirectional"], hx, c["batch_first"])
+    np.testing.assert_allclose(out, g["out/y"], **TOL)
+    if c["rnn_type"] == 0:
+        np.testing.assert_allclose(hid[0], g["out/hn"], **TOL)
+        np.testing.assert_allclose(hid[1], g["out/cn"], **TOL)
+    else:
+        np.testing.assert_allclose(hid, g["out/hn"], **TOL)
+
+
+@pytest.mark.parametrize("name", golden_names("hard_lstm_"))
+def test_hard_lstm(name):
+    g = Golden(name)
+    c = g.cfg
+    sd = {k[len("rnn."):]: v for k, v in g.sd().items()}
+    out, hid = O.hard_lstm_forward(g["in/x"], sd, c["hidden_size"], c["num_layers"], c["bidirectional"],
+                                   (g["in/h0"], g["in/c0"]), c["batch_first"])
+    np.testing.assert_allclose(out, g["out/y"], **TOL)
+    np.testing.assert_allclose(hid[0], g["out/hn"], **TOL)
+    np.testing.assert_allclose(hid[1], g["out/cn"], **TOL)
+
+
+@pytest.mark.parametrize("name", golden_names("conv2d_"))
+def test_conv2d(name):
+    g = Golden(name)
+    c = g.cfg
+    y, nl = O.mask_conv2d(g["in/x"], g["in/lens"], g["sd/weight"], g["sd/bias"], tuple(c["stride"]), c["same"])
+    np.testing.assert_allclose(y, g["out/y"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(nl, g["out/lens"])
+    assert nl.dtype == g["out/lens"].dtype
+    np.testing.assert_array_equal(O._mask_time(g["in/x"], g["in/lens"]), g["out/x_after"])
+
+
+@pytest.mark.parametrize("name", golden_names("conv1d_"))
+def test_conv1d(name):
+    g = Golden(name)
+    c = g.cfg
+    y, nl = O.mask_conv1d(g["in/x"], g["in/lens"], g["sd/weight"], g["sd/bias"], c["stride"], c["same"])
+    np.testing.assert_allclose(y, g["out/y"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(nl, g["out/lens"])
+    assert nl.dtype == g["out/lens"].dtype
+
+
+def test_pad_same_values():
+    # SURVEY 8a6, computed with the reference
+    assert O.pad_same(80, 41, 2) == (20, 20)
+    assert O.pad_same(1001, 11, 2) == (5, 6)
+    assert O.pad_same(40, 21, 2) == (10, 10)
+    assert O.pad_same(501, 11, 1) == (5, 5)
+    for bad in [(0, 1, 1, 1), (1, 0, 1, 1), (1, 1, 0, 1), (1, 1, 1, 0)]:
+        with pytest.raises(ValueError):
+            O.pad_same(*bad)
+
+
+@pytest.mark.parametrize("name", golden_names("fc_"))
+def test_fc(name):
+    g = Golden(name)
+    c = g.cfg
+    sd = g.sd()
+    if c["num_hidden_layers"] == 0:
+        layers = [(sd["fully_connected.weight"], sd["fully_connected.bias"])]
+    else:
+        idx = sorted({int(k.split(".")[1]) for k in sd if k.endswith(".weight")})
+        layers = [(sd[f"fully_connected.{i}.weight"], sd[f"fully_connected.{i}.bias"]) for i in idx]
+    act = (0.0, np.inf) if c["act"] == "relu" else c["act"]
+    y = O.fully_connected(g["in/x"], layers, act)
+    np.testing.assert_allclose(y, g["out/y"], **TOL)
+
+
+@pytest.mark.parametrize("name", golden_names("lookahead_"))
+def test_lookahead(name):
+    g = Golden(name)
+    np.testing.assert_allclose(O.lookahead(g["in/x"], g["sd/weight"]), g["out/y"], **TOL)
+
+
+@pytest.mark.parametrize("name", golden_names("ds2_tiny"))
+def test_ds2_tiny(name):
+    g = Golden(name)
+    c = g.cfg
+    hx = g["in/h0"] if g.has("in/h0") else None
+    cfg = dict(convs=[dict(kind=v["kind"], idx=v["idx"], stride=v["stride"], same=v["same"], act=v["act"])
+                      for v in c["convs"]],
+               rnn=dict(kind=c["rnn"]["kind"], hidden=c["rnn"]["hidden"], layers=c["rnn"]["layers"],
+                        bidirectional=c["rnn"]["bidirectional"]),
+               lookahead=c["lookahead"], fc=dict(n_hidden=c["fc"]["n_hidden"], act=c["fc"]["act"]))
+    y, nl, hid = O.deep_speech_2_forward(g["in/x"], g["in/lens"], cfg, g.sd(), hx)
+    np.testing.assert_allclose(y, g["out/y"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(nl, g["out/lens"])
+    if g.has("out/greedy_flat"):
+        assert O.ctc_greedy_decode(y, nl, c["blank"]) == unragged(g["out/greedy_flat"], g["out/greedy_lens"])
+
+
+@pytest.mark.parametrize("name", golden_names("ds1_tiny"))
+def test_ds1_tiny(name):
+    g = Golden(name)
+    c = g.cfg
+    y, nl, hid = O.deep_speech_1_forward(g["in/x"], g["in/lens"], g.sd(), c["n_hidden"], c["relu_clip"],
+                                         c["hard_lstm"])
+    np.testing.assert_allclose(y, g["out/y"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(hid[0], g["out/hn"], rtol=1e-4, atol=1e-4)
+
+
+def test_ctc_loss_small():
+    g = Golden("ctc_loss_small")
+    b = g.cfg["blank"]
+    for red in ("none", "mean", "sum"):
+        for zi in (0, 1):
+            got = O.ctc_loss(g["in/x"], g["in/x_lens"], g["in/y"], g["in/y_lens"], b, red, bool(zi))
+            np.testing.assert_allclose(got, g[f"out/{red}_{zi}"], rtol=1e-4, atol=1e-4)
+    got = O.ctc_loss(g["in/x"], g["in/x_lens"], g["in/y_flat"], g["in/y_lens"], b, "none")
+    np.testing.assert_allclose(got, g["out/none_flat"], rtol=1e-4, atol=1e-4)
+
+
+def test_ctc_loss_v29():
+    g = Golden("ctc_loss_v29")
+    for red in ("none", "mean", "sum"):
+        got = O.ctc_loss(g["in/x"], g["in/x_lens"], g["in/y"], g["in/y_lens"], 28, red)
+        np.testing.assert_allclose(got, g[f"out/{red}_0"], rtol=1e-4, atol=1e-3)
+
+
+def test_greedy_golden():
+    g = Golden("greedy_ties")
+    for b in g.cfg["blanks"]:
+        assert O.ctc_greedy_decode(g["in/x"], g["in/lens"], b) == unragged(g[f"out/flat_b{b}"], g[f"out/lens_b{b}"])
+
+
+def test_greedy_reference_kat():
+    # restates tests/post_process/test_ctc_greedy_decoder.py:16-102: logits whose argmax
+    # spells a blank-separated sentence decode to exactly that sentence
+    rng = np.random.default_rng(0)
+    V, blank = 7, 6
+    sent = [[1, 2, 2, 3], [4], []]
+    rows = []
+    for s in sent:
+        path = []
+        for k, c in enumerate(s):
+            path += [c] * int(rng.integers(1, 4)) + [blank] * int(rng.integers(1, 3))
+        rows.append(path)
+    T = max(len(r) for r in rows) + 2
+    x = rng.normal(size=(T, len(sent), V)).astype(np.float32)
+    lens = []
+    for n, r in enumerate(rows):
+        for t, c in enumerate(r):
+            x[t, n, c] = 10.0
+        lens.append(len(r))
+    for dt in (np.uint8, np.int8, np.int16, np.int32, np.int64):
+        assert O.ctc_greedy_decode(x, np.array(lens, dtype=dt), blank) == sent
+    with pytest.raises(ValueError):
+        O.ctc_greedy_decode(x, np.array(lens, dtype=np.float32), blank)
+    with pytest.raises(ValueError):
+        O.ctc_greedy_decode(x, np.array(lens[:-1]), blank)
+    with pytest.raises(ValueError):
+        O.ctc_greedy_decode(x, np.array([T + 1] * len(sent)), blank)
+
+
+def test_beam_kats():
+    g = Golden("beam_kats")
+    assert O.ctc_beam_decode(g["kat2x2/x"], np.array([2], np.int8), 1, 2, 0.0) == [list(g["kat2x2/out"])]
+    x = g["katlm/x"]
+    ln = np.array([4], np.int8)
+    al = dict(zip("deouw_ ", range(7)))
+    assert O.ctc_beam_decode(x, ln, al["_"], 20) == [[al[c] for c in "do"]] == [list(g["katlm/out_nolm"])]
+    for target in ("dew", "due"):
+        tt = tuple(al[c] for c in target) + (al[" "],)
+        got = O.ctc_beam_decode(x, ln, al["_"], 20, language_model=lambda w, tt=tt: 2.0 if w == tt else 0.0,
+                                lm_weight=10.0, separator_index=al[" "], word_weight=2.0)
+        assert got == [[al[c] for c in target + " "]] == [list(g[f"katlm/out_{target}"])]
+
+
+def test_beam_random():
+    g = Golden("beam_random")
+    for c in g.cfg["cases"]:
+        s = c["set"]
+        key = f"{s}/out{c['idx']}"
+        want = unragged(g[key + "_flat"], g[key + "_lens"])
+        lm = O.toy_language_model if c["lm"] else None
+        got = O.ctc_beam_decode(g[f"{s}/x"], g[f"{s}/lens"], c["blank"], c["beam_width"], c["prune"], lm,
+                                c.get("lm_weight"), c["sep"], c["word_weight"])
+        assert got == want, c
