@@ -1,0 +1,177 @@
+/*
+ * ms_hotpath.h -- C ABI of the MI355X-native myrtlespeech hot path.
+ *
+ * libms_hotpath.so is the drop-in boundary: plain pointers, sizes and a HIP
+ * stream, no torch types.  The reference (MyrtleSoftware/myrtlespeech) has no
+ * FFI of its own -- every FLOP on its hot path is a stock PyTorch op called
+ * from a torch.nn.Module -- so each entry point below cites the reference
+ * call site (file:line under src/myrtlespeech/) whose arithmetic it replaces.
+ * The host-side mirror of those modules lives in myrtlespeech_amd/ (Python,
+ * as the reference is Python); INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - tensors are dense, row-major, float32 unless stated; lengths are int32;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls only enqueue
+ *     work, they never synchronise (ms_rnn_status is the one exception);
+ *   - return value: MS_OK or an MS_ERR_* code; ms_last_error() describes the
+ *     last failure on the calling thread;
+ *   - outputs are caller-allocated; nothing is freed or retained.
+ */
+#ifndef MS_HOTPATH_H
+#define MS_HOTPATH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MS_ABI_VERSION 1
+
+enum {
+  MS_OK = 0,
+  MS_ERR_INVALID = 1,     /* bad argument (shape, NULL pointer, unsupported value) */
+  MS_ERR_HIP = 2,         /* a HIP runtime call failed */
+  MS_ERR_WORKSPACE = 3,   /* workspace too small */
+  MS_ERR_TIMEOUT = 4,     /* a persistent kernel gave up waiting for its peers */
+  MS_ERR_UNSUPPORTED = 5
+};
+
+/* recurrent cell kinds: model/rnn.py:9-12 RNNType (+ model/hard_lstm.py) */
+enum { MS_CELL_LSTM = 0, MS_CELL_GRU = 1, MS_CELL_RNN_TANH = 2, MS_CELL_HARD_LSTM = 3 };
+
+/* activation fused into an epilogue: builders/activation.py:31-42 */
+enum { MS_ACT_NONE = 0, MS_ACT_CLAMP = 1 /* Hardtanh(lo,hi); ReLU = clamp(0,+inf) */ };
+
+int ms_abi_version(void);
+const char* ms_last_error(void);
+
+/* ---- model/cnn.py ------------------------------------------------------- */
+
+/* MaskConv{1,2}d._mask_ (cnn.py:280-293, 425-443): x[n, :, t] = 0 for t >= lens[n],
+ * in place.  x is [N, inner, T]. */
+int ms_mask_time_(float* x, const int32_t* lens, int N, int inner, int T, void* stream);
+
+/* Bytes of the packed filter bank ms_maskconv_pack writes (Cout = all groups). */
+size_t ms_maskconv_packed_bytes(int Cout, int Cin_g, int KF, int KT, int groups);
+
+/* Re-lays torch's Conv weight [Cout, Cin_g, KF, KT] (cnn.py:238-246, 377-385)
+ * into the [group][cout-tile][cin*KF+kf][kt (padded even)][32] bank the kernel stages. */
+int ms_maskconv_pack(const float* w, void* packed, int Cout, int Cin_g, int KF, int KT, int groups, void* stream);
+
+/* MaskConv2d.forward (cnn.py:445-483) = mask + F.pad + Conv2d (+ the following
+ * SeqLenWrapper activation, seq_len_wrapper.py:28-32), fused: frames t >= lens[n]
+ * of the input read as 0, SAME padding is index arithmetic (pad_f_l / pad_t_l are
+ * the LEFT pads of cnn.py:148-163), bias and clamp in the epilogue.
+ * x [N, Cin, Fin, Tin] -> y [N, Cout, Fout, Tout].  MaskConv1d (cnn.py:295-333)
+ * is the Fin = KF = SF = 1 case.  lens may be NULL (no masking).  groups >= 1. */
+int ms_maskconv_forward(const float* x, const int32_t* lens, const void* packed_w, const float* bias, float* y,
+                        int N, int Cin, int Fin, int Tin, int Cout, int Fout, int Tout, int KF, int KT, int SF,
+                        int ST, int DF, int DT, int pad_f_l, int pad_t_l, int groups, int act, float act_lo,
+                        float act_hi, void* stream);
+
+/* DeepSpeech2._conv_to_rnn_size (deep_speech_2.py:114-117): [N, CF, T] -> [T, N, CF]. */
+int ms_nct_to_tnc(const float* x, float* y, int N, int CF, int T, void* stream);
+
+/* Elementwise clamp (SeqLenWrapper(Hardtanh/ReLU) on its own); y may alias x. */
+int ms_clamp(const float* x, float* y, size_t n, float lo, float hi, void* stream);
+
+/* ---- model/fully_connected.py ------------------------------------------ */
+
+/* torch.nn.Linear (+ hidden activation) (fully_connected.py:107-131, 164; also
+ * deep_speech_1.py:124-136): y[M,N] = act(x[M,K] . w[N,K]^T + bias[N]). bias may be NULL. */
+int ms_linear_forward(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
+                      float act_lo, float act_hi, void* stream);
+
+/* ---- model/lookahead.py ------------------------------------------------- */
+
+/* Lookahead.forward (lookahead.py:65-69): y[n,f,t] = sum_k w[f,k] * x[n,f,t+k]
+ * (zero beyond T).  Element strides let the caller pass the [T,N,F] RNN output
+ * directly (deep_speech_2.py:119-121, 161-164).  w is [F, ctx]. */
+int ms_lookahead_forward(const float* x, const float* w, float* y, int N, int F, int T, int ctx, long xs_n,
+                         long xs_f, long xs_t, long ys_n, long ys_f, long ys_t, int act, float act_lo,
+                         float act_hi, void* stream);
+
+/* ---- model/rnn.py / model/hard_lstm.py ---------------------------------- */
+
+/* One layer (all directions) of torch.nn.LSTM/GRU/RNN as RNN.forward drives it
+ * (rnn.py:170-183: pack_padded_sequence -> rnn -> pad_packed_sequence) or of
+ * HardLSTM (hard_lstm.py:346-379, 416-456, 513-561).
+ *
+ * Packing: weights in torch layout, per direction d (0 fwd, 1 reverse):
+ * w_ih[d] [G*H, In], w_hh[d] [G*H, H], b_ih[d]/b_hh[d] [G*H] or NULL (bias=False);
+ * G = 4 (LSTM, gate order i,f,g,o), 3 (GRU: r,z,n), 1 (RNN).  The pointer arrays
+ * themselves are HOST arrays of device pointers. */
+size_t ms_rnn_packed_bytes(int cell, int In, int H, int ndir);
+int ms_rnn_pack(int cell, int In, int H, int ndir, const float* const* w_ih_host, const float* const* w_hh_host,
+                const float* const* b_ih_host, const float* const* b_hh_host, void* packed, void* stream);
+
+size_t ms_rnn_workspace_bytes(int cell, int T, int N, int In, int H, int ndir);
+
+/* x [T, N, In] time-major; lens [N] sorted descending (enforce_sorted=True,
+ * rnn.py:174) or NULL = all T (HardLSTM ignores lengths, hard_lstm.py:36);
+ * max_len = lens[0] (host copy; T if lens is NULL); h0/c0 [ndir, N, H] (c0 only
+ * for LSTM cells; NULL = zeros, rnn.py:187-205); out [T, N, ndir*H] (rows
+ * t >= lens[n] are written as 0); hn/cn [ndir, N, H] = state at each sequence's
+ * last valid step. */
+int ms_rnn_layer_forward(int cell, const void* packed, const float* x, const int32_t* lens, int max_len,
+                         const float* h0, const float* c0, float* out, float* hn, float* cn, int T, int N, int In,
+                         int H, int ndir, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Synchronises `stream` and reports whether the last ms_rnn_layer_forward that
+ * used `workspace` completed (MS_OK) or a persistent kernel timed out. */
+int ms_rnn_status(const void* workspace, void* stream);
+
+/* ---- loss/ctc_loss.py ---------------------------------------------------- */
+
+size_t ms_ctc_loss_workspace_bytes(int T, int N, int V, int S_max);
+
+/* CTCLoss.forward (ctc_loss.py:95-101) = LogSoftmax(dim=-1) + torch.nn.CTCLoss:
+ * log-space alpha recursion per utterance.  logits [T,N,V] unnormalised;
+ * targets int32, utterance n's labels start at tgt_offsets[n] (covers both the
+ * padded [N,S] and the concatenated 1-D form, ctc_loss.py:74-83).
+ * nll [N] = -log p(target | input) (reduction='none');
+ * reduced [1] = 'sum' (reduction=2) or 'mean' (reduction=1: nll/clamp(len,1),
+ * batch mean, ctc_loss.py:17-19); zero_infinity replaces inf by 0. */
+int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, const int32_t* targets,
+                        const int32_t* tgt_offsets, const int32_t* tgt_lens, float* nll, float* reduced, int T,
+                        int N, int V, int S_max, int blank, int reduction, int zero_infinity, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* ---- post_process/ctc_greedy_decoder.py ---------------------------------- */
+
+/* CTCGreedyDecoder.forward (ctc_greedy_decoder.py:74-92): argmax over symbols
+ * (ties -> lowest index), drop repeats and blanks.  x [T,N,V] (any real scores);
+ * out_idx [N, T] int32, out_len [N]. */
+int ms_ctc_greedy_decode(const float* x, const int32_t* lens, int32_t* out_idx, int32_t* out_len, int T, int N,
+                         int V, int blank, void* stream);
+
+/* ---- post_process/ctc_beam_decoder.py ------------------------------------ */
+
+size_t ms_ctc_beam_workspace_bytes(int T, int N, int V, int beam_width);
+
+/* CTCBeamDecoder.forward (ctc_beam_decoder.py:175-258): prefix beam search in
+ * linear float32 arithmetic in the reference's visiting order, bit-exact beam.
+ * probs [T,N,V] normalised.  separator < 0 = None; word_factor [T+2] (or NULL
+ * when separator < 0) holds float32((1 + n_words) ** word_weight) for
+ * n_words = 0..T+1, evaluated by the host exactly as ctc_beam_decoder.py:248-253.  One call advances every
+ * utterance over time steps [t_begin, t_end); state persists in `workspace`
+ * (t_begin = 0 initialises it), so a host language model can be consulted
+ * between steps: lm_factor [N, beam_width] float32 (or NULL) multiplies the
+ * separator extension of beam entry w (= float32(lm(l+sep) ** lm_weight),
+ * ctc_beam_decoder.py:222-228).  When finish != 0 the best prefix of each
+ * utterance is written to out_idx [N, T] / out_len [N]; beam_len [N] and
+ * beam_idx [N, beam_width, T] / beam_plen [N, beam_width] (may be NULL) expose
+ * the current beam for the LM callback. */
+int ms_ctc_beam_decode(const float* probs, const int32_t* lens, int32_t* out_idx, int32_t* out_len, int T, int N,
+                       int V, int blank, int beam_width, float prune_threshold, int separator, const float* word_factor,
+                       int t_begin, int t_end, const float* lm_factor, int finish, int32_t* beam_len,
+                       int32_t* beam_idx, int32_t* beam_plen, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MS_HOTPATH_H */

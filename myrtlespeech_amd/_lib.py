@@ -1,0 +1,124 @@
+"""ctypes binding of ``libms_hotpath.so`` (see ``include/ms_hotpath.h``).
+
+The product path has no CPU fallback: if the library is missing, loading fails
+loudly; if there is no HIP device, every op raises ``RuntimeError``.
+"""
+import ctypes
+import os
+import re
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_long, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libms_hotpath.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ms_hotpath.h")
+
+MS_OK = 0
+ERR_NAMES = {1: "MS_ERR_INVALID", 2: "MS_ERR_HIP", 3: "MS_ERR_WORKSPACE", 4: "MS_ERR_TIMEOUT", 5: "MS_ERR_UNSUPPORTED"}
+
+CELL_LSTM, CELL_GRU, CELL_RNN_TANH, CELL_HARD_LSTM = 0, 1, 2, 3
+ACT_NONE, ACT_CLAMP = 0, 1
+
+_P = c_void_p
+_PP = POINTER(c_void_p)
+
+# name -> (restype, argtypes); mirrors include/ms_hotpath.h one to one
+SIGNATURES = {
+    "ms_abi_version": (c_int, []),
+    "ms_last_error": (c_char_p, []),
+    "ms_mask_time_": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ms_maskconv_packed_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "ms_maskconv_pack": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ms_maskconv_forward": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 17 + [c_float, c_float, _P]),
+    "ms_nct_to_tnc": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ms_clamp": (c_int, [_P, _P, c_size_t, c_float, c_float, _P]),
+    "ms_linear_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
+    "ms_lookahead_forward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_int, c_float, c_float, _P]),
+    "ms_rnn_packed_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "ms_rnn_pack": (c_int, [c_int, c_int, c_int, c_int, _PP, _PP, _PP, _PP, _P, _P]),
+    "ms_rnn_workspace_bytes": (c_size_t, [c_int] * 6),
+    "ms_rnn_layer_forward": (c_int, [c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P] + [c_int] * 5 + [_P, c_size_t, _P]),
+    "ms_rnn_status": (c_int, [_P, _P]),
+    "ms_ctc_loss_workspace_bytes": (c_size_t, [c_int] * 4),
+    "ms_ctc_loss_forward": (c_int, [_P] * 7 + [c_int] * 7 + [_P, c_size_t, _P]),
+    "ms_ctc_greedy_decode": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ms_ctc_beam_workspace_bytes": (c_size_t, [c_int] * 4),
+    "ms_ctc_beam_decode": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_int, c_int,
+                                   _P, c_int, _P, _P, _P, _P, c_size_t, _P]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Every function name declared in include/ms_hotpath.h."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(ms_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the .so is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C myrtlespeech_amd/csrc`). There is no CPU fallback."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("myrtlespeech_amd: a HIP device (MI355X) is required; there is no CPU fallback")
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return c_void_p(0)
+    return c_void_p(t.data_ptr())
+
+
+def check(rc, what):
+    if rc != MS_OK:
+        msg = load().ms_last_error().decode()
+        raise RuntimeError(f"{what} failed with {ERR_NAMES.get(rc, rc)}: {msg}")
+
+
+def f32c(t):
+    """float32, contiguous, on the GPU (torch only moves bytes here)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    if not t.is_cuda:
+        t = t.cuda()
+    return t.contiguous()
+
+
+def lens_i32(lens):
+    """int32 device copy of a lengths tensor."""
+    return lens.to(device="cuda", dtype=torch.int32).contiguous()
+
+
+class Workspace:
+    """Grow-only device scratch buffer owned by a module."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes):
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device="cuda")
+        return self.buf

@@ -1,0 +1,45 @@
+// Shared host/device helpers for libms_hotpath.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/ms_hotpath.h"
+
+namespace ms {
+
+void set_error(const std::string& s);
+
+#define MS_REQUIRE(cond, msg)                                              \
+  do {                                                                     \
+    if (!(cond)) {                                                         \
+      ms::set_error(std::string(__func__) + ": " + (msg));                 \
+      return MS_ERR_INVALID;                                               \
+    }                                                                      \
+  } while (0)
+
+#define MS_HIP(call)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      ms::set_error(std::string(__func__) + ": " #call " -> " + hipGetErrorString(e_));     \
+      return MS_ERR_HIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+
+#define MS_LAUNCH_CHECK() MS_HIP(hipGetLastError())
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Row of accumulator register `reg` of a 32x32 MFMA tile held by `lane`
+// (column is lane & 31): cdna_hip_programming.md §3.
+__device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+int num_cus();
+
+}  // namespace ms

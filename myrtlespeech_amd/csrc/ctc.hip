@@ -1,0 +1,213 @@
+// CTC loss (log-space alpha recursion) and CTC greedy decode.  No MFMA: these are
+// scan / compaction kernels built from wavefront ballot + prefix counts (64-wide waves).
+//
+//   ms_ctc_loss_forward   <- loss/ctc_loss.py:95-101 (LogSoftmax + torch.nn.CTCLoss)
+//   ms_ctc_greedy_decode  <- post_process/ctc_greedy_decoder.py:74-92
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int CTC_THREADS = 256;
+
+__device__ __forceinline__ float neg_inf() { return -INFINITY; }
+
+// log(exp(a)+exp(b)+exp(c)) with the max trick; all -inf -> -inf
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+  const float m = fmaxf(fmaxf(a, b), c);
+  if (m == neg_inf()) return neg_inf();
+  return logf(expf(a - m) + expf(b - m) + expf(c - m)) + m;
+}
+
+// One workgroup per utterance.
+//   phase 1: logZ[t] = logsumexp_v logits[t,n,:]            (threads over t)
+//   phase 2: alpha recursion over the 2L+1 extended states  (threads over states, one barrier per frame)
+// LDS: ext labels [S], alpha double buffer [2][S]; logZ lives in the global workspace.
+__global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_kernel(const float* __restrict__ logits,
+                                                                const int32_t* __restrict__ in_lens,
+                                                                const int32_t* __restrict__ targets,
+                                                                const int32_t* __restrict__ tgt_offsets,
+                                                                const int32_t* __restrict__ tgt_lens,
+                                                                float* __restrict__ nll, float* __restrict__ logz_ws,
+                                                                int T, int N, int V, int S_max, int blank) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  int* ext = reinterpret_cast<int*>(smem);   // [S_max]
+  float* alpha0 = smem + S_max;              // [S_max]
+  float* alpha1 = alpha0 + S_max;            // [S_max]
+  const int Tn = min(max(in_lens[n], 0), T);
+  const int L = max(tgt_lens[n], 0);
+  const int S = 2 * L + 1;
+  float* logz = logz_ws + (size_t)n * T;
+  const int32_t* tg = targets + tgt_offsets[n];
+
+  for (int t = tid; t < Tn; t += CTC_THREADS) {
+    const float* row = logits + ((size_t)t * N + n) * V;
+    float m = neg_inf();
+    for (int v = 0; v < V; ++v) m = fmaxf(m, row[v]);
+    float sum = 0.f;
+    for (int v = 0; v < V; ++v) sum += expf(row[v] - m);
+    logz[t] = logf(sum) + m;
+  }
+  for (int s = tid; s < S; s += CTC_THREADS) {
+    ext[s] = (s & 1) ? tg[s >> 1] : blank;
+    alpha0[s] = neg_inf();
+  }
+  __syncthreads();
+  if (Tn > 0) {
+    const float* row = logits + (size_t)n * V;
+    if (tid == 0) alpha0[0] = row[blank] - logz[0];
+    if (tid == 1 && S > 1) alpha0[1] = row[ext[1]] - logz[0];
+  }
+  __syncthreads();
+  float* cur = alpha0;
+  float* nxt = alpha1;
+  for (int t = 1; t < Tn; ++t) {
+    const float* row = logits + ((size_t)t * N + n) * V;
+    const float lz = logz[t];
+    for (int s = tid; s < S; s += CTC_THREADS) {
+      const int lab = ext[s];
+      const float a0 = cur[s];
+      const float a1 = (s >= 1) ? cur[s - 1] : neg_inf();
+      const float a2 = (s >= 2 && lab != blank && lab != ext[s - 2]) ? cur[s - 2] : neg_inf();
+      const float l = lse3(a0, a1, a2);
+      nxt[s] = (l == neg_inf()) ? neg_inf() : l + (row[lab] - lz);
+    }
+    __syncthreads();
+    float* tmp = cur; cur = nxt; nxt = tmp;
+  }
+  if (tid == 0) {
+    float ll;
+    if (Tn == 0) {
+      ll = (S == 1) ? 0.f : neg_inf();
+    } else {
+      const float l1 = cur[S - 1];
+      const float l2 = (S > 1) ? cur[S - 2] : neg_inf();
+      const float m = fmaxf(l1, l2);
+      ll = (m == neg_inf()) ? neg_inf() : logf(expf(l1 - m) + expf(l2 - m)) + m;
+    }
+    nll[n] = -ll;
+  }
+}
+
+// Deterministic single-workgroup reduction of the per-utterance losses.
+__global__ void ctc_reduce_kernel(float* __restrict__ nll, const int32_t* __restrict__ tgt_lens,
+                                  float* __restrict__ reduced, int N, int reduction, int zero_infinity) {
+  __shared__ float part[256];
+  const int tid = threadIdx.x;
+  float acc = 0.f;
+  for (int n = tid; n < N; n += 256) {
+    float v = nll[n];
+    if (zero_infinity && isinf(v)) {
+      v = 0.f;
+      nll[n] = 0.f;
+    }
+    if (reduction == 1) v = v / fmaxf((float)tgt_lens[n], 1.f);
+    acc += v;
+  }
+  part[tid] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) part[tid] += part[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0 && reduced) reduced[0] = (reduction == 1) ? part[0] / (float)N : part[0];
+}
+
+// One workgroup (256 threads = 4 waves) per utterance.  Frames are processed in chunks of
+// 256: argmax per frame (first maximum wins, NaN counts as maximum like torch.argmax),
+// keep = sym != blank && (t == 0 || sym != sym[t-1]); kept symbols are compacted with a
+// wave ballot + popcount prefix and a 4-entry cross-wave scan.
+__global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict__ x, const int32_t* __restrict__ lens,
+                                                         int32_t* __restrict__ out_idx, int32_t* __restrict__ out_len,
+                                                         int T, int N, int V, int blank) {
+  __shared__ int wave_cnt[4];
+  __shared__ int wave_last[4];
+  __shared__ int last_sym;   // argmax of the last frame of the previous chunk
+  __shared__ int base;
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int len = min(max(lens[n], 0), T);
+  if (tid == 0) { last_sym = -1; base = 0; }
+  __syncthreads();
+  for (int t0 = 0; t0 < len; t0 += 256) {
+    const int t = t0 + tid;
+    int sym = -1;
+    if (t < len) {
+      const float* row = x + ((size_t)t * N + n) * V;
+      float best = row[0];
+      sym = 0;
+      for (int v = 1; v < V; ++v) {
+        const float c = row[v];
+        if (c > best || (c != c && best == best)) { best = c; sym = v; }
+      }
+    }
+    int prev = __shfl_up(sym, 1, 64);
+    // cross-wave / cross-chunk predecessor
+    if (lane == 63) wave_last[wave] = sym;
+    __syncthreads();
+    if (lane == 0) prev = (wave == 0) ? last_sym : wave_last[wave - 1];
+    const bool keep = (t < len) && (sym != blank) && (t == 0 || sym != prev);
+    const unsigned long long mask = __ballot(keep);
+    const int before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(mask);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (keep) out_idx[(size_t)n * T + off + before] = sym;
+    __syncthreads();
+    if (tid == 255) last_sym = sym;
+    if (tid == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (tid == 0) out_len[n] = base;
+}
+
+}  // namespace
+
+extern "C" size_t ms_ctc_loss_workspace_bytes(int T, int N, int V, int S_max) {
+  (void)V; (void)S_max;
+  if (T <= 0 || N <= 0) return 0;
+  return ms::align_up((size_t)T * N * sizeof(float), 256);
+}
+
+extern "C" int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, const int32_t* targets,
+                                   const int32_t* tgt_offsets, const int32_t* tgt_lens, float* nll, float* reduced,
+                                   int T, int N, int V, int S_max, int blank, int reduction, int zero_infinity,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  MS_REQUIRE(logits && in_lens && targets && tgt_offsets && tgt_lens && nll && workspace, "null pointer");
+  MS_REQUIRE(T > 0 && N > 0 && V > 0 && S_max >= 1, "bad shape");
+  MS_REQUIRE(blank >= 0 && blank < V, "blank out of range");
+  MS_REQUIRE(reduction >= 0 && reduction <= 2, "reduction must be 0 (none), 1 (mean) or 2 (sum)");
+  MS_REQUIRE(reduction == 0 || reduced, "reduced output required");
+  if (workspace_bytes < ms_ctc_loss_workspace_bytes(T, N, V, S_max)) {
+    ms::set_error("ms_ctc_loss_forward: workspace too small");
+    return MS_ERR_WORKSPACE;
+  }
+  const size_t lds = (size_t)3 * S_max * sizeof(float);
+  MS_REQUIRE(lds <= 160 * 1024, "target too long for the LDS-resident alpha rows");
+  static bool attr_set = false;
+  if (!attr_set) {
+    MS_HIP(hipFuncSetAttribute((const void*)ctc_alpha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ctc_alpha_kernel, dim3(N), dim3(CTC_THREADS), lds, (hipStream_t)stream, logits, in_lens, targets,
+                     tgt_offsets, tgt_lens, nll, (float*)workspace, T, N, V, S_max, blank);
+  MS_LAUNCH_CHECK();
+  if (reduction != 0 || zero_infinity) {
+    hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nll, tgt_lens, reduced, N,
+                       reduction, zero_infinity);
+    MS_LAUNCH_CHECK();
+  }
+  return MS_OK;
+}
+
+extern "C" int ms_ctc_greedy_decode(const float* x, const int32_t* lens, int32_t* out_idx, int32_t* out_len, int T,
+                                    int N, int V, int blank, void* stream) {
+  MS_REQUIRE(x && lens && out_idx && out_len, "null pointer");
+  MS_REQUIRE(T > 0 && N > 0 && V > 0, "bad shape");
+  hipLaunchKernelGGL(ctc_greedy_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, lens, out_idx, out_len, T, N, V,
+                     blank);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}

@@ -1,0 +1,72 @@
+// DS2 lookahead convolution (model/lookahead.py:65-69): right-pad context-1 frames, then a
+// depthwise conv over the future `ctx` frames:  y[n,f,t] = sum_k w[f,k] * x[n,f,t+k].
+// HBM/L2-bound sliding dot product, no MFMA.  Element strides on x and y let the caller
+// hand over the RNN output in its native [T,N,F] layout (deep_speech_2.py:119-121,161-164)
+// and receive [N,T,F] for the fully-connected stack without materialising a permute.
+//
+// Two access patterns: time-contiguous (xs_t == 1: one workgroup stages a row segment of a
+// single (n,f) in LDS) and feature-contiguous (xs_f == 1: lanes walk f, every tap is a
+// coalesced row read that the L2 serves on re-use).
+#include "common.h"
+
+namespace {
+
+constexpr int LA_TB = 256;  // output frames per workgroup (time-contiguous variant)
+
+__global__ __launch_bounds__(256) void lookahead_tcontig_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                float* __restrict__ y, int F, int T, int ctx, long xs_n,
+                                                                long xs_f, long ys_n, long ys_f, long ys_t, int act,
+                                                                float lo, float hi) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                 // [LA_TB + ctx - 1]
+  float* ws = smem + LA_TB + ctx;   // [ctx]
+  const int f = blockIdx.y, n = blockIdx.z, t0 = blockIdx.x * LA_TB, tid = threadIdx.x;
+  const float* xr = x + n * xs_n + f * xs_f;
+  for (int i = tid; i < LA_TB + ctx - 1; i += 256) xs[i] = (t0 + i < T) ? xr[t0 + i] : 0.f;
+  for (int i = tid; i < ctx; i += 256) ws[i] = w[(size_t)f * ctx + i];
+  __syncthreads();
+  const int t = t0 + tid;
+  if (t < T) {
+    float acc = 0.f;
+    for (int k = 0; k < ctx; ++k) acc += ws[k] * xs[tid + k];
+    if (act == MS_ACT_CLAMP) acc = fminf(fmaxf(acc, lo), hi);
+    y[n * ys_n + f * ys_f + t * ys_t] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void lookahead_strided_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                float* __restrict__ y, int F, int T, int ctx, long xs_n,
+                                                                long xs_f, long xs_t, long ys_n, long ys_f, long ys_t,
+                                                                int act, float lo, float hi) {
+  const int f = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y, n = blockIdx.z;
+  if (f >= F) return;
+  const float* xr = x + n * xs_n + f * xs_f;
+  const float* wr = w + (size_t)f * ctx;
+  float acc = 0.f;
+  const int kmax = min(ctx, T - t);
+  for (int k = 0; k < kmax; ++k) acc += wr[k] * xr[(long)(t + k) * xs_t];
+  if (act == MS_ACT_CLAMP) acc = fminf(fmaxf(acc, lo), hi);
+  y[n * ys_n + f * ys_f + t * ys_t] = acc;
+}
+
+}  // namespace
+
+extern "C" int ms_lookahead_forward(const float* x, const float* w, float* y, int N, int F, int T, int ctx, long xs_n,
+                                    long xs_f, long xs_t, long ys_n, long ys_f, long ys_t, int act, float act_lo,
+                                    float act_hi, void* stream) {
+  MS_REQUIRE(x && w && y, "null pointer");
+  MS_REQUIRE(N > 0 && F > 0 && T > 0 && ctx > 0, "bad shape");
+  MS_REQUIRE(act == MS_ACT_NONE || act == MS_ACT_CLAMP, "bad act");
+  MS_REQUIRE(N <= 65535 && F <= 65535 && T <= 65535, "dimension exceeds grid limits");
+  if (xs_t == 1) {
+    const size_t lds = (size_t)(LA_TB + 2 * ctx) * sizeof(float);
+    MS_REQUIRE(lds <= 64 * 1024, "context too large");
+    hipLaunchKernelGGL(lookahead_tcontig_kernel, dim3(ms::cdiv(T, LA_TB), F, N), dim3(256), lds, (hipStream_t)stream, x,
+                       w, y, F, T, ctx, xs_n, xs_f, ys_n, ys_f, ys_t, act, act_lo, act_hi);
+  } else {
+    hipLaunchKernelGGL(lookahead_strided_kernel, dim3(ms::cdiv(F, 256), T, N), dim3(256), 0, (hipStream_t)stream, x, w, y,
+                       F, T, ctx, xs_n, xs_f, xs_t, ys_n, ys_f, ys_t, act, act_lo, act_hi);
+  }
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}

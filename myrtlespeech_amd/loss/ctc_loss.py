@@ -1,0 +1,77 @@
+"""CTC loss: mirror of myrtlespeech/loss/ctc_loss.py.
+
+``CTCLoss(blank, reduction, zero_infinity, dim)`` applied to
+``((x[T,N,V], x_lens), (y, y_lens))`` = log-softmax over symbols followed by the
+log-space CTC forward recursion (``ms_ctc_loss_forward``, one workgroup per
+utterance).  ``log_softmax`` / ``ctc_loss`` attributes exist for repr/API parity
+with the reference; they hold configuration only.  Forward (inference / scoring)
+only: the returned tensor carries no autograd graph.
+"""
+from typing import Tuple
+
+import torch
+
+from myrtlespeech_amd import _lib
+
+_REDUCTION = {"none": 0, "mean": 1, "sum": 2}
+
+
+class CTCLoss(torch.nn.Module):
+    """ctc_loss.py:7-101."""
+
+    def __init__(self, blank: int = 0, reduction: str = "mean", zero_infinity: bool = False, dim: int = -1):
+        super().__init__()
+        if reduction not in _REDUCTION:
+            raise ValueError(f"{reduction} is not a valid value for reduction")
+        self.log_softmax = torch.nn.LogSoftmax(dim=dim)
+        self.ctc_loss = torch.nn.CTCLoss(blank=blank, reduction=reduction, zero_infinity=zero_infinity)
+        self.use_cuda = torch.cuda.is_available()
+        self._workspace = _lib.Workspace()
+
+    def forward(self, inputs: Tuple[torch.Tensor, torch.Tensor], targets: Tuple[torch.Tensor, torch.Tensor]
+                ) -> torch.Tensor:
+        _lib.require_gpu()
+        lib = _lib.load()
+        x, x_lens = inputs
+        y, y_lens = targets
+        if x.dim() != 3:
+            raise RuntimeError("inputs must be [max_seq_len, batch, features]")
+        dim = self.log_softmax.dim
+        if dim not in (-1, 2):
+            raise NotImplementedError("log-softmax is fused over the symbol axis (dim=-1) only")
+        x = _lib.f32c(x)
+        t, n, v = x.shape
+        blank = self.ctc_loss.blank
+        if not 0 <= blank < v:
+            raise RuntimeError("blank must be in label range")
+        xl = x_lens.detach().to("cpu", torch.int64)
+        yl = y_lens.detach().to("cpu", torch.int64)
+        if xl.numel() != n or yl.numel() != n:
+            raise RuntimeError("input_lengths and target_lengths must be of size batch_size")
+        if xl.numel() and (int(xl.max()) > t or int(xl.min()) < 0):
+            raise RuntimeError("input lengths must be in [0, max_seq_len]")
+        if y.dim() == 2:  # padded [N, S]
+            s_pad = y.shape[1]
+            if yl.numel() and int(yl.max()) > s_pad:
+                raise RuntimeError("target length exceeds the padded target width")
+            offsets = torch.arange(n, dtype=torch.int64) * s_pad
+        elif y.dim() == 1:  # concatenated
+            offsets = torch.cumsum(yl, 0) - yl
+            if int(yl.sum()) > y.numel():
+                raise RuntimeError("sum(target_lengths) exceeds the number of targets")
+        else:
+            raise RuntimeError("targets must be [batch, max_target_len] or 1-D")
+        s_max = 2 * int(yl.max() if yl.numel() else 0) + 1
+        y_dev = y.detach().to(device="cuda", dtype=torch.int32).contiguous().reshape(-1)
+        if y_dev.numel() == 0:
+            y_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+        red = _REDUCTION[self.ctc_loss.reduction]
+        nll = torch.empty(n, dtype=torch.float32, device="cuda")
+        reduced = torch.empty(1, dtype=torch.float32, device="cuda")
+        ws = self._workspace.get(lib.ms_ctc_loss_workspace_bytes(t, n, v, s_max))
+        _lib.check(lib.ms_ctc_loss_forward(_lib.ptr(x), _lib.ptr(_lib.lens_i32(xl)), _lib.ptr(y_dev),
+                                           _lib.ptr(_lib.lens_i32(offsets)), _lib.ptr(_lib.lens_i32(yl)), _lib.ptr(nll),
+                                           _lib.ptr(reduced), t, n, v, s_max, blank, red,
+                                           int(bool(self.ctc_loss.zero_infinity)), _lib.ptr(ws), ws.numel(),
+                                           _lib.stream_ptr()), "ms_ctc_loss_forward")
+        return nll if red == 0 else reduced[0]

@@ -1,0 +1,104 @@
+"""Fully connected stack: mirror of myrtlespeech/model/fully_connected.py.
+
+``self.fully_connected`` is built exactly like the reference (``torch.nn.Linear``
+[+ activation] [+ Dropout] per hidden layer, then the output ``Linear``), so the
+state_dict keys (``fully_connected.{0,2,..}.weight``) and repr match; the modules
+are parameter containers -- the forward pass runs each Linear (+ its clamp) as one
+MFMA GEMM with a fused epilogue (``ms_linear_forward``).
+"""
+from typing import List, Optional, Tuple, Union
+
+import torch
+
+from myrtlespeech_amd import _lib
+from myrtlespeech_amd.model.utils import activation_clamp
+
+
+def linear_stack_plan(module: Union[torch.nn.Linear, torch.nn.Sequential], training: bool
+                      ) -> List[Tuple[torch.nn.Linear, Optional[Tuple[float, float]]]]:
+    """[(linear, fused clamp | None), ...] for a Linear/activation/Dropout chain."""
+    mods = [module] if isinstance(module, torch.nn.Linear) else list(module)
+    plan: List[Tuple[torch.nn.Linear, Optional[Tuple[float, float]]]] = []
+    for m in mods:
+        if isinstance(m, torch.nn.Linear):
+            plan.append((m, None))
+        elif isinstance(m, torch.nn.Dropout):
+            if training and m.p > 0:
+                raise RuntimeError("training-mode Dropout is outside the inference hot path; call .eval()")
+        else:
+            clamp = activation_clamp(m)
+            if clamp is not None:
+                if not plan or plan[-1][1] is not None:
+                    raise NotImplementedError("activation without a preceding Linear")
+                plan[-1] = (plan[-1][0], clamp)
+    return plan
+
+
+def run_linear_stack(x2d: torch.Tensor, plan) -> torch.Tensor:
+    """x2d [M, K] float32 cuda contiguous."""
+    lib = _lib.load()
+    h = x2d
+    for lin, clamp in plan:
+        m, k = h.shape
+        n = lin.out_features
+        if k != lin.in_features:
+            raise RuntimeError(f"size mismatch: input has {k} features, Linear expects {lin.in_features}")
+        y = torch.empty((m, n), dtype=torch.float32, device="cuda")
+        a, lo, hi = (_lib.ACT_NONE, 0.0, 0.0) if clamp is None else (_lib.ACT_CLAMP, clamp[0], clamp[1])
+        w = _lib.f32c(lin.weight.detach())
+        b = None if lin.bias is None else _lib.f32c(lin.bias.detach())
+        _lib.check(lib.ms_linear_forward(_lib.ptr(h), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), m, k, n, a, lo, hi,
+                                         _lib.stream_ptr()), "ms_linear_forward")
+        h = y
+    return h
+
+
+class FullyConnected(torch.nn.Module):
+    """A fully connected neural network (fully_connected.py:9-166)."""
+
+    def __init__(self, in_features: int, out_features: int, num_hidden_layers: int, hidden_size: Optional[int],
+                 hidden_activation_fn: Optional[torch.nn.Module], dropout: Optional[float] = None):
+        if num_hidden_layers < 0:
+            raise ValueError("num_hidden_layers must be >= 0")
+        if dropout and (dropout < 0 or dropout > 1):
+            raise ValueError(f"dropout must be >= 0. and <= 1. but dropout={dropout}")
+        if num_hidden_layers == 0:
+            if hidden_size is not None:
+                raise ValueError("num_hidden_layers==0 but hidden_size is not None")
+            if hidden_activation_fn is not None:
+                raise ValueError("num_hidden_layers==0 but hidden_activation_fn is not None")
+            if dropout is not None:
+                raise ValueError("num_hidden_layers==0 so dropout must be None.")
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.dropout = dropout
+        self.fully_connected = self._build_fully_connected(in_features, out_features, num_hidden_layers, hidden_size,
+                                                           hidden_activation_fn, dropout)
+        self.use_cuda = torch.cuda.is_available()
+        if self.use_cuda:
+            self.fully_connected = self.fully_connected.cuda()
+
+    def _build_fully_connected(self, in_features, out_features, num_hidden_layers, hidden_size, hidden_activation_fn,
+                               dropout) -> Union[torch.nn.Linear, torch.nn.Sequential]:
+        hidden = []
+        width = in_features
+        for _ in range(num_hidden_layers):
+            hidden.append(torch.nn.Linear(width, hidden_size))
+            if hidden_activation_fn:
+                hidden.append(hidden_activation_fn)
+            if dropout:
+                hidden.append(torch.nn.Dropout(p=dropout))
+            width = hidden_size
+        last = torch.nn.Linear(width, out_features)
+        return torch.nn.Sequential(*hidden, last) if hidden else last
+
+    def forward(self, x: Tuple[torch.Tensor, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """``[batch, max_seq_len, in_features] -> [batch, max_seq_len, out_features]``;
+        lengths pass through (moved to the device like fully_connected.py:160-162)."""
+        _lib.require_gpu()
+        x_inp, x_len = x
+        h = _lib.f32c(x_inp)
+        lead = h.shape[:-1]
+        y = run_linear_stack(h.reshape(-1, h.shape[-1]), linear_stack_plan(self.fully_connected, self.training))
+        return y.reshape(*lead, y.shape[-1]), x_len.cuda()

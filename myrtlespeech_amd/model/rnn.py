@@ -1,0 +1,177 @@
+"""Recurrent layers: mirror of myrtlespeech/model/rnn.py.
+
+``RNN`` keeps the reference's constructor, ``(data, lengths)`` convention, hidden
+state layout ``[num_layers * num_directions, batch, hidden]`` and state_dict keys
+(``rnn.weight_ih_l{k}[_reverse]`` ...).  ``self.rnn`` is a ``torch.nn.LSTM`` /
+``GRU`` / ``RNN`` used purely as the parameter container (identical
+initialisation and key names); the forward pass is ``ms_rnn_layer_forward``
+(``csrc/rnn.hip``): an MFMA input-projection GEMM plus a persistent recurrent
+kernel, with ``pack_padded_sequence`` semantics folded into a per-frame predicate.
+"""
+import ctypes
+from enum import IntEnum
+from typing import List, Optional, Tuple, TypeVar
+
+import torch
+
+from myrtlespeech_amd import _lib
+
+
+class RNNType(IntEnum):
+    """rnn.py:9-12."""
+
+    LSTM = 0
+    GRU = 1
+    BASIC_RNN = 2
+
+
+RNNState = TypeVar("RNNState", torch.Tensor, Tuple[torch.Tensor, torch.Tensor])
+RNNData = TypeVar("RNNData", bound=torch.Tensor)
+Lengths = TypeVar("Lengths", bound=torch.Tensor)
+
+_CELL = {RNNType.LSTM: _lib.CELL_LSTM, RNNType.GRU: _lib.CELL_GRU, RNNType.BASIC_RNN: _lib.CELL_RNN_TANH}
+
+
+class PackedLayer:
+    """Kernel-layout copy of one layer's weights, rebuilt when a parameter changes."""
+
+    def __init__(self):
+        self.key = None
+        self.buf = None
+
+    def get(self, cell: int, in_size: int, hidden: int, params: List[Tuple[Optional[torch.Tensor], ...]]):
+        """params: per direction (w_ih, w_hh, b_ih | None, b_hh | None)."""
+        key = tuple((p.data_ptr(), p._version) if p is not None else None for d in params for p in d)
+        if key != self.key:
+            lib = _lib.load()
+            ndir = len(params)
+            nbytes = lib.ms_rnn_packed_bytes(cell, in_size, hidden, ndir)
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            keep = [[None if p is None else _lib.f32c(p.detach()) for p in d] for d in params]
+            arr = ctypes.c_void_p * ndir
+
+            def col(i):
+                if keep[0][i] is None:
+                    return ctypes.cast(None, ctypes.POINTER(ctypes.c_void_p))
+                return ctypes.cast(arr(*[k[i].data_ptr() for k in keep]), ctypes.POINTER(ctypes.c_void_p))
+
+            _lib.check(lib.ms_rnn_pack(cell, in_size, hidden, ndir, col(0), col(1), col(2), col(3), _lib.ptr(self.buf),
+                                       _lib.stream_ptr()), "ms_rnn_pack")
+            self.key = key
+        return self.buf
+
+
+def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max_len: int,
+               layer_params: List[List[Tuple[Optional[torch.Tensor], ...]]], packed: List[PackedLayer], hidden: int,
+               h0: Optional[torch.Tensor], c0: Optional[torch.Tensor], workspace: _lib.Workspace, check: bool = True):
+    """x [T,N,In] float32 cuda contiguous -> (out [T,N,D*H], hn, cn|None)."""
+    lib = _lib.load()
+    t, n, _ = x.shape
+    ndir = len(layer_params[0])
+    nl = len(layer_params)
+    lstm_like = cell in (_lib.CELL_LSTM, _lib.CELL_HARD_LSTM)
+    hn = torch.empty((nl * ndir, n, hidden), dtype=torch.float32, device="cuda")
+    cn = torch.empty_like(hn) if lstm_like else None
+    inp = x
+    for layer in range(nl):
+        in_size = inp.shape[2]
+        pk = packed[layer].get(cell, in_size, hidden, layer_params[layer])
+        ws = workspace.get(lib.ms_rnn_workspace_bytes(cell, t, n, in_size, hidden, ndir))
+        out = torch.empty((t, n, ndir * hidden), dtype=torch.float32, device="cuda")
+        sl = slice(layer * ndir, (layer + 1) * ndir)
+        h0l = None if h0 is None else h0[sl].contiguous()
+        c0l = None if (c0 is None or not lstm_like) else c0[sl].contiguous()
+        hnl = hn[sl]
+        cnl = cn[sl] if lstm_like else None
+        _lib.check(lib.ms_rnn_layer_forward(cell, _lib.ptr(pk), _lib.ptr(inp), _lib.ptr(lens_dev), max_len,
+                                            _lib.ptr(h0l), _lib.ptr(c0l), _lib.ptr(out), _lib.ptr(hnl), _lib.ptr(cnl), t,
+                                            n, in_size, hidden, ndir, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                   "ms_rnn_layer_forward")
+        if check:
+            _lib.check(lib.ms_rnn_status(_lib.ptr(ws), _lib.stream_ptr()), "ms_rnn_layer_forward")
+        inp = out
+    return inp, hn, cn
+
+
+class RNN(torch.nn.Module):
+    """A recurrent neural network (rnn.py:41-205); see the module docstring."""
+
+    def __init__(self, rnn_type: RNNType, input_size: int, hidden_size: int, num_layers: int = 1, bias: bool = True,
+                 dropout: float = 0.0, bidirectional: bool = False, forget_gate_bias: Optional[float] = None,
+                 batch_first: bool = False):
+        super().__init__()
+        if rnn_type == RNNType.LSTM:
+            rnn_cls = torch.nn.LSTM
+        elif rnn_type == RNNType.GRU:
+            rnn_cls = torch.nn.GRU
+        elif rnn_type == RNNType.BASIC_RNN:
+            rnn_cls = torch.nn.RNN
+        else:
+            raise ValueError(f"unknown rnn_type {rnn_type}")
+        self.batch_first = batch_first
+        self.bidirectional = bidirectional
+        self.rnn_type = rnn_type
+        # parameter container only: never called
+        self.rnn = rnn_cls(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers, bias=bias,
+                           batch_first=batch_first, dropout=dropout, bidirectional=bidirectional)
+        if rnn_type == RNNType.LSTM and bias and forget_gate_bias is not None:
+            # forward-direction biases only, like rnn.py:122-127
+            for layer in range(num_layers):
+                getattr(self.rnn, f"bias_ih_l{layer}").data[hidden_size:2 * hidden_size] = forget_gate_bias
+                getattr(self.rnn, f"bias_hh_l{layer}").data[hidden_size:2 * hidden_size] = 0.0
+        self._packed = [PackedLayer() for _ in range(num_layers)]
+        self._workspace = _lib.Workspace()
+        self.check_status = True
+        self.use_cuda = torch.cuda.is_available()
+        if self.use_cuda:
+            self.rnn = self.rnn.cuda()
+
+    def _layer_params(self):
+        r = self.rnn
+        out = []
+        for layer in range(r.num_layers):
+            dirs = []
+            for sfx in ([""] + (["_reverse"] if self.bidirectional else [])):
+                g = lambda n: getattr(r, f"{n}_l{layer}{sfx}")  # noqa: E731
+                dirs.append((g("weight_ih"), g("weight_hh"), g("bias_ih") if r.bias else None,
+                             g("bias_hh") if r.bias else None))
+            out.append(dirs)
+        return out
+
+    def forward(self, x: Tuple[RNNData, Lengths], hx: Optional[RNNState] = None
+                ) -> Tuple[Tuple[RNNData, Lengths], RNNState]:
+        """``((out, lengths), hid)`` exactly as rnn.py:133-185: rows past each
+        sequence's length are 0, ``hid`` holds each sequence's last valid state."""
+        _lib.require_gpu()
+        inp, lengths = x
+        if self.training and self.rnn.dropout > 0 and self.rnn.num_layers > 1:
+            raise RuntimeError("inter-layer dropout in training mode is outside the inference hot path")
+        lens_cpu = lengths.detach().to("cpu", torch.int64)
+        if lens_cpu.numel() > 1 and bool((lens_cpu[:-1] < lens_cpu[1:]).any()):
+            # pack_padded_sequence(enforce_sorted=True), rnn.py:170-175
+            raise RuntimeError("`lengths` array must be sorted in decreasing order when `enforce_sorted` is True")
+        max_len = int(lens_cpu[0]) if lens_cpu.numel() else 0
+        data = _lib.f32c(inp.transpose(0, 1) if self.batch_first else inp)  # time-major [T, N, In]
+        t, n, _ = data.shape
+        if lens_cpu.numel() != n:
+            raise RuntimeError(f"expected {n} lengths, got {lens_cpu.numel()}")
+        if max_len < 1 or max_len > t or int(lens_cpu.min()) < 1:
+            raise RuntimeError("lengths must be in [1, seq_len]")
+        h0 = c0 = None
+        if hx is not None:
+            if self.rnn_type == RNNType.LSTM:
+                h0, c0 = _lib.f32c(hx[0]), _lib.f32c(hx[1])
+            else:
+                h0 = _lib.f32c(hx)
+        out, hn, cn = run_layers(_CELL[self.rnn_type], data, _lib.lens_i32(lens_cpu), max_len, self._layer_params(),
+                                 self._packed, self.rnn.hidden_size, h0, c0, self._workspace, self.check_status)
+        if self.batch_first:
+            out = out.transpose(0, 1)
+        hid = (hn, cn) if self.rnn_type == RNNType.LSTM else hn
+        return (out, lengths), hid
+
+    def _init_hidden(self, batch: int, dtype: torch.dtype) -> RNNState:
+        """rnn.py:187-205 (zeros; one tensor object shared by h0 and c0)."""
+        zeros = torch.zeros(self.rnn.num_layers * (2 if self.bidirectional else 1), batch, self.rnn.hidden_size,
+                            dtype=dtype)
+        return (zeros, zeros) if self.rnn_type == RNNType.LSTM else zeros

@@ -1,0 +1,321 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors generated
+from the reference and against the CPU oracle.  Needs a real MI355X: -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ds_oracle as O
+from util import Golden, golden_names, unragged
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def load_sd(module, sd):
+    module.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    return module.eval()
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------- linear
+@pytest.mark.parametrize("M,K,N", [(1, 1, 1), (7, 5, 3), (33, 17, 29), (130, 64, 129), (257, 100, 64), (300, 640, 200),
+                                   (64, 36, 32)])
+@pytest.mark.parametrize("act", [None, (0.0, 20.0)])
+def test_linear(lib, M, K, N, act):
+    from myrtlespeech_amd import _lib
+    rng = np.random.default_rng(M * 1000 + K * 10 + N)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    w = rng.normal(size=(N, K)).astype(np.float32)
+    b = rng.normal(size=(N,)).astype(np.float32)
+    xd, wd, bd = T(x).cuda(), T(w).cuda(), T(b).cuda()
+    y = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    a, lo, hi = (0, 0.0, 0.0) if act is None else (1, act[0], act[1])
+    _lib.check(lib.ms_linear_forward(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), M, K, N, a, lo, hi,
+                                     _lib.stream_ptr()), "linear")
+    want = x.astype(np.float64) @ w.T.astype(np.float64) + b
+    if act is not None:
+        want = np.clip(want, *act)
+    np.testing.assert_allclose(cpu(y), want, rtol=1e-4, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- rnn
+@pytest.mark.parametrize("name", golden_names("rnn_"))
+def test_rnn_golden(name):
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    g = Golden(name)
+    c = g.cfg
+    m = RNN(RNNType(c["rnn_type"]), c["input_size"], c["hidden_size"], num_layers=c["num_layers"],
+            bidirectional=c["bidirectional"], forget_gate_bias=c["forget_gate_bias"], batch_first=c["batch_first"])
+    load_sd(m, g.sd())
+    hx = None
+    if g.has("in/h0"):
+        hx = (T(g["in/h0"]), T(g["in/c0"])) if c["rnn_type"] == 0 else T(g["in/h0"])
+    (out, lens), hid = m((T(g["in/x"]), T(g["in/lens"])), hx)
+    np.testing.assert_allclose(cpu(out), g["out/y"], **TOL)
+    np.testing.assert_array_equal(cpu(lens), g["out/lens"])
+    if c["rnn_type"] == 0:
+        np.testing.assert_allclose(cpu(hid[0]), g["out/hn"], **TOL)
+        np.testing.assert_allclose(cpu(hid[1]), g["out/cn"], **TOL)
+    else:
+        np.testing.assert_allclose(cpu(hid), g["out/hn"], **TOL)
+
+
+def test_rnn_rejects_unsorted():
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    m = RNN(RNNType.LSTM, 4, 8)
+    with pytest.raises(RuntimeError):
+        m((torch.randn(5, 2, 4), torch.tensor([3, 5])))
+
+
+@pytest.mark.parametrize("H,N,T_,bidir", [(256, 32, 9, True), (512, 7, 5, True), (1024, 32, 6, True), (256, 64, 4, False),
+                                          (96, 40, 7, True)])
+def test_lstm_persistent_vs_oracle(H, N, T_, bidir):
+    """Shapes that take the persistent kernel (incl. its pipelined H%256==0 loop, two batch
+    tiles and the config-2 width) against the numpy oracle, ragged lengths, random hx."""
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    torch.manual_seed(H + N)
+    In = 48
+    m = RNN(RNNType.LSTM, In, H, num_layers=2, bidirectional=bidir, forget_gate_bias=1.0).eval()
+    rng = np.random.default_rng(H * 7 + N)
+    lens = np.sort(rng.integers(1, T_ + 1, size=N))[::-1].copy()
+    lens[0] = T_
+    x = rng.normal(size=(T_, N, In)).astype(np.float32)
+    D = 2 if bidir else 1
+    h0 = (rng.normal(size=(2 * D, N, H)) * 0.3).astype(np.float32)
+    c0 = (rng.normal(size=(2 * D, N, H)) * 0.3).astype(np.float32)
+    (out, _), (hn, cn) = m((T(x), T(lens)), (T(h0), T(c0)))
+    sd = {k[len("rnn."):]: cpu(v) for k, v in m.state_dict().items()}
+    want, (whn, wcn) = O.rnn_forward(O.LSTM, x, lens, sd, H, 2, bidir, (h0, c0))
+    np.testing.assert_allclose(cpu(out), want, **TOL)
+    np.testing.assert_allclose(cpu(hn), whn, **TOL)
+    np.testing.assert_allclose(cpu(cn), wcn, **TOL)
+
+
+@pytest.mark.parametrize("name", golden_names("hard_lstm_"))
+def test_hard_lstm_golden(name):
+    from myrtlespeech_amd.model.hard_lstm import HardLSTM
+    g = Golden(name)
+    c = g.cfg
+    m = HardLSTM(c["input_size"], c["hidden_size"], num_layers=c["num_layers"], bidirectional=c["bidirectional"],
+                 batch_first=c["batch_first"], forget_gate_bias=c["forget_gate_bias"])
+    load_sd(m, g.sd())
+    (out, _), (hn, cn) = m((T(g["in/x"]), T(g["in/lens"])), (T(g["in/h0"]), T(g["in/c0"])))
+    np.testing.assert_allclose(cpu(out), g["out/y"], **TOL)
+    np.testing.assert_allclose(cpu(hn), g["out/hn"], **TOL)
+    np.testing.assert_allclose(cpu(cn), g["out/cn"], **TOL)
+
+
+def test_hard_lstm_persistent_vs_oracle():
+    from myrtlespeech_amd.model.hard_lstm import HardLSTM
+    torch.manual_seed(5)
+    m = HardLSTM(20, 64, num_layers=1, bidirectional=True, forget_gate_bias=1.0).eval()
+    rng = np.random.default_rng(5)
+    x = (rng.normal(size=(6, 9, 20)) * 2).astype(np.float32)
+    (out, _), (hn, cn) = m((T(x), torch.tensor([6] * 9)))
+    sd = {k[len("rnn."):]: cpu(v) for k, v in m.state_dict().items()}
+    want, (whn, wcn) = O.hard_lstm_forward(x, sd, 64, 1, True)
+    np.testing.assert_allclose(cpu(out), want, **TOL)
+    np.testing.assert_allclose(cpu(cn), wcn, **TOL)
+
+
+# ----------------------------------------------------------------------------- conv
+@pytest.mark.parametrize("name", golden_names("conv2d_"))
+def test_conv2d_golden(name):
+    from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+    g = Golden(name)
+    c = g.cfg
+    m = MaskConv2d(c["in_channels"], c["out_channels"], c["kernel_size"], c["stride"],
+                   PaddingMode.SAME if c["same"] else PaddingMode.NONE)
+    load_sd(m, g.sd())
+    x = T(g["in/x"]).cuda()
+    y, lens = m((x, T(g["in/lens"])))
+    np.testing.assert_allclose(cpu(y), g["out/y"], **TOL)
+    np.testing.assert_array_equal(cpu(lens), g["out/lens"])
+    assert cpu(lens).dtype == g["out/lens"].dtype
+    np.testing.assert_array_equal(cpu(x), g["out/x_after"])  # input masked in place like the reference
+
+
+@pytest.mark.parametrize("name", golden_names("conv1d_"))
+def test_conv1d_golden(name):
+    from myrtlespeech_amd.model.cnn import MaskConv1d, PaddingMode
+    g = Golden(name)
+    c = g.cfg
+    m = MaskConv1d(c["in_channels"], c["out_channels"], c["kernel_size"], c["stride"],
+                   PaddingMode.SAME if c["same"] else PaddingMode.NONE)
+    load_sd(m, g.sd())
+    y, lens = m((T(g["in/x"]), T(g["in/lens"])))
+    np.testing.assert_allclose(cpu(y), g["out/y"], **TOL)
+    np.testing.assert_array_equal(cpu(lens), g["out/lens"])
+
+
+def test_conv2d_groups_dilation_vs_oracle():
+    from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+    torch.manual_seed(3)
+    m = MaskConv2d(4, 6, [3, 4], [1, 2], PaddingMode.SAME, groups=2).eval()
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(2, 4, 7, 21)).astype(np.float32)
+    lens = np.array([21, 13])
+    y, nl = m((T(x), T(lens)))
+    want, wl = O.mask_conv2d(x, lens, cpu(m.weight), cpu(m.bias), (1, 2), True, (1, 1), groups=2)
+    np.testing.assert_allclose(cpu(y), want, **TOL)
+    np.testing.assert_array_equal(cpu(nl), wl)
+
+
+# ----------------------------------------------------------------------------- fc / lookahead
+@pytest.mark.parametrize("name", golden_names("fc_"))
+def test_fc_golden(name):
+    from myrtlespeech_amd.model.fully_connected import FullyConnected
+    g = Golden(name)
+    c = g.cfg
+    act = None
+    if c["act"] == "relu":
+        act = torch.nn.ReLU()
+    elif c["act"] is not None:
+        act = torch.nn.Hardtanh(*c["act"])
+    m = FullyConnected(c["in_features"], c["out_features"], c["num_hidden_layers"], c["hidden_size"], act)
+    load_sd(m, g.sd())
+    y, _ = m((T(g["in/x"]), T(g["in/lens"])))
+    np.testing.assert_allclose(cpu(y), g["out/y"], **TOL)
+
+
+@pytest.mark.parametrize("name", golden_names("lookahead_"))
+def test_lookahead_golden(name):
+    from myrtlespeech_amd.model.lookahead import Lookahead
+    g = Golden(name)
+    m = Lookahead(g.cfg["in_features"], g.cfg["context"])
+    load_sd(m, g.sd())
+    y, _ = m((T(g["in/x"]), T(g["in/lens"])))
+    np.testing.assert_allclose(cpu(y), g["out/y"], **TOL)
+    # strided (feature-contiguous) variant: hand over a permuted view of a [T,N,F] tensor
+    x_tnf = T(g["in/x"]).permute(2, 0, 1).contiguous().cuda()
+    y2, _ = m((x_tnf.permute(1, 2, 0), T(g["in/lens"])))
+    np.testing.assert_allclose(cpu(y2), g["out/y"], **TOL)
+
+
+# ----------------------------------------------------------------------------- DS2 / DS1
+def build_ds2(cfg):
+    from myrtlespeech_amd.model.cnn import Conv1dTo2d, Conv2dTo1d, MaskConv1d, MaskConv2d, PaddingMode
+    from myrtlespeech_amd.model.deep_speech_2 import DeepSpeech2
+    from myrtlespeech_amd.model.fully_connected import FullyConnected
+    from myrtlespeech_amd.model.lookahead import Lookahead
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    from myrtlespeech_amd.model.seq_len_wrapper import SeqLenWrapper
+
+    def act(a):
+        return torch.nn.Identity() if a is None else torch.nn.Hardtanh(*a)
+
+    layers, dims = [], 4
+    for c in cfg["convs"]:
+        pm = PaddingMode.SAME if c["same"] else PaddingMode.NONE
+        if c["kind"] == "conv2d":
+            if dims == 3:
+                layers.append(Conv1dTo2d())
+                dims = 4
+            layers.append(MaskConv2d(c["in_channels"], c["out_channels"], c["kernel"], c["stride"], pm))
+        else:
+            if dims == 4:
+                layers.append(Conv2dTo1d())
+                dims = 3
+            layers.append(MaskConv1d(c["in_channels"], c["out_channels"], c["kernel"], c["stride"], pm))
+        layers.append(SeqLenWrapper(act(c["act"]), torch.nn.Identity()))
+    if dims == 3:
+        layers.append(Conv1dTo2d())
+    r = cfg["rnn"]
+    rnn = RNN(RNNType(r["kind"]), r["input"], r["hidden"], num_layers=r["layers"], bidirectional=r["bidirectional"],
+              forget_gate_bias=r["forget_gate_bias"])
+    la = None
+    if cfg["lookahead"] is not None:
+        la = torch.nn.Sequential(Lookahead(r["hidden"] * (2 if r["bidirectional"] else 1), cfg["lookahead"]["context"]),
+                                 SeqLenWrapper(act(cfg["lookahead"]["act"]), torch.nn.Identity()))
+    f = cfg["fc"]
+    fc = FullyConnected(f["in_features"], f["out_features"], f["n_hidden"], f["hidden"],
+                        None if f["act"] is None else torch.nn.Hardtanh(*f["act"]))
+    return DeepSpeech2(torch.nn.Sequential(*layers), rnn, la, fc)
+
+
+@pytest.mark.parametrize("name", golden_names("ds2_tiny"))
+def test_ds2_tiny_golden(name):
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    g = Golden(name)
+    m = load_sd(build_ds2(g.cfg), g.sd())
+    hx = T(g["in/h0"]) if g.has("in/h0") else None
+    (y, lens), hid = m((T(g["in/x"]), T(g["in/lens"])), hx)
+    np.testing.assert_allclose(cpu(y), g["out/y"], **TOL)
+    np.testing.assert_array_equal(cpu(lens), g["out/lens"])
+    hn = hid[0] if isinstance(hid, tuple) else hid
+    np.testing.assert_allclose(cpu(hn), g["out/hn"], **TOL)
+    if g.has("out/greedy_flat"):
+        dec = CTCGreedyDecoder(g.cfg["blank"])(y, lens)
+        assert dec == unragged(g["out/greedy_flat"], g["out/greedy_lens"])
+
+
+@pytest.mark.parametrize("name", golden_names("ds1_tiny"))
+def test_ds1_tiny_golden(name):
+    from myrtlespeech_amd.model.deep_speech_1 import DeepSpeech1
+    g = Golden(name)
+    c = g.cfg
+    m = DeepSpeech1(c["input_features"], c["input_channels"], c["n_hidden"], c["out_features"], drop_prob=0.25,
+                    relu_clip=c["relu_clip"], hard_lstm=c["hard_lstm"])
+    load_sd(m, g.sd())
+    (y, lens), hid = m((T(g["in/x"]), T(g["in/lens"])))
+    np.testing.assert_allclose(cpu(y), g["out/y"], **TOL)
+    np.testing.assert_allclose(cpu(hid[0]), g["out/hn"], **TOL)
+    np.testing.assert_allclose(cpu(hid[1]), g["out/cn"], **TOL)
+
+
+# ----------------------------------------------------------------------------- CTC loss / greedy
+def test_ctc_loss_golden():
+    from myrtlespeech_amd.loss.ctc_loss import CTCLoss
+    g = Golden("ctc_loss_small")
+    b = g.cfg["blank"]
+    for red in ("none", "mean", "sum"):
+        for zi in (0, 1):
+            got = CTCLoss(blank=b, reduction=red, zero_infinity=bool(zi))(
+                (T(g["in/x"]), T(g["in/x_lens"])), (T(g["in/y"]), T(g["in/y_lens"])))
+            np.testing.assert_allclose(cpu(got), g[f"out/{red}_{zi}"], rtol=1e-4, atol=1e-4)
+    got = CTCLoss(blank=b, reduction="none")((T(g["in/x"]), T(g["in/x_lens"])), (T(g["in/y_flat"]), T(g["in/y_lens"])))
+    np.testing.assert_allclose(cpu(got), g["out/none_flat"], rtol=1e-4, atol=1e-4)
+    g = Golden("ctc_loss_v29")
+    for red in ("none", "mean", "sum"):
+        got = CTCLoss(blank=28, reduction=red)((T(g["in/x"]), T(g["in/x_lens"])), (T(g["in/y"]), T(g["in/y_lens"])))
+        np.testing.assert_allclose(cpu(got), g[f"out/{red}_0"], rtol=1e-4, atol=1e-3)
+
+
+def test_ctc_loss_full_size_vs_oracle():
+    from myrtlespeech_amd.loss.ctc_loss import CTCLoss
+    rng = np.random.default_rng(9)
+    Tn, N, V, S = 501, 32, 29, 120
+    x = rng.normal(size=(Tn, N, V)).astype(np.float32)
+    xl = np.sort(rng.integers(300, Tn + 1, size=N))[::-1].astype(np.int32)
+    yl = rng.integers(1, S + 1, size=N).astype(np.int32)
+    y = rng.integers(0, 28, size=(N, S)).astype(np.int32)
+    got = CTCLoss(blank=28, reduction="none")((T(x), T(xl)), (T(y), T(yl)))
+    want = O.ctc_loss(x, xl, y, yl, 28, "none")
+    np.testing.assert_allclose(cpu(got), want, rtol=2e-4, atol=1e-2)
+
+
+def test_greedy_golden():
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    g = Golden("greedy_ties")
+    for b in g.cfg["blanks"]:
+        got = CTCGreedyDecoder(b)(T(g["in/x"]), T(g["in/lens"]))
+        assert got == unragged(g[f"out/flat_b{b}"], g[f"out/lens_b{b}"])
+
+
+@pytest.mark.parametrize("Tn,N,V", [(501, 32, 29), (1000, 3, 5), (257, 5, 64), (1, 1, 2)])
+def test_greedy_vs_oracle(Tn, N, V):
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    rng = np.random.default_rng(Tn + N + V)
+    x = (rng.normal(size=(Tn, N, V)) * 2).round().astype(np.float32) / 2  # many ties and repeats
+    lens = rng.integers(0, Tn + 1, size=N).astype(np.int64)
+    lens[0] = Tn
+    got = CTCGreedyDecoder(V - 1)(T(x), T(lens))
+    assert got == O.ctc_greedy_decode(x, lens, V - 1)
