@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DS2 (2x masked conv2d -> 5xBiLSTM-1024 -> FC 1024 -> 29) forward +
+CTC greedy decode on synthetic 80-feature 10 s clips, batch 32 per GPU (BASELINE.json
+configs[1]); utterances are sharded across GPUs (weak scaling, one process per GPU).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see the task contract): metric = audio-sec/s with inputs
+resident in HBM, plus `roofline` for the dominant kernel (the persistent LSTM recurrence,
+priced against SURVEY 8d's algorithmic bytes) and `cpu_baseline` (the numpy oracle timed on
+this box's host cores, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH_PER_GPU = 32
+FRAMES = 1001          # 10 s @ 16 kHz, hop 160 (configs/deep_speech_2_en.config:5-11)
+FEATURES = 80
+CLIP_SECONDS = 10.0
+HIDDEN = 1024
+LAYERS = 5
+VOCAB = 29
+BLANK = 28
+# algorithmic bytes of ONE LSTM layer-direction-timestep at H=1024, N=32, fp32:
+#   W_hh 4H*H*4 + x-gates N*4H*4 + h read/write 2*N*H*4 + c read/write 2*N*H*4
+LSTM_STEP_BYTES = 4 * HIDDEN * HIDDEN * 4 + BATCH_PER_GPU * 4 * HIDDEN * 4 + 4 * BATCH_PER_GPU * HIDDEN * 4
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def build_model():
+    from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+    from myrtlespeech_amd.model.deep_speech_2 import DeepSpeech2
+    from myrtlespeech_amd.model.fully_connected import FullyConnected
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    from myrtlespeech_amd.model.seq_len_wrapper import SeqLenWrapper
+
+    def act():
+        return SeqLenWrapper(torch.nn.Hardtanh(0.0, 20.0), torch.nn.Identity())
+
+    torch.manual_seed(0)
+    cnn = torch.nn.Sequential(MaskConv2d(1, 32, [41, 11], [2, 2], PaddingMode.SAME), act(),
+                              MaskConv2d(32, 32, [21, 11], [2, 1], PaddingMode.SAME), act())
+    rnn = RNN(RNNType.LSTM, 640, HIDDEN, num_layers=LAYERS, bidirectional=True, forget_gate_bias=1.0)
+    fc = FullyConnected(2 * HIDDEN, VOCAB, 1, 1024, torch.nn.Hardtanh(0.0, 20.0))
+    return DeepSpeech2(cnn, rnn, None, fc).eval()
+
+
+def cpu_baseline(model, sample_batch=8):
+    """Oracle (numpy restatement of the reference path) on a bounded sample of the same
+    workload: `sample_batch` full-length clips through the full-size network."""
+    from oracle import ds_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    cfg = dict(convs=[dict(kind="conv2d", idx=0, stride=(2, 2), same=True, act=(0.0, 20.0)),
+                      dict(kind="conv2d", idx=2, stride=(2, 1), same=True, act=(0.0, 20.0))],
+               rnn=dict(kind=O.LSTM, hidden=HIDDEN, layers=LAYERS, bidirectional=True), lookahead=None,
+               fc=dict(n_hidden=1, act=(0.0, 20.0)))
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((sample_batch, 1, FEATURES, FRAMES), dtype=np.float32)
+    lens = np.full(sample_batch, FRAMES, dtype=np.int64)
+    t0 = time.perf_counter()
+    y, yl, _ = O.deep_speech_2_forward(x, lens, cfg, sd)
+    O.ctc_greedy_decode(y, yl, BLANK)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_batch * CLIP_SECONDS / dt, 2), "unit": "audio-sec/s", "cores": int(threads),
+            "kind": "port", "sample": f"{sample_batch} of the 32 clips (full 10 s, full-size network), "
+                                      f"numpy oracle, {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from myrtlespeech_amd import _lib
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    lib = _lib.load()
+    model = build_model()
+    model.rnn.check_status = False  # no per-layer host sync inside the timed region (checked once afterwards)
+    decoder = CTCGreedyDecoder(BLANK)
+
+    # this rank's shard of the global batch: 32 utterances, resident in HBM before timing starts
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(BATCH_PER_GPU, 1, FEATURES, FRAMES, generator=g).cuda()
+    lens = torch.full((BATCH_PER_GPU,), FRAMES, dtype=torch.int64)
+
+    def step():
+        (logits, out_lens), _ = model((x, lens))
+        return decoder(logits, out_lens)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    lib.ms_prof_enable(1)
+    ms = (ctypes.c_float * 2)()
+    cnt = (ctypes.c_int * 2)()
+    lib.ms_prof_read(ms, cnt)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    lib.ms_prof_read(ms, cnt)
+    lib.ms_prof_enable(0)
+    ws = model.rnn._workspace.buf
+    _lib.check(lib.ms_rnn_status(_lib.ptr(ws), _lib.stream_ptr()), "persistent LSTM")
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * BATCH_PER_GPU * CLIP_SECONDS * args.steps / elapsed
+        rec_ms = ms[1] / max(cnt[1], 1)          # one persistent launch = one layer, both directions
+        t_out = 501
+        launch_bytes = t_out * 2 * LSTM_STEP_BYTES
+        achieved = launch_bytes / (rec_ms * 1e-3) / 1e9 if rec_ms > 0 else 0.0
+        out = {
+            "metric": "audio-sec/s (RTF), DS2 5xBiLSTM-1024 encoder forward + CTC greedy, 80-feature 10 s clips @ batch 32/GPU",
+            "value": round(value, 1), "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: DS2 2xconv2d + 5xBiLSTM-1024 + FC, 80-feature x 1001 "
+                                   "frames (10 s), batch 32 per GPU, CTC greedy decode (blank 28)",
+                       "global_batch": world * BATCH_PER_GPU, "frames": FRAMES, "parallelism": f"utterance-shard x{world}"},
+            "encoder_ms_per_rnn_step": round(ms_per_step / t_out, 4),
+            "kernel_ms": {"lstm_recurrent_per_layer": round(rec_ms, 3), "lstm_input_projection_per_layer":
+                          round(ms[0] / max(cnt[0], 1), 3)},
+            "roofline": {"bound": "hbm", "kernel": "lstm_persistent_kernel (one launch = 1 layer x 2 directions x 501 steps)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": launch_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -124,6 +124,15 @@ int ms_rnn_layer_forward(int cell, const void* packed, const float* x, const int
  * used `workspace` completed (MS_OK) or a persistent kernel timed out. */
 int ms_rnn_status(const void* workspace, void* stream);
 
+/* Optional launch timing for bench.py's roofline line (not part of the reference
+ * surface).  While enabled, ms_rnn_layer_forward brackets its input-projection
+ * GEMM and its recurrent kernel with HIP events on the caller's stream.
+ * ms_prof_read synchronises those events and returns the summed milliseconds and
+ * launch counts since the last read: out_ms[0]/out_n[0] = input projection,
+ * out_ms[1]/out_n[1] = recurrent kernel(s) of one layer. */
+int ms_prof_enable(int on);
+int ms_prof_read(float* out_ms_host, int* out_n_host);
+
 /* ---- loss/ctc_loss.py ---------------------------------------------------- */
 
 size_t ms_ctc_loss_workspace_bytes(int T, int N, int V, int S_max);

@@ -25,6 +25,7 @@
 // (hidden unit, direction), K split across lanes.  Correct for every shape; not tuned.
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "common.h"
 
@@ -433,6 +434,54 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_kernel(LstmP p) {
 
 }  // namespace
 
+// ================================================================================================ launch timing
+
+namespace {
+struct ProfSpan { hipEvent_t a, b; int kind; };
+bool g_prof_on = false;
+std::vector<ProfSpan> g_spans;      // recorded, not yet read
+std::vector<ProfSpan> g_free;       // event pairs ready for re-use
+
+struct ProfScope {
+  ProfSpan s{};
+  hipStream_t stream;
+  bool on;
+  ProfScope(int kind, hipStream_t st) : stream(st), on(g_prof_on) {
+    if (!on) return;
+    if (!g_free.empty()) { s = g_free.back(); g_free.pop_back(); }
+    else if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) { on = false; return; }
+    s.kind = kind;
+    (void)hipEventRecord(s.a, stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(s.b, stream);
+    g_spans.push_back(s);
+  }
+};
+}  // namespace
+
+extern "C" int ms_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return MS_OK;
+}
+
+extern "C" int ms_prof_read(float* out_ms, int* out_n) {
+  MS_REQUIRE(out_ms && out_n, "null pointer");
+  out_ms[0] = out_ms[1] = 0.f;
+  out_n[0] = out_n[1] = 0;
+  for (auto& s : g_spans) {
+    MS_HIP(hipEventSynchronize(s.b));
+    float ms = 0.f;
+    MS_HIP(hipEventElapsedTime(&ms, s.a, s.b));
+    out_ms[s.kind] += ms;
+    out_n[s.kind] += 1;
+    g_free.push_back(s);
+  }
+  g_spans.clear();
+  return MS_OK;
+}
+
 // ================================================================================================ C ABI
 
 extern "C" size_t ms_rnn_packed_bytes(int cell, int In, int H, int ndir) {
@@ -528,9 +577,14 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
 
   // (i) input projection for every frame of every direction: [steps*N, In] x [ndir*GH, In]^T
   float* xproj = (float*)(ws + W.xproj);
-  int rc = ms::linear_launch(x, (const float*)(pk + L.wih), (const float*)(pk + L.bias_x), xproj, steps * N, In,
-                             (int)(ndir * GH), MS_ACT_NONE, 0.f, 0.f, stream);
+  int rc;
+  {
+    ProfScope prof(0, stream);
+    rc = ms::linear_launch(x, (const float*)(pk + L.wih), (const float*)(pk + L.bias_x), xproj, steps * N, In,
+                           (int)(ndir * GH), MS_ACT_NONE, 0.f, 0.f, stream);
+  }
   if (rc != MS_OK) return rc;
+  ProfScope prof_rec(1, stream);
 
   if (fast) {
     // batch groups of <= 64 sequences, one persistent launch each (stream-ordered; the epoch

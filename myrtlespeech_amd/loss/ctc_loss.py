@@ -69,8 +69,9 @@ class CTCLoss(torch.nn.Module):
         nll = torch.empty(n, dtype=torch.float32, device="cuda")
         reduced = torch.empty(1, dtype=torch.float32, device="cuda")
         ws = self._workspace.get(lib.ms_ctc_loss_workspace_bytes(t, n, v, s_max))
-        _lib.check(lib.ms_ctc_loss_forward(_lib.ptr(x), _lib.ptr(_lib.lens_i32(xl)), _lib.ptr(y_dev),
-                                           _lib.ptr(_lib.lens_i32(offsets)), _lib.ptr(_lib.lens_i32(yl)), _lib.ptr(nll),
+        xl_dev, off_dev, yl_dev = _lib.lens_i32(xl), _lib.lens_i32(offsets), _lib.lens_i32(yl)
+        _lib.check(lib.ms_ctc_loss_forward(_lib.ptr(x), _lib.ptr(xl_dev), _lib.ptr(y_dev), _lib.ptr(off_dev),
+                                           _lib.ptr(yl_dev), _lib.ptr(nll),
                                            _lib.ptr(reduced), t, n, v, s_max, blank, red,
                                            int(bool(self.ctc_loss.zero_infinity)), _lib.ptr(ws), ws.numel(),
                                            _lib.stream_ptr()), "ms_ctc_loss_forward")

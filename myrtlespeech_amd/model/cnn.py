@@ -100,8 +100,9 @@ def _mask_in_place(acts: torch.Tensor, seq_lens: torch.Tensor):
     if acts.is_cuda and acts.dtype == torch.float32 and acts.is_contiguous():
         n, t = acts.shape[0], acts.shape[-1]
         inner = acts.numel() // (n * t)
-        _lib.check(_lib.load().ms_mask_time_(_lib.ptr(acts), _lib.ptr(_lib.lens_i32(seq_lens)), n, inner, t,
-                                             _lib.stream_ptr()), "ms_mask_time_")
+        lens_dev = _lib.lens_i32(seq_lens)  # keep alive until the launch is enqueued
+        _lib.check(_lib.load().ms_mask_time_(_lib.ptr(acts), _lib.ptr(lens_dev), n, inner, t, _lib.stream_ptr()),
+                   "ms_mask_time_")
         return True
     return False
 

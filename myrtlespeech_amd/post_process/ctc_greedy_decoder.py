@@ -24,7 +24,8 @@ class CTCGreedyDecoder(torch.nn.Module):
         xd = _lib.f32c(x)
         out_idx = torch.empty((batch, seq_len), dtype=torch.int32, device="cuda")
         out_len = torch.empty(batch, dtype=torch.int32, device="cuda")
-        _lib.check(_lib.load().ms_ctc_greedy_decode(_lib.ptr(xd), _lib.ptr(_lib.lens_i32(lengths)), _lib.ptr(out_idx),
+        lens_dev = _lib.lens_i32(lengths)
+        _lib.check(_lib.load().ms_ctc_greedy_decode(_lib.ptr(xd), _lib.ptr(lens_dev), _lib.ptr(out_idx),
                                                     _lib.ptr(out_len), seq_len, batch, symbols, self.blank_index,
                                                     _lib.stream_ptr()), "ms_ctc_greedy_decode")
         return ragged_to_lists(out_idx, out_len)
