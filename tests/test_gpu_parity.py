@@ -349,3 +349,56 @@ def test_ds2_cfg2_full_size_vs_reference_summary():
     assert dec == unragged(g["out/greedy_flat"], g["out/greedy_lens"])
     err = float(np.abs(cpu(y[::25, ::4, :]) - g["out/y_sub"]).max())
     print(f"cfg2 full-size max |logit err| on the sub-grid: {err:.3e} (mean |logit| {float(g['out/y_abs_mean']):.3e})")
+
+
+# ----------------------------------------------------------------------------- CTC beam search
+def test_beam_reference_kats():
+    """tests/post_process/test_ctc_beam_decoder.py:17-102 (the reference's own known answers)."""
+    from myrtlespeech_amd.post_process.ctc_beam_decoder import CTCBeamDecoder
+    g = Golden("beam_kats")
+    dec = CTCBeamDecoder(blank_index=1, beam_width=2, prune_threshold=0.0)
+    assert dec(T(g["kat2x2/x"]), torch.tensor([2], dtype=torch.int8)) == [[0]]
+    al = dict(zip("deouw_ ", range(7)))
+    x, ln = T(g["katlm/x"]), torch.tensor([4], dtype=torch.int8)
+    assert CTCBeamDecoder(blank_index=al["_"], beam_width=20)(x, ln) == [[al[c] for c in "do"]]
+    for target in ("dew", "due"):
+        tt = tuple(al[c] for c in target) + (al[" "],)
+        dec = CTCBeamDecoder(blank_index=al["_"], beam_width=20, separator_index=al[" "],
+                             language_model=lambda w, tt=tt: 2.0 if w == tt else 0.0, lm_weight=10.0, word_weight=2.0)
+        assert dec(x, ln) == [[al[c] for c in target + " "]]
+
+
+def test_beam_golden_random():
+    from myrtlespeech_amd.post_process.ctc_beam_decoder import CTCBeamDecoder
+    g = Golden("beam_random")
+    for c in g.cfg["cases"]:
+        s = c["set"]
+        key = f"{s}/out{c['idx']}"
+        want = unragged(g[key + "_flat"], g[key + "_lens"])
+        dec = CTCBeamDecoder(c["blank"], c["beam_width"], c["prune"],
+                             language_model=O.toy_language_model if c["lm"] else None, lm_weight=c.get("lm_weight"),
+                             separator_index=c["sep"], word_weight=c["word_weight"])
+        assert dec(T(g[f"{s}/x"]), T(g[f"{s}/lens"])) == want, c
+
+
+@pytest.mark.parametrize("Tn,N,V,W,thr,sep,temp", [(60, 6, 29, 8, 0.001, None, 6.0), (40, 4, 12, 20, 0.0, 3, 2.0),
+                                                    (80, 3, 6, 3, 0.05, 0, 1.0), (30, 5, 40, 16, 0.001, None, 3.0)])
+def test_beam_vs_oracle(Tn, N, V, W, thr, sep, temp):
+    from myrtlespeech_amd.post_process.ctc_beam_decoder import CTCBeamDecoder
+    rng = np.random.default_rng(Tn * 31 + V)
+    z = rng.normal(size=(Tn, N, V)) * temp
+    x = np.exp(z - z.max(-1, keepdims=True))
+    x = (x / x.sum(-1, keepdims=True)).astype(np.float32)
+    lens = rng.integers(0, Tn + 1, size=N).astype(np.int64)
+    lens[0] = Tn
+    got = CTCBeamDecoder(V - 1, W, thr, separator_index=sep, word_weight=1.7)(T(x), T(lens))
+    assert got == O.ctc_beam_decode(x, lens, V - 1, W, thr, separator_index=sep, word_weight=1.7)
+
+
+def test_beam_one_output_per_batch_element_on_garbage():
+    """tests/post_process/test_ctc_beam_decoder.py:105-114: uninitialised input, only the shape is pinned."""
+    from myrtlespeech_amd.post_process.ctc_beam_decoder import CTCBeamDecoder
+    x = torch.empty(7, 5, 4)
+    x[0, 0, 0] = float("nan")
+    out = CTCBeamDecoder(0, 3)(x, torch.tensor([7, 7, 3, 1, 0]))
+    assert len(out) == 5 and all(isinstance(o, list) for o in out)
