@@ -1,0 +1,90 @@
+"""Utterance sharding across the GPUs of one node (new design; the reference has no
+distributed code at all -- SURVEY 0.2, only the DataParallel remark at rnn.py:167-168).
+
+Every stage of the hot path is independent per utterance, so the batch is cut
+into contiguous shards *after* the length-descending sort the reference's collate applies
+(data/batch.py:97-100): each shard stays sorted, as ``enforce_sorted=True`` (rnn.py:174)
+requires, weights are replicated, and the encoder needs no collective.  The single
+exchange step is for a *batched* decode on every rank: an all-gather (RCCL over xGMI on
+the GPU, gloo in the CPU tests) of the per-shard logits padded to the global frame count,
+plus the lengths.  At 1.86 MB per shard this is latency-bound, so it is one direct
+all-gather, not a ring of smaller pieces.  When decoding per shard, only the ragged index
+lists are gathered (host objects) and no device collective runs.
+"""
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(batch: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """[begin, end) of rank's contiguous shard; earlier ranks take the remainder."""
+    if not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} not in [0, {world_size})")
+    base, extra = divmod(batch, world_size)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def shard_batch(x: torch.Tensor, lens: torch.Tensor, world_size: int, rank: int, batch_dim: int = 0
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """This rank's utterances of a length-sorted batch ``(x, lens)``."""
+    if lens.numel() > 1 and bool((lens[:-1] < lens[1:]).any()):
+        raise ValueError("shard_batch expects lengths sorted in decreasing order (data/batch.py:97-100)")
+    b, e = shard_bounds(lens.numel(), world_size, rank)
+    return x.narrow(batch_dim, b, e - b), lens[b:e]
+
+
+def gather_logits(logits: torch.Tensor, lens: torch.Tensor, group: Optional[dist.ProcessGroup] = None
+                  ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """All-gather ``(logits[T_r, N_r, V], lens[N_r])`` of every rank into the full batch
+    ``(logits[T_max, sum N_r, V], lens[sum N_r])`` on every rank, shards in rank order.
+    Frames past a shard's own T_r are zero (they lie beyond every length of that shard)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return logits, lens
+    world = dist.get_world_size(group)
+    dev = logits.device
+    meta = torch.tensor([logits.shape[0], logits.shape[1]], dtype=torch.int64, device=dev)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    t_all = [int(m[0]) for m in metas]
+    n_all = [int(m[1]) for m in metas]
+    t_max, n_max, v = max(t_all), max(n_all), logits.shape[2]
+    # equal-sized payloads so the exchange is ONE all-gather
+    pad = torch.zeros((t_max, n_max, v), dtype=logits.dtype, device=dev)
+    pad[:logits.shape[0], :logits.shape[1]] = logits
+    lens_pad = torch.zeros(n_max, dtype=torch.int64, device=dev)
+    lens_pad[:lens.numel()] = lens.to(device=dev, dtype=torch.int64)
+    out = torch.empty((world * t_max, n_max, v), dtype=logits.dtype, device=dev)
+    out_lens = torch.empty(world * n_max, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    dist.all_gather_into_tensor(out_lens, lens_pad, group=group)
+    out = out.view(world, t_max, n_max, v)
+    out_lens = out_lens.view(world, n_max)
+    full = torch.cat([out[r, :, :n_all[r]] for r in range(world)], dim=1)
+    full_lens = torch.cat([out_lens[r, :n_all[r]] for r in range(world)]).to(lens.dtype)
+    return full, full_lens
+
+
+def gather_transcripts(local: Sequence[List[int]], group: Optional[dist.ProcessGroup] = None) -> List[List[int]]:
+    """Per-shard decode results -> the full batch's ``List[List[int]]`` on every rank
+    (host objects only; no device collective)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [list(s) for s in local]
+    parts: List[Optional[List[List[int]]]] = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, [list(s) for s in local], group=group)
+    return [s for part in parts for s in part]
+
+
+def sharded_forward_decode(model, decoder, x: torch.Tensor, lens: torch.Tensor, batched_decode: bool = False,
+                           group: Optional[dist.ProcessGroup] = None):
+    """Run ``model`` on this rank's shard of the sorted global batch ``(x[N,...], lens[N])``
+    and return the whole batch's transcripts on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    xs, ls = shard_batch(x, lens, world, rank)
+    (logits, out_lens), _ = model((xs, ls))
+    if batched_decode:
+        full, full_lens = gather_logits(logits, out_lens, group)
+        return decoder(full, full_lens)
+    return gather_transcripts(decoder(logits, out_lens), group)
