@@ -39,6 +39,22 @@ LSTM_STEP_BYTES = 4 * HIDDEN * HIDDEN * 4 + BATCH_PER_GPU * 4 * HIDDEN * 4 + 4 *
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def precision_label():
+    """Arithmetic of the two dominant kernels (LSTM recurrence + input projection): by default every
+    f32 operand is split into bf16 hi+lo and multiplied as hi*hi + lo*hi + hi*lo with f32 accumulation
+    (MS_PRECISION=f32 selects exact-f32 MFMA instead); conv / FC / CTC are exact f32."""
+    return "f32" if os.environ.get("MS_PRECISION") == "f32" else "bf16x3 (f32 split into bf16 hi+lo, f32 accumulate)"
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_lstm.json")) as f:
+            return json.load(f)["hbm_bytes_per_launch"] if os.environ.get("MS_PRECISION") != "f32" else None
+    except Exception:
+        return None
+
+
 def build_model():
     from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
     from myrtlespeech_amd.model.deep_speech_2 import DeepSpeech2
@@ -160,16 +176,16 @@ def main():
             "metric": "audio-sec/s (RTF), DS2 5xBiLSTM-1024 encoder forward + CTC greedy, 80-feature 10 s clips @ batch 32/GPU",
             "value": round(value, 1), "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": precision_label(), "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: DS2 2xconv2d + 5xBiLSTM-1024 + FC, 80-feature x 1001 "
                                    "frames (10 s), batch 32 per GPU, CTC greedy decode (blank 28)",
                        "global_batch": world * BATCH_PER_GPU, "frames": FRAMES, "parallelism": f"utterance-shard x{world}"},
             "encoder_ms_per_rnn_step": round(ms_per_step / t_out, 4),
             "kernel_ms": {"lstm_recurrent_per_layer": round(rec_ms, 3), "lstm_input_projection_per_layer":
                           round(ms[0] / max(cnt[0], 1), 3)},
-            "roofline": {"bound": "hbm", "kernel": "lstm_persistent_kernel (one launch = 1 layer x 2 directions x 501 steps)",
+            "roofline": {"bound": "hbm", "kernel": "lstm_persistent_split_kernel (one launch = 1 layer x 2 directions x 501 steps)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
                          "algorithmic_bytes_per_launch": launch_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:

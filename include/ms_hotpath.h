@@ -124,6 +124,11 @@ int ms_rnn_layer_forward(int cell, const void* packed, const float* x, const int
  * used `workspace` completed (MS_OK) or a persistent kernel timed out. */
 int ms_rnn_status(const void* workspace, void* stream);
 
+/* Diagnostic: byte offset inside the RNN workspace of the per-workgroup stamp sums
+ * [ndir*H/8][8] (u64 wall-clock ticks, 100 MHz: wait, MFMA loop, reduce+cell, publish)
+ * that the persistent LSTM kernel fills when MS_LSTM_STAMPS=1 is set in the environment. */
+size_t ms_rnn_debug_offset(int cell, int T, int N, int In, int H, int ndir);
+
 /* Optional launch timing for bench.py's roofline line (not part of the reference
  * surface).  While enabled, ms_rnn_layer_forward brackets its input-projection
  * GEMM and its recurrent kernel with HIP events on the caller's stream.

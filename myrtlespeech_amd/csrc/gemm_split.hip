@@ -1,0 +1,191 @@
+// y[M,N] = x[M,K] . w[N,K]^T + bias[N] with float32 operands split into bf16 (hi, lo) pairs:
+//   x.w ~= x_hi.w_hi + x_lo.w_hi + x_hi.w_lo      (f32 accumulate, relative error ~2^-17 per
+// product instead of 2^-24; measured end to end in DESIGN.md).  Three v_mfma_f32_32x32x16_bf16
+// per 16-deep k-step run at 3/16 of the cost of the eight exact-f32 MFMAs they replace.
+//
+// Used for the LSTM input projection (rnn.hip), the dominant GEMM of the encoder
+// (torch.nn.LSTM's x.W_ih^T inside rnn.py:177).
+//
+//   split_planes_kernel : x f32 [M,K]  ->  hi, lo bf16 [M,K]                (HBM-bound)
+//   gemm_nt_bf16x3_kernel: 256x128 block tile, BK = 32, 4 waves (each 64 rows x 128 cols =
+//       2x4 MFMA tiles), all four operand planes of a K-block staged once in LDS as
+//       [k/8][row][8 bf16] granules (one conflict-free ds_read_b128 = one MFMA operand),
+//       register prefetch of the next K-block, XCD-aware tile order, bias epilogue.
+#include <algorithm>
+
+#include "common.h"
+
+namespace ms {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned bf16_hi_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
+
+__global__ void split_planes_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi,
+                                    unsigned short* __restrict__ lo, size_t n4) {
+  // n4 = number of 4-element groups
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = bf16_hi_bits(v[e]);
+      l[e] = bf16_hi_bits(v[e] - __uint_as_float(h[e] << 16));
+    }
+    u32x2 ho = {h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+    u32x2 lo2 = {l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+    reinterpret_cast<u32x2*>(hi)[i] = ho;
+    reinterpret_cast<u32x2*>(lo)[i] = lo2;
+  }
+}
+
+constexpr int SB_M = 256, SB_N = 128, SB_K = 32;
+constexpr int A_PLANE = SB_M * 16 + 32;  // bytes per k-group plane (+32 B: conflict-free ds_write_b128)
+constexpr int B_PLANE = SB_N * 16 + 32;
+constexpr int A_TILE = 4 * A_PLANE, B_TILE = 4 * B_PLANE;
+constexpr int SPLIT_LDS = 2 * A_TILE + 2 * B_TILE;
+
+__device__ __forceinline__ u32x4 ld_granule(const unsigned short* __restrict__ p, int rows, int K, int row, int k) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (row < rows && k < K) v = *reinterpret_cast<const u32x4*>(p + (size_t)row * K + k);
+  return v;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel(const unsigned short* __restrict__ Ah,
+                                                                const unsigned short* __restrict__ Al,
+                                                                const unsigned short* __restrict__ Wh,
+                                                                const unsigned short* __restrict__ Wl,
+                                                                const float* __restrict__ bias, float* __restrict__ Y,
+                                                                int M, int K, int N) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* sAh = lds;
+  char* sAl = lds + A_TILE;
+  char* sBh = lds + 2 * A_TILE;
+  char* sBl = lds + 2 * A_TILE + B_TILE;
+
+  const int nbn = (N + SB_N - 1) / SB_N, nbm = (M + SB_M - 1) / SB_M;
+  const int nwg = nbn * nbm;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int bn = bid % nbn, bm = bid / nbn;
+  const int m0 = bm * SB_M, n0 = bn * SB_N;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int kg = tid & 3, r_in = tid >> 2;  // loader mapping: 4 k-groups x 64 rows per pass
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 rah[4], ral[4], rbh[2], rbl[2];
+  auto load_regs = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rah[i] = ld_granule(Ah, M, K, m0 + r_in + 64 * i, k0 + kg * 8);
+      ral[i] = ld_granule(Al, M, K, m0 + r_in + 64 * i, k0 + kg * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      rbh[i] = ld_granule(Wh, N, K, n0 + r_in + 64 * i, k0 + kg * 8);
+      rbl[i] = ld_granule(Wl, N, K, n0 + r_in + 64 * i, k0 + kg * 8);
+    }
+  };
+  auto store_regs = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(sAh + kg * A_PLANE + (r_in + 64 * i) * 16) = rah[i];
+      *reinterpret_cast<u32x4*>(sAl + kg * A_PLANE + (r_in + 64 * i) * 16) = ral[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<u32x4*>(sBh + kg * B_PLANE + (r_in + 64 * i) * 16) = rbh[i];
+      *reinterpret_cast<u32x4*>(sBl + kg * B_PLANE + (r_in + 64 * i) * 16) = rbl[i];
+    }
+  };
+
+  const int nk = (K + SB_K - 1) / SB_K;
+  load_regs(0);
+  store_regs();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_regs((kt + 1) * SB_K);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int g = 2 * s + half;
+      bf16x8 ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int off = g * A_PLANE + (wave * 64 + i * 32 + l31) * 16;
+        ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sAh + off));
+        al[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sAl + off));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int off = g * B_PLANE + (j * 32 + l31) * 16;
+        bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sBh + off));
+        bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sBl + off));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      store_regs();
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + j * 32 + l31;
+    const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wave * 64 + i * 32 + mfma32_row(r, lane);
+        if (m < M && n < N) Y[(size_t)m * N + n] = acc[i][j][r] + bv;
+      }
+  }
+}
+
+// hi/lo planes of an f32 matrix [rows, K] (K % 4 == 0, 16-byte aligned)
+int split_planes_launch(const float* x, unsigned short* hi, unsigned short* lo, size_t elems, hipStream_t stream) {
+  const size_t n4 = elems / 4;
+  const int blocks = (int)std::min<size_t>((n4 + 255) / 256, 4096);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, x, hi, lo, n4);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}
+
+// requires K % 8 == 0 and 16-byte aligned planes
+int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
+                       const unsigned short* wl, const float* bias, float* y, int M, int K, int N, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS));
+    attr_set = true;
+  }
+  const int nwg = cdiv(M, SB_M) * cdiv(N, SB_N);
+  hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, dim3(nwg), dim3(256), SPLIT_LDS, stream, ah, al, wh, wl, bias, y, M, K, N);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}
+
+}  // namespace ms

@@ -30,6 +30,9 @@
 #include "common.h"
 
 namespace ms {
+int split_planes_launch(const float* x, unsigned short* hi, unsigned short* lo, size_t elems, hipStream_t stream);
+int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
+                       const unsigned short* wl, const float* bias, float* y, int M, int K, int N, hipStream_t stream);
 int linear_launch(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act, float lo,
                   float hi, hipStream_t stream);
 }
@@ -62,6 +65,21 @@ bool use_fast(int cell, int H, int ndir) {
   return ndir * (H / 8) <= ms::num_cus();
 }
 
+// Operand precision of the persistent recurrence: "f32" = exact float32 MFMA,
+// "bf16x3" (default) = every f32 operand split into bf16 hi + lo, products hi*hi + lo*hi +
+// hi*lo accumulated in f32 (relative error ~2^-17 per product instead of 2^-24).
+bool want_split() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MS_PRECISION");
+    v = (e && strcmp(e, "f32") == 0) ? 0 : 1;
+  }
+  return v == 1;
+}
+bool use_split(int cell, int H, int ndir) { return use_fast(cell, H, ndir) && want_split() && H % 64 == 0; }
+// the input projection runs as the bf16x3 GEMM whenever the recurrence is split and In allows 16-byte granules
+bool use_split_gemm(int cell, int H, int ndir, int In) { return use_split(cell, H, ndir) && In % 8 == 0; }
+
 struct PackLayout {
   size_t wih, bias_x, whh, bhh, total;  // byte offsets
 };
@@ -78,9 +96,9 @@ PackLayout pack_layout(int cell, int In, int H, int ndir) {
 }
 
 struct WsLayout {
-  size_t status, flags, xproj, hx, state_h, state_c, total;
+  size_t status, flags, xproj, hx, state_h, state_c, dbg, xsplit, total;
 };
-WsLayout ws_layout(int cell, int T, int N, int H, int ndir) {
+WsLayout ws_layout(int cell, int T, int N, int H, int ndir, int In) {
   const size_t GH = (size_t)gates_of(cell) * H;
   const int npad = ms::cdiv(N, 32) * 32;
   WsLayout L;
@@ -91,6 +109,8 @@ WsLayout ws_layout(int cell, int T, int N, int H, int ndir) {
   L.hx = o; o += ms::align_up((size_t)ndir * 2 * H * std::min(npad, 64) * sizeof(float), 256);
   L.state_h = o; o += ms::align_up((size_t)2 * ndir * N * H * sizeof(float), 256);
   L.state_c = o; o += ms::align_up((size_t)ndir * N * H * sizeof(float), 256);
+  L.dbg = o; o += ms::align_up((size_t)ndir * std::max(H / 8, 1) * 8 * sizeof(unsigned long long), 256);
+  L.xsplit = o; o += ms::align_up((size_t)T * N * In * 4, 256);  // bf16 hi + lo planes of the layer input
   L.total = o;
   return L;
 }
@@ -104,6 +124,20 @@ __global__ void pack_rows_fast_kernel(const float* __restrict__ w, float* __rest
   const float* src = w + (size_t)(g * H + 8 * j + u) * In;
   float* d = dst + (size_t)row * In;
   for (int k = threadIdx.x; k < In; k += blockDim.x) d[k] = src[k];
+}
+
+// same row order, written as bf16 hi / lo planes (plane stride = rows_total * In elements)
+__global__ void pack_rows_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ hi,
+                                       unsigned short* __restrict__ lo, int H, int In) {
+  const int row = blockIdx.x;
+  const int j = row / 32, g = (row % 32) / 8, u = row % 8;
+  const float* src = w + (size_t)(g * H + 8 * j + u) * In;
+  for (int k = threadIdx.x; k < In; k += blockDim.x) {
+    const float x = src[k];
+    const __bf16 h = (__bf16)x;
+    hi[(size_t)row * In + k] = __builtin_bit_cast(unsigned short, h);
+    lo[(size_t)row * In + k] = __builtin_bit_cast(unsigned short, (__bf16)(x - (float)h));
+  }
 }
 
 __global__ void pack_bias_fast_kernel(const float* __restrict__ b_ih, const float* __restrict__ b_hh,
@@ -125,6 +159,25 @@ __global__ void pack_whh_fast_kernel(const float* __restrict__ w, float* __restr
     const int j = (i >> 7) / (H / 4);
     const int g = r >> 3, u = r & 7;
     dst[i] = w[(size_t)(g * H + 8 * j + u) * H + 4 * kq + e];
+  }
+}
+
+// whh_s[j][plane][kg][r = g*8+u][e] (bf16) = hi / lo part of w_hh[g*H + 8j + u][8kg + e]
+__global__ void pack_whh_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int H) {
+  const size_t total = (size_t)4 * H * H;  // elements per plane
+  const int KG = H / 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = i & 7;
+    const int r = (i >> 3) & 31;
+    const int kg = (i >> 8) % KG;
+    const int j = (i >> 8) / KG;
+    const int g = r >> 3, u = r & 7;
+    const float x = w[(size_t)(g * H + 8 * j + u) * H + 8 * kg + e];
+    const __bf16 hi = (__bf16)x;
+    const __bf16 lo = (__bf16)(x - (float)hi);
+    const size_t base = (size_t)j * 2 * KG * 256 + ((size_t)kg * 32 + r) * 8 + e;
+    dst[base] = __builtin_bit_cast(unsigned short, hi);
+    dst[base + (size_t)KG * 256] = __builtin_bit_cast(unsigned short, lo);
   }
 }
 
@@ -234,6 +287,7 @@ struct LstmP {
   float* hx;            // [ndir][2][H/4][NPAD][4]
   unsigned* flags;      // [ndir][J]
   unsigned* status;     // [0]: nonzero = a wait timed out
+  unsigned long long* dbg;  // [ndir*J][8] stamp sums (diagnostic build only)
   int steps, N, n_base, N_total, H, ndir, J, NPAD;
 };
 
@@ -267,7 +321,7 @@ __device__ __forceinline__ bool wait_flags(const unsigned* flags, int count, uns
   }
 }
 
-template <int NB, bool HARD, bool PIPE>
+template <int NB, bool HARD, bool PIPE, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void lstm_persistent_kernel(LstmP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ws = smem;                        // [H/4][32][4]
@@ -312,6 +366,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_kernel(LstmP p) {
   const int kq_base = wave * (KQ / 4);
   const int xcols = p.ndir * 4 * H;
   bool alive = true;
+  unsigned long long st_sum[4] = {0, 0, 0, 0}, st_prev = 0;
+  if (STAMP) st_prev = wall_clock64();
 
   for (int s = 0; s < p.steps; ++s) {
     const int t = d ? (p.steps - 1 - s) : s;
@@ -328,6 +384,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_kernel(LstmP p) {
     }
 
     if (alive) alive = wait_flags(wave_flags, p.J / 4, (unsigned)(s + 1), p.status, lane);
+    if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[0] += now - st_prev; st_prev = now; }
 
     f32x16 acc[NB];
 #pragma unroll
@@ -382,6 +439,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_kernel(LstmP p) {
       }
     }
 
+    if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[1] += now - st_prev; st_prev = now; }
     float hout[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -411,15 +469,288 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_kernel(LstmP p) {
       hout[b] = active ? hnew : 0.f;
       store_sc1_f32(hx_d + (par ^ 1) * KQ * p.NPAD * 4 + hx_slot + (b * 32 + nl) * 4, h[b]);
     }
+    if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[2] += now - st_prev; st_prev = now; }
     // publish h_s: every storing wave drains, then one lane raises this producer's epoch
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(my_flag, (unsigned)(s + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[3] += now - st_prev; st_prev = now; }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const int n = b * 32 + nl;
       if (n < N) p.out[((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit] = hout[b];
     }
+  }
+  if (STAMP && (tid & 63) == 0) {
+    for (int k = 0; k < 4; ++k) atomicAdd(&p.dbg[(size_t)blockIdx.x * 8 + k], st_sum[k]);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int n = b * 32 + nl;
+    if (n < N) {
+      const size_t sidx = ((size_t)d * p.N_total + p.n_base + n) * H + unit;
+      p.hn[sidx] = h[b];
+      p.cn[sidx] = c[b];
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------ persistent LSTM, split-bf16
+//
+// Same decomposition as lstm_persistent_kernel, two changes:
+//  * operands are bf16 (hi, lo) pairs and the product is three v_mfma_f32_32x32x16_bf16
+//    (hi*hi + lo*hi + hi*lo, f32 accumulate): 48 MFMA x 32 cycles per wave and step instead
+//    of 128 x 64;
+//  * the hand-off carries its own validity: every 16-bit element of the exchanged h has its
+//    least significant mantissa bit replaced by a 1-bit epoch tag (the lo part is computed
+//    against the tagged hi, so the split stays exact to 2^-17).  A consumer simply loads
+//    (sc1) and re-loads until every element of its chunk shows the expected tag -- no flag,
+//    no producer-side drain, no second hop (MI355X_MICROARCH.md "R2: the data IS the flag",
+//    with per-element tags so even a torn 16-byte transfer is detected).  The exchange
+//    buffers are memset to 0xFF (tag 1 = invalid for the first epoch) before every launch.
+// hx layout per direction: [plane hi|lo][parity][k/8][N pad 32][8 bf16].
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned bf16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ float bf16_val(unsigned bits) { return __uint_as_float(bits << 16); }
+
+// sc1 + the intrinsic's "volatile" marker (aux bit 31): a re-load inside a polling loop
+// must never be merged with the previous one.
+__device__ __forceinline__ u32x4 load_sc1_u128(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, (int)(0x80000000u | 16u));
+}
+
+// Packs this thread's h (unit u = lane & 7 of batch row lane >> 3) with its 7 neighbours
+// and lets lane u == 0 store the 8 hi parts, lane u == 1 the 8 lo parts (16-byte sc1 stores).
+__device__ __forceinline__ void publish_split(float hval, unsigned tag, __amdgpu_buffer_rsrc_t rsrc, int off_hi, int off_lo,
+                                              int lane) {
+  const unsigned hi = (bf16_bits(hval) & 0xFFFEu) | tag;
+  const unsigned lo = (bf16_bits(hval - bf16_val(hi)) & 0xFFFEu) | tag;
+  const unsigned v = hi | (lo << 16);
+  const int base = lane & ~7;
+  unsigned g[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) g[k] = __shfl(v, base + k, 64);
+  const int u = lane & 7;
+  if (u < 2) {
+    u32x4 o;
+    if (u == 0) {
+      o[0] = (g[0] & 0xFFFFu) | (g[1] << 16); o[1] = (g[2] & 0xFFFFu) | (g[3] << 16);
+      o[2] = (g[4] & 0xFFFFu) | (g[5] << 16); o[3] = (g[6] & 0xFFFFu) | (g[7] << 16);
+    } else {
+      o[0] = (g[0] >> 16) | (g[1] & 0xFFFF0000u); o[1] = (g[2] >> 16) | (g[3] & 0xFFFF0000u);
+      o[2] = (g[4] >> 16) | (g[5] & 0xFFFF0000u); o[3] = (g[6] >> 16) | (g[7] & 0xFFFF0000u);
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, u == 0 ? off_hi : off_lo, 0, /*aux: sc1*/ 16);
+  }
+}
+
+// NCH > 0: the wave's K-quarter is NCH chunks of 4 k-steps (K = 64 each), all held in registers;
+// NCH == 0: any H % 64 == 0, one k-step at a time.
+template <int NB, int NCH, bool HARD, bool STAMP = false>
+__global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = p.H, N = p.N, KG = H / 8;
+  const char* Wbytes = reinterpret_cast<const char*>(smem);  // [hi|lo][KG][32][8 bf16]
+  float* red = smem + (size_t)H * 32;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int d = blockIdx.x / p.J, j = blockIdx.x % p.J;
+  const int nl = tid >> 3, u = tid & 7;
+  const int unit = 8 * j + u;
+
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.whh) + ((size_t)d * p.J + j) * 128 * H);
+    u32x4* dst = reinterpret_cast<u32x4*>(smem);
+    for (int i = tid; i < H * 8; i += 256) dst[i] = src[i];
+  }
+
+  const int plane_bytes = 2 * KG * p.NPAD * 16;
+  char* hx_d = reinterpret_cast<char*>(p.hx) + (size_t)d * 2 * plane_bytes;
+  const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx_d, 0, 2 * plane_bytes, 0x00020000);
+
+  float c[NB], h[NB];
+  int len_n[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int n = b * 32 + nl;
+    const bool valid = n < N;
+    const size_t sidx = ((size_t)d * p.N_total + p.n_base + n) * H + unit;
+    h[b] = (valid && p.h0) ? p.h0[sidx] : 0.f;
+    c[b] = (valid && p.c0) ? p.c0[sidx] : 0.f;
+    len_n[b] = valid ? (p.lens ? p.lens[p.n_base + n] : p.steps) : 0;
+    const int off = (j * p.NPAD + n) * 16;  // parity 0
+    publish_split(h[b], 0u, hx_rsrc, off, plane_bytes + off, lane);
+  }
+  __syncthreads();  // weights are in LDS
+
+  const int kg_base = wave * (KG / 4);
+  const int xcols = p.ndir * 4 * H;
+  bool alive = true;
+  unsigned long long st_sum[4] = {0, 0, 0, 0}, st_prev = 0;
+  if (STAMP) st_prev = wall_clock64();
+
+  for (int s = 0; s < p.steps; ++s) {
+    const int t = d ? (p.steps - 1 - s) : s;
+    const int par = s & 1;
+    const unsigned em = ((s >> 1) & 1) ? 0x00010001u : 0u;  // expected tag, replicated to both halves
+
+    float xg[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int n = b * 32 + nl;
+      const float* xp = p.xproj + ((size_t)t * p.N_total + p.n_base + n) * xcols + d * 4 * H + j * 32 + u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xg[b][g] = (n < N) ? xp[g * 8] : 0.f;
+    }
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+    const int par_off = par * KG * p.NPAD * 16;
+    const unsigned long long t_wait0 = wall_clock64();
+    unsigned spins = 0;
+
+    // one k-step = 16 values of k = two 8-groups (lane half picks one); operands of k-group kg:
+    //   A (h):  hi at par_off + (kg*NPAD + n)*16, lo one plane further
+    //   B (W):  LDS (kg*32 + row)*16, lo KG*512 bytes further
+    auto a_off = [&](int kg, int b) { return par_off + (kg * p.NPAD + b * 32 + l31) * 16; };
+    auto mfma3 = [&](const u32x4& ah, const u32x4& al, int kg, f32x16& accb) {
+      const u32x4 bh = *reinterpret_cast<const u32x4*>(Wbytes + (kg * 32 + l31) * 16);
+      const u32x4 bl = *reinterpret_cast<const u32x4*>(Wbytes + KG * 512 + (kg * 32 + l31) * 16);
+      accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), accb, 0, 0, 0);
+      accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), accb, 0, 0, 0);
+      accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), accb, 0, 0, 0);
+    };
+    auto give_up = [&]() -> bool {  // called while waiting; true = stop waiting for the rest of the launch
+      if ((++spins & 63u) != 0) { __builtin_amdgcn_s_sleep(1); return false; }
+      const unsigned dead = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (dead != 0 || wall_clock64() - t_wait0 > SPIN_LIMIT_TICKS) {
+        if (lane == 0) __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+      }
+      return false;
+    };
+
+    if (NCH > 0) {
+      u32x4 ah[NCH > 0 ? NCH : 1][4][NB], al[NCH > 0 ? NCH : 1][4][NB];
+      auto issue = [&](int cidx, u32x4(&xh)[4][NB], u32x4(&xl)[4][NB]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int kg = kg_base + 2 * (4 * cidx + ks) + half;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            xh[ks][b] = load_sc1_u128(hx_rsrc, a_off(kg, b));
+            xl[ks][b] = load_sc1_u128(hx_rsrc, plane_bytes + a_off(kg, b));
+          }
+        }
+      };
+      auto fresh = [&](u32x4(&xh)[4][NB], u32x4(&xl)[4][NB]) -> bool {
+        unsigned bad = 0;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bad |= (xh[ks][b][e] ^ em) | (xl[ks][b][e] ^ em);
+        return !__any((bad & 0x00010001u) != 0);
+      };
+      // poll on the first chunk only, then fetch the rest in one burst
+      issue(0, ah[0], al[0]);
+      while (alive && !fresh(ah[0], al[0])) {
+        if (give_up()) { alive = false; break; }
+        issue(0, ah[0], al[0]);
+      }
+      if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[0] += now - st_prev; st_prev = now; }
+#pragma unroll
+      for (int cidx = 1; cidx < NCH; ++cidx) issue(cidx, ah[cidx], al[cidx]);
+#pragma unroll
+      for (int cidx = 0; cidx < NCH; ++cidx) {
+        if (cidx > 0) {
+          while (alive && !fresh(ah[cidx], al[cidx])) {
+            if (give_up()) { alive = false; break; }
+            issue(cidx, ah[cidx], al[cidx]);
+          }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int kg = kg_base + 2 * (4 * cidx + ks) + half;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) mfma3(ah[cidx][ks][b], al[cidx][ks][b], kg, acc[b]);
+        }
+      }
+    } else {
+      const int ksteps = KG / 8;  // per wave
+      for (int ks = 0; ks < ksteps; ++ks) {
+        const int kg = kg_base + 2 * ks + half;
+        u32x4 xh[NB], xl[NB];
+        for (;;) {
+          unsigned bad = 0;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            xh[b] = load_sc1_u128(hx_rsrc, a_off(kg, b));
+            xl[b] = load_sc1_u128(hx_rsrc, plane_bytes + a_off(kg, b));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bad |= (xh[b][e] ^ em) | (xl[b][e] ^ em);
+          }
+          if (!alive || !__any((bad & 0x00010001u) != 0)) break;
+          if (give_up()) { alive = false; break; }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) mfma3(xh[b], xl[b], kg, acc[b]);
+      }
+      if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[0] += now - st_prev; st_prev = now; }
+    }
+    if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[1] += now - st_prev; st_prev = now; }
+
+    const unsigned wtag = (unsigned)(((s + 1) >> 1) & 1);
+    float hout[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      __syncthreads();  // previous reads of `red` (earlier tile or earlier step) are done
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave * 32 + ms::mfma32_row(r, lane)) * RED_STRIDE + l31] = acc[b][r];
+      __syncthreads();
+      float gsum[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v = xg[b][g];
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) v += red[(w2 * 32 + nl) * RED_STRIDE + g * 8 + u];
+        gsum[g] = v;
+      }
+      float cnew, hnew;
+      if (HARD) {
+        cnew = clamp01(0.2f * gsum[1] + 0.5f) * c[b] + clamp01(0.2f * gsum[0] + 0.5f) * clamp11(gsum[2]);
+        hnew = clamp01(0.2f * gsum[3] + 0.5f) * clamp11(cnew);
+      } else {
+        cnew = sigmoidf_(gsum[1]) * c[b] + sigmoidf_(gsum[0]) * tanhf(gsum[2]);
+        hnew = sigmoidf_(gsum[3]) * tanhf(cnew);
+      }
+      const bool active = t < len_n[b];
+      c[b] = active ? cnew : c[b];
+      h[b] = active ? hnew : h[b];
+      hout[b] = active ? hnew : 0.f;
+      const int off = (par ^ 1) * KG * p.NPAD * 16 + (j * p.NPAD + b * 32 + nl) * 16;
+      publish_split(h[b], wtag, hx_rsrc, off, plane_bytes + off, lane);
+    }
+    if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[2] += now - st_prev; st_prev = now; }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int n = b * 32 + nl;
+      if (n < N) p.out[((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit] = hout[b];
+    }
+    if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[3] += now - st_prev; st_prev = now; }
+  }
+  if (STAMP && (tid & 63) == 0) {
+    for (int k = 0; k < 4; ++k) atomicAdd(&p.dbg[(size_t)blockIdx.x * 8 + k], st_sum[k]);
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -509,9 +840,20 @@ extern "C" int ms_rnn_pack(int cell, int In, int H, int ndir, const float* const
     const float* bi = b_ih ? b_ih[d] : nullptr;
     const float* bh = b_hh ? b_hh[d] : nullptr;
     if (fast) {
-      hipLaunchKernelGGL(pack_rows_fast_kernel, dim3(4 * H), dim3(128), 0, stream, w_ih[d], wih_d, H, In);
+      if (use_split_gemm(cell, H, ndir, In)) {
+        unsigned short* hi0 = (unsigned short*)(base + L.wih);
+        unsigned short* lo0 = hi0 + (size_t)ndir * GH * In;
+        hipLaunchKernelGGL(pack_rows_split_kernel, dim3(4 * H), dim3(128), 0, stream, w_ih[d], hi0 + (size_t)d * GH * In,
+                           lo0 + (size_t)d * GH * In, H, In);
+      } else {
+        hipLaunchKernelGGL(pack_rows_fast_kernel, dim3(4 * H), dim3(128), 0, stream, w_ih[d], wih_d, H, In);
+      }
       hipLaunchKernelGGL(pack_bias_fast_kernel, dim3(ms::cdiv(4 * H, 256)), dim3(256), 0, stream, bi, bh, bx_d, H);
-      hipLaunchKernelGGL(pack_whh_fast_kernel, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d], whh_d, H);
+      if (use_split(cell, H, ndir))
+        hipLaunchKernelGGL(pack_whh_split_kernel, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d],
+                           (unsigned short*)whh_d, H);
+      else
+        hipLaunchKernelGGL(pack_whh_fast_kernel, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d], whh_d, H);
       hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH)), dim3(256), 0, stream, (const float*)nullptr, bhh_d,
                          GH);
     } else {
@@ -526,21 +868,34 @@ extern "C" int ms_rnn_pack(int cell, int In, int H, int ndir, const float* const
 }
 
 extern "C" size_t ms_rnn_workspace_bytes(int cell, int T, int N, int In, int H, int ndir) {
-  (void)In;
-  if (cell < 0 || cell > MS_CELL_HARD_LSTM || T <= 0 || N <= 0 || H <= 0 || ndir < 1 || ndir > 2) return 0;
-  return ws_layout(cell, T, N, H, ndir).total;
+  if (cell < 0 || cell > MS_CELL_HARD_LSTM || T <= 0 || N <= 0 || In <= 0 || H <= 0 || ndir < 1 || ndir > 2) return 0;
+  return ws_layout(cell, T, N, H, ndir, In).total;
 }
 
-template <int NB, bool HARD, bool PIPE>
+template <int NB, bool HARD, bool PIPE, bool STAMP = false>
 static int launch_persistent(const LstmP& p, hipStream_t stream) {
   const size_t lds = ((size_t)p.H * 32 + RED_FLOATS) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_kernel<NB, HARD, PIPE>,
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_kernel<NB, HARD, PIPE, STAMP>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((lstm_persistent_kernel<NB, HARD, PIPE>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((lstm_persistent_kernel<NB, HARD, PIPE, STAMP>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}
+
+template <int NB, int NCH, bool HARD, bool STAMP = false>
+static int launch_split(const LstmP& p, hipStream_t stream) {
+  const size_t lds = ((size_t)p.H * 32 + RED_FLOATS) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_split_kernel<NB, NCH, HARD, STAMP>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((lstm_persistent_split_kernel<NB, NCH, HARD, STAMP>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }
@@ -557,7 +912,7 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
   hipStream_t stream = (hipStream_t)stream_;
   const int G = gates_of(cell);
   const size_t GH = (size_t)G * H;
-  const WsLayout W = ws_layout(cell, T, N, H, ndir);
+  const WsLayout W = ws_layout(cell, T, N, H, ndir, In);
   if (workspace_bytes < W.total) {
     ms::set_error("ms_rnn_layer_forward: workspace too small");
     return MS_ERR_WORKSPACE;
@@ -580,8 +935,19 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
   int rc;
   {
     ProfScope prof(0, stream);
-    rc = ms::linear_launch(x, (const float*)(pk + L.wih), (const float*)(pk + L.bias_x), xproj, steps * N, In,
-                           (int)(ndir * GH), MS_ACT_NONE, 0.f, 0.f, stream);
+    if (use_split_gemm(cell, H, ndir, In)) {
+      unsigned short* xh = (unsigned short*)(ws + W.xsplit);
+      unsigned short* xl = xh + (size_t)steps * N * In;
+      const unsigned short* wh = (const unsigned short*)(pk + L.wih);
+      const unsigned short* wl = wh + (size_t)ndir * GH * In;
+      rc = ms::split_planes_launch(x, xh, xl, (size_t)steps * N * In, stream);
+      if (rc == MS_OK)
+        rc = ms::gemm_bf16x3_launch(xh, xl, wh, wl, (const float*)(pk + L.bias_x), xproj, steps * N, In, (int)(ndir * GH),
+                                    stream);
+    } else {
+      rc = ms::linear_launch(x, (const float*)(pk + L.wih), (const float*)(pk + L.bias_x), xproj, steps * N, In,
+                             (int)(ndir * GH), MS_ACT_NONE, 0.f, 0.f, stream);
+    }
   }
   if (rc != MS_OK) return rc;
   ProfScope prof_rec(1, stream);
@@ -603,7 +969,31 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
       p.steps = steps; p.N = ng; p.n_base = n0; p.N_total = N; p.H = H; p.ndir = ndir; p.J = H / 8;
       p.NPAD = ms::cdiv(ng, 32) * 32;
       const bool hard = (cell == MS_CELL_HARD_LSTM);
+      p.dbg = (unsigned long long*)(ws + W.dbg);
       const bool pipe = (H % 256 == 0);
+      static const bool stamps = getenv("MS_LSTM_STAMPS") && getenv("MS_LSTM_STAMPS")[0] == '1';
+      if (use_split(cell, H, ndir)) {
+        // tag 1 everywhere = "not yet written" for the first epoch of either parity
+        MS_HIP(hipMemsetAsync(ws + W.hx, 0xFF, W.state_h - W.hx, stream));
+        const bool hard_ = (cell == MS_CELL_HARD_LSTM);
+        if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.total - W.dbg, stream));
+        if (p.NPAD == 32 && H == 1024) {
+          if (stamps && !hard_) rc = launch_split<1, 4, false, true>(p, stream);
+          else rc = hard_ ? launch_split<1, 4, true>(p, stream) : launch_split<1, 4, false>(p, stream);
+        } else if (p.NPAD == 32) {
+          rc = hard_ ? launch_split<1, 0, true>(p, stream) : launch_split<1, 0, false>(p, stream);
+        } else {
+          rc = hard_ ? launch_split<2, 0, true>(p, stream) : launch_split<2, 0, false>(p, stream);
+        }
+        if (rc != MS_OK) return rc;
+        continue;
+      }
+      if (stamps && pipe && p.NPAD == 32 && !(cell == MS_CELL_HARD_LSTM)) {
+        MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.total - W.dbg, stream));
+        rc = launch_persistent<1, false, true, true>(p, stream);
+        if (rc != MS_OK) return rc;
+        continue;
+      }
       if (p.NPAD == 32) {
         if (pipe) rc = hard ? launch_persistent<1, true, true>(p, stream) : launch_persistent<1, false, true>(p, stream);
         else rc = hard ? launch_persistent<1, true, false>(p, stream) : launch_persistent<1, false, false>(p, stream);
@@ -640,6 +1030,10 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
   }
   MS_LAUNCH_CHECK();
   return MS_OK;
+}
+
+extern "C" size_t ms_rnn_debug_offset(int cell, int T, int N, int In, int H, int ndir) {
+  return ws_layout(cell, T, N, H, ndir, In).dbg;
 }
 
 extern "C" int ms_rnn_status(const void* workspace, void* stream) {
