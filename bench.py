@@ -111,7 +111,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torchrun (also with one rank) the collective path is exercised
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -183,7 +183,7 @@ def main():
             "encoder_ms_per_rnn_step": round(ms_per_step / t_out, 4),
             "kernel_ms": {"lstm_recurrent_per_layer": round(rec_ms, 3), "lstm_input_projection_per_layer":
                           round(ms[0] / max(cnt[0], 1), 3)},
-            "roofline": {"bound": "hbm", "kernel": "lstm_persistent_split_kernel (one launch = 1 layer x 2 directions x 501 steps)",
+            "roofline": {"bound": "hbm", "kernel": "lstm_persistent_split2_kernel (one launch = 1 layer x 2 directions x 501 steps)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
                          "algorithmic_bytes_per_launch": launch_bytes},

@@ -85,6 +85,13 @@ int ms_clamp(const float* x, float* y, size_t n, float lo, float hi, void* strea
 int ms_linear_forward(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
                       float act_lo, float act_hi, void* stream);
 
+/* Same contract as ms_linear_forward for K % 32 == 0, computed with float32 operands split
+ * into bf16 hi + lo (x.w ~= x_hi.w_hi + x_lo.w_hi + x_hi.w_lo, f32 accumulate; relative error
+ * ~2^-17 per product).  The workspace holds the four bf16 planes. */
+size_t ms_linear_split_workspace_bytes(int M, int K, int N);
+int ms_linear_split_forward(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
+                            float act_lo, float act_hi, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- model/lookahead.py ------------------------------------------------- */
 
 /* Lookahead.forward (lookahead.py:65-69): y[n,f,t] = sum_k w[f,k] * x[n,f,t+k]

@@ -34,6 +34,8 @@ SIGNATURES = {
     "ms_nct_to_tnc": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ms_clamp": (c_int, [_P, _P, c_size_t, c_float, c_float, _P]),
     "ms_linear_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
+    "ms_linear_split_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ms_linear_split_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
     "ms_lookahead_forward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_int, c_float, c_float, _P]),
     "ms_rnn_packed_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ms_rnn_pack": (c_int, [c_int, c_int, c_int, c_int, _PP, _PP, _PP, _PP, _P, _P]),
@@ -113,6 +115,11 @@ def f32c(t):
 def lens_i32(lens):
     """int32 device copy of a lengths tensor."""
     return lens.to(device="cuda", dtype=torch.int32).contiguous()
+
+
+def split_precision():
+    """True unless MS_PRECISION=f32 (exact float32 MFMA everywhere)."""
+    return os.environ.get("MS_PRECISION") != "f32"
 
 
 class Workspace:

@@ -47,10 +47,10 @@ constexpr int B_PLANE = SB_N * 16 + 32;
 constexpr int A_TILE = 4 * A_PLANE, B_TILE = 4 * B_PLANE;
 constexpr int SPLIT_LDS = 2 * A_TILE + 2 * B_TILE;
 
+// Rows past the matrix edge are clamped to the last row (their products are never stored), so
+// the loads need no predicate; K % 32 == 0 is a launch precondition.
 __device__ __forceinline__ u32x4 ld_granule(const unsigned short* __restrict__ p, int rows, int K, int row, int k) {
-  u32x4 v = {0u, 0u, 0u, 0u};
-  if (row < rows && k < K) v = *reinterpret_cast<const u32x4*>(p + (size_t)row * K + k);
-  return v;
+  return *reinterpret_cast<const u32x4*>(p + (size_t)min(row, rows - 1) * K + k);
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel(const unsigned short* __restrict__ Ah,
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel(const unsigned s
                                                                 const unsigned short* __restrict__ Wh,
                                                                 const unsigned short* __restrict__ Wl,
                                                                 const float* __restrict__ bias, float* __restrict__ Y,
-                                                                int M, int K, int N) {
+                                                                int M, int K, int N, int act, float lo, float hi) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* sAh = lds;
   char* sAl = lds + A_TILE;
@@ -160,7 +160,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel(const unsigned s
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wave * 64 + i * 32 + mfma32_row(r, lane);
-        if (m < M && n < N) Y[(size_t)m * N + n] = acc[i][j][r] + bv;
+        if (m < M && n < N) {
+          float v = acc[i][j][r] + bv;
+          if (act == MS_ACT_CLAMP) v = fminf(fmaxf(v, lo), hi);
+          Y[(size_t)m * N + n] = v;
+        }
       }
   }
 }
@@ -174,18 +178,47 @@ int split_planes_launch(const float* x, unsigned short* hi, unsigned short* lo, 
   return MS_OK;
 }
 
-// requires K % 8 == 0 and 16-byte aligned planes
+// requires K % 32 == 0 and 16-byte aligned planes
 int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
-                       const unsigned short* wl, const float* bias, float* y, int M, int K, int N, hipStream_t stream) {
+                       const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
+                       float hi, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS));
     attr_set = true;
   }
   const int nwg = cdiv(M, SB_M) * cdiv(N, SB_N);
-  hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, dim3(nwg), dim3(256), SPLIT_LDS, stream, ah, al, wh, wl, bias, y, M, K, N);
+  hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, dim3(nwg), dim3(256), SPLIT_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }
 
 }  // namespace ms
+
+extern "C" size_t ms_linear_split_workspace_bytes(int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 0;
+  return ms::align_up((size_t)M * K * 4, 256) + ms::align_up((size_t)N * K * 4, 256);
+}
+
+extern "C" int ms_linear_split_forward(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
+                                       int act, float act_lo, float act_hi, void* workspace, size_t workspace_bytes,
+                                       void* stream_) {
+  MS_REQUIRE(x && w && y && workspace, "null pointer");
+  MS_REQUIRE(M > 0 && K > 0 && N > 0, "bad shape");
+  MS_REQUIRE(K % 32 == 0, "K must be a multiple of 32 (use ms_linear_forward otherwise)");
+  MS_REQUIRE(act == MS_ACT_NONE || act == MS_ACT_CLAMP, "bad act");
+  MS_REQUIRE((((uintptr_t)x | (uintptr_t)w) & 15) == 0, "x and w must be 16-byte aligned");
+  if (workspace_bytes < ms_linear_split_workspace_bytes(M, K, N)) {
+    ms::set_error("ms_linear_split_forward: workspace too small");
+    return MS_ERR_WORKSPACE;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  unsigned short* xh = (unsigned short*)workspace;
+  unsigned short* xl = xh + (size_t)M * K;
+  unsigned short* wh = (unsigned short*)((char*)workspace + ms::align_up((size_t)M * K * 4, 256));
+  unsigned short* wl = wh + (size_t)N * K;
+  int rc = ms::split_planes_launch(x, xh, xl, (size_t)M * K, stream);
+  if (rc == MS_OK) rc = ms::split_planes_launch(w, wh, wl, (size_t)N * K, stream);
+  if (rc == MS_OK) rc = ms::gemm_bf16x3_launch(xh, xl, wh, wl, bias, y, M, K, N, act, act_lo, act_hi, stream);
+  return rc;
+}

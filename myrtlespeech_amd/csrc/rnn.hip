@@ -32,7 +32,8 @@
 namespace ms {
 int split_planes_launch(const float* x, unsigned short* hi, unsigned short* lo, size_t elems, hipStream_t stream);
 int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
-                       const unsigned short* wl, const float* bias, float* y, int M, int K, int N, hipStream_t stream);
+                       const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
+                       float hi, hipStream_t stream);
 int linear_launch(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act, float lo,
                   float hi, hipStream_t stream);
 }
@@ -78,7 +79,7 @@ bool want_split() {
 }
 bool use_split(int cell, int H, int ndir) { return use_fast(cell, H, ndir) && want_split() && H % 64 == 0; }
 // the input projection runs as the bf16x3 GEMM whenever the recurrence is split and In allows 16-byte granules
-bool use_split_gemm(int cell, int H, int ndir, int In) { return use_split(cell, H, ndir) && In % 8 == 0; }
+bool use_split_gemm(int cell, int H, int ndir, int In) { return use_split(cell, H, ndir) && In % 32 == 0; }
 
 struct PackLayout {
   size_t wih, bias_x, whh, bhh, total;  // byte offsets
@@ -191,6 +192,14 @@ int blocks_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 2048); 
 // ------------------------------------------------------------------------------------------------ generic step
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// v_exp_f32 / v_rcp_f32 forms for the persistent kernels (1 ulp each; the generic path keeps
+// the libm versions): the cell update sits on the per-step latency chain.
+__device__ __forceinline__ float fast_sigmoid(float v) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * v));
+}
+__device__ __forceinline__ float fast_tanh(float v) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177793f * v));
+}
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
 __device__ __forceinline__ float clamp11(float v) { return fminf(fmaxf(v, -1.f), 1.f); }
 
@@ -524,27 +533,29 @@ __device__ __forceinline__ u32x4 load_sc1_u128(__amdgpu_buffer_rsrc_t rsrc, int 
 }
 
 // Packs this thread's h (unit u = lane & 7 of batch row lane >> 3) with its 7 neighbours
-// and lets lane u == 0 store the 8 hi parts, lane u == 1 the 8 lo parts (16-byte sc1 stores).
+// (DPP row shifts: lane i reads lane i+k of its 16-lane row) and lets lane u == 0 store the
+// 8 hi parts and the 8 lo parts (two 16-byte sc1 stores).
+template <int K>
+__device__ __forceinline__ unsigned row_shl(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + K, 0xF, 0xF, true);
+}
 __device__ __forceinline__ void publish_split(float hval, unsigned tag, __amdgpu_buffer_rsrc_t rsrc, int off_hi, int off_lo,
                                               int lane) {
   const unsigned hi = (bf16_bits(hval) & 0xFFFEu) | tag;
   const unsigned lo = (bf16_bits(hval - bf16_val(hi)) & 0xFFFEu) | tag;
   const unsigned v = hi | (lo << 16);
-  const int base = lane & ~7;
   unsigned g[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) g[k] = __shfl(v, base + k, 64);
-  const int u = lane & 7;
-  if (u < 2) {
-    u32x4 o;
-    if (u == 0) {
-      o[0] = (g[0] & 0xFFFFu) | (g[1] << 16); o[1] = (g[2] & 0xFFFFu) | (g[3] << 16);
-      o[2] = (g[4] & 0xFFFFu) | (g[5] << 16); o[3] = (g[6] & 0xFFFFu) | (g[7] << 16);
-    } else {
-      o[0] = (g[0] >> 16) | (g[1] & 0xFFFF0000u); o[1] = (g[2] >> 16) | (g[3] & 0xFFFF0000u);
-      o[2] = (g[4] >> 16) | (g[5] & 0xFFFF0000u); o[3] = (g[6] >> 16) | (g[7] & 0xFFFF0000u);
-    }
-    __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, u == 0 ? off_hi : off_lo, 0, /*aux: sc1*/ 16);
+  g[0] = v;
+  g[1] = row_shl<1>(v); g[2] = row_shl<2>(v); g[3] = row_shl<3>(v); g[4] = row_shl<4>(v);
+  g[5] = row_shl<5>(v); g[6] = row_shl<6>(v); g[7] = row_shl<7>(v);
+  if ((lane & 7) == 0) {
+    u32x4 oh, ol;
+    oh[0] = (g[0] & 0xFFFFu) | (g[1] << 16); oh[1] = (g[2] & 0xFFFFu) | (g[3] << 16);
+    oh[2] = (g[4] & 0xFFFFu) | (g[5] << 16); oh[3] = (g[6] & 0xFFFFu) | (g[7] << 16);
+    ol[0] = (g[0] >> 16) | (g[1] & 0xFFFF0000u); ol[1] = (g[2] >> 16) | (g[3] & 0xFFFF0000u);
+    ol[2] = (g[4] >> 16) | (g[5] & 0xFFFF0000u); ol[3] = (g[6] >> 16) | (g[7] & 0xFFFF0000u);
+    __builtin_amdgcn_raw_buffer_store_b128(oh, rsrc, off_hi, 0, /*aux: sc1*/ 16);
+    __builtin_amdgcn_raw_buffer_store_b128(ol, rsrc, off_lo, 0, /*aux: sc1*/ 16);
   }
 }
 
@@ -594,6 +605,18 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) 
   unsigned long long st_sum[4] = {0, 0, 0, 0}, st_prev = 0;
   if (STAMP) st_prev = wall_clock64();
 
+  // NCH > 0: this wave's share of W_hh (its K-quarter x 32 gate rows, hi and lo) lives in
+  // 128 VGPRs per lane for the whole sequence -- the MFMA B operand never touches LDS.
+  u32x4 wreg_h[NCH > 0 ? 4 * NCH : 1], wreg_l[NCH > 0 ? 4 * NCH : 1];
+  if (NCH > 0) {
+#pragma unroll
+    for (int i = 0; i < 4 * NCH; ++i) {
+      const int kg = kg_base + 2 * i + half;
+      wreg_h[i] = *reinterpret_cast<const u32x4*>(Wbytes + (kg * 32 + l31) * 16);
+      wreg_l[i] = *reinterpret_cast<const u32x4*>(Wbytes + KG * 512 + (kg * 32 + l31) * 16);
+    }
+  }
+
   for (int s = 0; s < p.steps; ++s) {
     const int t = d ? (p.steps - 1 - s) : s;
     const int par = s & 1;
@@ -640,6 +663,11 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) 
     };
 
     if (NCH > 0) {
+      auto mfma3r = [&](const u32x4& xh, const u32x4& xl, const u32x4& bh, const u32x4& bl, f32x16& accb) {
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xh), __builtin_bit_cast(bf16x8, bh), accb, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xl), __builtin_bit_cast(bf16x8, bh), accb, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xh), __builtin_bit_cast(bf16x8, bl), accb, 0, 0, 0);
+      };
       u32x4 ah[NCH > 0 ? NCH : 1][4][NB], al[NCH > 0 ? NCH : 1][4][NB];
       auto issue = [&](int cidx, u32x4(&xh)[4][NB], u32x4(&xl)[4][NB]) {
 #pragma unroll
@@ -681,9 +709,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) 
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          const int kg = kg_base + 2 * (4 * cidx + ks) + half;
 #pragma unroll
-          for (int b = 0; b < NB; ++b) mfma3(ah[cidx][ks][b], al[cidx][ks][b], kg, acc[b]);
+          for (int b = 0; b < NB; ++b) mfma3r(ah[cidx][ks][b], al[cidx][ks][b], wreg_h[4 * cidx + ks], wreg_l[4 * cidx + ks], acc[b]);
         }
       }
     } else {
@@ -731,8 +758,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) 
         cnew = clamp01(0.2f * gsum[1] + 0.5f) * c[b] + clamp01(0.2f * gsum[0] + 0.5f) * clamp11(gsum[2]);
         hnew = clamp01(0.2f * gsum[3] + 0.5f) * clamp11(cnew);
       } else {
-        cnew = sigmoidf_(gsum[1]) * c[b] + sigmoidf_(gsum[0]) * tanhf(gsum[2]);
-        hnew = sigmoidf_(gsum[3]) * tanhf(cnew);
+        cnew = fast_sigmoid(gsum[1]) * c[b] + fast_sigmoid(gsum[0]) * fast_tanh(gsum[2]);
+        hnew = fast_sigmoid(gsum[3]) * fast_tanh(cnew);
       }
       const bool active = t < len_n[b];
       c[b] = active ? cnew : c[b];
@@ -759,6 +786,192 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) 
       const size_t sidx = ((size_t)d * p.N_total + p.n_base + n) * H + unit;
       p.hn[sidx] = h[b];
       p.cn[sidx] = c[b];
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------ persistent LSTM, split-bf16, two streams
+//
+// The recurrence of one batch is a latency chain: publish h_t -> visible on the other CUs
+// (~1 us) -> load -> MFMA -> cell -> publish h_{t+1}.  Batch rows are independent, so the 32 rows
+// are cut into two streams of 16 that alternate on the same workgroup: while stream A's h_t is
+// in flight through the fabric, the workgroup computes stream B's step, and vice versa.  The
+// MFMA shape drops to 16x16x32 (16 batch rows x 16 gate rows, two column tiles), which costs
+// exactly half the cycles of the 32x32x16 tile, so no matrix throughput is lost.
+// H == 1024, N <= 32.  hx layout per direction: [stream][plane hi|lo][parity][k/8][16][8 bf16].
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <bool HARD, bool STAMP = false>
+__global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p) {
+  constexpr int H = 1024, KG = H / 8, KS = KG / 16;  // KS k-steps (K = 32) per wave
+  constexpr int RED2 = 4 * 16 * RED_STRIDE;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* red = smem;  // [stream][4 waves][16 rows][RED_STRIDE]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q = lane >> 4;
+  const int d = blockIdx.x / p.J, j = blockIdx.x % p.J;
+  const int nl = (tid >> 3) & 15, u = tid & 7;  // cell threads are waves 0 and 1
+  const int unit = 8 * j + u;
+  const int N = p.N;
+
+  // this wave's share of W_hh (its K-quarter x 32 gate rows, hi and lo planes) stays in 128 VGPRs
+  // per lane for the whole sequence: the MFMA B operand never touches LDS or HBM again
+  u32x4 wh0[KS], wh1[KS], wl0[KS], wl1[KS];
+  {
+    const char* wsrc = reinterpret_cast<const char*>(p.whh) + ((size_t)d * p.J + j) * 128 * H;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int kg = wave * (KG / 4) + 4 * ks + q;
+      const char* wp = wsrc + (kg * 32 + c16) * 16;
+      wh0[ks] = *reinterpret_cast<const u32x4*>(wp);
+      wh1[ks] = *reinterpret_cast<const u32x4*>(wp + 256);
+      wl0[ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512);
+      wl1[ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512 + 256);
+    }
+  }
+
+  constexpr int PLANE = 2 * KG * 256;       // bytes: [parity][kg][16][8 bf16]
+  constexpr int STREAM = 2 * PLANE;
+  char* hx_d = reinterpret_cast<char*>(p.hx) + (size_t)d * 2 * STREAM;
+  const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx_d, 0, 2 * STREAM, 0x00020000);
+
+  float c[2] = {0.f, 0.f}, h[2] = {0.f, 0.f};
+  int len_n[2] = {0, 0};
+  if (wave < 2) {
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      const int n = sg * 16 + nl;
+      const bool valid = n < N;
+      const size_t sidx = ((size_t)d * p.N_total + p.n_base + n) * H + unit;
+      h[sg] = (valid && p.h0) ? p.h0[sidx] : 0.f;
+      c[sg] = (valid && p.c0) ? p.c0[sidx] : 0.f;
+      len_n[sg] = valid ? (p.lens ? p.lens[p.n_base + n] : p.steps) : 0;
+      const int off = sg * STREAM + j * 256 + nl * 16;  // parity 0
+      publish_split(h[sg], 0u, hx_rsrc, off, PLANE + off, lane);
+    }
+  }
+  __syncthreads();
+
+  const int kg_base = wave * (KG / 4);
+  const int xcols = p.ndir * 4 * H;
+  bool alive = true;
+  unsigned long long st_sum[4] = {0, 0, 0, 0}, st_prev = 0;
+  if (STAMP) st_prev = wall_clock64();
+
+  for (int s = 0; s < p.steps; ++s) {
+    const int t = d ? (p.steps - 1 - s) : s;
+    const int par = s & 1;
+    const unsigned em = ((s >> 1) & 1) ? 0x00010001u : 0u;
+    const unsigned wtag = (unsigned)(((s + 1) >> 1) & 1);
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      float xg[4] = {0.f, 0.f, 0.f, 0.f};
+      const int n = sg * 16 + nl;
+      if (wave < 2 && n < N) {
+        const float* xp = p.xproj + ((size_t)t * p.N_total + p.n_base + n) * xcols + d * 4 * H + j * 32 + u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xg[g] = xp[g * 8];
+      }
+
+      // ---- h_{t-1} of this stream: all 8 k-steps of the wave's K-quarter at once
+      const int base = sg * STREAM + par * KG * 256 + c16 * 16;
+      u32x4 ah[KS], al[KS];
+      const unsigned long long t_wait0 = wall_clock64();
+      unsigned spins = 0;
+      for (;;) {
+        unsigned bad = 0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int kg = kg_base + 4 * ks + q;
+          ah[ks] = load_sc1_u128(hx_rsrc, base + kg * 256);
+          al[ks] = load_sc1_u128(hx_rsrc, PLANE + base + kg * 256);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bad |= (ah[ks][e] ^ em) | (al[ks][e] ^ em);
+        if (!alive || !__any((bad & 0x00010001u) != 0)) break;
+        if ((++spins & 63u) == 0) {
+          const unsigned dead = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (dead != 0 || wall_clock64() - t_wait0 > SPIN_LIMIT_TICKS) {
+            if (lane == 0) __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            alive = false;
+            break;
+          }
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[0] += now - st_prev; st_prev = now; }
+
+      f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 bh0 = __builtin_bit_cast(bf16x8, wh0[ks]);
+        const bf16x8 bh1 = __builtin_bit_cast(bf16x8, wh1[ks]);
+        const bf16x8 bl0 = __builtin_bit_cast(bf16x8, wl0[ks]);
+        const bf16x8 bl1 = __builtin_bit_cast(bf16x8, wl1[ks]);
+        const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]);
+        const bf16x8 xl = __builtin_bit_cast(bf16x8, al[ks]);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl1, acc1, 0, 0, 0);
+      }
+      if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[1] += now - st_prev; st_prev = now; }
+
+      // ---- reduce the 4 K-quarters, cell update on waves 0/1, publish.  `red` is double-buffered
+      // by stream, so the only barrier is write -> read (the readers of this buffer two
+      // stream-steps ago have since passed the other stream's barrier).
+      float* redb = red + sg * RED2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        redb[(wave * 16 + 4 * q + i) * RED_STRIDE + c16] = acc0[i];
+        redb[(wave * 16 + 4 * q + i) * RED_STRIDE + 16 + c16] = acc1[i];
+      }
+      __syncthreads();
+      if (wave < 2) {
+        float gsum[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v = xg[g];
+#pragma unroll
+          for (int w2 = 0; w2 < 4; ++w2) v += redb[(w2 * 16 + nl) * RED_STRIDE + g * 8 + u];
+          gsum[g] = v;
+        }
+        float cnew, hnew;
+        if (HARD) {
+          cnew = clamp01(0.2f * gsum[1] + 0.5f) * c[sg] + clamp01(0.2f * gsum[0] + 0.5f) * clamp11(gsum[2]);
+          hnew = clamp01(0.2f * gsum[3] + 0.5f) * clamp11(cnew);
+        } else {
+          cnew = fast_sigmoid(gsum[1]) * c[sg] + fast_sigmoid(gsum[0]) * fast_tanh(gsum[2]);
+          hnew = fast_sigmoid(gsum[3]) * fast_tanh(cnew);
+        }
+        const bool active = t < len_n[sg];
+        c[sg] = active ? cnew : c[sg];
+        h[sg] = active ? hnew : h[sg];
+        const int off = sg * STREAM + (par ^ 1) * KG * 256 + j * 256 + nl * 16;
+        publish_split(h[sg], wtag, hx_rsrc, off, PLANE + off, lane);
+        if (n < N) p.out[((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit] = active ? hnew : 0.f;
+      }
+      if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[2] += now - st_prev; st_prev = now; }
+    }
+  }
+  if (STAMP && (tid & 63) == 0) {
+    for (int k = 0; k < 4; ++k) atomicAdd(&p.dbg[(size_t)blockIdx.x * 8 + k], st_sum[k]);
+  }
+  if (wave < 2) {
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      const int n = sg * 16 + nl;
+      if (n < N) {
+        const size_t sidx = ((size_t)d * p.N_total + p.n_base + n) * H + unit;
+        p.hn[sidx] = h[sg];
+        p.cn[sidx] = c[sg];
+      }
     }
   }
 }
@@ -900,6 +1113,20 @@ static int launch_split(const LstmP& p, hipStream_t stream) {
   return MS_OK;
 }
 
+template <bool HARD, bool STAMP = false>
+static int launch_split2(const LstmP& p, hipStream_t stream) {
+  const size_t lds = (size_t)RED_FLOATS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_split2_kernel<HARD, STAMP>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((lstm_persistent_split2_kernel<HARD, STAMP>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}
+
 extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x, const int32_t* lens, int max_len,
                                     const float* h0, const float* c0, float* out, float* hn, float* cn, int T, int N,
                                     int In, int H, int ndir, void* workspace, size_t workspace_bytes, void* stream_) {
@@ -943,7 +1170,7 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
       rc = ms::split_planes_launch(x, xh, xl, (size_t)steps * N * In, stream);
       if (rc == MS_OK)
         rc = ms::gemm_bf16x3_launch(xh, xl, wh, wl, (const float*)(pk + L.bias_x), xproj, steps * N, In, (int)(ndir * GH),
-                                    stream);
+                                    MS_ACT_NONE, 0.f, 0.f, stream);
     } else {
       rc = ms::linear_launch(x, (const float*)(pk + L.wih), (const float*)(pk + L.bias_x), xproj, steps * N, In,
                              (int)(ndir * GH), MS_ACT_NONE, 0.f, 0.f, stream);
@@ -977,7 +1204,11 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
         MS_HIP(hipMemsetAsync(ws + W.hx, 0xFF, W.state_h - W.hx, stream));
         const bool hard_ = (cell == MS_CELL_HARD_LSTM);
         if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.total - W.dbg, stream));
-        if (p.NPAD == 32 && H == 1024) {
+        static const bool one_stream = getenv("MS_LSTM_ONE_STREAM") && getenv("MS_LSTM_ONE_STREAM")[0] == '1';
+        if (p.NPAD == 32 && H == 1024 && !one_stream) {
+          if (stamps && !hard_) rc = launch_split2<false, true>(p, stream);
+          else rc = hard_ ? launch_split2<true>(p, stream) : launch_split2<false>(p, stream);
+        } else if (p.NPAD == 32 && H == 1024) {
           if (stamps && !hard_) rc = launch_split<1, 4, false, true>(p, stream);
           else rc = hard_ ? launch_split<1, 4, true>(p, stream) : launch_split<1, 4, false>(p, stream);
         } else if (p.NPAD == 32) {

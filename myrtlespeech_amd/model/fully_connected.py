@@ -34,8 +34,13 @@ def linear_stack_plan(module: Union[torch.nn.Linear, torch.nn.Sequential], train
     return plan
 
 
+_SPLIT_MIN_FLOPS = 2e9  # below this the two plane-split passes cost more than they save
+_split_ws = _lib.Workspace()
+
+
 def run_linear_stack(x2d: torch.Tensor, plan) -> torch.Tensor:
-    """x2d [M, K] float32 cuda contiguous."""
+    """x2d [M, K] float32 cuda contiguous.  Large layers with K % 32 == 0 run as the
+    split-bf16 GEMM (unless MS_PRECISION=f32), the rest as the exact-f32 GEMM."""
     lib = _lib.load()
     h = x2d
     for lin, clamp in plan:
@@ -47,8 +52,13 @@ def run_linear_stack(x2d: torch.Tensor, plan) -> torch.Tensor:
         a, lo, hi = (_lib.ACT_NONE, 0.0, 0.0) if clamp is None else (_lib.ACT_CLAMP, clamp[0], clamp[1])
         w = _lib.f32c(lin.weight.detach())
         b = None if lin.bias is None else _lib.f32c(lin.bias.detach())
-        _lib.check(lib.ms_linear_forward(_lib.ptr(h), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), m, k, n, a, lo, hi,
-                                         _lib.stream_ptr()), "ms_linear_forward")
+        if _lib.split_precision() and k % 32 == 0 and 2.0 * m * k * n >= _SPLIT_MIN_FLOPS:
+            ws = _split_ws.get(lib.ms_linear_split_workspace_bytes(m, k, n))
+            _lib.check(lib.ms_linear_split_forward(_lib.ptr(h), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), m, k, n, a, lo, hi,
+                                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "ms_linear_split_forward")
+        else:
+            _lib.check(lib.ms_linear_forward(_lib.ptr(h), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), m, k, n, a, lo, hi,
+                                             _lib.stream_ptr()), "ms_linear_forward")
         h = y
     return h
 

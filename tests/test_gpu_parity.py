@@ -402,3 +402,25 @@ def test_beam_one_output_per_batch_element_on_garbage():
     x[0, 0, 0] = float("nan")
     out = CTCBeamDecoder(0, 3)(x, torch.tensor([7, 7, 3, 1, 0]))
     assert len(out) == 5 and all(isinstance(o, list) for o in out)
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 64, 200), (257, 2048, 129), (1000, 640, 8192)])
+@pytest.mark.parametrize("act", [None, (0.0, 20.0)])
+def test_linear_split_bf16x3(lib, M, K, N, act):
+    """x.w as x_hi.w_hi + x_lo.w_hi + x_hi.w_lo: within 1e-5 of |x|.|w| per output."""
+    from myrtlespeech_amd import _lib
+    rng = np.random.default_rng(M + K + N)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.normal(size=(N,)).astype(np.float32)
+    xd, wd, bd = T(x).cuda(), T(w).cuda(), T(b).cuda()
+    y = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    ws = torch.empty(lib.ms_linear_split_workspace_bytes(M, K, N), dtype=torch.uint8, device="cuda")
+    a, lo, hi = (0, 0.0, 0.0) if act is None else (1, act[0], act[1])
+    _lib.check(lib.ms_linear_split_forward(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), M, K, N, a, lo, hi,
+                                           _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "linear_split")
+    want = x.astype(np.float64) @ w.T.astype(np.float64) + b
+    if act is not None:
+        want = np.clip(want, *act)
+    bound = 1e-5 * (np.abs(x).astype(np.float64) @ np.abs(w.T).astype(np.float64)).max() + 1e-6
+    assert np.abs(cpu(y) - want).max() <= bound
