@@ -12,6 +12,7 @@
 //       [k/8][row][8 bf16] granules (one conflict-free ds_read_b128 = one MFMA operand),
 //       register prefetch of the next K-block, XCD-aware tile order, bias epilogue.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -169,6 +170,121 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel(const unsigned s
   }
 }
 
+// ---- 256x256 block tile, 8 waves (4 along M x 2 along N, each 64x128), BK = 32, LDS double buffered:
+// per K-block one barrier; the next block's ds_writes and the block-after-next's global loads are
+// issued ahead of the MFMAs of the current block.
+constexpr int S2_M = 256, S2_N = 256;
+constexpr int S2_PLANE = 256 * 16 + 32;
+constexpr int S2_TILE = 4 * S2_PLANE;           // one operand plane-set (hi or lo) of one matrix
+constexpr int S2_BUF = 4 * S2_TILE;             // A_hi, A_lo, B_hi, B_lo
+constexpr int SPLIT2_LDS = 2 * S2_BUF;
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel2(const unsigned short* __restrict__ Ah,
+                                                                 const unsigned short* __restrict__ Al,
+                                                                 const unsigned short* __restrict__ Wh,
+                                                                 const unsigned short* __restrict__ Wl,
+                                                                 const float* __restrict__ bias, float* __restrict__ Y,
+                                                                 int M, int K, int N, int act, float lo, float hi) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int nbn = (N + S2_N - 1) / S2_N, nbm = (M + S2_M - 1) / S2_M;
+  const int nwg = nbn * nbm;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int bn = bid % nbn, bm = bid / nbn;
+  const int m0 = bm * S2_M, n0 = bn * S2_N;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int kg = tid & 3, r_in = tid >> 2;  // 4 k-groups x 128 rows per pass
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 rah[2], ral[2], rbh[2], rbl[2];
+  auto load_regs = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      rah[i] = ld_granule(Ah, M, K, m0 + r_in + 128 * i, k0 + kg * 8);
+      ral[i] = ld_granule(Al, M, K, m0 + r_in + 128 * i, k0 + kg * 8);
+      rbh[i] = ld_granule(Wh, N, K, n0 + r_in + 128 * i, k0 + kg * 8);
+      rbl[i] = ld_granule(Wl, N, K, n0 + r_in + 128 * i, k0 + kg * 8);
+    }
+  };
+  auto store_regs = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = kg * S2_PLANE + (r_in + 128 * i) * 16;
+      *reinterpret_cast<u32x4*>(buf + off) = rah[i];
+      *reinterpret_cast<u32x4*>(buf + S2_TILE + off) = ral[i];
+      *reinterpret_cast<u32x4*>(buf + 2 * S2_TILE + off) = rbh[i];
+      *reinterpret_cast<u32x4*>(buf + 3 * S2_TILE + off) = rbl[i];
+    }
+  };
+
+  const int nk = K / SB_K;
+  load_regs(0);
+  store_regs(lds);
+  if (nk > 1) load_regs(SB_K);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = lds + (kt & 1) * S2_BUF;
+    if (kt + 1 < nk) store_regs(lds + ((kt + 1) & 1) * S2_BUF);
+    if (kt + 2 < nk) load_regs((kt + 2) * SB_K);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int g = 2 * s + half;
+      bf16x8 ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int off = g * S2_PLANE + (wm * 64 + i * 32 + l31) * 16;
+        ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + off));
+        al[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + S2_TILE + off));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int off = g * S2_PLANE + (wn * 128 + j * 32 + l31) * 16;
+        bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + 2 * S2_TILE + off));
+        bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + 3 * S2_TILE + off));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wn * 128 + j * 32 + l31;
+    const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
+        if (m < M && n < N) {
+          float v = acc[i][j][r] + bv;
+          if (act == MS_ACT_CLAMP) v = fminf(fmaxf(v, lo), hi);
+          Y[(size_t)m * N + n] = v;
+        }
+      }
+  }
+}
+
 // hi/lo planes of an f32 matrix [rows, K] (K % 4 == 0, 16-byte aligned)
 int split_planes_launch(const float* x, unsigned short* hi, unsigned short* lo, size_t elems, hipStream_t stream) {
   const size_t n4 = elems / 4;
@@ -185,7 +301,16 @@ int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const
   static bool attr_set = false;
   if (!attr_set) {
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel2, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT2_LDS));
     attr_set = true;
+  }
+  static const bool small_tile = getenv("MS_GEMM_TILE128") && getenv("MS_GEMM_TILE128")[0] == '1';
+  if (!small_tile && (long)M * N >= 4L * 1024 * 1024) {
+    const int nwg2 = cdiv(M, S2_M) * cdiv(N, S2_N);
+    hipLaunchKernelGGL(gemm_nt_bf16x3_kernel2, dim3(nwg2), dim3(512), SPLIT2_LDS, stream, ah, al, wh, wl, bias, y, M, K, N,
+                       act, lo, hi);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
   }
   const int nwg = cdiv(M, SB_M) * cdiv(N, SB_N);
   hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, dim3(nwg), dim3(256), SPLIT_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);

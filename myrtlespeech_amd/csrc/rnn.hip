@@ -298,6 +298,7 @@ struct LstmP {
   unsigned* status;     // [0]: nonzero = a wait timed out
   unsigned long long* dbg;  // [ndir*J][8] stamp sums (diagnostic build only)
   int steps, N, n_base, N_total, H, ndir, J, NPAD;
+  int poll_sleep;  // s_sleep(1) repetitions between polls of the exchange buffer
 };
 
 __device__ __forceinline__ f32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
@@ -901,7 +902,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
             break;
           }
         }
-        __builtin_amdgcn_s_sleep(1);
+        for (int z = 0; z < p.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
       }
       if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[0] += now - st_prev; st_prev = now; }
 
@@ -1195,6 +1196,10 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
       p.status = (unsigned*)(ws + W.status);
       p.steps = steps; p.N = ng; p.n_base = n0; p.N_total = N; p.H = H; p.ndir = ndir; p.J = H / 8;
       p.NPAD = ms::cdiv(ng, 32) * 32;
+      {
+        static const int ps = getenv("MS_LSTM_POLL_SLEEP") ? atoi(getenv("MS_LSTM_POLL_SLEEP")) : 1;
+        p.poll_sleep = ps > 0 ? ps : 1;
+      }
       const bool hard = (cell == MS_CELL_HARD_LSTM);
       p.dbg = (unsigned long long*)(ws + W.dbg);
       const bool pipe = (H % 256 == 0);
