@@ -424,3 +424,43 @@ def test_linear_split_bf16x3(lib, M, K, N, act):
         want = np.clip(want, *act)
     bound = 1e-5 * (np.abs(x).astype(np.float64) @ np.abs(w.T).astype(np.float64)).max() + 1e-6
     assert np.abs(cpu(y) - want).max() <= bound
+
+
+# ----------------------------------------------------------------------------- protobuf builders
+def test_builder_built_ds2_matches_reference_golden():
+    """A text-format config -> builders -> modules; with the reference's weights loaded it must
+    reproduce the reference's output (same state_dict keys, same arithmetic)."""
+    from myrtlespeech_amd import protos as P
+    from myrtlespeech_amd.builders.speech_to_text import build as build_stt
+    from myrtlespeech_amd.wer import WordErrorRate, WordSegmentor
+    g = Golden("ds2_tiny_bilstm")
+    cfg = P.parse('''
+    alphabet: " abcdefghi_";
+    pre_process_step { stage: TRAIN_AND_EVAL; mfcc { n_mfcc: 16; win_length: 400; hop_length: 160; } }
+    deep_speech_2 {
+      conv_block { conv2d { output_channels: 4; kernel_feature: 5; kernel_time: 3; stride_feature: 2; stride_time: 2;
+                            padding_mode: SAME; bias: true; } activation { hardtanh { min_val: 0.0; max_val: 20.0; } } }
+      conv_block { conv2d { output_channels: 4; kernel_feature: 3; kernel_time: 3; stride_feature: 2; stride_time: 1;
+                            padding_mode: SAME; bias: true; } activation { hardtanh { min_val: 0.0; max_val: 20.0; } } }
+      rnn { rnn_type: LSTM; hidden_size: 16; num_layers: 2; bias: true; bidirectional: true; forget_gate_bias { value: 1.0 } }
+      lookahead_block { no_lookahead {} activation { identity {} } }
+      fully_connected { num_hidden_layers: 1; hidden_size: 24; activation { hardtanh { min_val: 0.0; max_val: 20.0; } } }
+    }
+    ctc_loss { blank_index: 10; reduction: SUM; }
+    ctc_greedy_decoder { blank_index: 10; }
+    ''', P.SpeechToText)
+    stt = build_stt(cfg).eval()
+    load_sd(stt.model, g.sd())
+    (y, lens), _ = stt.model((T(g["in/x"]), T(g["in/lens"])))
+    np.testing.assert_allclose(cpu(y), g["out/y"], **TOL)
+    hyp = stt.post_process(y, lens)
+    assert hyp == unragged(g["out/greedy_flat"], g["out/greedy_lens"])
+    # loss + WER plumbing on the same outputs
+    tgt = torch.tensor([[1, 2, 0, 3], [4, 0, 5, 0], [6, 0, 0, 0]], dtype=torch.int32)
+    tl = torch.tensor([4, 3, 1], dtype=torch.int32)
+    loss = stt.loss((y, lens), (tgt, tl))
+    want = O.ctc_loss(g["out/y"], g["out/lens"], tgt.numpy(), tl.numpy(), 10, "sum")
+    np.testing.assert_allclose(cpu(loss), want, rtol=1e-4, atol=1e-3)
+    wer = WordErrorRate(stt.alphabet, WordSegmentor(" "))
+    wer.update(hyp, tgt, tl)
+    assert wer.value() >= 0.0 and len(wer.transcripts) == 3
