@@ -1,0 +1,68 @@
+"""Chunked (streaming) Deep Speech 2 inference (new -- the reference only has the
+``hx`` in / ``hid`` out plumbing of rnn.py:133-185 and deep_speech_2.py:123-172, no chunker).
+
+Definition (pinned by ``tests/golden/stream_*.npz``, generated with the reference itself):
+the input is cut into consecutive ``chunk_frames``-frame slices; every slice goes through the
+ordinary ``DeepSpeech2.forward`` with the recurrent state returned by the previous slice.
+Convolutions therefore see each slice on its own (SAME padding at the slice edges) and the
+backward direction of a bidirectional RNN restarts per slice -- by construction, exactly as a
+caller of the reference would get.  Utterances that have ended leave the batch (lengths are
+sorted in decreasing order, so they are a suffix); their final state is kept.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from myrtlespeech_amd import _lib
+
+
+class ChunkedDeepSpeech2:
+    def __init__(self, model, chunk_frames: int):
+        if chunk_frames <= 0:
+            raise ValueError(f"chunk_frames={chunk_frames} must be > 0")
+        self.model = model
+        self.chunk_frames = chunk_frames
+
+    def step(self, chunk: torch.Tensor, chunk_lens: torch.Tensor, state=None):
+        """One slice: ``chunk [n_alive, C, F, <=chunk_frames]``; returns ``((y, out_lens), new_state)``."""
+        return self.model((chunk, chunk_lens), state)
+
+    def __call__(self, x: torch.Tensor, lens: torch.Tensor):
+        """Whole (padded, length-sorted) batch, processed slice by slice.  Returns
+        ``((logits[T_out, N, V], out_lens[N]), (h_n, c_n) | h_n)`` with T_out the sum of the
+        slices' output frames and the state of every utterance at its own last slice."""
+        _lib.require_gpu()
+        n, t_total = x.shape[0], x.shape[-1]
+        lens_cpu = lens.detach().to("cpu", torch.int64)
+        if n > 1 and bool((lens_cpu[:-1] < lens_cpu[1:]).any()):
+            raise RuntimeError("lengths must be sorted in decreasing order")
+        x = x if x.is_cuda else x.cuda()
+        outs, out_lens = [], torch.zeros(n, dtype=torch.int64)
+        state = None
+        full_state = None
+        t0 = 0
+        while t0 < t_total:
+            alive = int((lens_cpu > t0).sum())
+            if alive == 0:
+                break
+            xc = x[:alive, :, :, t0:t0 + self.chunk_frames].contiguous()
+            lc = (lens_cpu[:alive] - t0).clamp(max=xc.shape[-1])
+            hx = None
+            if state is not None:
+                hx = tuple(s[:, :alive].contiguous() for s in state) if isinstance(state, tuple) else \
+                    state[:, :alive].contiguous()
+            (y, ol), state = self.step(xc, lc, hx)
+            if full_state is None:
+                full_state = tuple(torch.zeros(s.shape[0], n, s.shape[2], device=s.device) for s in state) \
+                    if isinstance(state, tuple) else torch.zeros(state.shape[0], n, state.shape[2], device=state.device)
+            if isinstance(state, tuple):
+                for fs, s in zip(full_state, state):
+                    fs[:, :alive] = s
+            else:
+                full_state[:, :alive] = state
+            block = torch.zeros((y.shape[0], n, y.shape[2]), dtype=y.dtype, device=y.device)
+            block[:, :alive] = y
+            outs.append(block)
+            out_lens[:alive] += ol.detach().to("cpu", torch.int64)
+            t0 += self.chunk_frames
+        return (torch.cat(outs, 0), out_lens.to(lens.dtype)), full_state

@@ -453,3 +453,54 @@ if __name__ == "__main__":
         gen_beam()
     if "cfg2" in which:
         gen_ds2_cfg2_summary()
+
+
+# ----------------------------------------------------------------------------- streaming (hx threaded chunk to chunk)
+def gen_streaming():
+    """the reference has no chunker, only hx-in / hid-out plumbing.  The fixture
+    DEFINES chunked streaming as: call the reference DeepSpeech2.forward on consecutive
+    chunk_frames-frame slices of the input, feeding each call the state the previous one
+    returned; utterances that have ended leave the batch (lengths are sorted)."""
+    torch.manual_seed(71)
+    cnn = torch.nn.Sequential(
+        MaskConv2d(1, 4, [5, 3], [2, 2], PaddingMode.SAME), act_wrap(0.0, 20.0),
+        MaskConv2d(4, 4, [3, 3], [2, 1], PaddingMode.SAME), act_wrap(0.0, 20.0),
+    )
+    for name, bidir in (("stream_uni", False), ("stream_bi", True)):
+        rnn = RNN(RNNType.LSTM, 4 * 4, 64, num_layers=2, bidirectional=bidir, forget_gate_bias=1.0)
+        fc = FullyConnected(128 if bidir else 64, 9, 1, 24, torch.nn.Hardtanh(0.0, 20.0))
+        m = DeepSpeech2(cnn, rnn, None, fc).eval()
+        N, T, chunk = 4, 80, 32
+        x = torch.randn(N, 1, 16, T)
+        lens = torch.tensor([80, 70, 33, 20], dtype=torch.int64)
+        outs, out_lens = [], torch.zeros(N, dtype=torch.int64)
+        hid = None
+        t0 = 0
+        while t0 < T:
+            alive = int((lens > t0).sum())
+            if alive == 0:
+                break
+            xc = x[:alive, :, :, t0:t0 + chunk].clone()
+            lc = (lens[:alive] - t0).clamp(max=xc.shape[-1])
+            hx = None if hid is None else (hid[0][:, :alive].contiguous(), hid[1][:, :alive].contiguous())
+            (y, ol), hid = m((xc, lc), hx)
+            full = torch.zeros(y.shape[0], N, y.shape[2])
+            full[:, :alive] = y
+            outs.append(full)
+            out_lens[:alive] += ol
+            t0 += chunk
+        arrays = {"in/x": npy(x), "in/lens": npy(lens), "out/y": npy(torch.cat(outs, 0)), "out/lens": npy(out_lens),
+                  "out/hn_last": npy(hid[0]), "out/cn_last": npy(hid[1])}
+        arrays.update(sd_arrays(m))
+        cfg = dict(convs=[dict(kind="conv2d", idx=0, in_channels=1, out_channels=4, kernel=[5, 3], stride=[2, 2],
+                               same=True, act=[0.0, 20.0]),
+                          dict(kind="conv2d", idx=2, in_channels=4, out_channels=4, kernel=[3, 3], stride=[2, 1],
+                               same=True, act=[0.0, 20.0])],
+                   rnn=dict(kind=0, input=16, hidden=64, layers=2, bidirectional=bidir, forget_gate_bias=1.0),
+                   lookahead=None, fc=dict(in_features=128 if bidir else 64, out_features=9, n_hidden=1, hidden=24,
+                                           act=[0.0, 20.0]), chunk_frames=chunk)
+        save(name, cfg, arrays)
+
+
+if __name__ == "__main__" and "stream" in sys.argv[1:]:
+    gen_streaming()

@@ -464,3 +464,17 @@ def test_builder_built_ds2_matches_reference_golden():
     wer = WordErrorRate(stt.alphabet, WordSegmentor(" "))
     wer.update(hyp, tgt, tl)
     assert wer.value() >= 0.0 and len(wer.transcripts) == 3
+
+
+# ----------------------------------------------------------------------------- chunked streaming (a16)
+@pytest.mark.parametrize("name", golden_names("stream_"))
+def test_chunked_streaming_matches_reference_hx_threading(name):
+    from myrtlespeech_amd.streaming import ChunkedDeepSpeech2
+    g = Golden(name)
+    m = load_sd(build_ds2(g.cfg), g.sd())
+    (y, lens), (hn, cn) = ChunkedDeepSpeech2(m, g.cfg["chunk_frames"])(T(g["in/x"]), T(g["in/lens"]))
+    np.testing.assert_allclose(cpu(y), g["out/y"], **TOL)
+    np.testing.assert_array_equal(cpu(lens), g["out/lens"])
+    alive_last = g["out/hn_last"].shape[1]
+    np.testing.assert_allclose(cpu(hn)[:, :alive_last], g["out/hn_last"], **TOL)
+    np.testing.assert_allclose(cpu(cn)[:, :alive_last], g["out/cn_last"], **TOL)

@@ -197,3 +197,31 @@ def test_beam_random():
         got = O.ctc_beam_decode(g[f"{s}/x"], g[f"{s}/lens"], c["blank"], c["beam_width"], c["prune"], lm,
                                 c.get("lm_weight"), c["sep"], c["word_weight"])
         assert got == want, c
+
+
+@pytest.mark.parametrize("name", golden_names("stream_"))
+def test_oracle_chunked_streaming(name):
+    """The streaming definition (hx threaded through consecutive slices) restated on the oracle."""
+    g = Golden(name)
+    c = g.cfg
+    cfg = dict(convs=[dict(kind=v["kind"], idx=v["idx"], stride=v["stride"], same=v["same"], act=v["act"])
+                      for v in c["convs"]],
+               rnn=dict(kind=c["rnn"]["kind"], hidden=c["rnn"]["hidden"], layers=c["rnn"]["layers"],
+                        bidirectional=c["rnn"]["bidirectional"]),
+               lookahead=None, fc=dict(n_hidden=c["fc"]["n_hidden"], act=c["fc"]["act"]))
+    x, lens, chunk = g["in/x"], g["in/lens"], c["chunk_frames"]
+    outs, hid, t0 = [], None, 0
+    while t0 < x.shape[-1]:
+        alive = int((lens > t0).sum())
+        if alive == 0:
+            break
+        xc = x[:alive, :, :, t0:t0 + chunk]
+        lc = np.minimum(lens[:alive] - t0, xc.shape[-1])
+        hx = None if hid is None else (hid[0][:, :alive], hid[1][:, :alive])
+        y, _, hid = O.deep_speech_2_forward(xc, lc, cfg, g.sd(), hx)
+        full = np.zeros((y.shape[0], x.shape[0], y.shape[2]), np.float32)
+        full[:, :alive] = y
+        outs.append(full)
+        t0 += chunk
+    np.testing.assert_allclose(np.concatenate(outs, 0), g["out/y"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(hid[0], g["out/hn_last"], rtol=1e-4, atol=1e-4)
