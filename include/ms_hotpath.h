@@ -192,6 +192,21 @@ int ms_ctc_beam_decode(const float* probs, const int32_t* lens, int32_t* out_idx
                        int32_t* beam_idx, int32_t* beam_plen, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* ---- RNN-T decode step (own specification: the reference snapshot has no transducer,
+ *      SURVEY 0.3 / 8 a15; see myrtlespeech_amd/model/rnnt.py) ------------------------------ */
+
+/* out[r,:] = table[idx[r],:]  (prediction-network embedding; idx clamped to [0, V1)). */
+int ms_embedding_forward(const float* table, const int32_t* idx, float* out, int R, int D, int V1, void* stream);
+
+/* logp[r,:] = log_softmax(w_out . tanh(enc_p[enc_row[r],:] + pred_p[r,:]) + b_out) for R hypothesis rows;
+ * enc_p [*, J] are the projected encoder frames, pred_p [R, J] the projected predictor outputs. */
+int ms_rnnt_joint_forward(const float* enc_p, const int32_t* enc_row, const float* pred_p, const float* w_out,
+                          const float* b_out, float* logp, int R, int J, int V1, void* stream);
+
+/* Per row b of scores [B, C]: the k largest entries in descending order (ties -> lowest index);
+ * -inf entries are never selected (index -1 is written when fewer than k finite candidates exist). */
+int ms_rnnt_topk(const float* scores, int32_t* out_idx, float* out_val, int B, int C, int k, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

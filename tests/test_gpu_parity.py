@@ -478,3 +478,56 @@ def test_chunked_streaming_matches_reference_hx_threading(name):
     alive_last = g["out/hn_last"].shape[1]
     np.testing.assert_allclose(cpu(hn)[:, :alive_last], g["out/hn_last"], **TOL)
     np.testing.assert_allclose(cpu(cn)[:, :alive_last], g["out/cn_last"], **TOL)
+
+
+# ----------------------------------------------------------------------------- RNN-T (own spec, a15)
+def _rnnt_parts(V=11, E=40, D=16, P=96, J=48, seed=3):
+    from myrtlespeech_amd.model.rnnt import RNNTJoint, RNNTPredictor
+    torch.manual_seed(seed)
+    pred = RNNTPredictor(V, D, P, num_layers=2).eval()
+    joint = RNNTJoint(E, P, J, V).eval()
+    psd = {k: cpu(v) for k, v in pred.state_dict().items()}
+    jsd = {k: cpu(v) for k, v in joint.state_dict().items()}
+    return pred, joint, psd, jsd
+
+
+def test_rnnt_kernels_vs_numpy(lib):
+    from myrtlespeech_amd import _lib
+    rng = np.random.default_rng(0)
+    R, J, V1, C = 37, 200, 30, 240
+    enc = rng.normal(size=(50, J)).astype(np.float32)
+    rows = rng.integers(0, 50, size=R).astype(np.int32)
+    pp = rng.normal(size=(R, J)).astype(np.float32)
+    w = (rng.normal(size=(V1, J)) * 0.2).astype(np.float32)
+    b = rng.normal(size=(V1,)).astype(np.float32)
+    logp = torch.empty((R, V1), device="cuda")
+    a = [T(v).cuda() for v in (enc, rows, pp, w, b)]
+    _lib.check(lib.ms_rnnt_joint_forward(*[_lib.ptr(v) for v in a], _lib.ptr(logp), R, J, V1, _lib.stream_ptr()), "joint")
+    want = O.log_softmax((np.tanh(enc[rows] + pp) @ w.T + b).astype(np.float32))
+    np.testing.assert_allclose(cpu(logp), want, rtol=1e-4, atol=1e-4)
+    sc = (rng.normal(size=(5, C)) * 3).round().astype(np.float32)  # many ties
+    sc[2, 10:] = -np.inf
+    idx = torch.empty((5, 8), dtype=torch.int32, device="cuda")
+    val = torch.empty((5, 8), device="cuda")
+    scd = T(sc).cuda()
+    _lib.check(lib.ms_rnnt_topk(_lib.ptr(scd), _lib.ptr(idx), _lib.ptr(val), 5, C, 8, _lib.stream_ptr()), "topk")
+    for r in range(5):
+        order = np.argsort(-sc[r], kind="stable")[:8]
+        np.testing.assert_array_equal(cpu(idx)[r], order)
+        np.testing.assert_array_equal(cpu(val)[r], sc[r][order])
+
+
+def test_rnnt_greedy_and_beam_vs_oracle():
+    """Own-spec transducer decode (parity unpinned by the reference: it has none): HIP path vs oracle."""
+    from myrtlespeech_amd.post_process.rnnt_decoder import RNNTBeamDecoder, RNNTGreedyDecoder
+    from oracle import rnnt_oracle as RO
+    V, E, P = 11, 40, 96
+    pred, joint, psd, jsd = _rnnt_parts(V=V, E=E, P=P)
+    rng = np.random.default_rng(1)
+    enc = (rng.normal(size=(14, 3, E)) * 1.5).astype(np.float32)
+    lens = np.array([14, 9, 4])
+    got = RNNTGreedyDecoder(pred, joint, max_symbols=3)(T(enc), T(lens))
+    assert got == RO.greedy_decode(enc, lens, psd, jsd, P, 2, V, 3)
+    got = RNNTBeamDecoder(pred, joint, beam_width=4, max_symbols=3)(T(enc), T(lens))
+    want, _ = RO.beam_decode(enc, lens, psd, jsd, P, 2, V, 4, 3)
+    assert got == want
