@@ -193,7 +193,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel2(const unsigned 
     const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
   }
-  const int bn = bid % nbn, bm = bid / nbn;
+  // grouped order: 32 consecutive tiles (one XCD's CUs) form a 4 x 8 patch, so every A row-block is
+  // shared by 8 tiles and every W column-block by 4 while they sweep K together (L2 reuse)
+  constexpr int GM = 4;
+  const int per_group = GM * nbn;
+  const int first_m = (bid / per_group) * GM;
+  const int gm = min(GM, nbm - first_m);
+  const int bm = first_m + (bid % per_group) % gm;
+  const int bn = (bid % per_group) / gm;
   const int m0 = bm * S2_M, n0 = bn * S2_N;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
