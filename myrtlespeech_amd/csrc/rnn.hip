@@ -79,6 +79,7 @@ bool want_split() {
 }
 bool use_split(int cell, int H, int ndir) { return use_fast(cell, H, ndir) && want_split() && H % 64 == 0; }
 // the input projection runs as the bf16x3 GEMM whenever the recurrence is split and In allows 16-byte granules
+bool two_stream_shape(int H) { return H == 256 || H == 512 || H == 768 || H == 1024; }
 bool use_split_gemm(int cell, int H, int ndir, int In) { return use_split(cell, H, ndir) && In % 32 == 0; }
 
 struct PackLayout {
@@ -800,12 +801,12 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) 
 // in flight through the fabric, the workgroup computes stream B's step, and vice versa.  The
 // MFMA shape drops to 16x16x32 (16 batch rows x 16 gate rows, two column tiles), which costs
 // exactly half the cycles of the 32x32x16 tile, so no matrix throughput is lost.
-// H == 1024, N <= 32.  hx layout per direction: [stream][plane hi|lo][parity][k/8][16][8 bf16].
+// H in {256, 512, 768, 1024}, N <= 32 per launch.  hx layout per direction: [stream][plane hi|lo][parity][k/8][16][8 bf16].
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <bool HARD, bool STAMP = false>
+template <int KS, bool HARD, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p) {
-  constexpr int H = 1024, KG = H / 8, KS = KG / 16;  // KS k-steps (K = 32) per wave
+  constexpr int H = 128 * KS, KG = H / 8;  // KS k-steps (K = 32) per wave; H in {256, 512, 768, 1024}
   constexpr int RED2 = 4 * 16 * RED_STRIDE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* red = smem;  // [stream][4 waves][16 rows][RED_STRIDE]
@@ -1114,18 +1115,23 @@ static int launch_split(const LstmP& p, hipStream_t stream) {
   return MS_OK;
 }
 
-template <bool HARD, bool STAMP = false>
+template <int KS, bool HARD, bool STAMP = false>
 static int launch_split2(const LstmP& p, hipStream_t stream) {
   const size_t lds = (size_t)RED_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_split2_kernel<HARD, STAMP>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((lstm_persistent_split2_kernel<HARD, STAMP>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((lstm_persistent_split2_kernel<KS, HARD, STAMP>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
   MS_LAUNCH_CHECK();
   return MS_OK;
+}
+
+static int launch_split2_any(const LstmP& p, bool hard, bool stamps, hipStream_t stream) {
+  switch (p.H) {
+    case 256: return hard ? launch_split2<2, true>(p, stream) : launch_split2<2, false>(p, stream);
+    case 512: return hard ? launch_split2<4, true>(p, stream) : launch_split2<4, false>(p, stream);
+    case 768: return hard ? launch_split2<6, true>(p, stream) : launch_split2<6, false>(p, stream);
+    default:
+      if (stamps && !hard) return launch_split2<8, false, true>(p, stream);
+      return hard ? launch_split2<8, true>(p, stream) : launch_split2<8, false>(p, stream);
+  }
 }
 
 extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x, const int32_t* lens, int max_len,
@@ -1183,8 +1189,9 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
   if (fast) {
     // batch groups of <= 64 sequences, one persistent launch each (stream-ordered; the epoch
     // flags are re-zeroed in between, the status word is kept so any time-out is reported)
-    for (int n0 = 0; n0 < N; n0 += 64) {
-      const int ng = std::min(64, N - n0);
+    const int group = (use_split(cell, H, ndir) && two_stream_shape(H)) ? 32 : 64;
+    for (int n0 = 0; n0 < N; n0 += group) {
+      const int ng = std::min(group, N - n0);
       if (n0 > 0) MS_HIP(hipMemsetAsync(ws + W.flags, 0, W.xproj - W.flags, stream));
       LstmP p;
       p.xproj = xproj;
@@ -1210,9 +1217,8 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
         const bool hard_ = (cell == MS_CELL_HARD_LSTM);
         if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.total - W.dbg, stream));
         static const bool one_stream = getenv("MS_LSTM_ONE_STREAM") && getenv("MS_LSTM_ONE_STREAM")[0] == '1';
-        if (p.NPAD == 32 && H == 1024 && !one_stream) {
-          if (stamps && !hard_) rc = launch_split2<false, true>(p, stream);
-          else rc = hard_ ? launch_split2<true>(p, stream) : launch_split2<false>(p, stream);
+        if (p.NPAD == 32 && two_stream_shape(H) && !one_stream) {
+          rc = launch_split2_any(p, hard_, stamps, stream);
         } else if (p.NPAD == 32 && H == 1024) {
           if (stamps && !hard_) rc = launch_split<1, 4, false, true>(p, stream);
           else rc = hard_ ? launch_split<1, 4, true>(p, stream) : launch_split<1, 4, false>(p, stream);

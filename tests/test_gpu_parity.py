@@ -531,3 +531,32 @@ def test_rnnt_greedy_and_beam_vs_oracle():
     got = RNNTBeamDecoder(pred, joint, beam_width=4, max_symbols=3)(T(enc), T(lens))
     want, _ = RO.beam_decode(enc, lens, psd, jsd, P, 2, V, 4, 3)
     assert got == want
+
+
+def test_exact_f32_mode_in_subprocess():
+    """MS_PRECISION=f32 is read once per process, so the exact-f32 persistent kernel and GEMM at
+    the config-2 width are exercised in one child process (H=1024 and H=256, ragged, 2 layers)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from myrtlespeech_amd.model.rnn import RNN, RNNType
+from oracle import ds_oracle as O
+for H, N, T_ in ((1024, 32, 5), (256, 40, 6)):
+    torch.manual_seed(H)
+    m = RNN(RNNType.LSTM, 64, H, num_layers=2, bidirectional=True, forget_gate_bias=1.0).eval()
+    rng = np.random.default_rng(H)
+    lens = np.sort(rng.integers(1, T_ + 1, size=N))[::-1].copy(); lens[0] = T_
+    x = rng.normal(size=(T_, N, 64)).astype(np.float32)
+    (out, _), (hn, cn) = m((torch.from_numpy(x), torch.from_numpy(lens)))
+    sd = {k[4:]: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    want, (whn, wcn) = O.rnn_forward(O.LSTM, x, lens, sd, H, 2, True)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(cn.cpu().numpy(), wcn, rtol=1e-5, atol=2e-6)
+print("f32 mode ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MS_PRECISION="f32")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "f32 mode ok" in r.stdout, r.stdout + r.stderr
