@@ -72,6 +72,18 @@ int ms_maskconv_forward(const float* x, const int32_t* lens, const void* packed_
                         int ST, int DF, int DT, int pad_f_l, int pad_t_l, int groups, int act, float act_lo,
                         float act_hi, void* stream);
 
+/* Same contract as ms_maskconv_forward for groups == 1 and Cin % 16 == 0 (e.g. the second DS2
+ * convolution), computed as a split-bf16 implicit GEMM over channels (x.w ~= x_hi.w_hi +
+ * x_lo.w_hi + x_hi.w_lo, f32 accumulate).  The workspace receives the channels-last bf16
+ * planes of the input. */
+size_t ms_maskconv_cl_packed_bytes(int Cout, int Cin, int KF, int KT);
+int ms_maskconv_cl_pack(const float* w, void* packed, int Cout, int Cin, int KF, int KT, void* stream);
+size_t ms_maskconv_cl_workspace_bytes(int N, int Cin, int Fin, int Tin);
+int ms_maskconv_cl_forward(const float* x, const int32_t* lens, const void* packed_w, const float* bias, float* y,
+                           int N, int Cin, int Fin, int Tin, int Cout, int Fout, int Tout, int KF, int KT, int SF,
+                           int ST, int DF, int DT, int pad_f_l, int pad_t_l, int act, float act_lo, float act_hi,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* DeepSpeech2._conv_to_rnn_size (deep_speech_2.py:114-117): [N, CF, T] -> [T, N, CF]. */
 int ms_nct_to_tnc(const float* x, float* y, int N, int CF, int T, void* stream);
 

@@ -1,0 +1,257 @@
+// Masked 2-D convolution for multi-channel inputs as a split-bf16 implicit GEMM over CHANNELS.
+//
+// The second DS2 convolution (32 -> 32 channels, 21 x 11 taps: 152 GFLOP of the encoder's 170)
+// spends 1.9 ms in the exact-f32 kernel of conv.hip.  Here the reduction runs over input channels
+// (k-groups of 8 channels = one MFMA operand granule), so it needs no tap padding and every
+// LDS read is an aligned 16-byte granule:
+//
+//   input   : channels-last bf16 planes  X_hi, X_lo [N][Fin][Tin][Cin]   (made from the f32 NCHW
+//             input by nchw_to_cl_split_kernel: one tiled transpose + split, ~40 us)
+//   filters : packed planes [hi|lo][KF][KT][Cin/8][Cout 32][8]            (ms_maskconv_cl_pack)
+//   per workgroup (4 waves): 32 output channels x 128 output frames x 2 output feature rows;
+//   wave w owns frames [32w, 32w+32).  For each kernel-feature row kf the workgroup stages the
+//   two input rows it touches as [Cin/8][frame][8] granules and that row's KT filter taps; per tap
+//   and 16-channel k-step: A = filter granule (rows = cout), B = input granule (cols = frames),
+//   3 MFMAs (hi*hi + lo*hi + hi*lo) per output row.
+//   _mask_ / _pad of cnn.py:391-443 are load predicates; bias + clamp in the epilogue; the
+//   output is f32 NCHW (time contiguous) like conv.hip.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int CL_T = 128;  // output frames per workgroup
+constexpr int CL_F = 2;    // output feature rows per workgroup
+
+struct ClP {
+  int N, Cin, Fin, Tin, Cout, Fout, Tout, KF, KT, SF, ST, DF, DT, pad_f, pad_t;
+  int KG;        // Cin / 8
+  int PW;        // staged frames per input row = (CL_T-1)*ST + (KT-1)*DT + 1
+  int co_tiles;
+  int act;
+  float lo, hi;
+};
+
+__device__ __forceinline__ unsigned bf16b(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
+
+// packed[plane][kf][kt][kg][cout_pad][8] <- w[cout][cin][kf][kt]
+__global__ void conv_cl_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int Cout, int Cin,
+                                    int KF, int KT, int cout_pad) {
+  const int KG = Cin / 8;
+  const size_t plane = (size_t)KF * KT * KG * cout_pad * 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = i & 7;
+    const int co = (i >> 3) % cout_pad;
+    const int kg = (i / ((size_t)8 * cout_pad)) % KG;
+    const int kt = (i / ((size_t)8 * cout_pad * KG)) % KT;
+    const int kf = i / ((size_t)8 * cout_pad * KG * KT);
+    float x = 0.f;
+    if (co < Cout) x = w[(((size_t)co * Cin + kg * 8 + e) * KF + kf) * KT + kt];
+    const unsigned h = bf16b(x);
+    packed[i] = (unsigned short)h;
+    packed[plane + i] = (unsigned short)bf16b(x - __uint_as_float(h << 16));
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned short* __restrict__ xh,
+                                                             const unsigned short* __restrict__ xl,
+                                                             const int32_t* __restrict__ lens,
+                                                             const unsigned short* __restrict__ wp,
+                                                             const float* __restrict__ bias, float* __restrict__ y, ClP p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  // [plane 2][row CL_F][kg][PW][16 B]  then filters [plane 2][KT][kg][32][16 B]
+  const int row_bytes = p.KG * p.PW * 16;
+  char* Ph = lds;
+  char* Pl = lds + CL_F * row_bytes;
+  char* Wh = lds + 2 * CL_F * row_bytes;
+  const int wtap = p.KG * 32 * 16;            // bytes of one tap's filters (one plane)
+  char* Wl = Wh + ((p.KT + 1) / 2) * wtap;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int t0 = blockIdx.x * CL_T;
+  const int fo0 = blockIdx.y * CL_F;
+  const int n = blockIdx.z / p.co_tiles, tile = blockIdx.z % p.co_tiles;
+  const int len = lens ? min(lens[n], p.Tin) : p.Tin;
+  const int cout_pad = p.co_tiles * 32;
+  const size_t wplane = (size_t)p.KF * p.KT * p.KG * cout_pad * 8;  // elements
+
+  ms::f32x16 acc[CL_F];
+#pragma unroll
+  for (int f = 0; f < CL_F; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+  const int tin0 = t0 * p.ST - p.pad_t;
+  const int ngran = p.KG * p.PW;  // granules per staged input row
+
+  for (int kf = 0; kf < p.KF; ++kf) {
+    // ---- stage the two input rows this kf touches (masked, zero padded)
+    for (int f = 0; f < CL_F; ++f) {
+      const int fin = (fo0 + f) * p.SF - p.pad_f + kf * p.DF;
+      const bool frow = (fo0 + f) < p.Fout && fin >= 0 && fin < p.Fin;
+      const size_t rbase = ((size_t)n * p.Fin + (frow ? fin : 0)) * p.Tin;
+      for (int i = tid; i < ngran; i += 256) {
+        const int q = i / p.KG, kg = i - q * p.KG;  // frame-major so 4 lanes cover one frame's 64 B
+        const int tin = tin0 + q;
+        u32x4 vh = {0u, 0u, 0u, 0u}, vl = {0u, 0u, 0u, 0u};
+        if (frow && tin >= 0 && tin < len) {
+          const size_t off = (rbase + tin) * p.Cin + kg * 8;
+          vh = *reinterpret_cast<const u32x4*>(xh + off);
+          vl = *reinterpret_cast<const u32x4*>(xl + off);
+        }
+        *reinterpret_cast<u32x4*>(Ph + f * row_bytes + (kg * p.PW + q) * 16) = vh;
+        *reinterpret_cast<u32x4*>(Pl + f * row_bytes + (kg * p.PW + q) * 16) = vl;
+      }
+    }
+    // ---- this kf row's filters go through LDS in two halves of the KT taps (keeps the
+    // workgroup under 80 KiB so two of them share a CU and hide each other's staging)
+    const int taps_per_stage = (p.KT + 1) / 2;
+    for (int kt0 = 0; kt0 < p.KT; kt0 += taps_per_stage) {
+      const int ntap = min(taps_per_stage, p.KT - kt0);
+      if (kt0 > 0) __syncthreads();  // the previous half's reads are done
+      {
+        const int ng = ntap * p.KG * 32;
+        for (int i = tid; i < ng; i += 256) {
+          const int co = i & 31, rest = i >> 5;  // rest = kt_local*KG + kg
+          const size_t src = ((((size_t)kf * p.KT + kt0) * p.KG + rest) * cout_pad + tile * 32 + co) * 8;
+          *reinterpret_cast<u32x4*>(Wh + i * 16) = *reinterpret_cast<const u32x4*>(wp + src);
+          *reinterpret_cast<u32x4*>(Wl + i * 16) = *reinterpret_cast<const u32x4*>(wp + wplane + src);
+        }
+      }
+      __syncthreads();
+      for (int ktl = 0; ktl < ntap; ++ktl) {
+        const int tq = (wave * 32 + l31) * p.ST + (kt0 + ktl) * p.DT;
+        for (int s = 0; s < p.KG / 2; ++s) {
+          const int kg = 2 * s + half;
+          const int woff = ((ktl * p.KG + kg) * 32 + l31) * 16;
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Wh + woff));
+          const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Wl + woff));
+#pragma unroll
+          for (int f = 0; f < CL_F; ++f) {
+            const int poff = f * row_bytes + (kg * p.PW + tq) * 16;
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ph + poff));
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Pl + poff));
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[f], 0, 0, 0);
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[f], 0, 0, 0);
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[f], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  const int t = t0 + wave * 32 + l31;
+  if (t < p.Tout) {
+#pragma unroll
+    for (int f = 0; f < CL_F; ++f) {
+      const int fo = fo0 + f;
+      if (fo >= p.Fout) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = tile * 32 + ms::mfma32_row(r, lane);
+        if (co < p.Cout) {
+          float v = acc[f][r] + (bias ? bias[co] : 0.f);
+          if (p.act == MS_ACT_CLAMP) v = fminf(fmaxf(v, p.lo), p.hi);
+          y[(((size_t)n * p.Cout + co) * p.Fout + fo) * p.Tout + t] = v;
+        }
+      }
+    }
+  }
+}
+
+// f32 NCHW [N][C][F][T] -> channels-last bf16 hi / lo planes [N][F][T][C]  (C % 8 == 0)
+__global__ void nchw_to_cl_split_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi,
+                                        unsigned short* __restrict__ lo, int C, int F, int T) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z / F, f = blockIdx.z % F;
+  const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x, ty = threadIdx.y;  // (32, 8)
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, t = t0 + tx;
+    tile[i][tx] = (c < C && t < T) ? x[(((size_t)n * C + c) * F + f) * T + t] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, c = c0 + tx;
+    if (t < T && c < C) {
+      const float v = tile[tx][i];
+      const unsigned h = bf16b(v);
+      const size_t o = (((size_t)n * F + f) * T + t) * C + c;
+      hi[o] = (unsigned short)h;
+      lo[o] = (unsigned short)bf16b(v - __uint_as_float(h << 16));
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t ms_maskconv_cl_packed_bytes(int Cout, int Cin, int KF, int KT) {
+  if (Cout <= 0 || Cin <= 0 || Cin % 16 || KF <= 0 || KT <= 0) return 0;
+  return (size_t)2 * KF * KT * (Cin / 8) * (ms::cdiv(Cout, 32) * 32) * 8 * sizeof(unsigned short);
+}
+
+extern "C" int ms_maskconv_cl_pack(const float* w, void* packed, int Cout, int Cin, int KF, int KT, void* stream) {
+  MS_REQUIRE(w && packed, "null pointer");
+  MS_REQUIRE(Cout > 0 && Cin > 0 && Cin % 16 == 0 && KF > 0 && KT > 0, "bad shape (Cin must be a multiple of 16)");
+  const int cout_pad = ms::cdiv(Cout, 32) * 32;
+  const size_t plane = (size_t)KF * KT * (Cin / 8) * cout_pad * 8;
+  const int blocks = (int)std::min<size_t>((plane + 255) / 256, 2048);
+  hipLaunchKernelGGL(conv_cl_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)packed, Cout,
+                     Cin, KF, KT, cout_pad);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}
+
+extern "C" size_t ms_maskconv_cl_workspace_bytes(int N, int Cin, int Fin, int Tin) {
+  if (N <= 0 || Cin <= 0 || Fin <= 0 || Tin <= 0) return 0;
+  return ms::align_up((size_t)N * Cin * Fin * Tin * 4, 256);  // hi + lo planes of the input
+}
+
+extern "C" int ms_maskconv_cl_forward(const float* x, const int32_t* lens, const void* packed_w, const float* bias, float* y,
+                                      int N, int Cin, int Fin, int Tin, int Cout, int Fout, int Tout, int KF, int KT,
+                                      int SF, int ST, int DF, int DT, int pad_f_l, int pad_t_l, int act, float act_lo,
+                                      float act_hi, void* workspace, size_t workspace_bytes, void* stream_) {
+  MS_REQUIRE(x && packed_w && y && workspace, "null pointer");
+  MS_REQUIRE(N > 0 && Cin > 0 && Cin % 16 == 0 && Fin > 0 && Tin > 0 && Cout > 0 && Fout > 0 && Tout > 0, "bad shape");
+  MS_REQUIRE(KF > 0 && KT > 0 && SF > 0 && ST > 0 && DF > 0 && DT > 0 && pad_f_l >= 0 && pad_t_l >= 0, "bad kernel");
+  MS_REQUIRE(act == MS_ACT_NONE || act == MS_ACT_CLAMP, "bad act");
+  if (workspace_bytes < ms_maskconv_cl_workspace_bytes(N, Cin, Fin, Tin)) {
+    ms::set_error("ms_maskconv_cl_forward: workspace too small");
+    return MS_ERR_WORKSPACE;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  ClP p;
+  p.N = N; p.Cin = Cin; p.Fin = Fin; p.Tin = Tin; p.Cout = Cout; p.Fout = Fout; p.Tout = Tout; p.KF = KF; p.KT = KT;
+  p.SF = SF; p.ST = ST; p.DF = DF; p.DT = DT; p.pad_f = pad_f_l; p.pad_t = pad_t_l; p.KG = Cin / 8;
+  p.PW = (CL_T - 1) * ST + (KT - 1) * DT + 1;
+  p.co_tiles = ms::cdiv(Cout, 32);
+  p.act = act; p.lo = act_lo; p.hi = act_hi;
+  const size_t lds = (size_t)2 * CL_F * p.KG * p.PW * 16 + (size_t)2 * ((KT + 1) / 2) * p.KG * 32 * 16;
+  if (lds > 160 * 1024 || (long)N * p.co_tiles > 65535 || ms::cdiv(Fout, CL_F) > 65535) {
+    ms::set_error("ms_maskconv_cl_forward: shape outside the LDS / grid budget");
+    return MS_ERR_UNSUPPORTED;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  unsigned short* xh = (unsigned short*)workspace;
+  unsigned short* xl = xh + (size_t)N * Cin * Fin * Tin;
+  MS_REQUIRE(N * Fin <= 65535, "N*Fin exceeds grid limits");
+  hipLaunchKernelGGL(nchw_to_cl_split_kernel, dim3(ms::cdiv(Tin, 32), ms::cdiv(Cin, 32), N * Fin), dim3(32, 8), 0, stream, x,
+                     xh, xl, Cin, Fin, Tin);
+  MS_LAUNCH_CHECK();
+  dim3 grid(ms::cdiv(Tout, CL_T), ms::cdiv(Fout, CL_F), N * p.co_tiles);
+  hipLaunchKernelGGL(maskconv_cl_kernel, grid, dim3(256), lds, stream, xh, xl, lens, (const unsigned short*)packed_w, bias, y,
+                     p);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}

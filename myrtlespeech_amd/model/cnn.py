@@ -51,6 +51,22 @@ class _PackedFilters:
     def __init__(self):
         self.key = None
         self.buf = None
+        self.key_cl = None
+        self.buf_cl = None
+        self.workspace = _lib.Workspace()
+
+    def get_cl(self, weight: torch.Tensor) -> torch.Tensor:
+        """Split-bf16 channels-last bank for the multi-channel kernel (conv_cl.hip)."""
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape))
+        if key != self.key_cl:
+            lib = _lib.load()
+            cout, cin, kf, kt = weight.shape
+            self.buf_cl = torch.empty(lib.ms_maskconv_cl_packed_bytes(cout, cin, kf, kt), dtype=torch.uint8, device="cuda")
+            w = _lib.f32c(weight.detach())
+            _lib.check(lib.ms_maskconv_cl_pack(_lib.ptr(w), _lib.ptr(self.buf_cl), cout, cin, kf, kt, _lib.stream_ptr()),
+                       "ms_maskconv_cl_pack")
+            self.key_cl = key
+        return self.buf_cl
 
     def get(self, weight: torch.Tensor, groups: int) -> torch.Tensor:
         key = (weight.data_ptr(), weight._version, tuple(weight.shape), groups)
@@ -86,9 +102,19 @@ def _conv_forward(x4: torch.Tensor, seq_lens: torch.Tensor, weight4: torch.Tenso
     new_lens = out_lens(seq_lens, kt, st, dt, sum(pt))
     y = torch.empty((n, cout, fout, tout), dtype=torch.float32, device="cuda")
     lens_dev = _lib.lens_i32(seq_lens)
-    pk = packed.get(weight4, groups)
     a, lo, hi = (_lib.ACT_NONE, 0.0, 0.0) if act is None else (_lib.ACT_CLAMP, act[0], act[1])
     b = None if bias is None else _lib.f32c(bias.detach())
+    if _lib.split_precision() and groups == 1 and cin % 16 == 0 and 2.0 * y.numel() * cin * kf * kt >= 1e9:
+        # many input channels: split-bf16 implicit GEMM over channels (conv_cl.hip)
+        pk = packed.get_cl(weight4)
+        ws = packed.workspace.get(lib.ms_maskconv_cl_workspace_bytes(n, cin, fin, tin))
+        rc = lib.ms_maskconv_cl_forward(_lib.ptr(x4), _lib.ptr(lens_dev), _lib.ptr(pk), _lib.ptr(b), _lib.ptr(y), n, cin,
+                                        fin, tin, cout, fout, tout, kf, kt, sf, st, df, dt, pf[0], pt[0], a, lo, hi,
+                                        _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        if rc != 5:  # MS_ERR_UNSUPPORTED -> the exact-f32 kernel below
+            _lib.check(rc, "ms_maskconv_cl_forward")
+            return y, new_lens
+    pk = packed.get(weight4, groups)
     _lib.check(lib.ms_maskconv_forward(_lib.ptr(x4), _lib.ptr(lens_dev), _lib.ptr(pk), _lib.ptr(b), _lib.ptr(y), n, cin,
                                        fin, tin, cout, fout, tout, kf, kt, sf, st, df, dt, pf[0], pt[0], groups, a, lo,
                                        hi, _lib.stream_ptr()), "ms_maskconv_forward")

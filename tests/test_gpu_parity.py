@@ -560,3 +560,21 @@ print("f32 mode ok")
     env = dict(os.environ, MS_PRECISION="f32")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "f32 mode ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("cin,cout,k,s,same,F,Tn,N", [(32, 32, [21, 11], [2, 1], True, 40, 140, 2),
+                                                      (16, 40, [3, 5], [1, 2], False, 9, 300, 3),
+                                                      (48, 33, [5, 4], [2, 1], True, 12, 131, 2)])
+def test_conv2d_channels_last_split_vs_oracle(cin, cout, k, s, same, F, Tn, N):
+    """Multi-channel convolutions take the split-bf16 channels-last kernel (conv_cl.hip)."""
+    from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+    torch.manual_seed(cin + cout)
+    m = MaskConv2d(cin, cout, k, s, PaddingMode.SAME if same else PaddingMode.NONE).eval()
+    rng = np.random.default_rng(cin)
+    x = rng.normal(size=(N, cin, F, Tn)).astype(np.float32)
+    lens = np.sort(rng.integers(Tn // 2, Tn + 1, size=N))[::-1].copy()
+    y, nl = m((T(x), T(lens)), fused_activation=(0.0, 20.0))
+    want, wl = O.mask_conv2d(x, lens, cpu(m.weight), cpu(m.bias), tuple(s), same)
+    want = np.clip(want, 0.0, 20.0)
+    np.testing.assert_allclose(cpu(y), want, rtol=1e-4, atol=2e-4)
+    np.testing.assert_array_equal(cpu(nl), wl)
