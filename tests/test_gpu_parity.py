@@ -578,3 +578,57 @@ def test_conv2d_channels_last_split_vs_oracle(cin, cout, k, s, same, F, Tn, N):
     want = np.clip(want, 0.0, 20.0)
     np.testing.assert_allclose(cpu(y), want, rtol=1e-4, atol=2e-4)
     np.testing.assert_array_equal(cpu(nl), wl)
+
+
+# ----------------------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("kind,H,bidir", [(0, 1024, True), (0, 64, True), (0, 48, False), (1, 256, True), (2, 200, True)])
+def test_rnn_all_lengths_shorter_than_the_buffer(kind, H, bidir):
+    """total_length > max(lengths) (rnn.py:179-183): frames past every sequence are zero, on the
+    two-stream / one-stream / exact-f32 persistent kernels and on the generic GRU / tanh path."""
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    torch.manual_seed(kind * 10 + H)
+    In, N, Tn = 24, 3, 9
+    m = RNN(RNNType(kind), In, H, num_layers=1, bidirectional=bidir, forget_gate_bias=1.0 if kind == 0 else None).eval()
+    rng = np.random.default_rng(H)
+    x = rng.normal(size=(Tn, N, In)).astype(np.float32)
+    lens = np.array([6, 6, 1])
+    (out, _), hid = m((T(x), T(lens)))
+    sd = {k[len("rnn."):]: cpu(v) for k, v in m.state_dict().items()}
+    want, whid = O.rnn_forward(kind, x, lens, sd, H, 1, bidir)
+    np.testing.assert_allclose(cpu(out), want, **TOL)
+    assert float(cpu(out)[6:].__abs__().max()) == 0.0
+    hn = hid[0] if kind == 0 else hid
+    np.testing.assert_allclose(cpu(hn), whid[0] if kind == 0 else whid, **TOL)
+
+
+def test_single_frame_single_utterance():
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    from myrtlespeech_amd.post_process.ctc_beam_decoder import CTCBeamDecoder
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    torch.manual_seed(1)
+    m = RNN(RNNType.LSTM, 8, 256, bidirectional=True).eval()
+    x = np.random.default_rng(1).normal(size=(1, 1, 8)).astype(np.float32)
+    (out, _), _ = m((T(x), torch.tensor([1])))
+    sd = {k[len("rnn."):]: cpu(v) for k, v in m.state_dict().items()}
+    want, _ = O.rnn_forward(O.LSTM, x, np.array([1]), sd, 256, 1, True)
+    np.testing.assert_allclose(cpu(out), want, **TOL)
+    p = torch.tensor([[[0.2, 0.5, 0.3]]])
+    assert CTCGreedyDecoder(2)(p, torch.tensor([1])) == [[1]]
+    assert CTCBeamDecoder(2, 4)(p, torch.tensor([1])) == O.ctc_beam_decode(p.numpy(), np.array([1]), 2, 4)
+
+
+def test_greedy_and_beam_max_sizes():
+    """Config-2 decode shapes (T=501, N=32, V=29) and a wide beam, against the oracle on a slice."""
+    from myrtlespeech_amd.post_process.ctc_beam_decoder import CTCBeamDecoder
+    rng = np.random.default_rng(77)
+    z = rng.normal(size=(501, 32, 29)) * 7
+    x = np.exp(z - z.max(-1, keepdims=True))
+    x = (x / x.sum(-1, keepdims=True)).astype(np.float32)
+    lens = np.sort(rng.integers(100, 502, size=32))[::-1].astype(np.int64)
+    lens[0] = 501
+    got = CTCBeamDecoder(28, 8)(T(x), T(lens))
+    sel = [0, 13, 31]
+    want = O.ctc_beam_decode(x[:, sel], lens[sel], 28, 8)
+    assert [got[i] for i in sel] == want
+    got = CTCBeamDecoder(28, 64, 0.0)(T(x[:60, :2]), torch.tensor([60, 41]))
+    assert got == O.ctc_beam_decode(x[:60, :2], np.array([60, 41]), 28, 64, 0.0)
