@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-logits", action="store_true",
+                    help="batched-decode path: all-gather every shard's logits (RCCL over xGMI) and decode the whole "
+                         "global batch on every rank instead of decoding per shard")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -135,6 +138,9 @@ def main():
 
     def step():
         (logits, out_lens), _ = model((x, lens))
+        if args.gather_logits and dist is not None:
+            from myrtlespeech_amd.parallel import gather_logits
+            logits, out_lens = gather_logits(logits, out_lens)
         return decoder(logits, out_lens)
 
     def barrier():
@@ -179,7 +185,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": precision_label(), "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: DS2 2xconv2d + 5xBiLSTM-1024 + FC, 80-feature x 1001 "
                                    "frames (10 s), batch 32 per GPU, CTC greedy decode (blank 28)",
-                       "global_batch": world * BATCH_PER_GPU, "frames": FRAMES, "parallelism": f"utterance-shard x{world}"},
+                       "global_batch": world * BATCH_PER_GPU, "frames": FRAMES, "parallelism": f"utterance-shard x{world}",
+                       "decode": "all-gather logits, batched decode on every rank" if args.gather_logits else
+                                 "per-shard decode (no data-path collective)"},
             "encoder_ms_per_rnn_step": round(ms_per_step / t_out, 4),
             "kernel_ms": {"lstm_recurrent_per_layer": round(rec_ms, 3), "lstm_input_projection_per_layer":
                           round(ms[0] / max(cnt[0], 1), 3)},
