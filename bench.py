@@ -43,14 +43,19 @@ def precision_label():
     """Arithmetic of the two dominant kernels (LSTM recurrence + input projection): by default every
     f32 operand is split into bf16 hi+lo and multiplied as hi*hi + lo*hi + hi*lo with f32 accumulation
     (MS_PRECISION=f32 selects exact-f32 MFMA instead); conv / FC / CTC are exact f32."""
-    return "f32" if os.environ.get("MS_PRECISION") == "f32" else "bf16x3 (f32 split into bf16 hi+lo, f32 accumulate)"
+    mode = os.environ.get("MS_PRECISION")
+    if mode == "f32":
+        return "f32"
+    if mode == "fp16":
+        return "fp16 (single-pass fp16 operands, f32 accumulate; optional fast mode, outside the 1e-3 parity gate)"
+    return "bf16x3 (f32 split into bf16 hi+lo, f32 accumulate)"
 
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/), or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_lstm.json")) as f:
-            return json.load(f)["hbm_bytes_per_launch"] if os.environ.get("MS_PRECISION") != "f32" else None
+            return json.load(f)["hbm_bytes_per_launch"] if os.environ.get("MS_PRECISION") in (None, "", "bf16x3") else None
     except Exception:
         return None
 

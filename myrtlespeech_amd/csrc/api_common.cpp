@@ -1,4 +1,7 @@
 // Error string + device query shared by every entry point.
+#include <cstdlib>
+#include <cstring>
+
 #include "common.h"
 
 namespace ms {
@@ -13,6 +16,16 @@ int num_cus() {
     cus = p.multiProcessorCount;
   }
   return cus;
+}
+int precision_mode() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MS_PRECISION");
+    v = PREC_BF16X3;
+    if (e && strcmp(e, "f32") == 0) v = PREC_F32;
+    if (e && strcmp(e, "fp16") == 0) v = PREC_F16;
+  }
+  return v;
 }
 }  // namespace ms
 

@@ -42,4 +42,9 @@ __device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) 
 
 int num_cus();
 
+// Operand precision of the split kernels, from MS_PRECISION: 0 = "f32" (exact float32 MFMA),
+// 1 = "bf16x3" (default: bf16 hi+lo, three MFMAs), 2 = "fp16" (single fp16 pass; ~2^-11 operands).
+enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_F16 = 2 };
+int precision_mode();
+
 }  // namespace ms

@@ -24,6 +24,7 @@ namespace {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int CL_T = 128;  // output frames per workgroup
 constexpr int CL_F = 2;    // output feature rows per workgroup
@@ -38,10 +39,11 @@ struct ClP {
 };
 
 __device__ __forceinline__ unsigned bf16b(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ unsigned f16b(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x); }
 
 // packed[plane][kf][kt][kg][cout_pad][8] <- w[cout][cin][kf][kt]
 __global__ void conv_cl_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int Cout, int Cin,
-                                    int KF, int KT, int cout_pad) {
+                                    int KF, int KT, int cout_pad, int f16) {
   const int KG = Cin / 8;
   const size_t plane = (size_t)KF * KT * KG * cout_pad * 8;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x) {
@@ -52,12 +54,18 @@ __global__ void conv_cl_pack_kernel(const float* __restrict__ w, unsigned short*
     const int kf = i / ((size_t)8 * cout_pad * KG * KT);
     float x = 0.f;
     if (co < Cout) x = w[(((size_t)co * Cin + kg * 8 + e) * KF + kf) * KT + kt];
-    const unsigned h = bf16b(x);
-    packed[i] = (unsigned short)h;
-    packed[plane + i] = (unsigned short)bf16b(x - __uint_as_float(h << 16));
+    if (f16) {
+      packed[i] = (unsigned short)f16b(x);
+      packed[plane + i] = 0;
+    } else {
+      const unsigned h = bf16b(x);
+      packed[i] = (unsigned short)h;
+      packed[plane + i] = (unsigned short)bf16b(x - __uint_as_float(h << 16));
+    }
   }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned short* __restrict__ xh,
                                                              const unsigned short* __restrict__ xl,
                                                              const int32_t* __restrict__ lens,
@@ -103,10 +111,10 @@ __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned shor
         if (frow && tin >= 0 && tin < len) {
           const size_t off = (rbase + tin) * p.Cin + kg * 8;
           vh = *reinterpret_cast<const u32x4*>(xh + off);
-          vl = *reinterpret_cast<const u32x4*>(xl + off);
+          if (!F16) vl = *reinterpret_cast<const u32x4*>(xl + off);
         }
         *reinterpret_cast<u32x4*>(Ph + f * row_bytes + (kg * p.PW + q) * 16) = vh;
-        *reinterpret_cast<u32x4*>(Pl + f * row_bytes + (kg * p.PW + q) * 16) = vl;
+        if (!F16) *reinterpret_cast<u32x4*>(Pl + f * row_bytes + (kg * p.PW + q) * 16) = vl;
       }
     }
     // ---- this kf row's filters go through LDS in two halves of the KT taps (keeps the
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned shor
           const int co = i & 31, rest = i >> 5;  // rest = kt_local*KG + kg
           const size_t src = ((((size_t)kf * p.KT + kt0) * p.KG + rest) * cout_pad + tile * 32 + co) * 8;
           *reinterpret_cast<u32x4*>(Wh + i * 16) = *reinterpret_cast<const u32x4*>(wp + src);
-          *reinterpret_cast<u32x4*>(Wl + i * 16) = *reinterpret_cast<const u32x4*>(wp + wplane + src);
+          if (!F16) *reinterpret_cast<u32x4*>(Wl + i * 16) = *reinterpret_cast<const u32x4*>(wp + wplane + src);
         }
       }
       __syncthreads();
@@ -130,16 +138,21 @@ __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned shor
         for (int s = 0; s < p.KG / 2; ++s) {
           const int kg = 2 * s + half;
           const int woff = ((ktl * p.KG + kg) * 32 + l31) * 16;
-          const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Wh + woff));
-          const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Wl + woff));
+          const u32x4 ah = *reinterpret_cast<const u32x4*>(Wh + woff);
+          u32x4 al = ah;
+          if (!F16) al = *reinterpret_cast<const u32x4*>(Wl + woff);
 #pragma unroll
           for (int f = 0; f < CL_F; ++f) {
             const int poff = f * row_bytes + (kg * p.PW + tq) * 16;
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ph + poff));
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Pl + poff));
-            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[f], 0, 0, 0);
-            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[f], 0, 0, 0);
-            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[f], 0, 0, 0);
+            const u32x4 bh = *reinterpret_cast<const u32x4*>(Ph + poff);
+            if (F16) {
+              acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), acc[f], 0, 0, 0);
+            } else {
+              const u32x4 bl = *reinterpret_cast<const u32x4*>(Pl + poff);
+              acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc[f], 0, 0, 0);
+              acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc[f], 0, 0, 0);
+              acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc[f], 0, 0, 0);
+            }
           }
         }
       }
@@ -168,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned shor
 
 // f32 NCHW [N][C][F][T] -> channels-last bf16 hi / lo planes [N][F][T][C]  (C % 8 == 0)
 __global__ void nchw_to_cl_split_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi,
-                                        unsigned short* __restrict__ lo, int C, int F, int T) {
+                                        unsigned short* __restrict__ lo, int C, int F, int T, int f16) {
   __shared__ float tile[32][33];
   const int n = blockIdx.z / F, f = blockIdx.z % F;
   const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -182,10 +195,14 @@ __global__ void nchw_to_cl_split_kernel(const float* __restrict__ x, unsigned sh
     const int t = t0 + i, c = c0 + tx;
     if (t < T && c < C) {
       const float v = tile[tx][i];
-      const unsigned h = bf16b(v);
       const size_t o = (((size_t)n * F + f) * T + t) * C + c;
-      hi[o] = (unsigned short)h;
-      lo[o] = (unsigned short)bf16b(v - __uint_as_float(h << 16));
+      if (f16) {
+        hi[o] = (unsigned short)f16b(v);
+      } else {
+        const unsigned h = bf16b(v);
+        hi[o] = (unsigned short)h;
+        lo[o] = (unsigned short)bf16b(v - __uint_as_float(h << 16));
+      }
     }
   }
 }
@@ -204,7 +221,7 @@ extern "C" int ms_maskconv_cl_pack(const float* w, void* packed, int Cout, int C
   const size_t plane = (size_t)KF * KT * (Cin / 8) * cout_pad * 8;
   const int blocks = (int)std::min<size_t>((plane + 255) / 256, 2048);
   hipLaunchKernelGGL(conv_cl_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)packed, Cout,
-                     Cin, KF, KT, cout_pad);
+                     Cin, KF, KT, cout_pad, ms::precision_mode() == ms::PREC_F16 ? 1 : 0);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }
@@ -240,18 +257,24 @@ extern "C" int ms_maskconv_cl_forward(const float* x, const int32_t* lens, const
   }
   static bool attr_set = false;
   if (!attr_set) {
-    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   unsigned short* xh = (unsigned short*)workspace;
   unsigned short* xl = xh + (size_t)N * Cin * Fin * Tin;
   MS_REQUIRE(N * Fin <= 65535, "N*Fin exceeds grid limits");
+  const bool f16 = ms::precision_mode() == ms::PREC_F16;
   hipLaunchKernelGGL(nchw_to_cl_split_kernel, dim3(ms::cdiv(Tin, 32), ms::cdiv(Cin, 32), N * Fin), dim3(32, 8), 0, stream, x,
-                     xh, xl, Cin, Fin, Tin);
+                     xh, xl, Cin, Fin, Tin, f16 ? 1 : 0);
   MS_LAUNCH_CHECK();
   dim3 grid(ms::cdiv(Tout, CL_T), ms::cdiv(Fout, CL_F), N * p.co_tiles);
-  hipLaunchKernelGGL(maskconv_cl_kernel, grid, dim3(256), lds, stream, xh, xl, lens, (const unsigned short*)packed_w, bias, y,
-                     p);
+  if (f16)
+    hipLaunchKernelGGL(maskconv_cl_kernel<true>, grid, dim3(256), lds, stream, xh, xl, lens, (const unsigned short*)packed_w,
+                       bias, y, p);
+  else
+    hipLaunchKernelGGL(maskconv_cl_kernel<false>, grid, dim3(256), lds, stream, xh, xl, lens, (const unsigned short*)packed_w,
+                       bias, y, p);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }

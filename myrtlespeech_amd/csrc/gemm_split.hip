@@ -21,8 +21,20 @@ namespace ms {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ unsigned bf16_hi_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
+
+__device__ __forceinline__ unsigned f16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x); }
+
+// fp16 mode: one plane of round-to-nearest fp16 values
+__global__ void to_f16_plane_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    u32x2 ho = {f16_bits(v[0]) | (f16_bits(v[1]) << 16), f16_bits(v[2]) | (f16_bits(v[3]) << 16)};
+    reinterpret_cast<u32x2*>(hi)[i] = ho;
+  }
+}
 
 __global__ void split_planes_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi,
                                     unsigned short* __restrict__ lo, size_t n4) {
@@ -179,6 +191,7 @@ constexpr int S2_TILE = 4 * S2_PLANE;           // one operand plane-set (hi or 
 constexpr int S2_BUF = 4 * S2_TILE;             // A_hi, A_lo, B_hi, B_lo
 constexpr int SPLIT2_LDS = 2 * S2_BUF;
 
+template <bool F16>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel2(const unsigned short* __restrict__ Ah,
                                                                  const unsigned short* __restrict__ Al,
                                                                  const unsigned short* __restrict__ Wh,
@@ -221,9 +234,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel2(const unsigned 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       rah[i] = ld_granule(Ah, M, K, m0 + r_in + 128 * i, k0 + kg * 8);
-      ral[i] = ld_granule(Al, M, K, m0 + r_in + 128 * i, k0 + kg * 8);
       rbh[i] = ld_granule(Wh, N, K, n0 + r_in + 128 * i, k0 + kg * 8);
-      rbl[i] = ld_granule(Wl, N, K, n0 + r_in + 128 * i, k0 + kg * 8);
+      if (!F16) {
+        ral[i] = ld_granule(Al, M, K, m0 + r_in + 128 * i, k0 + kg * 8);
+        rbl[i] = ld_granule(Wl, N, K, n0 + r_in + 128 * i, k0 + kg * 8);
+      }
     }
   };
   auto store_regs = [&](char* buf) {
@@ -231,9 +246,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel2(const unsigned 
     for (int i = 0; i < 2; ++i) {
       const int off = kg * S2_PLANE + (r_in + 128 * i) * 16;
       *reinterpret_cast<u32x4*>(buf + off) = rah[i];
-      *reinterpret_cast<u32x4*>(buf + S2_TILE + off) = ral[i];
       *reinterpret_cast<u32x4*>(buf + 2 * S2_TILE + off) = rbh[i];
-      *reinterpret_cast<u32x4*>(buf + 3 * S2_TILE + off) = rbl[i];
+      if (!F16) {
+        *reinterpret_cast<u32x4*>(buf + S2_TILE + off) = ral[i];
+        *reinterpret_cast<u32x4*>(buf + 3 * S2_TILE + off) = rbl[i];
+      }
     }
   };
 
@@ -249,26 +266,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel2(const unsigned 
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int g = 2 * s + half;
-      bf16x8 ah[2], al[2], bh[4], bl[4];
+      u32x4 ah[2], al[2], bh[4], bl[4];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int off = g * S2_PLANE + (wm * 64 + i * 32 + l31) * 16;
-        ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + off));
-        al[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + S2_TILE + off));
+        ah[i] = *reinterpret_cast<const u32x4*>(cur + off);
+        if (!F16) al[i] = *reinterpret_cast<const u32x4*>(cur + S2_TILE + off);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int off = g * S2_PLANE + (wn * 128 + j * 32 + l31) * 16;
-        bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + 2 * S2_TILE + off));
-        bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + 3 * S2_TILE + off));
+        bh[j] = *reinterpret_cast<const u32x4*>(cur + 2 * S2_TILE + off);
+        if (!F16) bl[j] = *reinterpret_cast<const u32x4*>(cur + 3 * S2_TILE + off);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if (F16) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[i]), __builtin_bit_cast(f16x8, bh[j]),
+                                                               acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
+          }
         }
     }
     __syncthreads();
@@ -293,10 +315,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel2(const unsigned 
 }
 
 // hi/lo planes of an f32 matrix [rows, K] (K % 4 == 0, 16-byte aligned)
-int split_planes_launch(const float* x, unsigned short* hi, unsigned short* lo, size_t elems, hipStream_t stream) {
+int split_planes_launch(const float* x, unsigned short* hi, unsigned short* lo, size_t elems, int prec, hipStream_t stream) {
   const size_t n4 = elems / 4;
   const int blocks = (int)std::min<size_t>((n4 + 255) / 256, 4096);
-  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, x, hi, lo, n4);
+  if (prec == PREC_F16)
+    hipLaunchKernelGGL(to_f16_plane_kernel, dim3(blocks), dim3(256), 0, stream, x, hi, n4);
+  else
+    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, x, hi, lo, n4);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }
@@ -304,18 +329,24 @@ int split_planes_launch(const float* x, unsigned short* hi, unsigned short* lo, 
 // requires K % 32 == 0 and 16-byte aligned planes
 int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
                        const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
-                       float hi, hipStream_t stream) {
+                       float hi, int prec, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel2, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT2_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT2_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT2_LDS));
     attr_set = true;
   }
   static const bool small_tile = getenv("MS_GEMM_TILE128") && getenv("MS_GEMM_TILE128")[0] == '1';
-  if (!small_tile && (long)M * N >= 4L * 1024 * 1024) {
+  const bool f16 = prec == PREC_F16;
+  if (f16 || (!small_tile && (long)M * N >= 4L * 1024 * 1024)) {
     const int nwg2 = cdiv(M, S2_M) * cdiv(N, S2_N);
-    hipLaunchKernelGGL(gemm_nt_bf16x3_kernel2, dim3(nwg2), dim3(512), SPLIT2_LDS, stream, ah, al, wh, wl, bias, y, M, K, N,
-                       act, lo, hi);
+    if (f16)
+      hipLaunchKernelGGL(gemm_nt_bf16x3_kernel2<true>, dim3(nwg2), dim3(512), SPLIT2_LDS, stream, ah, al, wh, wl, bias, y, M,
+                         K, N, act, lo, hi);
+    else
+      hipLaunchKernelGGL(gemm_nt_bf16x3_kernel2<false>, dim3(nwg2), dim3(512), SPLIT2_LDS, stream, ah, al, wh, wl, bias, y, M,
+                         K, N, act, lo, hi);
     MS_LAUNCH_CHECK();
     return MS_OK;
   }
@@ -349,8 +380,9 @@ extern "C" int ms_linear_split_forward(const float* x, const float* w, const flo
   unsigned short* xl = xh + (size_t)M * K;
   unsigned short* wh = (unsigned short*)((char*)workspace + ms::align_up((size_t)M * K * 4, 256));
   unsigned short* wl = wh + (size_t)N * K;
-  int rc = ms::split_planes_launch(x, xh, xl, (size_t)M * K, stream);
-  if (rc == MS_OK) rc = ms::split_planes_launch(w, wh, wl, (size_t)N * K, stream);
-  if (rc == MS_OK) rc = ms::gemm_bf16x3_launch(xh, xl, wh, wl, bias, y, M, K, N, act, act_lo, act_hi, stream);
+  const int prec = ms::precision_mode() == ms::PREC_F16 ? ms::PREC_F16 : ms::PREC_BF16X3;
+  int rc = ms::split_planes_launch(x, xh, xl, (size_t)M * K, prec, stream);
+  if (rc == MS_OK) rc = ms::split_planes_launch(w, wh, wl, (size_t)N * K, prec, stream);
+  if (rc == MS_OK) rc = ms::gemm_bf16x3_launch(xh, xl, wh, wl, bias, y, M, K, N, act, act_lo, act_hi, prec, stream);
   return rc;
 }

@@ -30,10 +30,10 @@
 #include "common.h"
 
 namespace ms {
-int split_planes_launch(const float* x, unsigned short* hi, unsigned short* lo, size_t elems, hipStream_t stream);
+int split_planes_launch(const float* x, unsigned short* hi, unsigned short* lo, size_t elems, int prec, hipStream_t stream);
 int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
                        const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
-                       float hi, hipStream_t stream);
+                       float hi, int prec, hipStream_t stream);
 int linear_launch(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act, float lo,
                   float hi, hipStream_t stream);
 }
@@ -69,17 +69,14 @@ bool use_fast(int cell, int H, int ndir) {
 // Operand precision of the persistent recurrence: "f32" = exact float32 MFMA,
 // "bf16x3" (default) = every f32 operand split into bf16 hi + lo, products hi*hi + lo*hi +
 // hi*lo accumulated in f32 (relative error ~2^-17 per product instead of 2^-24).
-bool want_split() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MS_PRECISION");
-    v = (e && strcmp(e, "f32") == 0) ? 0 : 1;
-  }
-  return v == 1;
-}
+bool want_split() { return ms::precision_mode() != ms::PREC_F32; }
 bool use_split(int cell, int H, int ndir) { return use_fast(cell, H, ndir) && want_split() && H % 64 == 0; }
 // the input projection runs as the bf16x3 GEMM whenever the recurrence is split and In allows 16-byte granules
 bool two_stream_shape(int H) { return H == 256 || H == 512 || H == 768 || H == 1024; }
+// MS_PRECISION=fp16: single-pass fp16 operands, only on the two-stream kernel's shapes (elsewhere bf16x3)
+bool use_f16(int cell, int H, int ndir) {
+  return ms::precision_mode() == ms::PREC_F16 && use_split(cell, H, ndir) && two_stream_shape(H);
+}
 bool use_split_gemm(int cell, int H, int ndir, int In) { return use_split(cell, H, ndir) && In % 32 == 0; }
 
 struct PackLayout {
@@ -129,6 +126,7 @@ __global__ void pack_rows_fast_kernel(const float* __restrict__ w, float* __rest
 }
 
 // same row order, written as bf16 hi / lo planes (plane stride = rows_total * In elements)
+template <bool F16>
 __global__ void pack_rows_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ hi,
                                        unsigned short* __restrict__ lo, int H, int In) {
   const int row = blockIdx.x;
@@ -136,9 +134,13 @@ __global__ void pack_rows_split_kernel(const float* __restrict__ w, unsigned sho
   const float* src = w + (size_t)(g * H + 8 * j + u) * In;
   for (int k = threadIdx.x; k < In; k += blockDim.x) {
     const float x = src[k];
-    const __bf16 h = (__bf16)x;
-    hi[(size_t)row * In + k] = __builtin_bit_cast(unsigned short, h);
-    lo[(size_t)row * In + k] = __builtin_bit_cast(unsigned short, (__bf16)(x - (float)h));
+    if (F16) {
+      hi[(size_t)row * In + k] = __builtin_bit_cast(unsigned short, (_Float16)x);
+    } else {
+      const __bf16 h = (__bf16)x;
+      hi[(size_t)row * In + k] = __builtin_bit_cast(unsigned short, h);
+      lo[(size_t)row * In + k] = __builtin_bit_cast(unsigned short, (__bf16)(x - (float)h));
+    }
   }
 }
 
@@ -165,6 +167,7 @@ __global__ void pack_whh_fast_kernel(const float* __restrict__ w, float* __restr
 }
 
 // whh_s[j][plane][kg][r = g*8+u][e] (bf16) = hi / lo part of w_hh[g*H + 8j + u][8kg + e]
+template <bool F16>
 __global__ void pack_whh_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int H) {
   const size_t total = (size_t)4 * H * H;  // elements per plane
   const int KG = H / 8;
@@ -175,11 +178,16 @@ __global__ void pack_whh_split_kernel(const float* __restrict__ w, unsigned shor
     const int j = (i >> 8) / KG;
     const int g = r >> 3, u = r & 7;
     const float x = w[(size_t)(g * H + 8 * j + u) * H + 8 * kg + e];
-    const __bf16 hi = (__bf16)x;
-    const __bf16 lo = (__bf16)(x - (float)hi);
     const size_t base = (size_t)j * 2 * KG * 256 + ((size_t)kg * 32 + r) * 8 + e;
-    dst[base] = __builtin_bit_cast(unsigned short, hi);
-    dst[base + (size_t)KG * 256] = __builtin_bit_cast(unsigned short, lo);
+    if (F16) {
+      dst[base] = __builtin_bit_cast(unsigned short, (_Float16)x);
+      dst[base + (size_t)KG * 256] = 0;
+    } else {
+      const __bf16 hi = (__bf16)x;
+      const __bf16 lo = (__bf16)(x - (float)hi);
+      dst[base] = __builtin_bit_cast(unsigned short, hi);
+      dst[base + (size_t)KG * 256] = __builtin_bit_cast(unsigned short, lo);
+    }
   }
 }
 
@@ -541,10 +549,20 @@ template <int K>
 __device__ __forceinline__ unsigned row_shl(unsigned v) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + K, 0xF, 0xF, true);
 }
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+
+// F16: the hi plane carries tagged fp16 values and the lo plane is not used.
+template <bool F16 = false>
 __device__ __forceinline__ void publish_split(float hval, unsigned tag, __amdgpu_buffer_rsrc_t rsrc, int off_hi, int off_lo,
                                               int lane) {
-  const unsigned hi = (bf16_bits(hval) & 0xFFFEu) | tag;
-  const unsigned lo = (bf16_bits(hval - bf16_val(hi)) & 0xFFFEu) | tag;
+  unsigned hi, lo;
+  if (F16) {
+    hi = ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)hval) & 0xFFFEu) | tag;
+    lo = 0u;
+  } else {
+    hi = (bf16_bits(hval) & 0xFFFEu) | tag;
+    lo = (bf16_bits(hval - bf16_val(hi)) & 0xFFFEu) | tag;
+  }
   const unsigned v = hi | (lo << 16);
   unsigned g[8];
   g[0] = v;
@@ -557,7 +575,7 @@ __device__ __forceinline__ void publish_split(float hval, unsigned tag, __amdgpu
     ol[0] = (g[0] >> 16) | (g[1] & 0xFFFF0000u); ol[1] = (g[2] >> 16) | (g[3] & 0xFFFF0000u);
     ol[2] = (g[4] >> 16) | (g[5] & 0xFFFF0000u); ol[3] = (g[6] >> 16) | (g[7] & 0xFFFF0000u);
     __builtin_amdgcn_raw_buffer_store_b128(oh, rsrc, off_hi, 0, /*aux: sc1*/ 16);
-    __builtin_amdgcn_raw_buffer_store_b128(ol, rsrc, off_lo, 0, /*aux: sc1*/ 16);
+    if (!F16) __builtin_amdgcn_raw_buffer_store_b128(ol, rsrc, off_lo, 0, /*aux: sc1*/ 16);
   }
 }
 
@@ -804,7 +822,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) 
 // H in {256, 512, 768, 1024}, N <= 32 per launch.  hx layout per direction: [stream][plane hi|lo][parity][k/8][16][8 bf16].
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int KS, bool HARD, bool STAMP = false>
+template <int KS, bool HARD, bool STAMP = false, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p) {
   constexpr int H = 128 * KS, KG = H / 8;  // KS k-steps (K = 32) per wave; H in {256, 512, 768, 1024}
   constexpr int RED2 = 4 * 16 * RED_STRIDE;
@@ -829,8 +847,10 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
       const char* wp = wsrc + (kg * 32 + c16) * 16;
       wh0[ks] = *reinterpret_cast<const u32x4*>(wp);
       wh1[ks] = *reinterpret_cast<const u32x4*>(wp + 256);
-      wl0[ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512);
-      wl1[ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512 + 256);
+      if (!F16) {
+        wl0[ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512);
+        wl1[ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512 + 256);
+      }
     }
   }
 
@@ -851,7 +871,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
       c[sg] = (valid && p.c0) ? p.c0[sidx] : 0.f;
       len_n[sg] = valid ? (p.lens ? p.lens[p.n_base + n] : p.steps) : 0;
       const int off = sg * STREAM + j * 256 + nl * 16;  // parity 0
-      publish_split(h[sg], 0u, hx_rsrc, off, PLANE + off, lane);
+      publish_split<F16>(h[sg], 0u, hx_rsrc, off, PLANE + off, lane);
     }
   }
   __syncthreads();
@@ -888,12 +908,12 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
         for (int ks = 0; ks < KS; ++ks) {
           const int kg = kg_base + 4 * ks + q;
           ah[ks] = load_sc1_u128(hx_rsrc, base + kg * 256);
-          al[ks] = load_sc1_u128(hx_rsrc, PLANE + base + kg * 256);
+          if (!F16) al[ks] = load_sc1_u128(hx_rsrc, PLANE + base + kg * 256);
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) bad |= (ah[ks][e] ^ em) | (al[ks][e] ^ em);
+          for (int e = 0; e < 4; ++e) bad |= (ah[ks][e] ^ em) | (F16 ? 0u : (al[ks][e] ^ em));
         if (!alive || !__any((bad & 0x00010001u) != 0)) break;
         if ((++spins & 63u) == 0) {
           const unsigned dead = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -910,18 +930,24 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
       f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 bh0 = __builtin_bit_cast(bf16x8, wh0[ks]);
-        const bf16x8 bh1 = __builtin_bit_cast(bf16x8, wh1[ks]);
-        const bf16x8 bl0 = __builtin_bit_cast(bf16x8, wl0[ks]);
-        const bf16x8 bl1 = __builtin_bit_cast(bf16x8, wl1[ks]);
-        const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]);
-        const bf16x8 xl = __builtin_bit_cast(bf16x8, al[ks]);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh1, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh1, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl1, acc1, 0, 0, 0);
+        if (F16) {
+          const f16x8v xh = __builtin_bit_cast(f16x8v, ah[ks]);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, __builtin_bit_cast(f16x8v, wh0[ks]), acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, __builtin_bit_cast(f16x8v, wh1[ks]), acc1, 0, 0, 0);
+        } else {
+          const bf16x8 bh0 = __builtin_bit_cast(bf16x8, wh0[ks]);
+          const bf16x8 bh1 = __builtin_bit_cast(bf16x8, wh1[ks]);
+          const bf16x8 bl0 = __builtin_bit_cast(bf16x8, wl0[ks]);
+          const bf16x8 bl1 = __builtin_bit_cast(bf16x8, wl1[ks]);
+          const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]);
+          const bf16x8 xl = __builtin_bit_cast(bf16x8, al[ks]);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh1, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh1, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl1, acc1, 0, 0, 0);
+        }
       }
       if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[1] += now - st_prev; st_prev = now; }
 
@@ -956,7 +982,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
         c[sg] = active ? cnew : c[sg];
         h[sg] = active ? hnew : h[sg];
         const int off = sg * STREAM + (par ^ 1) * KG * 256 + j * 256 + nl * 16;
-        publish_split(h[sg], wtag, hx_rsrc, off, PLANE + off, lane);
+        publish_split<F16>(h[sg], wtag, hx_rsrc, off, PLANE + off, lane);
         if (n < N) p.out[((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit] = active ? hnew : 0.f;
       }
       if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[2] += now - st_prev; st_prev = now; }
@@ -1058,15 +1084,23 @@ extern "C" int ms_rnn_pack(int cell, int In, int H, int ndir, const float* const
       if (use_split_gemm(cell, H, ndir, In)) {
         unsigned short* hi0 = (unsigned short*)(base + L.wih);
         unsigned short* lo0 = hi0 + (size_t)ndir * GH * In;
-        hipLaunchKernelGGL(pack_rows_split_kernel, dim3(4 * H), dim3(128), 0, stream, w_ih[d], hi0 + (size_t)d * GH * In,
-                           lo0 + (size_t)d * GH * In, H, In);
+        if (use_f16(cell, H, ndir))
+          hipLaunchKernelGGL(pack_rows_split_kernel<true>, dim3(4 * H), dim3(128), 0, stream, w_ih[d],
+                             hi0 + (size_t)d * GH * In, lo0 + (size_t)d * GH * In, H, In);
+        else
+          hipLaunchKernelGGL(pack_rows_split_kernel<false>, dim3(4 * H), dim3(128), 0, stream, w_ih[d],
+                             hi0 + (size_t)d * GH * In, lo0 + (size_t)d * GH * In, H, In);
       } else {
         hipLaunchKernelGGL(pack_rows_fast_kernel, dim3(4 * H), dim3(128), 0, stream, w_ih[d], wih_d, H, In);
       }
       hipLaunchKernelGGL(pack_bias_fast_kernel, dim3(ms::cdiv(4 * H, 256)), dim3(256), 0, stream, bi, bh, bx_d, H);
       if (use_split(cell, H, ndir))
-        hipLaunchKernelGGL(pack_whh_split_kernel, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d],
-                           (unsigned short*)whh_d, H);
+        if (use_f16(cell, H, ndir))
+          hipLaunchKernelGGL(pack_whh_split_kernel<true>, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d],
+                             (unsigned short*)whh_d, H);
+        else
+          hipLaunchKernelGGL(pack_whh_split_kernel<false>, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d],
+                             (unsigned short*)whh_d, H);
       else
         hipLaunchKernelGGL(pack_whh_fast_kernel, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d], whh_d, H);
       hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH)), dim3(256), 0, stream, (const float*)nullptr, bhh_d,
@@ -1115,15 +1149,23 @@ static int launch_split(const LstmP& p, hipStream_t stream) {
   return MS_OK;
 }
 
-template <int KS, bool HARD, bool STAMP = false>
+template <int KS, bool HARD, bool STAMP = false, bool F16 = false>
 static int launch_split2(const LstmP& p, hipStream_t stream) {
   const size_t lds = (size_t)RED_FLOATS * sizeof(float);
-  hipLaunchKernelGGL((lstm_persistent_split2_kernel<KS, HARD, STAMP>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((lstm_persistent_split2_kernel<KS, HARD, STAMP, F16>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }
 
-static int launch_split2_any(const LstmP& p, bool hard, bool stamps, hipStream_t stream) {
+static int launch_split2_any(const LstmP& p, bool hard, bool stamps, bool f16, hipStream_t stream) {
+  if (f16) {
+    switch (p.H) {
+      case 256: return hard ? launch_split2<2, true, false, true>(p, stream) : launch_split2<2, false, false, true>(p, stream);
+      case 512: return hard ? launch_split2<4, true, false, true>(p, stream) : launch_split2<4, false, false, true>(p, stream);
+      case 768: return hard ? launch_split2<6, true, false, true>(p, stream) : launch_split2<6, false, false, true>(p, stream);
+      default: return hard ? launch_split2<8, true, false, true>(p, stream) : launch_split2<8, false, false, true>(p, stream);
+    }
+  }
   switch (p.H) {
     case 256: return hard ? launch_split2<2, true>(p, stream) : launch_split2<2, false>(p, stream);
     case 512: return hard ? launch_split2<4, true>(p, stream) : launch_split2<4, false>(p, stream);
@@ -1174,10 +1216,11 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
       unsigned short* xl = xh + (size_t)steps * N * In;
       const unsigned short* wh = (const unsigned short*)(pk + L.wih);
       const unsigned short* wl = wh + (size_t)ndir * GH * In;
-      rc = ms::split_planes_launch(x, xh, xl, (size_t)steps * N * In, stream);
+      const int prec = use_f16(cell, H, ndir) ? ms::PREC_F16 : ms::PREC_BF16X3;
+      rc = ms::split_planes_launch(x, xh, xl, (size_t)steps * N * In, prec, stream);
       if (rc == MS_OK)
         rc = ms::gemm_bf16x3_launch(xh, xl, wh, wl, (const float*)(pk + L.bias_x), xproj, steps * N, In, (int)(ndir * GH),
-                                    MS_ACT_NONE, 0.f, 0.f, stream);
+                                    MS_ACT_NONE, 0.f, 0.f, prec, stream);
     } else {
       rc = ms::linear_launch(x, (const float*)(pk + L.wih), (const float*)(pk + L.bias_x), xproj, steps * N, In,
                              (int)(ndir * GH), MS_ACT_NONE, 0.f, 0.f, stream);
@@ -1217,8 +1260,8 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
         const bool hard_ = (cell == MS_CELL_HARD_LSTM);
         if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.total - W.dbg, stream));
         static const bool one_stream = getenv("MS_LSTM_ONE_STREAM") && getenv("MS_LSTM_ONE_STREAM")[0] == '1';
-        if (p.NPAD == 32 && two_stream_shape(H) && !one_stream) {
-          rc = launch_split2_any(p, hard_, stamps, stream);
+        if (p.NPAD == 32 && two_stream_shape(H) && (!one_stream || use_f16(cell, H, ndir))) {
+          rc = launch_split2_any(p, hard_, stamps, use_f16(cell, H, ndir), stream);
         } else if (p.NPAD == 32 && H == 1024) {
           if (stamps && !hard_) rc = launch_split<1, 4, false, true>(p, stream);
           else rc = hard_ ? launch_split<1, 4, true>(p, stream) : launch_split<1, 4, false>(p, stream);

@@ -632,3 +632,44 @@ def test_greedy_and_beam_max_sizes():
     assert [got[i] for i in sel] == want
     got = CTCBeamDecoder(28, 64, 0.0)(T(x[:60, :2]), torch.tensor([60, 41]))
     assert got == O.ctc_beam_decode(x[:60, :2], np.array([60, 41]), 28, 64, 0.0)
+
+
+def test_fp16_mode_in_subprocess():
+    """MS_PRECISION=fp16 (optional fast mode for chunked streaming, BASELINE.json configs[4]): single-pass
+    fp16 operands in the two-stream LSTM, the projection GEMM, large Linears and the channels-last conv.
+    Checked at fp16-level tolerances against the oracle in one child process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from myrtlespeech_amd.model.rnn import RNN, RNNType
+from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+from oracle import ds_oracle as O
+for H, N, T_ in ((1024, 32, 6), (256, 20, 7)):
+    torch.manual_seed(H)
+    m = RNN(RNNType.LSTM, 64, H, num_layers=2, bidirectional=True, forget_gate_bias=1.0).eval()
+    rng = np.random.default_rng(H)
+    lens = np.sort(rng.integers(1, T_ + 1, size=N))[::-1].copy(); lens[0] = T_
+    x = rng.normal(size=(T_, N, 64)).astype(np.float32)
+    (out, _), (hn, cn) = m((torch.from_numpy(x), torch.from_numpy(lens)))
+    sd = {k[4:]: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    want, (whn, wcn) = O.rnn_forward(O.LSTM, x, lens, sd, H, 2, True)
+    err = float(np.abs(out.cpu().numpy() - want).max())
+    assert err < 3e-3, err
+    assert float(np.abs(out.cpu().numpy()[int(lens[-1]):, -1]).max() if int(lens[-1]) < T_ else 0.0) == 0.0
+    print("lstm fp16 err", H, err)
+torch.manual_seed(1)
+c = MaskConv2d(32, 32, [5, 5], [2, 1], PaddingMode.SAME).eval()
+x = np.random.default_rng(2).normal(size=(2, 32, 12, 300)).astype(np.float32)
+y, _ = c((torch.from_numpy(x), torch.tensor([300, 200])), fused_activation=(0.0, 20.0))
+want, _ = O.mask_conv2d(x, np.array([300, 200]), c.weight.detach().cpu().numpy(), c.bias.detach().cpu().numpy(), (2, 1), True)
+err = float(np.abs(y.cpu().numpy() - np.clip(want, 0, 20)).max())
+assert err < 2e-2, err
+print("conv fp16 err", err)
+print("fp16 mode ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MS_PRECISION="fp16")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fp16 mode ok" in r.stdout, r.stdout + r.stderr
