@@ -1,0 +1,1 @@
+"""Alphabet (symbol <-> index maps)."""

@@ -1,0 +1,1 @@
+"""CTC loss."""

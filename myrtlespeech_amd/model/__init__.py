@@ -1,0 +1,1 @@
+"""Encoder modules: masked convolutions, recurrent layers, DS1/DS2 compositions, RNN-T parts."""

@@ -1,0 +1,1 @@
+"""Decoders: CTC greedy / prefix beam search, RNN-T greedy / beam."""
