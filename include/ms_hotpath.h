@@ -204,6 +204,52 @@ int ms_ctc_beam_decode(const float* probs, const int32_t* lens, int32_t* out_idx
                        int32_t* beam_idx, int32_t* beam_plen, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* ---- feature front-end: data/preprocess.py + builders/pre_process_step.py ---- */
+
+/* torchaudio.transforms.MFCC as built by builders/pre_process_step.py:33-43 (torchaudio==0.4.0,
+ * environment.yml:171; absent here, so the pipeline is restated from its published algorithm):
+ * centred, reflect-padded STFT with `window` [n_fft] -> power -> mel_fb [n_mels, n_fft/2+1] ->
+ * 10*log10(max(.,1e-10)) floored at (per-utterance max - top_db) -> dct [n_mfcc, n_mels].
+ * wave [N, max_samples] zero-padded, wave_lens [N] (each > n_fft/2); dft [2*(n_fft/2+1), n_fft] holds
+ * the cos rows then the -sin rows.  out [N, n_mfcc, T], T = 1 + max_samples/hop; utterance n has
+ * 1 + wave_lens[n]/hop frames, later frames are zero (what data/batch.py:7-42 pads with).
+ * top_db < 0 disables the floor. */
+size_t ms_mfcc_workspace_bytes(int N, int T, int n_fft, int n_mels, int n_mfcc);
+int ms_mfcc_forward(const float* wave, const int32_t* wave_lens, const float* window, const float* dft,
+                    const float* mel_fb, const float* dct, float* out, int N, int max_samples, int T, int n_fft,
+                    int hop, int n_mels, int n_mfcc, float top_db, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* MFCCLegacy.__call__ (data/preprocess.py:262-319) = python_speech_features==0.6 `mfcc`
+ * (environment.yml:169; absent here, restated from its published algorithm) in float64: samples
+ * scaled to the int16 range and truncated, pre-emphasis, rectangular frames of frame_len every
+ * frame_step samples (zero-padded tail), |DFT_nfft|^2/nfft, fbank [nfilt, nfft/2+1], log,
+ * dct [numcep, nfilt], lifter [numcep], coefficient 0 := log(frame energy).  twiddle [nfft, 2] holds
+ * (cos, sin)(2 pi j / nfft).  out [N, numcep, T] float32, T = frame count of max_samples; frames
+ * past an utterance's own count are zero. */
+int ms_mfcc_legacy_forward(const float* wave, const int32_t* wave_lens, const double* twiddle, const double* fbank,
+                           const double* dct, const double* lifter, float* out, int N, int max_samples, int T,
+                           int frame_len, int frame_step, int nfft, int nfilt, int numcep, double preemph,
+                           void* stream);
+
+/* Standardize.__call__ (data/preprocess.py:57-63) per utterance: y = (x - mean) / std (unbiased)
+ * over x[n, :, t < lens[n]]; x, y [N, inner, T]; frames t >= lens[n] are written as 0.  lens may be
+ * NULL (every utterance is T frames long).  y may alias x. */
+size_t ms_standardize_workspace_bytes(int N);
+int ms_standardize_forward(const float* x, const int32_t* lens, float* y, int N, int inner, int T, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* AddContextFrames.__call__ (data/preprocess.py:117-141): x [N, F, T] -> y [N, 2c+1, F, T],
+ * y[n,w,f,t] = x[n,f,t+w-c] when both t and t+w-c lie inside utterance n, else 0. */
+int ms_context_frames_forward(const float* x, const int32_t* lens, float* y, int N, int F, int T, int n_context,
+                              void* stream);
+
+/* SpecAugment.__call__ (data/preprocess.py:193-218), the zeroing half: the host draws the bands in
+ * the reference's order; f_bands [N, n_f, 2] / t_bands [N, n_t, 2] hold (start, width) int32 pairs
+ * on the device.  x [N, C, F, T] is modified in place. */
+int ms_spec_augment_(float* x, const int32_t* f_bands, const int32_t* t_bands, int N, int C, int F, int T, int n_f,
+                     int n_t, void* stream);
+
 /* ---- RNN-T decode step (own specification: the reference snapshot has no transducer,
  *      SURVEY 0.3 / 8 a15; see myrtlespeech_amd/model/rnnt.py) ------------------------------ */
 

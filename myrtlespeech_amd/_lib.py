@@ -6,7 +6,7 @@ loudly; if there is no HIP device, every op raises ``RuntimeError``.
 import ctypes
 import os
 import re
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_long, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_long, c_size_t, c_void_p
 
 import torch
 
@@ -58,6 +58,13 @@ SIGNATURES = {
     "ms_ctc_beam_workspace_bytes": (c_size_t, [c_int] * 4),
     "ms_ctc_beam_decode": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_int, c_int,
                                    _P, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "ms_mfcc_workspace_bytes": (c_size_t, [c_int] * 5),
+    "ms_mfcc_forward": (c_int, [_P] * 7 + [c_int] * 7 + [c_float, _P, c_size_t, _P]),
+    "ms_mfcc_legacy_forward": (c_int, [_P] * 7 + [c_int] * 8 + [c_double, _P]),
+    "ms_standardize_workspace_bytes": (c_size_t, [c_int]),
+    "ms_standardize_forward": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "ms_context_frames_forward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ms_spec_augment_": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
 }
 
 _lib = None

@@ -1,35 +1,19 @@
-"""Mirror of myrtlespeech/builders/speech_to_text.py:29-272 for the model path.
-
-The audio front-end transforms (MFCC via torchaudio, Standardize, AddContextFrames,
-SpecAugment; builders/pre_process_step.py) are outside the hot path -- the encoder starts at
-feature tensors -- so each ``pre_process_step`` is turned into a :class:`FeatureStep` record
-that carries what the model builder needs (``n_mfcc`` -> input features, ``n_context`` ->
-input channels) and raises if it is actually called."""
+"""Mirror of myrtlespeech/builders/speech_to_text.py:29-272: alphabet, pre-processing steps (device front-end,
+``builders/pre_process_step.py``), model, loss and decoder for a ``SpeechToText`` config, with the reference's
+``ValueError`` checks on blank / separator indices."""
 from typing import Callable, List, Tuple
 
 from myrtlespeech_amd.builders.ctc_beam_decoder import build as build_ctc_beam_decoder
 from myrtlespeech_amd.builders.ctc_loss import build as build_ctc_loss
 from myrtlespeech_amd.builders.deep_speech_2 import build as build_deep_speech_2
+from myrtlespeech_amd.builders.pre_process_step import build as build_pre_process_step
 from myrtlespeech_amd.data.alphabet import Alphabet
+from myrtlespeech_amd.data.preprocess import AddContextFrames, MFCC, MFCCLegacy, SpecAugment, Standardize
 from myrtlespeech_amd.model.cnn import Conv1dTo2d
 from myrtlespeech_amd.model.deep_speech_1 import DeepSpeech1
 from myrtlespeech_amd.model.speech_to_text import SpeechToText
 from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
 from myrtlespeech_amd.stage import Stage
-
-
-class FeatureStep:
-    """Placeholder for an audio pre-processing step (not part of the accelerated path)."""
-
-    def __init__(self, kind: str, **params):
-        self.kind = kind
-        self.params = params
-
-    def __call__(self, x):
-        raise NotImplementedError(f"pre-processing step '{self.kind}' runs upstream of the accelerated hot path")
-
-    def __repr__(self) -> str:
-        return f"FeatureStep({self.kind}, {self.params})"
 
 
 def _check_index(name: str, value: int, alphabet: Alphabet) -> None:
@@ -86,27 +70,20 @@ def build(stt_cfg) -> SpeechToText:
 
 
 def _build_pre_process_steps(step_cfgs) -> Tuple[List[Tuple[Callable, Stage]], int, int]:
+    """(steps, input_features, input_channels): an MFCC step fixes the feature count, context frames the channel
+    count; a config without an MFCC step feeds raw ``[N, 1, T]`` audio through ``Conv1dTo2d`` (one feature)."""
     input_features = None
     input_channels = 1
     steps: List[Tuple[Callable, Stage]] = []
     for cfg in step_cfgs:
-        kind = cfg.WhichOneof("pre_process_step")
-        if kind == "mfcc":
-            input_features = cfg.mfcc.n_mfcc
-            step = FeatureStep("mfcc", n_mfcc=cfg.mfcc.n_mfcc, win_length=cfg.mfcc.win_length,
-                               hop_length=cfg.mfcc.hop_length, legacy=cfg.mfcc.legacy)
-        elif kind == "spec_augment":
-            s = cfg.spec_augment
-            step = FeatureStep("spec_augment", feature_mask=s.feature_mask, time_mask=s.time_mask,
-                               n_feature_masks=s.n_feature_masks, n_time_masks=s.n_time_masks)
-        elif kind == "standardize":
-            step = FeatureStep("standardize")
-        elif kind == "context_frames":
-            input_channels = 2 * cfg.context_frames.n_context + 1
-            step = FeatureStep("context_frames", n_context=cfg.context_frames.n_context)
-        else:
-            raise ValueError(f"unknown pre_process_step '{kind}'")
-        steps.append((step, Stage(cfg.stage)))
+        step, stage = build_pre_process_step(cfg)
+        if isinstance(step, (MFCC, MFCCLegacy)):
+            input_features = step.n_mfcc
+        elif isinstance(step, AddContextFrames):
+            input_channels = 2 * step.n_context + 1
+        elif not isinstance(step, (SpecAugment, Standardize)):
+            raise ValueError(f"unknown step={step}")
+        steps.append((step, stage))
     if input_features is None:
         steps.append((Conv1dTo2d(seq_len_support=False), Stage.TRAIN_AND_EVAL))
         input_features = 1

@@ -16,13 +16,27 @@ class _StagePipeline:
     def __init__(self, owner: torch.nn.Module):
         self._owner = owner
 
-    def __call__(self, x: Any) -> Any:
+    def active_steps(self):
         training = self._owner.training
         for step, stage in self._owner.pre_process_steps:
             skip = (stage is Stage.EVAL) if training else (stage is Stage.TRAIN)
             if not skip:
-                x = step(x)
+                yield step
+
+    def __call__(self, x: Any) -> Any:
+        for step in self.active_steps():
+            x = step(x)
         return x
+
+    def batch(self, x: torch.Tensor, lens: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The same steps over a zero-padded ragged batch: ``(waves [N, samples], sample counts)`` in,
+        ``(features [N, C, F, T], frame counts)`` out -- one launch set per step instead of one per utterance."""
+        for step in self.active_steps():
+            if hasattr(step, "batch"):
+                x, lens = step.batch(x, lens)
+            else:
+                x = step(x)
+        return x, lens
 
 
 class SeqToSeq(torch.nn.Module):
@@ -41,6 +55,9 @@ class SeqToSeq(torch.nn.Module):
     @property
     def pre_process(self) -> Callable:
         return _StagePipeline(self)
+
+    def pre_process_batch(self, x: torch.Tensor, lens: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        return _StagePipeline(self).batch(x, lens)
 
 
 class SpeechToText(SeqToSeq):

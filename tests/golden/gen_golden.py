@@ -504,3 +504,37 @@ def gen_streaming():
 
 if __name__ == "__main__" and "stream" in sys.argv[1:]:
     gen_streaming()
+
+
+# ----------------------------------------------------------------------------- front-end
+def gen_frontend():
+    """collate: the reference's own data/batch.py run on seeded ragged samples.
+    context_frames_doc: the input/expected pair printed in the AddContextFrames docstring
+    (data/preprocess.py:77-105) -- data/preprocess.py itself cannot be imported here
+    (python_speech_features is not installed), so the documented vector is the pin."""
+    from myrtlespeech.data.batch import pad_sequence, seq_to_seq_collate_fn
+
+    torch.manual_seed(5)
+    lens = [17, 30, 30, 9, 22, 1]
+    tlens = [4, 7, 2, 5, 1, 3]
+    batch = [((torch.randn(2, 3, l), torch.tensor(l)), (torch.randint(0, 28, (tl,)), torch.tensor(tl)))
+             for l, tl in zip(lens, tlens)]
+    (x, xl), (y, yl) = seq_to_seq_collate_fn(batch)
+    arrays = {"out/x": npy(x), "out/x_lens": npy(xl), "out/y": npy(y), "out/y_lens": npy(yl),
+              "out/pad7": npy(pad_sequence([b[0][0] for b in batch], 7))}
+    for i, ((xi, _), (yi, _)) in enumerate(batch):
+        arrays[f"in/x{i}"] = npy(xi)
+        arrays[f"in/y{i}"] = npy(yi)
+    save("collate", dict(n=len(batch)), arrays)
+
+    x = np.arange(15, dtype=np.int64).reshape(1, 3, 5)
+    exp = np.array([[[0, 0, 0, 1, 2], [0, 0, 5, 6, 7], [0, 0, 10, 11, 12]],
+                    [[0, 0, 1, 2, 3], [0, 5, 6, 7, 8], [0, 10, 11, 12, 13]],
+                    [[0, 1, 2, 3, 4], [5, 6, 7, 8, 9], [10, 11, 12, 13, 14]],
+                    [[1, 2, 3, 4, 0], [6, 7, 8, 9, 0], [11, 12, 13, 14, 0]],
+                    [[2, 3, 4, 0, 0], [7, 8, 9, 0, 0], [12, 13, 14, 0, 0]]], dtype=np.int64)
+    save("context_frames_doc", dict(n_context=2), {"in/x": x, "out/y": exp})
+
+
+if __name__ == "__main__" and "frontend" in sys.argv[1:]:
+    gen_frontend()
