@@ -115,6 +115,12 @@ def main():
                          "global batch on every rank instead of decoding per shard")
     args = ap.parse_args()
 
+    # Anything the runtime libraries print (RCCL's banner goes to stdout) is sent to stderr, so that stdout carries
+    # the ONE JSON line and nothing else.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -203,7 +209,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

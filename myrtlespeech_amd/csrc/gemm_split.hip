@@ -259,41 +259,78 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel2(const unsigned 
   store_regs(lds);
   if (nk > 1) load_regs(SB_K);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    char* cur = lds + (kt & 1) * S2_BUF;
-    if (kt + 1 < nk) store_regs(lds + ((kt + 1) & 1) * S2_BUF);
-    if (kt + 2 < nk) load_regs((kt + 2) * SB_K);
+
+  u32x4 ah[2], al[2], bh[4], bl[4];
+  auto read_ops = [&](const char* cur, int s) {
+    const int g = 2 * s + half;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int g = 2 * s + half;
-      u32x4 ah[2], al[2], bh[4], bl[4];
+    for (int i = 0; i < 2; ++i) {
+      const int off = g * S2_PLANE + (wm * 64 + i * 32 + l31) * 16;
+      ah[i] = *reinterpret_cast<const u32x4*>(cur + off);
+      if (!F16) al[i] = *reinterpret_cast<const u32x4*>(cur + S2_TILE + off);
+    }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int off = g * S2_PLANE + (wm * 64 + i * 32 + l31) * 16;
-        ah[i] = *reinterpret_cast<const u32x4*>(cur + off);
-        if (!F16) al[i] = *reinterpret_cast<const u32x4*>(cur + S2_TILE + off);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int off = g * S2_PLANE + (wn * 128 + j * 32 + l31) * 16;
-        bh[j] = *reinterpret_cast<const u32x4*>(cur + 2 * S2_TILE + off);
-        if (!F16) bl[j] = *reinterpret_cast<const u32x4*>(cur + 3 * S2_TILE + off);
-      }
+    for (int j = 0; j < 4; ++j) {
+      const int off = g * S2_PLANE + (wn * 128 + j * 32 + l31) * 16;
+      bh[j] = *reinterpret_cast<const u32x4*>(cur + 2 * S2_TILE + off);
+      if (!F16) bl[j] = *reinterpret_cast<const u32x4*>(cur + 3 * S2_TILE + off);
+    }
+  };
+  auto mfma_ops = [&]() {
+    if (F16) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (F16) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[i]), __builtin_bit_cast(f16x8, bh[j]),
-                                                               acc[i][j], 0, 0, 0);
-          } else {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
-          }
-        }
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[i]), __builtin_bit_cast(f16x8, bh[j]),
+                                                             acc[i][j], 0, 0, 0);
+    } else {
+      // pass-major order: the three dependent updates of one accumulator are 8 MFMAs apart
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
+  };
+  {
+    // One basic block per K-block (no conditionals: the tail re-loads the last block and re-stores it into the idle
+    // buffer), so the scheduler can be told to thread the 8 LDS stores through the first 24 MFMAs and the 8 global
+    // loads through the second 24 instead of issuing them in bursts that stall every wave at once.
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* cur = lds + (kt & 1) * S2_BUF;
+      read_ops(cur, 0);
+      store_regs(lds + ((kt + 1) & 1) * S2_BUF);
+      mfma_ops();
+      __builtin_amdgcn_sched_group_barrier(0x100, F16 ? 6 : 12, 0);
+#pragma unroll
+      for (int i = 0; i < (F16 ? 4 : 8); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, F16 ? 2 : 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      read_ops(cur, 1);
+      load_regs(min(kt + 2, nk - 1) * SB_K);
+      mfma_ops();
+      __builtin_amdgcn_sched_group_barrier(0x100, F16 ? 6 : 12, 0);
+#pragma unroll
+      for (int i = 0; i < (F16 ? 4 : 8); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, F16 ? 2 : 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+    }
   }
 
 #pragma unroll
@@ -341,12 +378,8 @@ int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const
   const bool f16 = prec == PREC_F16;
   if (f16 || (!small_tile && (long)M * N >= 4L * 1024 * 1024)) {
     const int nwg2 = cdiv(M, S2_M) * cdiv(N, S2_N);
-    if (f16)
-      hipLaunchKernelGGL(gemm_nt_bf16x3_kernel2<true>, dim3(nwg2), dim3(512), SPLIT2_LDS, stream, ah, al, wh, wl, bias, y, M,
-                         K, N, act, lo, hi);
-    else
-      hipLaunchKernelGGL(gemm_nt_bf16x3_kernel2<false>, dim3(nwg2), dim3(512), SPLIT2_LDS, stream, ah, al, wh, wl, bias, y, M,
-                         K, N, act, lo, hi);
+    auto kern = f16 ? gemm_nt_bf16x3_kernel2<true> : gemm_nt_bf16x3_kernel2<false>;
+    hipLaunchKernelGGL(kern, dim3(nwg2), dim3(512), SPLIT2_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);
     MS_LAUNCH_CHECK();
     return MS_OK;
   }
