@@ -961,6 +961,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
         redb[(wave * 16 + 4 * q + i) * RED_STRIDE + 16 + c16] = acc1[i];
       }
       __syncthreads();
+      if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[2] += now - st_prev; st_prev = now; }
       if (wave < 2) {
         float gsum[4];
 #pragma unroll
@@ -985,11 +986,12 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
         publish_split<F16>(h[sg], wtag, hx_rsrc, off, PLANE + off, lane);
         if (n < N) p.out[((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit] = active ? hnew : 0.f;
       }
-      if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[2] += now - st_prev; st_prev = now; }
+      if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[3] += now - st_prev; st_prev = now; }
     }
   }
   if (STAMP && (tid & 63) == 0) {
-    for (int k = 0; k < 4; ++k) atomicAdd(&p.dbg[(size_t)blockIdx.x * 8 + k], st_sum[k]);
+    // slots 0-3: the cell waves (0, 1); slots 4-7: waves 2, 3
+    for (int k = 0; k < 4; ++k) atomicAdd(&p.dbg[(size_t)blockIdx.x * 8 + (wave >= 2 ? 4 : 0) + k], st_sum[k]);
   }
   if (wave < 2) {
 #pragma unroll

@@ -110,6 +110,22 @@ def test_ds2_tiny(name):
         assert O.ctc_greedy_decode(y, nl, c["blank"]) == unragged(g["out/greedy_flat"], g["out/greedy_lens"])
 
 
+def test_torch_cpu_baseline_matches_reference_golden():
+    """The stock-torch CPU baseline timed by bench.py (oracle/torch_cpu.py) is pinned like the numpy oracle."""
+    from oracle import torch_cpu as TC
+    g = Golden("ds2_tiny_bilstm")
+    c = g.cfg
+    cfg = dict(convs=[dict(kind=v["kind"], idx=v["idx"], stride=v["stride"], same=v["same"], act=v["act"])
+                      for v in c["convs"]],
+               rnn=dict(kind=c["rnn"]["kind"], hidden=c["rnn"]["hidden"], layers=c["rnn"]["layers"],
+                        bidirectional=c["rnn"]["bidirectional"]),
+               lookahead=None, fc=dict(n_hidden=c["fc"]["n_hidden"], act=c["fc"]["act"]))
+    y, nl = TC.deep_speech_2_forward(g["in/x"], g["in/lens"], cfg, g.sd())
+    np.testing.assert_allclose(y, g["out/y"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(nl, g["out/lens"])
+    assert TC.ctc_greedy_decode(y, nl, c["blank"]) == unragged(g["out/greedy_flat"], g["out/greedy_lens"])
+
+
 @pytest.mark.parametrize("name", golden_names("ds1_tiny"))
 def test_ds1_tiny(name):
     g = Golden(name)

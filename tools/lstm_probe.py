@@ -27,9 +27,21 @@ for it in range(3):
 off = lib.ms_rnn_debug_offset(0, T, N, In, H, 2)
 ws = m._workspace.buf
 dbg = ws[off:off + 256 * 8 * 8].view(torch.int64).reshape(256, 8).cpu().double()
-per_wave = dbg[:, :4] / 4.0 / T * 10.0  # ns per step (4 waves add up; 100 MHz ticks = 10 ns)
-names = ["wait_flags", "mfma_loop", "reduce+cell", "publish"]
-for k, nm in enumerate(names):
-    c = per_wave[:, k]
-    print(f"{nm:12s} mean {c.mean():8.1f} ns  min {c.min():8.1f}  max {c.max():8.1f}")
-print(f"sum mean {per_wave.sum(1).mean():.1f} ns per step")
+two_stream = os.environ.get("MS_LSTM_ONE_STREAM") != "1" and os.environ.get("MS_PRECISION") != "f32"
+if two_stream:
+    # two-stream kernel: slots 0-3 = cell waves (0, 1), slots 4-7 = waves 2, 3; each slot sums 2 waves
+    names = ["wait h (tags)", "mfma issue", "lds write+barrier", "cell+publish"]
+    for grp, label in ((0, "waves 0-1"), (4, "waves 2-3")):
+        per = dbg[:, grp:grp + 4] / 2.0 / T * 10.0
+        print(label)
+        for k, nm in enumerate(names):
+            c = per[:, k]
+            print(f"  {nm:18s} mean {c.mean():8.1f} ns  min {c.min():8.1f}  max {c.max():8.1f}")
+        print(f"  sum mean {per.sum(1).mean():.1f} ns per step (both streams)")
+else:
+    per_wave = dbg[:, :4] / 4.0 / T * 10.0  # ns per step (4 waves add up; 100 MHz ticks = 10 ns)
+    names = ["wait_flags", "mfma_loop", "reduce+cell", "publish"]
+    for k, nm in enumerate(names):
+        c = per_wave[:, k]
+        print(f"{nm:12s} mean {c.mean():8.1f} ns  min {c.min():8.1f}  max {c.max():8.1f}")
+    print(f"sum mean {per_wave.sum(1).mean():.1f} ns per step")
