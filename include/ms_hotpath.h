@@ -265,6 +265,24 @@ int ms_rnnt_joint_forward(const float* enc_p, const int32_t* enc_row, const floa
  * -inf entries are never selected (index -1 is written when fewer than k finite candidates exist). */
 int ms_rnnt_topk(const float* scores, int32_t* out_idx, float* out_val, int B, int C, int k, void* stream);
 
+/* Whole-batch RNN-T decode on the device (own specification, oracle/rnnt_oracle.py): one call enqueues the
+ * complete frame loop; nothing is read back until the caller synchronises.  enc_p [T*N, J] are the encoder frames
+ * after RNNTJoint.enc_proj (row t*N + n); the prediction network is Embedding(V+1, D) + L LSTM layers given in
+ * torch layout (w_ih[l] [4H, In_l], w_hh[l] [4H, H], b_ih[l] / b_hh[l] [4H] or NULL, gate order i,f,g,o), w_pred
+ * [J, H] (no bias), w_out [V+1, J], b_out [V+1]; blank = V.
+ * greedy != 0: per frame, emit argmax labels until blank, at most max_symbols per frame; out_idx [N, T*max_symbols].
+ * greedy == 0: time-synchronous beam search of width beam_width (<= 32) with max_symbols rounds per frame (blank
+ * transitions of equal prefixes merged by float32 logaddexp evaluated in float64; the beam_width best label
+ * extensions, ties to the lowest (hypothesis, label) index, stay live); out_idx [N, T*(max_symbols-1) + 1].
+ * out_len [N]; out_score [N] (beam only, may be NULL) is the log-probability of the returned hypothesis. */
+size_t ms_rnnt_decode_workspace_bytes(int T, int N, int V, int D, int H, int L, int J, int beam_width, int max_symbols,
+                                      int greedy);
+int ms_rnnt_decode(const float* enc_p, const int32_t* lens, const float* embedding, const float* const* w_ih,
+                   const float* const* w_hh, const float* const* b_ih, const float* const* b_hh, const float* w_pred,
+                   const float* w_out, const float* b_out, int32_t* out_idx, int32_t* out_len, float* out_score, int T,
+                   int N, int V, int D, int H, int L, int J, int beam_width, int max_symbols, int greedy, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,8 @@ SIGNATURES = {
     "ms_ctc_beam_workspace_bytes": (c_size_t, [c_int] * 4),
     "ms_ctc_beam_decode": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_int, c_int,
                                    _P, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "ms_rnnt_decode_workspace_bytes": (c_size_t, [c_int] * 10),
+    "ms_rnnt_decode": (c_int, [_P, _P, _P, _PP, _PP, _PP, _PP, _P, _P, _P, _P, _P, _P] + [c_int] * 10 + [_P, c_size_t, _P]),
     "ms_mfcc_workspace_bytes": (c_size_t, [c_int] * 5),
     "ms_mfcc_forward": (c_int, [_P] * 7 + [c_int] * 7 + [c_float, _P, c_size_t, _P]),
     "ms_mfcc_legacy_forward": (c_int, [_P] * 7 + [c_int] * 8 + [c_double, _P]),

@@ -99,14 +99,20 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 ra[8], rb[8];
-  const int nk = (K + C::BK - 1) / C::BK;
-  load_tile<C, VEC>(A, M, K, m0, 0, ra, C::A_LD);
-  load_tile<C, VEC>(W, N, K, n0, 0, rb, C::B_LD);
+  // split-K: slice z = blockIdx.y of gridDim.y owns a contiguous range of K tiles and writes its partial sums to
+  // Y + z*M*N (the consumer adds the slices in a fixed order); the bias goes into slice 0
+  const int nk_all = (K + C::BK - 1) / C::BK;
+  const int kt0 = (int)((long)blockIdx.y * nk_all / gridDim.y);
+  const int nk = (int)((long)(blockIdx.y + 1) * nk_all / gridDim.y);
+  Y += (size_t)blockIdx.y * M * N;
+  if (blockIdx.y != 0) bias = nullptr;
+  load_tile<C, VEC>(A, M, K, m0, kt0 * C::BK, ra, C::A_LD);
+  load_tile<C, VEC>(W, N, K, n0, kt0 * C::BK, rb, C::B_LD);
   store_tile(As, C::A_STRIDE, ra, C::A_LD);
   store_tile(Bs, C::B_STRIDE, rb, C::B_LD);
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     if (kt + 1 < nk) {
       load_tile<C, VEC>(A, M, K, m0, (kt + 1) * C::BK, ra, C::A_LD);
       load_tile<C, VEC>(W, N, K, n0, (kt + 1) * C::BK, rb, C::B_LD);
@@ -159,16 +165,16 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 static int launch_cfg(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
-                      float lo, float hi, hipStream_t stream) {
+                      float lo, float hi, hipStream_t stream, int ksplit = 1) {
   using C = GemmCfg<WAVES_M, WAVES_N, TM, TN>;
   const int nwg = cdiv(M, C::BM) * cdiv(N, C::BN);
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
   const bool vec = (K % 4 == 0) && (((uintptr_t)x | (uintptr_t)w) % 16 == 0);
   if (vec)
-    hipLaunchKernelGGL((gemm_nt_f32_kernel<WAVES_M, WAVES_N, TM, TN, true>), dim3(nwg), dim3(256), lds, stream, x, w,
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<WAVES_M, WAVES_N, TM, TN, true>), dim3(nwg, ksplit), dim3(256), lds, stream, x, w,
                        bias, y, M, K, N, act, lo, hi);
   else
-    hipLaunchKernelGGL((gemm_nt_f32_kernel<WAVES_M, WAVES_N, TM, TN, false>), dim3(nwg), dim3(256), lds, stream, x, w,
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<WAVES_M, WAVES_N, TM, TN, false>), dim3(nwg, ksplit), dim3(256), lds, stream, x, w,
                        bias, y, M, K, N, act, lo, hi);
   MS_LAUNCH_CHECK();
   return MS_OK;
@@ -178,7 +184,19 @@ int linear_launch(const float* x, const float* w, const float* bias, float* y, i
                   float hi, hipStream_t stream) {
   if (N <= 32) return launch_cfg<4, 1, 1, 1>(x, w, bias, y, M, K, N, act, lo, hi, stream);   // 128 x 32
   if (N <= 64) return launch_cfg<2, 2, 2, 1>(x, w, bias, y, M, K, N, act, lo, hi, stream);   // 128 x 64
+  // few rows (decode steps, single clips): 128 x 128 tiles would occupy N/128 CUs only; narrower tiles spread the
+  // weight stream over 2x / 4x as many workgroups
+  const long wg128 = (long)cdiv(M, 128) * cdiv(N, 128);
+  if (wg128 * 4 <= num_cus()) return launch_cfg<4, 1, 1, 1>(x, w, bias, y, M, K, N, act, lo, hi, stream);   // 128 x 32
+  if (wg128 * 2 <= num_cus()) return launch_cfg<2, 2, 2, 1>(x, w, bias, y, M, K, N, act, lo, hi, stream);   // 128 x 64
   return launch_cfg<2, 2, 2, 2>(x, w, bias, y, M, K, N, act, lo, hi, stream);                // 128 x 128
+}
+
+// Few-row GEMM for decode steps (M <= 128): 128 x 32 tiles and `ksplit` K slices, so N/32 * ksplit workgroups stream
+// the weights; y holds ksplit partial results [ksplit][M][N] that the caller adds in slice order (deterministic).
+int linear_splitk_launch(const float* x, const float* w, const float* bias, float* y_parts, int M, int K, int N, int ksplit,
+                         hipStream_t stream) {
+  return launch_cfg<4, 1, 1, 1>(x, w, bias, y_parts, M, K, N, MS_ACT_NONE, 0.f, 0.f, stream, ksplit);
 }
 
 }  // namespace ms

@@ -1,0 +1,716 @@
+// Device-resident RNN-T decoding (greedy and time-synchronous beam search).  NOT reference-derived: the reference
+// snapshot has no transducer; the specification is this repository's own
+// (myrtlespeech_amd/model/rnnt.py, oracle/rnnt_oracle.py).
+//
+// The whole decode of a batch is ONE host call that enqueues a fixed launch sequence per frame and never reads anything
+// back: hypothesis lists, the prefix trie, the predictor-state pool and the emission lists all live in the caller's
+// workspace.  Per frame and emission round:
+//   joint_slots_kernel   log P(. | frame t, hypothesis) for every live hypothesis row (one workgroup per row)
+//   beam_round_kernel    per utterance: blank transitions merge into the next frame's set B (same prefix = same trie node,
+//                        float32 scores joined by logaddexp), the beam_width best label extensions become the live set
+//   greedy_round_kernel  per utterance: argmax; blank ends the frame, a label is emitted
+//   predictor step       gather [embedding(label) | h_src] rows -> exact-f32 MFMA GEMM against [W_ih | W_hh] ->
+//                        lstm_cell_kernel (writes the new state, builds the next layer's rows) -> ... -> pred_proj GEMM
+//   beam_frame_end_kernel  B sorted (stable, descending) -> beam_width survivors; their states move to the frame-start region
+// Rows of utterances that have ended (t >= len) or of empty beam slots are skipped inside the kernels, so the launch
+// sequence does not depend on the data.
+#include <math.h>
+
+#include "common.h"
+
+namespace ms {
+int linear_launch(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act, float lo,
+                  float hi, hipStream_t stream);
+int linear_splitk_launch(const float* x, const float* w, const float* bias, float* y_parts, int M, int K, int N, int ksplit,
+                         hipStream_t stream);
+}
+
+constexpr int KSPLIT = 8;  // K slices of the gate GEMMs (partials added in slice order by lstm_cell_kernel)
+
+namespace {
+
+struct DecLayout {
+  // hypothesis lists
+  size_t A_cnt, A_node, A_score, A_slot, oldA_dummy;
+  size_t B_cnt, B_node, B_score, B_slot;
+  size_t ext_label, ext_src, ext_dst;
+  size_t live, out_cnt;
+  // trie
+  size_t node_cnt, node_parent, node_label, child;
+  // predictor state pool + scratch
+  size_t st_h, st_c, pp, pp_tmp, xrow, gates, htop, logp, wcat, bcat;
+  size_t total;
+  int R, slots, maxn, bcap;
+  size_t wcat_off[8], bcat_off[8];
+};
+
+DecLayout dec_layout(int T, int N, int V, int D, int H, int L, int J, int w, int max_symbols, int greedy) {
+  DecLayout W{};
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t at = o; o += ms::align_up(bytes, 256); return at; };
+  const int R = N * w;
+  const int regions = greedy ? 1 : (2 + (max_symbols > 1 ? max_symbols - 1 : 0));
+  W.R = R;
+  W.slots = regions * R;
+  W.bcap = w * max_symbols;
+  W.maxn = greedy ? 1 : 1 + T * (max_symbols > 1 ? max_symbols - 1 : 0) * w;
+  const int V1 = V + 1;
+  W.A_cnt = take((size_t)N * 4);
+  W.A_node = take((size_t)R * 4);
+  W.A_score = take((size_t)R * 4);
+  W.A_slot = take((size_t)R * 4);
+  W.B_cnt = take((size_t)N * 4);
+  W.B_node = take((size_t)N * W.bcap * 4);
+  W.B_score = take((size_t)N * W.bcap * 4);
+  W.B_slot = take((size_t)N * W.bcap * 4);
+  W.ext_label = take((size_t)R * 4);
+  W.ext_src = take((size_t)R * 4);
+  W.ext_dst = take((size_t)R * 4);
+  W.live = take((size_t)N * 4);
+  W.out_cnt = take((size_t)N * 4);
+  W.node_cnt = take((size_t)N * 4);
+  W.node_parent = take((size_t)N * W.maxn * 4);
+  W.node_label = take((size_t)N * W.maxn * 4);
+  W.child = take(greedy ? 4 : (size_t)N * W.maxn * V * 4);
+  W.st_h = take((size_t)W.slots * L * H * 4);
+  W.st_c = take((size_t)W.slots * L * H * 4);
+  W.pp = take((size_t)W.slots * J * 4);
+  W.pp_tmp = take((size_t)KSPLIT * R * J * 4);
+  const int in_max = (D > H ? D : H) + H;
+  W.xrow = take((size_t)R * in_max * 4);
+  W.gates = take((size_t)KSPLIT * R * 4 * H * 4);
+  W.htop = take((size_t)R * H * 4);
+  W.logp = take((size_t)R * V1 * 4);
+  size_t wc = 0, bc = 0;
+  for (int l = 0; l < L; ++l) {
+    W.wcat_off[l] = wc;
+    W.bcat_off[l] = bc;
+    wc += (size_t)4 * H * ((l == 0 ? D : H) + H);
+    bc += (size_t)4 * H;
+  }
+  W.wcat = take(wc * 4);
+  W.bcat = take(bc * 4);
+  W.total = o;
+  return W;
+}
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// float32 logaddexp of the specification: evaluated in float64, rounded once.
+__device__ __forceinline__ float logaddexp32(float a, float b) {
+  const double x = (double)a, y = (double)b;
+  if (x == y) return (float)(x + 0.6931471805599453);
+  const double m = x > y ? x : y, d = x > y ? y - x : x - y;
+  return (float)(m + log1p(exp(d)));
+}
+
+// [W_ih | W_hh] rows and b_ih + b_hh of one layer (once per decode call).
+__global__ void pack_cat_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh, const float* __restrict__ b_ih,
+                                const float* __restrict__ b_hh, float* __restrict__ wcat, float* __restrict__ bcat, int H,
+                                int In) {
+  const int row = blockIdx.x;  // 4H rows
+  const int K = In + H;
+  for (int k = threadIdx.x; k < K; k += blockDim.x)
+    wcat[(size_t)row * K + k] = k < In ? w_ih[(size_t)row * In + k] : w_hh[(size_t)row * H + (k - In)];
+  if (threadIdx.x == 0) bcat[row] = (b_ih ? b_ih[row] : 0.f) + (b_hh ? b_hh[row] : 0.f);
+}
+
+// x0[r] = [embedding[label_r] | h[src_r][layer 0]]; rows without a request are zero.
+__global__ void pred_gather_kernel(const float* __restrict__ embedding, const int32_t* __restrict__ ext_label,
+                                   const int32_t* __restrict__ ext_src, const int32_t* __restrict__ ext_dst,
+                                   const float* __restrict__ st_h, float* __restrict__ xrow, int D, int H, int L, int V1) {
+  const int r = blockIdx.x;
+  const bool valid = ext_dst[r] >= 0;
+  const int src = ext_src[r];
+  const int lab = min(max(ext_label[r], 0), V1 - 1);
+  float* x = xrow + (size_t)r * (D + H);
+  for (int k = threadIdx.x; k < D + H; k += blockDim.x) {
+    float v = 0.f;
+    if (valid) v = k < D ? embedding[(size_t)lab * D + k] : (src >= 0 ? st_h[((size_t)src * L + 0) * H + (k - D)] : 0.f);
+    x[k] = v;
+  }
+}
+
+// gates [R, 4H] (i, f, g, o) of layer l -> new (h, c) of the destination slot; also the next layer's input row
+// [h' | h[src][l+1]] or, after the last layer, the row of `htop`.
+__global__ void lstm_cell_kernel(const float* __restrict__ gates, const int32_t* __restrict__ ext_src,
+                                 const int32_t* __restrict__ ext_dst, float* __restrict__ st_h, float* __restrict__ st_c,
+                                 float* __restrict__ xnext, float* __restrict__ htop, int H, int L, int l, int R) {
+  const int r = blockIdx.x;
+  const int src = ext_src[r], dst = ext_dst[r];
+  const float* g = gates + (size_t)r * 4 * H;
+  const size_t part = (size_t)R * 4 * H;  // stride between the K-slice partial sums
+  for (int u = threadIdx.x; u < H; u += blockDim.x) {
+    const float c_old = (dst >= 0 && src >= 0) ? st_c[((size_t)src * L + l) * H + u] : 0.f;
+    float pre[4];
+#pragma unroll
+    for (int gate = 0; gate < 4; ++gate) {
+      float v = g[gate * H + u];
+#pragma unroll
+      for (int z = 1; z < KSPLIT; ++z) v += g[z * part + gate * H + u];
+      pre[gate] = v;
+    }
+    const float gi = 1.f / (1.f + expf(-pre[0])), gf = 1.f / (1.f + expf(-pre[1]));
+    const float gg = tanhf(pre[2]), go = 1.f / (1.f + expf(-pre[3]));
+    const float c_new = gf * c_old + gi * gg;
+    const float h_new = go * tanhf(c_new);
+    float h_next_src = 0.f;
+    if (l + 1 < L && dst >= 0 && src >= 0) h_next_src = st_h[((size_t)src * L + l + 1) * H + u];
+    if (dst >= 0) {
+      st_h[((size_t)dst * L + l) * H + u] = h_new;
+      st_c[((size_t)dst * L + l) * H + u] = c_new;
+    }
+    if (l + 1 < L) {
+      xnext[(size_t)r * 2 * H + u] = dst >= 0 ? h_new : 0.f;
+      xnext[(size_t)r * 2 * H + H + u] = h_next_src;
+    } else {
+      htop[(size_t)r * H + u] = dst >= 0 ? h_new : 0.f;
+    }
+  }
+}
+
+// adds the K-slice partial sums of the pred_proj GEMM (slice order) into the destination slot's row
+__global__ void commit_pp_kernel(const float* __restrict__ pp_tmp, const int32_t* __restrict__ ext_dst, float* __restrict__ pp,
+                                 int J, int R) {
+  const int r = blockIdx.x, dst = ext_dst[r];
+  if (dst < 0) return;
+  const size_t part = (size_t)R * J;
+  for (int k = threadIdx.x; k < J; k += blockDim.x) {
+    float v = pp_tmp[(size_t)r * J + k];
+#pragma unroll
+    for (int z = 1; z < KSPLIT; ++z) v += pp_tmp[z * part + (size_t)r * J + k];
+    pp[(size_t)dst * J + k] = v;
+  }
+}
+
+// log_softmax(W_out . tanh(enc_p[t, i] + pp[slot]) + b_out) for hypothesis row r = i*w + j, if it is live.
+__global__ __launch_bounds__(256) void joint_slots_kernel(const float* __restrict__ enc_p, const int32_t* __restrict__ lens,
+                                                          const float* __restrict__ pp, const int32_t* __restrict__ A_slot,
+                                                          const int32_t* __restrict__ A_cnt, const float* __restrict__ w_out,
+                                                          const float* __restrict__ b_out, float* __restrict__ logp, int t,
+                                                          int N, int w, int J, int V1) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* z = smem;
+  float* lg = smem + J;
+  const int r = blockIdx.x, i = r / w, j = r - i * w;
+  // three independent loads (one memory round trip), then the test: these words were written by the previous kernel on
+  // another XCD, every dependent global load here costs ~2 us
+  const int len_i = lens[i], cnt_i = A_cnt[i], slot = A_slot[r];
+  if (t >= len_i || j >= cnt_i) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* e = enc_p + ((size_t)t * N + i) * J;
+  const float* p = pp + (size_t)slot * J;
+  for (int k = tid; k < J; k += 256) z[k] = tanhf(e[k] + p[k]);
+  __syncthreads();
+  // each wave owns symbols v = wave, wave + 4, ...; for V1 <= 64 their dot products run side by side so the loads
+  // of the W_out rows are independent and pipeline (a loop over v pays one L2 round trip per symbol)
+  if (V1 <= 64) {
+    float acc[16];
+#pragma unroll
+    for (int vi = 0; vi < 16; ++vi) acc[vi] = 0.f;
+    for (int k = lane; k < J; k += 64) {
+      const float zk = z[k];
+#pragma unroll
+      for (int vi = 0; vi < 16; ++vi) {
+        const int v = wave + 4 * vi;
+        if (v < V1) acc[vi] += w_out[(size_t)v * J + k] * zk;
+      }
+    }
+#pragma unroll
+    for (int vi = 0; vi < 16; ++vi) {
+      const int v = wave + 4 * vi;
+      if (v < V1) {
+        const float tot = wsum(acc[vi]);
+        if (lane == 0) lg[v] = tot + (b_out ? b_out[v] : 0.f);
+      }
+    }
+  } else {
+    for (int v = wave; v < V1; v += 4) {
+      const float* wr = w_out + (size_t)v * J;
+      float acc = 0.f;
+      for (int k = lane; k < J; k += 64) acc += wr[k] * z[k];
+      acc = wsum(acc);
+      if (lane == 0) lg[v] = acc + (b_out ? b_out[v] : 0.f);
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float m = -INFINITY;
+    for (int v = lane; v < V1; v += 64) m = fmaxf(m, lg[v]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float s = 0.f;
+    for (int v = lane; v < V1; v += 64) s += expf(lg[v] - m);
+    s = wsum(s);
+    const float lz = logf(s) + m;
+    for (int v = lane; v < V1; v += 64) logp[(size_t)r * V1 + v] = lg[v] - lz;
+  }
+}
+
+struct BeamP {
+  const int32_t* lens;
+  const float* logp;
+  int32_t *A_cnt, *A_node, *A_slot;
+  float* A_score;
+  int32_t *B_cnt, *B_node, *B_slot;
+  float* B_score;
+  int32_t *ext_label, *ext_src, *ext_dst;
+  int32_t *node_cnt, *node_parent, *node_label, *child;
+  int N, w, V, bcap, maxn, R;
+};
+
+// One emission round of one utterance (one workgroup).  Everything the round needs is fetched by independent loads at
+// the top (one memory round trip: the words were written by the previous kernel, usually on another XCD), the list
+// surgery then runs in LDS, and the trie insertions of the picked extensions go out in parallel.
+__global__ __launch_bounds__(256) void beam_round_kernel(BeamP p, int t, int region, int first, int last) {
+  extern __shared__ __attribute__((aligned(16))) float cand[];  // [w * V1] log-probabilities, then candidate scores
+  __shared__ float wv[4];
+  __shared__ int wi[4];
+  __shared__ int pick_idx[32];
+  __shared__ float pick_val[32];
+  __shared__ int old_node[32], old_slot[32];
+  __shared__ float old_score[32];
+  __shared__ int b_node[128], b_slot[128];
+  __shared__ float b_score[128];
+  __shared__ int n_pick, next_node;
+  const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w = p.w, V1 = p.V + 1, blank = p.V;
+  const int len_i = p.lens[i], cnt = p.A_cnt[i], bc0 = first ? 0 : p.B_cnt[i], nodes0 = p.node_cnt[i];
+  if (tid < w) {
+    old_node[tid] = p.A_node[i * w + tid];
+    old_slot[tid] = p.A_slot[i * w + tid];
+    old_score[tid] = p.A_score[i * w + tid];
+    p.ext_dst[i * w + tid] = -1;  // requests default to "none" (also for utterances that have ended)
+  }
+  if (tid < p.bcap) {
+    b_node[tid] = p.B_node[(size_t)i * p.bcap + tid];
+    b_score[tid] = p.B_score[(size_t)i * p.bcap + tid];
+    b_slot[tid] = p.B_slot[(size_t)i * p.bcap + tid];
+  }
+  for (int c = tid; c < w * V1; c += 256) cand[c] = p.logp[(size_t)i * w * V1 + c];
+  if (t >= len_i) return;
+  if (tid == 0) { n_pick = 0; next_node = nodes0; }
+  __syncthreads();
+  if (tid == 0) {
+    // blank transitions, in hypothesis order: same prefix (trie node) -> logaddexp, else append (first arrival keeps
+    // its predictor state)
+    int bc = bc0;
+    for (int j = 0; j < cnt; ++j) {
+      const float s = old_score[j] + cand[j * V1 + blank];
+      int at = -1;
+      for (int b = 0; b < bc; ++b)
+        if (b_node[b] == old_node[j]) { at = b; break; }
+      if (at >= 0) {
+        b_score[at] = logaddexp32(b_score[at], s);
+      } else if (bc < p.bcap) {
+        b_node[bc] = old_node[j];
+        b_score[bc] = s;
+        b_slot[bc] = old_slot[j];
+        ++bc;
+      }
+    }
+    p.B_cnt[i] = bc;
+    wi[0] = bc;
+    if (last) p.A_cnt[i] = 0;
+  }
+  __syncthreads();
+  {
+    const int bc = wi[0];
+    if (tid < bc) {
+      p.B_node[(size_t)i * p.bcap + tid] = b_node[tid];
+      p.B_score[(size_t)i * p.bcap + tid] = b_score[tid];
+      p.B_slot[(size_t)i * p.bcap + tid] = b_slot[tid];
+    }
+  }
+  if (last) return;
+  __syncthreads();
+  // label extensions: the w best of cnt * V1 candidates (score desc, ties -> lowest flat index), blank and
+  // non-finite scores excluded
+  const int C = cnt * V1;
+  for (int c = tid; c < C; c += 256) {
+    const int j = c / V1, k = c - j * V1;
+    const float s = old_score[j] + cand[c];
+    cand[c] = (k == blank || !isfinite(s)) ? -INFINITY : s;
+  }
+  __syncthreads();
+  for (int q = 0; q < w; ++q) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = tid; c < C; c += 256) {
+      const float v = cand[c];
+      if (v > bv) { bv = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { wv[wave] = bv; wi[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float fv = wv[0];
+      int fi = wi[0];
+      for (int x = 1; x < 4; ++x)
+        if (wv[x] > fv || (wv[x] == fv && wi[x] < fi)) { fv = wv[x]; fi = wi[x]; }
+      if (fi != 0x7fffffff && fv > -INFINITY) {
+        pick_idx[n_pick] = fi;
+        pick_val[n_pick] = fv;
+        cand[fi] = -INFINITY;
+        ++n_pick;
+      }
+    }
+    __syncthreads();
+  }
+  const int np = n_pick;
+  if (tid < np) {
+    // distinct picks are distinct (parent, label) pairs, so their trie insertions are independent; node numbers are
+    // identities only, an atomic counter hands them out
+    const int q = tid;
+    const int hi = pick_idx[q] / V1, k = pick_idx[q] - hi * V1;
+    const int parent = old_node[hi];
+    int32_t* ch = p.child + ((size_t)i * p.maxn + parent) * p.V + k;
+    int node = *ch;
+    if (node < 0) {
+      node = atomicAdd(&next_node, 1);
+      if (node < p.maxn) {
+        p.node_parent[(size_t)i * p.maxn + node] = parent;
+        p.node_label[(size_t)i * p.maxn + node] = k;
+        *ch = node;
+      } else {
+        node = parent;  // cannot happen: maxn bounds every possible insertion
+      }
+    }
+    const int slot = region * p.R + i * w + q;
+    p.A_node[i * w + q] = node;
+    p.A_score[i * w + q] = pick_val[q];
+    p.A_slot[i * w + q] = slot;
+    p.ext_label[i * w + q] = k;
+    p.ext_src[i * w + q] = old_slot[hi];
+    p.ext_dst[i * w + q] = slot;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    p.A_cnt[i] = np;
+    p.node_cnt[i] = min(next_node, p.maxn);
+  }
+}
+
+// End of frame t: the beam_width best entries of B (stable, descending) become the live set of the next frame; their
+// predictor states are copied into frame-start region (t + 1) & 1.  Grid (w, N): every workgroup repeats the (cheap, LDS)
+// selection and moves ONE survivor's state with all its loads in flight at once.
+__global__ __launch_bounds__(256) void beam_frame_end_kernel(BeamP p, float* st_h, float* st_c, float* pp, int t, int LH, int J) {
+  __shared__ int b_node[128], b_slot[128];
+  __shared__ float b_score[128];
+  __shared__ int sel_src[32], sel_node[32];
+  __shared__ float sel_score[32];
+  __shared__ int n_sel;
+  const int q = blockIdx.x, i = blockIdx.y, tid = threadIdx.x;
+  const int w = p.w;
+  const int len_i = p.lens[i], bc = p.B_cnt[i];
+  if (tid < p.bcap) {
+    b_node[tid] = p.B_node[(size_t)i * p.bcap + tid];
+    b_score[tid] = p.B_score[(size_t)i * p.bcap + tid];
+    b_slot[tid] = p.B_slot[(size_t)i * p.bcap + tid];
+  }
+  if (t >= len_i) return;
+  __syncthreads();
+  if (tid == 0) {
+    int ns = 0;
+    unsigned long long taken_lo = 0, taken_hi = 0;  // bcap <= 128
+    for (int x = 0; x < w && x < bc; ++x) {
+      int best = -1;
+      for (int b = 0; b < bc; ++b) {
+        const bool taken = b < 64 ? (taken_lo >> b) & 1ull : (taken_hi >> (b - 64)) & 1ull;
+        if (taken) continue;
+        if (best < 0 || b_score[b] > b_score[best]) best = b;  // first maximum = earliest arrival among equals
+      }
+      if (best < 0) break;
+      if (best < 64) taken_lo |= 1ull << best; else taken_hi |= 1ull << (best - 64);
+      sel_src[ns] = b_slot[best];
+      sel_node[ns] = b_node[best];
+      sel_score[ns] = b_score[best];
+      ++ns;
+    }
+    n_sel = ns;
+  }
+  __syncthreads();
+  const int ns = n_sel;
+  if (q == 0 && tid == 0) p.A_cnt[i] = ns;
+  if (q >= ns) return;
+  const size_t src = (size_t)sel_src[q], dst = (size_t)((t + 1) & 1) * p.R + i * w + q;
+  for (int base = 0; base < LH; base += 256 * 8) {
+    float vh[8], vc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int k = base + tid + 256 * m;
+      if (k < LH) { vh[m] = st_h[src * LH + k]; vc[m] = st_c[src * LH + k]; }
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int k = base + tid + 256 * m;
+      if (k < LH) { st_h[dst * LH + k] = vh[m]; st_c[dst * LH + k] = vc[m]; }
+    }
+  }
+  for (int k = tid; k < J; k += 256) pp[dst * J + k] = pp[src * J + k];
+  if (tid == 0) {
+    p.A_node[i * w + q] = sel_node[q];
+    p.A_score[i * w + q] = sel_score[q];
+    p.A_slot[i * w + q] = (int)dst;
+  }
+}
+
+// Best hypothesis (highest score, first among equals) -> label sequence by walking the trie to the root.
+__global__ void beam_finish_kernel(BeamP p, int32_t* out_idx, int32_t* out_len, float* out_score, int out_stride) {
+  const int i = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const int cnt = p.A_cnt[i];
+  int best = -1;
+  for (int j = 0; j < cnt; ++j)
+    if (best < 0 || p.A_score[i * p.w + j] > p.A_score[i * p.w + best]) best = j;
+  int len = 0;
+  if (best >= 0) {
+    int node = p.A_node[i * p.w + best];
+    for (int n = node; n > 0; n = p.node_parent[(size_t)i * p.maxn + n]) ++len;
+    int at = len;
+    for (int n = node; n > 0 && at > 0; n = p.node_parent[(size_t)i * p.maxn + n])
+      out_idx[(size_t)i * out_stride + --at] = p.node_label[(size_t)i * p.maxn + n];
+  }
+  out_len[i] = len;
+  if (out_score) out_score[i] = best >= 0 ? p.A_score[i * p.w + best] : -INFINITY;
+}
+
+// root hypothesis of every utterance + the request that creates its predictor state (blank on the zero state)
+__global__ void beam_init_kernel(BeamP p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.N) return;
+  for (int q = 0; q < p.w; ++q) p.ext_dst[i * p.w + q] = -1;
+  p.ext_label[i * p.w] = p.V;
+  p.ext_src[i * p.w] = -1;
+  p.ext_dst[i * p.w] = i * p.w;  // region 0, row i*w
+  p.A_cnt[i] = 1;
+  p.A_node[i * p.w] = 0;
+  p.A_score[i * p.w] = 0.f;
+  p.A_slot[i * p.w] = i * p.w;
+  p.B_cnt[i] = 0;
+  p.node_cnt[i] = 1;
+}
+
+// ---- greedy -----------------------------------------------------------------------------------------------------
+
+__global__ void greedy_init_kernel(int32_t* ext_label, int32_t* ext_src, int32_t* ext_dst, int32_t* slot, int32_t* out_cnt,
+                                   int N, int blank) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  ext_label[i] = blank;
+  ext_src[i] = -1;
+  ext_dst[i] = i;
+  slot[i] = i;
+  out_cnt[i] = 0;
+}
+
+__global__ void greedy_frame_start_kernel(const int32_t* __restrict__ lens, int32_t* __restrict__ live, int N, int t) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) live[i] = t < lens[i] ? 1 : 0;
+}
+
+// argmax over the symbols (first maximum); blank ends the frame for this utterance, a label is emitted and requests a
+// predictor step in place (source slot = destination slot = i).
+__global__ __launch_bounds__(64) void greedy_round_kernel(const float* __restrict__ logp, int32_t* __restrict__ live,
+                                                          int32_t* __restrict__ out_idx, int32_t* __restrict__ out_cnt,
+                                                          int32_t* __restrict__ ext_label, int32_t* __restrict__ ext_src,
+                                                          int32_t* __restrict__ ext_dst, int V1, int blank, int out_stride) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  if (lane == 0) ext_dst[i] = -1;
+  if (!live[i]) return;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int v = lane; v < V1; v += 64) {
+    const float x = logp[(size_t)i * V1 + v];
+    if (x > bv || (x == bv && v < bi) || bi == 0x7fffffff) { bv = x; bi = v; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) {
+    if (bi == blank) {
+      live[i] = 0;
+    } else {
+      const int n = out_cnt[i];
+      if (n < out_stride) out_idx[(size_t)i * out_stride + n] = bi;
+      out_cnt[i] = n + 1;
+      ext_label[i] = bi;
+      ext_src[i] = i;
+      ext_dst[i] = i;
+    }
+  }
+}
+
+struct Net {
+  const float* embedding;
+  const float* w_pred;
+  const float* w_out;
+  const float* b_out;
+  int V, D, H, L, J;
+};
+
+// One prediction-network step for the R request rows described by ext_label / ext_src / ext_dst.
+int predictor_step(const Net& n, const DecLayout& W, char* ws, hipStream_t s) {
+  const int R = W.R, H = n.H, L = n.L;
+  int32_t* ext_label = (int32_t*)(ws + W.ext_label);
+  int32_t* ext_src = (int32_t*)(ws + W.ext_src);
+  int32_t* ext_dst = (int32_t*)(ws + W.ext_dst);
+  float* st_h = (float*)(ws + W.st_h);
+  float* st_c = (float*)(ws + W.st_c);
+  float* xrow = (float*)(ws + W.xrow);
+  float* gates = (float*)(ws + W.gates);
+  float* htop = (float*)(ws + W.htop);
+  hipLaunchKernelGGL(pred_gather_kernel, dim3(R), dim3(256), 0, s, n.embedding, ext_label, ext_src, ext_dst, st_h, xrow, n.D,
+                     H, L, n.V + 1);
+  MS_LAUNCH_CHECK();
+  for (int l = 0; l < L; ++l) {
+    const int K = (l == 0 ? n.D : H) + H;
+    int rc = ms::linear_splitk_launch(xrow, (const float*)(ws + W.wcat) + W.wcat_off[l],
+                                      (const float*)(ws + W.bcat) + W.bcat_off[l], gates, R, K, 4 * H, KSPLIT, s);
+    if (rc != MS_OK) return rc;
+    hipLaunchKernelGGL(lstm_cell_kernel, dim3(R), dim3(256), 0, s, gates, ext_src, ext_dst, st_h, st_c, xrow, htop, H, L, l,
+                       R);
+    MS_LAUNCH_CHECK();
+  }
+  int rc = ms::linear_splitk_launch(htop, n.w_pred, nullptr, (float*)(ws + W.pp_tmp), R, H, n.J, KSPLIT, s);
+  if (rc != MS_OK) return rc;
+  hipLaunchKernelGGL(commit_pp_kernel, dim3(R), dim3(256), 0, s, (const float*)(ws + W.pp_tmp), ext_dst, (float*)(ws + W.pp),
+                     n.J, R);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ms_rnnt_decode_workspace_bytes(int T, int N, int V, int D, int H, int L, int J, int beam_width,
+                                                 int max_symbols, int greedy) {
+  if (T <= 0 || N <= 0 || V <= 0 || D <= 0 || H <= 0 || L <= 0 || L > 8 || J <= 0 || max_symbols <= 0) return 0;
+  if (!greedy && (beam_width <= 0 || beam_width > 32)) return 0;
+  return dec_layout(T, N, V, D, H, L, J, greedy ? 1 : beam_width, max_symbols, greedy).total;
+}
+
+extern "C" int ms_rnnt_decode(const float* enc_p, const int32_t* lens, const float* embedding, const float* const* w_ih,
+                              const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+                              const float* w_pred, const float* w_out, const float* b_out, int32_t* out_idx,
+                              int32_t* out_len, float* out_score, int T, int N, int V, int D, int H, int L, int J,
+                              int beam_width, int max_symbols, int greedy, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  MS_REQUIRE(enc_p && lens && embedding && w_ih && w_hh && b_ih && b_hh && w_pred && w_out && out_idx && out_len && workspace,
+             "null pointer");
+  MS_REQUIRE(T > 0 && N > 0 && V > 0 && D > 0 && H > 0 && L > 0 && L <= 8 && J > 0 && max_symbols > 0, "bad shape");
+  MS_REQUIRE(greedy || (beam_width > 0 && beam_width <= 32), "beam_width must be in [1, 32]");
+  const int w = greedy ? 1 : beam_width, V1 = V + 1;
+  MS_REQUIRE((size_t)(J + V1) * 4 <= 64 * 1024, "joint width too large");
+  MS_REQUIRE((size_t)w * V1 * 4 <= 60 * 1024, "beam_width * (V + 1) candidates exceed the LDS budget");
+  MS_REQUIRE(w * max_symbols <= 128, "beam_width * max_symbols must not exceed 128");
+  const DecLayout W = dec_layout(T, N, V, D, H, L, J, w, max_symbols, greedy);
+  MS_REQUIRE(workspace_bytes >= W.total, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  const int R = W.R;
+  const Net net{embedding, w_pred, w_out, b_out, V, D, H, L, J};
+
+  for (int l = 0; l < L; ++l) {
+    MS_REQUIRE(w_ih[l] && w_hh[l], "null layer weights");
+    hipLaunchKernelGGL(pack_cat_kernel, dim3(4 * H), dim3(256), 0, s, w_ih[l], w_hh[l], b_ih[l], b_hh[l],
+                       (float*)(ws + W.wcat) + W.wcat_off[l], (float*)(ws + W.bcat) + W.bcat_off[l], H, l == 0 ? D : H);
+    MS_LAUNCH_CHECK();
+  }
+  const size_t joint_lds = (size_t)(J + V1) * 4;
+  int32_t* A_cnt = (int32_t*)(ws + W.A_cnt);
+  int32_t* A_slot = (int32_t*)(ws + W.A_slot);
+  float* logp = (float*)(ws + W.logp);
+  float* pp = (float*)(ws + W.pp);
+
+  if (greedy) {
+    int32_t* live = (int32_t*)(ws + W.live);
+    int32_t* out_cnt = (int32_t*)(ws + W.out_cnt);
+    const int out_stride = T * max_symbols;
+    hipLaunchKernelGGL(greedy_init_kernel, dim3(ms::cdiv(N, 64)), dim3(64), 0, s, (int32_t*)(ws + W.ext_label),
+                       (int32_t*)(ws + W.ext_src), (int32_t*)(ws + W.ext_dst), A_slot, out_cnt, N, V);
+    MS_LAUNCH_CHECK();
+    int rc = predictor_step(net, W, ws, s);
+    if (rc != MS_OK) return rc;
+    for (int t = 0; t < T; ++t) {
+      hipLaunchKernelGGL(greedy_frame_start_kernel, dim3(ms::cdiv(N, 64)), dim3(64), 0, s, lens, live, N, t);
+      MS_LAUNCH_CHECK();
+      for (int v = 0; v < max_symbols; ++v) {
+        hipLaunchKernelGGL(joint_slots_kernel, dim3(R), dim3(256), joint_lds, s, enc_p, lens, pp, A_slot, live, w_out, b_out,
+                           logp, t, N, 1, J, V1);
+        MS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(greedy_round_kernel, dim3(N), dim3(64), 0, s, logp, live, out_idx, out_cnt,
+                           (int32_t*)(ws + W.ext_label), (int32_t*)(ws + W.ext_src), (int32_t*)(ws + W.ext_dst), V1, V,
+                           out_stride);
+        MS_LAUNCH_CHECK();
+        rc = predictor_step(net, W, ws, s);
+        if (rc != MS_OK) return rc;
+      }
+    }
+    MS_HIP(hipMemcpyAsync(out_len, out_cnt, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+    return MS_OK;
+  }
+
+  BeamP p;
+  p.lens = lens;
+  p.logp = logp;
+  p.A_cnt = A_cnt;
+  p.A_node = (int32_t*)(ws + W.A_node);
+  p.A_slot = A_slot;
+  p.A_score = (float*)(ws + W.A_score);
+  p.B_cnt = (int32_t*)(ws + W.B_cnt);
+  p.B_node = (int32_t*)(ws + W.B_node);
+  p.B_slot = (int32_t*)(ws + W.B_slot);
+  p.B_score = (float*)(ws + W.B_score);
+  p.ext_label = (int32_t*)(ws + W.ext_label);
+  p.ext_src = (int32_t*)(ws + W.ext_src);
+  p.ext_dst = (int32_t*)(ws + W.ext_dst);
+  p.node_cnt = (int32_t*)(ws + W.node_cnt);
+  p.node_parent = (int32_t*)(ws + W.node_parent);
+  p.node_label = (int32_t*)(ws + W.node_label);
+  p.child = (int32_t*)(ws + W.child);
+  p.N = N;
+  p.w = w;
+  p.V = V;
+  p.bcap = W.bcap;
+  p.maxn = W.maxn;
+  p.R = R;
+  MS_HIP(hipMemsetAsync(p.child, 0xFF, (size_t)N * W.maxn * V * 4, s));
+  hipLaunchKernelGGL(beam_init_kernel, dim3(ms::cdiv(N, 64)), dim3(64), 0, s, p);
+  MS_LAUNCH_CHECK();
+  int rc = predictor_step(net, W, ws, s);
+  if (rc != MS_OK) return rc;
+  const size_t cand_lds = (size_t)w * V1 * 4;
+  for (int t = 0; t < T; ++t) {
+    for (int v = 0; v < max_symbols; ++v) {
+      const int last = v == max_symbols - 1;
+      hipLaunchKernelGGL(joint_slots_kernel, dim3(R), dim3(256), joint_lds, s, enc_p, lens, pp, A_slot, A_cnt, w_out, b_out,
+                         logp, t, N, w, J, V1);
+      MS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(beam_round_kernel, dim3(N), dim3(256), cand_lds, s, p, t, 2 + v, v == 0, last);
+      MS_LAUNCH_CHECK();
+      if (!last) {
+        rc = predictor_step(net, W, ws, s);
+        if (rc != MS_OK) return rc;
+      }
+    }
+    hipLaunchKernelGGL(beam_frame_end_kernel, dim3(w, N), dim3(256), 0, s, p, (float*)(ws + W.st_h), (float*)(ws + W.st_c), pp,
+                       t, L * H, J);
+    MS_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(beam_finish_kernel, dim3(N), dim3(64), 0, s, p, out_idx, out_len, out_score,
+                     T * (max_symbols > 1 ? max_symbols - 1 : 0) + 1);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}

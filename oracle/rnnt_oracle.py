@@ -73,7 +73,7 @@ def beam_decode(enc, lens, pred_sd, joint_sd, hidden, layers, blank, beam_width,
                 for h, lp in zip(A, lps):
                     s = F32(h[1] + lp[blank])
                     if h[0] in B:
-                        B[h[0]][0] = F32(np.logaddexp(B[h[0]][0], s))
+                        B[h[0]][0] = F32(np.logaddexp(np.float64(B[h[0]][0]), np.float64(s)))  # spec: float64, rounded once
                     else:
                         B[h[0]] = [s, h[2], h[3]]
                         order.append(h[0])

@@ -528,9 +528,48 @@ def test_rnnt_greedy_and_beam_vs_oracle():
     lens = np.array([14, 9, 4])
     got = RNNTGreedyDecoder(pred, joint, max_symbols=3)(T(enc), T(lens))
     assert got == RO.greedy_decode(enc, lens, psd, jsd, P, 2, V, 3)
-    got = RNNTBeamDecoder(pred, joint, beam_width=4, max_symbols=3)(T(enc), T(lens))
-    want, _ = RO.beam_decode(enc, lens, psd, jsd, P, 2, V, 4, 3)
+    dec = RNNTBeamDecoder(pred, joint, beam_width=4, max_symbols=3)
+    got = dec(T(enc), T(lens))
+    want, want_scores = RO.beam_decode(enc, lens, psd, jsd, P, 2, V, 4, 3)
     assert got == want
+    np.testing.assert_allclose(dec.last_scores, want_scores, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("V,w,ms,N,steps,seed", [(4, 8, 3, 4, 24, 0), (11, 1, 2, 2, 12, 1), (6, 5, 4, 3, 10, 2),
+                                                 (28, 8, 3, 2, 8, 3), (3, 16, 2, 2, 16, 4)])
+def test_rnnt_device_decode_sweep(V, w, ms, N, steps, seed):
+    """Small vocabularies force same-prefix merges of blank transitions (the trie / logaddexp path); ragged lengths
+    including an empty utterance; every width / round count against the oracle, greedy as well."""
+    from myrtlespeech_amd.post_process.rnnt_decoder import RNNTBeamDecoder, RNNTGreedyDecoder
+    from oracle import rnnt_oracle as RO
+    E, P = 24, 64
+    pred, joint, psd, jsd = _rnnt_parts(V=V, E=E, D=8, P=P, J=32, seed=seed)
+    rng = np.random.default_rng(seed)
+    enc = (rng.normal(size=(steps, N, E)) * 2.0).astype(np.float32)
+    lens = np.sort(rng.integers(1, steps + 1, size=N))[::-1].copy()
+    lens[0] = steps
+    lens[-1] = 0 if seed % 2 == 0 else lens[-1]
+    dec = RNNTBeamDecoder(pred, joint, beam_width=w, max_symbols=ms)
+    got = dec(T(enc), T(lens))
+    want, want_scores = RO.beam_decode(enc, lens, psd, jsd, P, 2, V, w, ms)
+    assert got == want
+    np.testing.assert_allclose(dec.last_scores, want_scores, rtol=1e-4, atol=1e-4)
+    assert RNNTGreedyDecoder(pred, joint, max_symbols=ms)(T(enc), T(lens)) == RO.greedy_decode(enc, lens, psd, jsd, P, 2, V, ms)
+
+
+def test_rnnt_decode_validation():
+    from myrtlespeech_amd.post_process.rnnt_decoder import RNNTBeamDecoder, RNNTGreedyDecoder
+    pred, joint, _, _ = _rnnt_parts()
+    with pytest.raises(ValueError):
+        RNNTBeamDecoder(pred, joint, beam_width=0)
+    with pytest.raises(ValueError):
+        RNNTGreedyDecoder(pred, joint, max_symbols=0)
+    dec = RNNTBeamDecoder(pred, joint, beam_width=2)
+    with pytest.raises(ValueError):
+        dec(torch.randn(5, 2, 40), torch.tensor([5, 6]))
+    with pytest.raises(ValueError):
+        dec(torch.randn(5, 2, 40), torch.tensor([5]))
+    assert dec(torch.randn(5, 2, 40), torch.tensor([0, 0])) == [[], []]
 
 
 def test_exact_f32_mode_in_subprocess():
