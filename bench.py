@@ -92,6 +92,12 @@ def cpu_baseline(model, sample_batch=BATCH_PER_GPU):
     rng = np.random.default_rng(0)
     x = rng.standard_normal((sample_batch, 1, FEATURES, FRAMES), dtype=np.float32)
     lens = np.full(sample_batch, FRAMES, dtype=np.int64)
+    # the GPU box gives one GPU's job a share of 16 host cores: more torch threads than that only oversubscribe
+    try:
+        share = len(os.sched_getaffinity(0))
+    except AttributeError:
+        share = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, share)))
     t0 = time.perf_counter()
     y, yl = TC.deep_speech_2_forward(x, lens, cfg, sd)
     TC.ctc_greedy_decode(y, yl, BLANK)
