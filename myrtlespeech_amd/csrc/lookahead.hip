@@ -34,19 +34,48 @@ __global__ __launch_bounds__(256) void lookahead_tcontig_kernel(const float* __r
   }
 }
 
+// Feature-contiguous layout (the RNN output [T, N, F]): lanes walk f, so every tap of every frame is a coalesced row
+// read.  A thread keeps LA_TT consecutive output frames of its feature in registers and consumes the taps in chunks
+// of LA_KC: per chunk the LA_KC weights sit in registers and each of the LA_TT + LA_KC - 1 input frames is loaded
+// ONCE and fanned out to the outputs it contributes to (all indices static after unrolling) -- 7 loads per output
+// instead of one weight + one input load per tap (160 at context 80).
+constexpr int LA_TT = 32, LA_KC = 16;
+
 __global__ __launch_bounds__(256) void lookahead_strided_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 float* __restrict__ y, int F, int T, int ctx, long xs_n,
                                                                 long xs_f, long xs_t, long ys_n, long ys_f, long ys_t,
                                                                 int act, float lo, float hi) {
-  const int f = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y, n = blockIdx.z;
+  const int f = blockIdx.x * 256 + threadIdx.x, t0 = blockIdx.y * LA_TT, n = blockIdx.z;
   if (f >= F) return;
   const float* xr = x + n * xs_n + f * xs_f;
   const float* wr = w + (size_t)f * ctx;
-  float acc = 0.f;
-  const int kmax = min(ctx, T - t);
-  for (int k = 0; k < kmax; ++k) acc += wr[k] * xr[(long)(t + k) * xs_t];
-  if (act == MS_ACT_CLAMP) acc = fminf(fmaxf(acc, lo), hi);
-  y[n * ys_n + f * ys_f + t * ys_t] = acc;
+  float acc[LA_TT];
+#pragma unroll
+  for (int i = 0; i < LA_TT; ++i) acc[i] = 0.f;
+  for (int k0 = 0; k0 < ctx; k0 += LA_KC) {
+    float wk[LA_KC];
+#pragma unroll
+    for (int k = 0; k < LA_KC; ++k) wk[k] = (k0 + k < ctx) ? wr[k0 + k] : 0.f;
+#pragma unroll
+    for (int j = 0; j < LA_TT + LA_KC - 1; ++j) {
+      const int tt = t0 + k0 + j;
+      const float xv = tt < T ? xr[(long)tt * xs_t] : 0.f;
+#pragma unroll
+      for (int i = 0; i < LA_TT; ++i) {
+        const int k = j - i;  // static after unrolling
+        if (k >= 0 && k < LA_KC) acc[i] += wk[k] * xv;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LA_TT; ++i) {
+    const int t = t0 + i;
+    if (t < T) {
+      float v = acc[i];
+      if (act == MS_ACT_CLAMP) v = fminf(fmaxf(v, lo), hi);
+      y[n * ys_n + f * ys_f + t * ys_t] = v;
+    }
+  }
 }
 
 }  // namespace
@@ -64,7 +93,7 @@ extern "C" int ms_lookahead_forward(const float* x, const float* w, float* y, in
     hipLaunchKernelGGL(lookahead_tcontig_kernel, dim3(ms::cdiv(T, LA_TB), F, N), dim3(256), lds, (hipStream_t)stream, x,
                        w, y, F, T, ctx, xs_n, xs_f, ys_n, ys_f, ys_t, act, act_lo, act_hi);
   } else {
-    hipLaunchKernelGGL(lookahead_strided_kernel, dim3(ms::cdiv(F, 256), T, N), dim3(256), 0, (hipStream_t)stream, x, w, y,
+    hipLaunchKernelGGL(lookahead_strided_kernel, dim3(ms::cdiv(F, 256), ms::cdiv(T, LA_TT), N), dim3(256), 0, (hipStream_t)stream, x, w, y,
                        F, T, ctx, xs_n, xs_f, xs_t, ys_n, ys_f, ys_t, act, act_lo, act_hi);
   }
   MS_LAUNCH_CHECK();

@@ -71,13 +71,17 @@ bool use_fast(int cell, int H, int ndir) {
 // hi*lo accumulated in f32 (relative error ~2^-17 per product instead of 2^-24).
 bool want_split() { return ms::precision_mode() != ms::PREC_F32; }
 bool use_split(int cell, int H, int ndir) { return use_fast(cell, H, ndir) && want_split() && H % 64 == 0; }
-// the input projection runs as the bf16x3 GEMM whenever the recurrence is split and In allows 16-byte granules
 bool two_stream_shape(int H) { return H == 256 || H == 512 || H == 768 || H == 1024; }
 // MS_PRECISION=fp16: single-pass fp16 operands, only on the two-stream kernel's shapes (elsewhere bf16x3)
 bool use_f16(int cell, int H, int ndir) {
   return ms::precision_mode() == ms::PREC_F16 && use_split(cell, H, ndir) && two_stream_shape(H);
 }
-bool use_split_gemm(int cell, int H, int ndir, int In) { return use_split(cell, H, ndir) && In % 32 == 0; }
+// the input projection runs as the bf16x3 GEMM whenever the operands are split (every cell, also the streamed-weights
+// path) and In allows 16-byte granules
+bool use_split_gemm(int cell, int H, int ndir, int In) {
+  if (In % 32 != 0 || !want_split() || force_generic()) return false;
+  return use_split(cell, H, ndir) || !use_fast(cell, H, ndir);
+}
 
 struct PackLayout {
   size_t wih, bias_x, whh, bhh, total;  // byte offsets
@@ -289,6 +293,154 @@ __global__ __launch_bounds__(64) void rnn_step_generic_kernel(StepP p) {
       p.out[((size_t)t * N + n) * (p.ndir * H) + d * H + u] = active ? hnew : 0.f;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ streamed-weights step
+//
+// Cells / sizes whose W_hh cannot stay on chip (the reference's shipped DS2 config: 3 x GRU-2560, 78.6 MB of f32
+// recurrent weights per layer): one launch per time step, W_hh streamed from L2 / Infinity Cache through exact-f32
+// MFMA.  A workgroup owns 16 hidden units (all their gate rows) x up to 64 batch rows; its 4 waves split K = H in
+// quarters (16x16x4 tiles: A = h rows, B = W_hh rows, both as float4 per lane = four k-steps per load), wave 0 adds the
+// quarters (LDS) and applies the cell.  H % 64 == 0.
+template <int CELL, int NT>
+__global__ __launch_bounds__(256) void rnn_step_mfma_kernel(StepP p) {
+  constexpr int G = (CELL == MS_CELL_LSTM || CELL == MS_CELL_HARD_LSTM) ? 4 : (CELL == MS_CELL_GRU ? 3 : 1);
+  __shared__ f32x4 red[3][G][NT][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int x = lane & 15, kq = lane >> 4;
+  const int u0 = blockIdx.x * 16, d = blockIdx.y, n0 = blockIdx.z * (16 * NT);
+  const int H = p.H, N = p.N;
+  const int t = d ? (p.steps - 1 - p.s) : p.s;
+  const size_t GH = (size_t)G * H;
+  const float* wbase = p.whh + (size_t)d * GH * H;
+  const float* hbase = p.h_prev + (size_t)d * N * H;
+  const int kbeg = wave * (H / 4), kend = kbeg + H / 4;
+
+  f32x4 acc[G][NT];
+  const float* arow[NT];
+  const float* brow[G];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) arow[nt] = hbase + (size_t)min(n0 + nt * 16 + x, N - 1) * H + 4 * kq;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    brow[g] = wbase + ((size_t)g * H + u0 + x) * H + 4 * kq;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[g][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // A stage = 32 k-values = one whole 128-byte line of every W_hh / h row the wave touches: its two 16-deep halves are
+  // requested back to back (two float4 per lane), so each line is fetched from L2 / Infinity Cache once instead of once
+  // per half.  Two stages rotate: the loads of stage i+2 are issued as soon as stage i has been consumed.
+  constexpr int D = 2;
+  f32x4 a[D][2][NT], b[D][2][G];
+  auto load_stage = [&](int st, int kb) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      if (kb + 16 * hf < kend) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) a[st][hf][nt] = *reinterpret_cast<const f32x4*>(arow[nt] + kb + 16 * hf);
+#pragma unroll
+        for (int g = 0; g < G; ++g) b[st][hf][g] = *reinterpret_cast<const f32x4*>(brow[g] + kb + 16 * hf);
+      }
+    }
+  };
+#pragma unroll
+  for (int st = 0; st < D; ++st)
+    if (kbeg + 32 * st < kend) load_stage(st, kbeg + 32 * st);
+  for (int kb0 = kbeg; kb0 < kend; kb0 += 32 * D) {
+#pragma unroll
+    for (int st = 0; st < D; ++st) {
+      const int kb = kb0 + 32 * st;
+      if (kb < kend) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          if (kb + 16 * hf < kend) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                  acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st][hf][nt][e], b[st][hf][g][e], acc[g][nt], 0, 0, 0);
+          }
+        }
+        if (kb + 32 * D < kend) load_stage(st, kb + 32 * D);
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) red[wave - 1][g][nt][lane] = acc[g][nt];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int w2 = 0; w2 < 3; ++w2) acc[g][nt] += red[w2][g][nt][lane];
+
+  // lane holds (batch row n0 + nt*16 + 4*kq + r, unit u0 + x) for r = 0..3
+  const int u = u0 + x;
+  const float* bh = p.bhh + d * GH;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + nt * 16 + 4 * kq + r;
+      if (n >= N) continue;
+      const bool active = p.lens ? (t < p.lens[n]) : true;
+      const size_t sidx = ((size_t)d * N + n) * H + u;
+      const float* xp = p.xproj + ((size_t)t * N + n) * (p.ndir * GH) + d * GH;
+      const float hold = hbase[(size_t)n * H + u];
+      float hnew, cnew = 0.f;
+      if (CELL == MS_CELL_LSTM || CELL == MS_CELL_HARD_LSTM) {
+        const float gi = xp[u] + (acc[0][nt][r] + bh[u]);
+        const float gf = xp[H + u] + (acc[1 % G][nt][r] + bh[H + u]);
+        const float gg = xp[2 * H + u] + (acc[2 % G][nt][r] + bh[2 * H + u]);
+        const float go = xp[3 * H + u] + (acc[3 % G][nt][r] + bh[3 * H + u]);
+        const float cold = p.c_state[sidx];
+        if (CELL == MS_CELL_LSTM) {
+          cnew = sigmoidf_(gf) * cold + sigmoidf_(gi) * tanhf(gg);
+          hnew = sigmoidf_(go) * tanhf(cnew);
+        } else {
+          cnew = clamp01(0.2f * gf + 0.5f) * cold + clamp01(0.2f * gi + 0.5f) * clamp11(gg);
+          hnew = clamp01(0.2f * go + 0.5f) * clamp11(cnew);
+        }
+        const float cs = active ? cnew : cold;
+        p.c_state[sidx] = cs;
+        if (p.s == p.steps - 1) p.cn[sidx] = cs;
+      } else if (CELL == MS_CELL_GRU) {
+        const float rg = sigmoidf_(xp[u] + (acc[0][nt][r] + bh[u]));
+        const float z = sigmoidf_(xp[H + u] + (acc[1 % G][nt][r] + bh[H + u]));
+        const float nn = tanhf(xp[2 * H + u] + rg * (acc[2 % G][nt][r] + bh[2 * H + u]));
+        hnew = (1.0f - z) * nn + z * hold;
+      } else {
+        hnew = tanhf(xp[u] + (acc[0][nt][r] + bh[u]));
+      }
+      const float hs = active ? hnew : hold;
+      p.h_next[sidx] = hs;
+      if (p.s == p.steps - 1) p.hn[sidx] = hs;
+      p.out[((size_t)t * N + n) * (p.ndir * H) + d * H + u] = active ? hnew : 0.f;
+    }
+}
+
+template <int CELL>
+static void launch_step_mfma(const StepP& p, hipStream_t stream) {
+  const int tiles = ms::cdiv(p.N, 16);
+  static const int nt_env = getenv("MS_RNN_STEP_NT") ? atoi(getenv("MS_RNN_STEP_NT")) : 0;
+  if (nt_env == 1) {
+    hipLaunchKernelGGL((rnn_step_mfma_kernel<CELL, 1>), dim3(p.H / 16, p.ndir, tiles), dim3(256), 0, stream, p);
+    return;
+  }
+  if (tiles == 1)
+    hipLaunchKernelGGL((rnn_step_mfma_kernel<CELL, 1>), dim3(p.H / 16, p.ndir, 1), dim3(256), 0, stream, p);
+  else if (tiles == 2)
+    hipLaunchKernelGGL((rnn_step_mfma_kernel<CELL, 2>), dim3(p.H / 16, p.ndir, 1), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((rnn_step_mfma_kernel<CELL, 4>), dim3(p.H / 16, p.ndir, ms::cdiv(p.N, 64)), dim3(256), 0, stream, p);
 }
 
 // ------------------------------------------------------------------------------------------------ persistent LSTM
@@ -1108,7 +1260,16 @@ extern "C" int ms_rnn_pack(int cell, int In, int H, int ndir, const float* const
       hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH)), dim3(256), 0, stream, (const float*)nullptr, bhh_d,
                          GH);
     } else {
-      hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH * In)), dim3(256), 0, stream, w_ih[d], wih_d, GH * In);
+      if (use_split_gemm(cell, H, ndir, In)) {
+        // natural row order, bf16 hi / lo planes (plane stride = ndir * GH * In elements)
+        unsigned short* hi0 = (unsigned short*)(base + L.wih);
+        unsigned short* lo0 = hi0 + (size_t)ndir * GH * In;
+        int rc = ms::split_planes_launch(w_ih[d], hi0 + (size_t)d * GH * In, lo0 + (size_t)d * GH * In, GH * In,
+                                         ms::PREC_BF16X3, stream);
+        if (rc != MS_OK) return rc;
+      } else {
+        hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH * In)), dim3(256), 0, stream, w_ih[d], wih_d, GH * In);
+      }
       hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH)), dim3(256), 0, stream, bi, bx_d, GH);
       hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d], whh_d, GH * H);
       hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH)), dim3(256), 0, stream, bh, bhh_d, GH);
@@ -1307,6 +1468,15 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
     p.s = s;
     p.h_prev = sh + (size_t)(s & 1) * st;
     p.h_next = sh + (size_t)((s + 1) & 1) * st;
+    if (!force_generic() && H % 64 == 0) {
+      switch (cell) {
+        case MS_CELL_LSTM: launch_step_mfma<MS_CELL_LSTM>(p, stream); break;
+        case MS_CELL_GRU: launch_step_mfma<MS_CELL_GRU>(p, stream); break;
+        case MS_CELL_RNN_TANH: launch_step_mfma<MS_CELL_RNN_TANH>(p, stream); break;
+        default: launch_step_mfma<MS_CELL_HARD_LSTM>(p, stream); break;
+      }
+      continue;
+    }
     dim3 grid(H, ndir);
     switch (cell) {
       case MS_CELL_LSTM: hipLaunchKernelGGL(rnn_step_generic_kernel<MS_CELL_LSTM>, grid, dim3(64), 0, stream, p); break;

@@ -99,6 +99,37 @@ def test_lstm_persistent_vs_oracle(H, N, T_, bidir):
     np.testing.assert_allclose(cpu(cn), wcn, **TOL)
 
 
+@pytest.mark.parametrize("kind,H,N,T_,bidir,In", [("GRU", 64, 32, 7, False, 32), ("GRU", 128, 17, 5, True, 48),
+                                                  ("GRU", 256, 70, 4, False, 64), ("BASIC_RNN", 64, 5, 6, True, 20),
+                                                  ("BASIC_RNN", 192, 33, 3, False, 32), ("LSTM", 1280, 9, 3, False, 32),
+                                                  ("GRU", 2560, 32, 3, False, 96)])
+def test_streamed_weights_step_kernel_vs_oracle(kind, H, N, T_, bidir, In):
+    """Cells / sizes whose recurrent weights are streamed per step through the MFMA step kernel (H % 64 == 0: GRU,
+    tanh-RNN, LSTM wider than the persistent kernel, incl. the shipped DS2 config's GRU-2560): 1, 2 and 4 batch tiles,
+    a batch beyond 64, ragged lengths, random initial state, both directions, split-bf16 input projection."""
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    torch.manual_seed(H + N)
+    layers = 2 if H <= 256 else 1
+    m = RNN(getattr(RNNType, kind), In, H, num_layers=layers, bidirectional=bidir).eval()
+    rng = np.random.default_rng(H * 3 + N)
+    lens = np.sort(rng.integers(1, T_ + 1, size=N))[::-1].copy()
+    lens[0] = T_
+    x = rng.normal(size=(T_, N, In)).astype(np.float32)
+    D = 2 if bidir else 1
+    h0 = (rng.normal(size=(layers * D, N, H)) * 0.3).astype(np.float32)
+    sd = {k[len("rnn."):]: cpu(v) for k, v in m.state_dict().items()}
+    if kind == "LSTM":
+        c0 = (rng.normal(size=(layers * D, N, H)) * 0.3).astype(np.float32)
+        (out, _), (hn, cn) = m((T(x), T(lens)), (T(h0), T(c0)))
+        want, (whn, wcn) = O.rnn_forward(O.LSTM, x, lens, sd, H, layers, bidir, (h0, c0))
+        np.testing.assert_allclose(cpu(cn), wcn, **TOL)
+    else:
+        (out, _), hn = m((T(x), T(lens)), T(h0))
+        want, whn = O.rnn_forward(getattr(O, kind), x, lens, sd, H, layers, bidir, h0)
+    np.testing.assert_allclose(cpu(out), want, **TOL)
+    np.testing.assert_allclose(cpu(hn), whn, **TOL)
+
+
 @pytest.mark.parametrize("name", golden_names("hard_lstm_"))
 def test_hard_lstm_golden(name):
     from myrtlespeech_amd.model.hard_lstm import HardLSTM
