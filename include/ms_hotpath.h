@@ -173,6 +173,17 @@ int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, const int32
                         int N, int V, int S_max, int blank, int reduction, int zero_infinity, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* Gradient of ms_ctc_loss_forward's per-utterance losses with respect to the logits (what autograd gives the
+ * reference through LogSoftmax + torch.nn.CTCLoss, loss/ctc_loss.py:95-101): alpha rows forward, beta rows backward,
+ * grad_logits[t,n,k] = grad_nll[n] * (softmax(x)[t,k] - exp(logsumexp_{s: l'_s=k}(alpha_t(s)+beta_t(s)) + nll[n] - lp[t,k]))
+ * for t < in_lens[n], 0 on padding frames and, with zero_infinity, for utterances whose loss is infinite.  grad_nll
+ * [N] is the upstream gradient of each nll[n] (the host folds the reduction in: 1 for 'sum', 1/(N*max(len,1)) for
+ * 'mean').  grad_logits [T,N,V] is fully written. */
+size_t ms_ctc_loss_backward_workspace_bytes(int T, int N, int V, int S_max);
+int ms_ctc_loss_backward(const float* logits, const int32_t* in_lens, const int32_t* targets, const int32_t* tgt_offsets,
+                         const int32_t* tgt_lens, const float* grad_nll, float* grad_logits, int T, int N, int V,
+                         int S_max, int blank, int zero_infinity, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- post_process/ctc_greedy_decoder.py ---------------------------------- */
 
 /* CTCGreedyDecoder.forward (ctc_greedy_decoder.py:74-92): argmax over symbols

@@ -91,6 +91,142 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_kernel(const float* __r
   }
 }
 
+// Gradient of the per-utterance losses with respect to the logits (alpha-beta posteriors; loss/ctc_loss.py:95-101 under
+// autograd = LogSoftmax backward o torch ctc_loss backward, which at valid frames collapses to one expression):
+//   grad[t,n,k] = go[n] * ( softmax(x)[t,k] - exp( logsumexp_{s: l'_s = k}(alpha_t(s) + beta_t(s)) + nll - lp[t,k] ) )
+// One workgroup per utterance: the alpha rows go to the global workspace on the way forward, the beta recursion walks
+// back with a double buffer in LDS and emits one gradient row per frame; frames t >= input length get zeros.
+__global__ __launch_bounds__(CTC_THREADS) void ctc_grad_kernel(const float* __restrict__ logits,
+                                                               const int32_t* __restrict__ in_lens,
+                                                               const int32_t* __restrict__ targets,
+                                                               const int32_t* __restrict__ tgt_offsets,
+                                                               const int32_t* __restrict__ tgt_lens,
+                                                               const float* __restrict__ grad_nll, float* __restrict__ grad,
+                                                               float* __restrict__ logz_ws, float* __restrict__ alpha_ws,
+                                                               int T, int N, int V, int S_max, int blank,
+                                                               int zero_infinity) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  int* ext = reinterpret_cast<int*>(smem);   // [S_max]
+  float* buf0 = smem + S_max;                // [S_max] alpha / beta double buffer
+  float* buf1 = buf0 + S_max;                // [S_max]
+  float* ab = buf1 + S_max;                  // [S_max] alpha_t + beta_t
+  __shared__ float nll_s;
+  const int Tn = min(max(in_lens[n], 0), T);
+  const int L = max(tgt_lens[n], 0);
+  const int S = 2 * L + 1;
+  float* logz = logz_ws + (size_t)n * T;
+  float* alpha = alpha_ws + (size_t)n * T * S_max;
+  const int32_t* tg = targets + tgt_offsets[n];
+  const float go = grad_nll[n];
+
+  for (int t = tid; t < Tn; t += CTC_THREADS) {
+    const float* row = logits + ((size_t)t * N + n) * V;
+    float m = neg_inf();
+    for (int v = 0; v < V; ++v) m = fmaxf(m, row[v]);
+    float sum = 0.f;
+    for (int v = 0; v < V; ++v) sum += expf(row[v] - m);
+    logz[t] = logf(sum) + m;
+  }
+  for (int s = tid; s < S; s += CTC_THREADS) {
+    ext[s] = (s & 1) ? tg[s >> 1] : blank;
+    buf0[s] = neg_inf();
+  }
+  // padding frames carry no gradient
+  for (size_t i = (size_t)Tn * V + tid; i < (size_t)T * V; i += CTC_THREADS) {
+    const size_t t = i / V, v = i - t * V;
+    grad[(t * N + n) * V + v] = 0.f;
+  }
+  __syncthreads();
+  if (Tn == 0) return;
+  {
+    const float* row = logits + (size_t)n * V;
+    if (tid == 0) buf0[0] = row[blank] - logz[0];
+    if (tid == 1 && S > 1) buf0[1] = row[ext[1]] - logz[0];
+  }
+  __syncthreads();
+  float* cur = buf0;
+  float* nxt = buf1;
+  for (int s = tid; s < S; s += CTC_THREADS) alpha[s] = cur[s];
+  for (int t = 1; t < Tn; ++t) {
+    const float* row = logits + ((size_t)t * N + n) * V;
+    const float lz = logz[t];
+    for (int s = tid; s < S; s += CTC_THREADS) {
+      const int lab = ext[s];
+      const float a0 = cur[s];
+      const float a1 = (s >= 1) ? cur[s - 1] : neg_inf();
+      const float a2 = (s >= 2 && lab != blank && lab != ext[s - 2]) ? cur[s - 2] : neg_inf();
+      const float l = lse3(a0, a1, a2);
+      const float v = (l == neg_inf()) ? neg_inf() : l + (row[lab] - lz);
+      nxt[s] = v;
+      alpha[(size_t)t * S_max + s] = v;
+    }
+    __syncthreads();
+    float* tmp = cur; cur = nxt; nxt = tmp;
+  }
+  if (tid == 0) {
+    const float l1 = cur[S - 1];
+    const float l2 = (S > 1) ? cur[S - 2] : neg_inf();
+    const float m = fmaxf(l1, l2);
+    nll_s = (m == neg_inf()) ? INFINITY : -(logf(expf(l1 - m) + expf(l2 - m)) + m);
+  }
+  __syncthreads();
+  const float nll = nll_s;
+  if (zero_infinity && isinf(nll)) {
+    for (size_t i = tid; i < (size_t)Tn * V; i += CTC_THREADS) {
+      const size_t t = i / V, v = i - t * V;
+      grad[(t * N + n) * V + v] = 0.f;
+    }
+    return;
+  }
+  // beta_{Tn-1}: only the last blank and the last label can end a path
+  __syncthreads();
+  {
+    const float* row = logits + ((size_t)(Tn - 1) * N + n) * V;
+    const float lz = logz[Tn - 1];
+    for (int s = tid; s < S; s += CTC_THREADS) {
+      float v = neg_inf();
+      if (s == S - 1 || s == S - 2) v = row[ext[s]] - lz;
+      cur[s] = v;
+    }
+  }
+  __syncthreads();
+  for (int t = Tn - 1; t >= 0; --t) {
+    const float* row = logits + ((size_t)t * N + n) * V;
+    const float lz = logz[t];
+    if (t < Tn - 1) {
+      // beta_t(s) = lp[t, l'_s] + logsumexp(beta_{t+1}(s), beta_{t+1}(s+1), [l'_{s+2} != l'_s] beta_{t+1}(s+2))
+      for (int s = tid; s < S; s += CTC_THREADS) {
+        const int lab = ext[s];
+        const float b0 = nxt[s];
+        const float b1 = (s + 1 < S) ? nxt[s + 1] : neg_inf();
+        const float b2 = (s + 2 < S && ext[s + 2] != blank && ext[s + 2] != lab) ? nxt[s + 2] : neg_inf();
+        const float l = lse3(b0, b1, b2);
+        cur[s] = (l == neg_inf()) ? neg_inf() : l + (row[lab] - lz);
+      }
+      __syncthreads();
+    }
+    for (int s = tid; s < S; s += CTC_THREADS) ab[s] = alpha[(size_t)t * S_max + s] + cur[s];
+    __syncthreads();
+    for (int k = tid; k < V; k += CTC_THREADS) {
+      float m = neg_inf();
+      for (int s = 0; s < S; ++s)
+        if (ext[s] == k) m = fmaxf(m, ab[s]);
+      const float lp = row[k] - lz;
+      float res = expf(lp);
+      if (m != neg_inf()) {
+        float sum = 0.f;
+        for (int s = 0; s < S; ++s)
+          if (ext[s] == k) sum += expf(ab[s] - m);
+        res -= expf(logf(sum) + m + nll - lp);
+      }
+      grad[((size_t)t * N + n) * V + k] = res * go;
+    }
+    __syncthreads();
+    float* tmp = cur; cur = nxt; nxt = tmp;   // beta_t becomes "next" for frame t-1
+  }
+}
+
 // Deterministic single-workgroup reduction of the per-utterance losses.
 __global__ void ctc_reduce_kernel(float* __restrict__ nll, const int32_t* __restrict__ tgt_lens,
                                   float* __restrict__ reduced, int N, int reduction, int zero_infinity) {
@@ -208,6 +344,39 @@ extern "C" int ms_ctc_greedy_decode(const float* x, const int32_t* lens, int32_t
   MS_REQUIRE(T > 0 && N > 0 && V > 0, "bad shape");
   hipLaunchKernelGGL(ctc_greedy_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, lens, out_idx, out_len, T, N, V,
                      blank);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}
+
+extern "C" size_t ms_ctc_loss_backward_workspace_bytes(int T, int N, int V, int S_max) {
+  (void)V;
+  if (T <= 0 || N <= 0 || S_max < 1) return 0;
+  return ms::align_up((size_t)T * N * sizeof(float), 256) + ms::align_up((size_t)T * N * S_max * sizeof(float), 256);
+}
+
+extern "C" int ms_ctc_loss_backward(const float* logits, const int32_t* in_lens, const int32_t* targets,
+                                    const int32_t* tgt_offsets, const int32_t* tgt_lens, const float* grad_nll,
+                                    float* grad_logits, int T, int N, int V, int S_max, int blank, int zero_infinity,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  MS_REQUIRE(logits && in_lens && targets && tgt_offsets && tgt_lens && grad_nll && grad_logits && workspace, "null pointer");
+  MS_REQUIRE(T > 0 && N > 0 && V > 0 && S_max >= 1, "bad shape");
+  MS_REQUIRE(blank >= 0 && blank < V, "blank out of range");
+  if (workspace_bytes < ms_ctc_loss_backward_workspace_bytes(T, N, V, S_max)) {
+    ms::set_error("ms_ctc_loss_backward: workspace too small");
+    return MS_ERR_WORKSPACE;
+  }
+  const size_t lds = (size_t)4 * S_max * sizeof(float);
+  constexpr size_t GRAD_LDS_MAX = 160 * 1024 - 256;   // the kernel also has a static word
+  MS_REQUIRE(lds <= GRAD_LDS_MAX, "target too long for the LDS-resident alpha / beta rows");
+  static bool attr_set = false;
+  if (!attr_set) {
+    MS_HIP(hipFuncSetAttribute((const void*)ctc_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRAD_LDS_MAX));
+    attr_set = true;
+  }
+  float* logz = (float*)workspace;
+  float* alpha = (float*)((char*)workspace + ms::align_up((size_t)T * N * sizeof(float), 256));
+  hipLaunchKernelGGL(ctc_grad_kernel, dim3(N), dim3(CTC_THREADS), lds, (hipStream_t)stream, logits, in_lens, targets,
+                     tgt_offsets, tgt_lens, grad_nll, grad_logits, logz, alpha, T, N, V, S_max, blank, zero_infinity);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }

@@ -4,8 +4,9 @@
 ``((x[T,N,V], x_lens), (y, y_lens))`` = log-softmax over symbols followed by the
 log-space CTC forward recursion (``ms_ctc_loss_forward``, one workgroup per
 utterance).  ``log_softmax`` / ``ctc_loss`` attributes exist for repr/API parity
-with the reference; they hold configuration only.  Forward (inference / scoring)
-only: the returned tensor carries no autograd graph.
+with the reference; they hold configuration only.  When the logits require grad the loss is
+an autograd node whose backward is the alpha-beta posterior kernel (``ms_ctc_loss_backward``):
+``loss.backward()`` fills ``x.grad`` as it does through the reference's LogSoftmax + CTCLoss.
 """
 from typing import Tuple
 
@@ -14,6 +15,40 @@ import torch
 from myrtlespeech_amd import _lib
 
 _REDUCTION = {"none": 0, "mean": 1, "sum": 2}
+
+
+class _CTCLossFunction(torch.autograd.Function):
+    """Forward = ``ms_ctc_loss_forward``; backward = ``ms_ctc_loss_backward`` (logits gradient only)."""
+
+    @staticmethod
+    def forward(ctx, x, run_forward, meta):
+        out = run_forward(x)
+        ctx.save_for_backward(x)
+        ctx.meta = meta
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (x,) = ctx.saved_tensors
+        m = ctx.meta
+        lib = _lib.load()
+        t, n, v = x.shape
+        g = _lib.f32c(grad_out.detach())
+        if m["red"] == 0:
+            grad_nll = g.reshape(n)
+        elif m["red"] == 2:
+            grad_nll = g.reshape(1).expand(n)
+        else:  # mean: loss = mean_n(nll_n / max(len_n, 1))
+            grad_nll = g.reshape(1) / (m["yl_dev"].clamp(min=1).to(torch.float32) * n)
+        grad_nll = grad_nll.contiguous()
+        grad = torch.empty_like(x)
+        nbytes = lib.ms_ctc_loss_backward_workspace_bytes(t, n, v, m["s_max"])
+        ws = m["workspace"].get(nbytes)
+        _lib.check(lib.ms_ctc_loss_backward(_lib.ptr(x), _lib.ptr(m["xl_dev"]), _lib.ptr(m["y_dev"]), _lib.ptr(m["off_dev"]),
+                                            _lib.ptr(m["yl_dev"]), _lib.ptr(grad_nll), _lib.ptr(grad), t, n, v, m["s_max"],
+                                            m["blank"], m["zero_infinity"], _lib.ptr(ws), nbytes, _lib.stream_ptr()),
+                   "ms_ctc_loss_backward")
+        return grad, None, None
 
 
 class CTCLoss(torch.nn.Module):
@@ -27,6 +62,7 @@ class CTCLoss(torch.nn.Module):
         self.ctc_loss = torch.nn.CTCLoss(blank=blank, reduction=reduction, zero_infinity=zero_infinity)
         self.use_cuda = torch.cuda.is_available()
         self._workspace = _lib.Workspace()
+        self._bwd_workspace = _lib.Workspace()
 
     def forward(self, inputs: Tuple[torch.Tensor, torch.Tensor], targets: Tuple[torch.Tensor, torch.Tensor]
                 ) -> torch.Tensor:
@@ -66,13 +102,21 @@ class CTCLoss(torch.nn.Module):
         if y_dev.numel() == 0:
             y_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
         red = _REDUCTION[self.ctc_loss.reduction]
-        nll = torch.empty(n, dtype=torch.float32, device="cuda")
-        reduced = torch.empty(1, dtype=torch.float32, device="cuda")
-        ws = self._workspace.get(lib.ms_ctc_loss_workspace_bytes(t, n, v, s_max))
+        zero_inf = int(bool(self.ctc_loss.zero_infinity))
         xl_dev, off_dev, yl_dev = _lib.lens_i32(xl), _lib.lens_i32(offsets), _lib.lens_i32(yl)
-        _lib.check(lib.ms_ctc_loss_forward(_lib.ptr(x), _lib.ptr(xl_dev), _lib.ptr(y_dev), _lib.ptr(off_dev),
-                                           _lib.ptr(yl_dev), _lib.ptr(nll),
-                                           _lib.ptr(reduced), t, n, v, s_max, blank, red,
-                                           int(bool(self.ctc_loss.zero_infinity)), _lib.ptr(ws), ws.numel(),
-                                           _lib.stream_ptr()), "ms_ctc_loss_forward")
-        return nll if red == 0 else reduced[0]
+
+        def run_forward(logits: torch.Tensor) -> torch.Tensor:
+            nll = torch.empty(n, dtype=torch.float32, device="cuda")
+            reduced = torch.empty(1, dtype=torch.float32, device="cuda")
+            ws = self._workspace.get(lib.ms_ctc_loss_workspace_bytes(t, n, v, s_max))
+            _lib.check(lib.ms_ctc_loss_forward(_lib.ptr(logits), _lib.ptr(xl_dev), _lib.ptr(y_dev), _lib.ptr(off_dev),
+                                               _lib.ptr(yl_dev), _lib.ptr(nll), _lib.ptr(reduced), t, n, v, s_max, blank,
+                                               red, zero_inf, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                       "ms_ctc_loss_forward")
+            return nll if red == 0 else reduced[0]
+
+        if torch.is_grad_enabled() and x.requires_grad:
+            meta = dict(red=red, s_max=s_max, blank=blank, zero_infinity=zero_inf, xl_dev=xl_dev, off_dev=off_dev,
+                        yl_dev=yl_dev, y_dev=y_dev, workspace=self._bwd_workspace)
+            return _CTCLossFunction.apply(x, run_forward, meta)
+        return run_forward(x)

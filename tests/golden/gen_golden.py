@@ -538,3 +538,44 @@ def gen_frontend():
 
 if __name__ == "__main__" and "frontend" in sys.argv[1:]:
     gen_frontend()
+
+
+# ----------------------------------------------------------------------------- CTC gradient (alpha-beta posteriors)
+def gen_ctc_grad():
+    """x.grad through the reference's CTCLoss module (LogSoftmax + torch.nn.CTCLoss under autograd) for every
+    reduction; 'none' is contracted with seeded per-utterance weights so the upstream gradient differs per row.
+    Case A: ragged inputs, repeated labels, an empty target; the infeasible third utterance only with
+    zero_infinity (its gradient is then zero).  Case B: V = 29, longer targets."""
+    torch.set_grad_enabled(True)
+    try:
+        for name, (T, N, V, blank, x_lens, tgt, seed) in {
+            "ctc_grad_small": (14, 4, 6, 5, [14, 11, 7, 3], [[1, 2, 2, 3], [4, 1], [0, 0, 1, 4, 2, 3, 1, 4], []], 43),
+            "ctc_grad_v29": (60, 3, 29, 28, [60, 45, 30], None, 44),
+        }.items():
+            torch.manual_seed(seed)
+            x0 = torch.randn(T, N, V) * (2 if V == 6 else 1)
+            xl = torch.tensor(x_lens, dtype=torch.int32)
+            if tgt is None:
+                yl = torch.tensor([20, 14, 9], dtype=torch.int32)
+                y = torch.randint(0, 28, (N, 20), dtype=torch.int32)
+            else:
+                S = max(len(t) for t in tgt)
+                y = torch.zeros(N, S, dtype=torch.int32)
+                for n, t in enumerate(tgt):
+                    y[n, :len(t)] = torch.tensor(t, dtype=torch.int32)
+                yl = torch.tensor([len(t) for t in tgt], dtype=torch.int32)
+            wts = torch.rand(N) + 0.5
+            arrays = {"in/x": npy(x0), "in/x_lens": npy(xl), "in/y": npy(y), "in/y_lens": npy(yl), "in/w": npy(wts)}
+            for red in ("none", "mean", "sum"):
+                for zi in ((True,) if tgt is not None else (False, True)):
+                    x = x0.clone().requires_grad_(True)
+                    out = CTCLoss(blank=blank, reduction=red, zero_infinity=zi)((x, xl), (y, yl))
+                    (out * wts).sum().backward() if red == "none" else (out * 1.7).backward()
+                    arrays[f"grad/{red}_{int(zi)}"] = npy(x.grad)
+            save(name, dict(blank=blank, scale=1.7), arrays)
+    finally:
+        torch.set_grad_enabled(False)
+
+
+if __name__ == "__main__" and "ctcgrad" in sys.argv[1:]:
+    gen_ctc_grad()

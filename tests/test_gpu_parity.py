@@ -457,6 +457,45 @@ def test_linear_split_bf16x3(lib, M, K, N, act):
     assert np.abs(cpu(y) - want).max() <= bound
 
 
+@pytest.mark.parametrize("name", ["ctc_grad_small", "ctc_grad_v29"])
+def test_ctc_loss_backward_matches_reference_autograd(name):
+    """loss.backward() through the accelerated CTCLoss fills x.grad like the reference module (golden x.grad from the
+    reference's LogSoftmax + torch.nn.CTCLoss under autograd): every reduction, per-utterance upstream weights,
+    ragged inputs, repeated labels, an empty target, an infeasible utterance under zero_infinity."""
+    from myrtlespeech_amd.loss.ctc_loss import CTCLoss
+    g = Golden(name)
+    w = T(g["in/w"]).cuda()
+    for key in [k for k in g.a if k.startswith("grad/")]:
+        red, zi = key[len("grad/"):].rsplit("_", 1)
+        x = T(g["in/x"]).cuda().requires_grad_(True)
+        out = CTCLoss(blank=g.cfg["blank"], reduction=red, zero_infinity=bool(int(zi)))((x, T(g["in/x_lens"])),
+                                                                                       (T(g["in/y"]), T(g["in/y_lens"])))
+        ((out * w).sum() if red == "none" else out * g.cfg["scale"]).backward()
+        np.testing.assert_allclose(cpu(x.grad), g[key], rtol=1e-4, atol=2e-5)
+
+
+def test_ctc_loss_backward_full_size_vs_oracle_rows_and_properties():
+    """Config-2 logits shape [501, 32, 29], targets of 120: gradient rows of two utterances against the float64 oracle,
+    and for all of them the CTC posterior identity: every valid frame's gradient sums to zero (softmax mass 1 minus
+    occupation mass 1), padding frames are exactly zero."""
+    from myrtlespeech_amd.loss.ctc_loss import CTCLoss
+    rng = np.random.default_rng(3)
+    t_, n_, v_ = 501, 32, 29
+    x_np = rng.normal(size=(t_, n_, v_)).astype(np.float32)
+    xl = np.sort(rng.integers(300, t_ + 1, size=n_))[::-1].copy()
+    y = rng.integers(0, 28, size=(n_, 120)).astype(np.int32)
+    yl = rng.integers(60, 121, size=n_).astype(np.int32)
+    x = T(x_np).cuda().requires_grad_(True)
+    CTCLoss(blank=28, reduction="sum")((x, T(xl)), (T(y), T(yl))).backward()
+    gr = cpu(x.grad)
+    for n in range(n_):
+        assert np.all(gr[xl[n]:, n] == 0)
+        assert np.abs(gr[:xl[n], n].sum(axis=1)).max() < 2e-3  # float32 log-space sums of magnitude ~800 (ulp 6e-5)
+    sel = [0, 17]
+    want = O.ctc_grad(x_np[:, sel], xl[sel], y[sel], yl[sel], np.ones(2, np.float32), 28)
+    np.testing.assert_allclose(gr[:, sel], want, rtol=2e-3, atol=1e-3)
+
+
 # ----------------------------------------------------------------------------- protobuf builders
 def test_builder_built_ds2_matches_reference_golden():
     """A text-format config -> builders -> modules; with the reference's weights loaded it must

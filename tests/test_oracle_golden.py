@@ -241,3 +241,21 @@ def test_oracle_chunked_streaming(name):
         t0 += chunk
     np.testing.assert_allclose(np.concatenate(outs, 0), g["out/y"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(hid[0], g["out/hn_last"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["ctc_grad_small", "ctc_grad_v29"])
+def test_ctc_grad_oracle_matches_reference_autograd(name):
+    """The alpha-beta gradient restatement against x.grad obtained through the reference's CTCLoss module."""
+    g = Golden(name)
+    x, xl, y, yl, w = g["in/x"], g["in/x_lens"], g["in/y"], g["in/y_lens"], g["in/w"]
+    n = x.shape[1]
+    for key in [k for k in g.a if k.startswith("grad/")]:
+        red, zi = key[len("grad/"):].rsplit("_", 1)
+        if red == "none":
+            gn = w
+        elif red == "sum":
+            gn = np.full(n, g.cfg["scale"], np.float32)
+        else:
+            gn = g.cfg["scale"] / (np.maximum(yl.astype(np.float32), 1.0) * n)
+        got = O.ctc_grad(x, xl, y, yl, gn, g.cfg["blank"], bool(int(zi)))
+        np.testing.assert_allclose(got, g[key], rtol=1e-4, atol=2e-5)  # the reference subtracts two float32 exponentials
