@@ -83,6 +83,17 @@ bool use_split_gemm(int cell, int H, int ndir, int In) {
   return use_split(cell, H, ndir) || !use_fast(cell, H, ndir);
 }
 
+// GRU whose recurrent weights fit the register files when cut into 10-unit workgroups (one per CU): H in {1280, 2560}
+// -- the reference's shipped DS2 config is 3 x GRU-2560, unidirectional.  MS_GRU_PERSISTENT=0 falls back to the per-step
+// streamed-weights kernel.
+constexpr int GRU_U = 10;
+bool use_gru_persistent(int cell, int H, int ndir) {
+  static const bool off = getenv("MS_GRU_PERSISTENT") && getenv("MS_GRU_PERSISTENT")[0] == '0';
+  if (off || force_generic() || !want_split() || cell != MS_CELL_GRU) return false;
+  if (H != 1280 && H != 2560) return false;
+  return ndir * (H / GRU_U) <= ms::num_cus();
+}
+
 struct PackLayout {
   size_t wih, bias_x, whh, bhh, total;  // byte offsets
 };
@@ -92,7 +103,9 @@ PackLayout pack_layout(int cell, int In, int H, int ndir) {
   size_t o = 0;
   L.wih = o; o += ms::align_up(ndir * GH * In * sizeof(float), 256);
   L.bias_x = o; o += ms::align_up(ndir * GH * sizeof(float), 256);
-  L.whh = o; o += ms::align_up(ndir * GH * H * sizeof(float), 256);
+  size_t whh_bytes = ndir * GH * H * sizeof(float);
+  if (use_gru_persistent(cell, H, ndir)) whh_bytes = (size_t)ndir * (H / GRU_U) * 128 * H;  // 32 packed rows per workgroup
+  L.whh = o; o += ms::align_up(whh_bytes, 256);
   L.bhh = o; o += ms::align_up(ndir * GH * sizeof(float), 256);
   L.total = o;
   return L;
@@ -1158,6 +1171,225 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ persistent GRU, split-bf16
+//
+// The reference's SHIPPED DS2 config is 3 x GRU-2560: 78.6 MB of f32 recurrent weights per layer, far beyond the L2, so
+// a per-step launch re-streams them from the Infinity Cache every step (rnn_step_mfma_kernel: 35 us / step).  With
+// U = 10 units per workgroup the layer is H / 10 = 256 workgroups = one per CU, and a workgroup's slice -- 30 gate rows
+// (r, z, n of its 10 units, padded to 32) x H, bf16 hi + lo = 307 KB at H = 2560 -- fits the CU's register file:
+// each wave keeps its K-quarter x 32 rows x 2 planes in 16*KS VGPRs per lane for the whole sequence, exactly like
+// lstm_persistent_split2_kernel, and the per-step traffic shrinks to the exchange of h (two streams of 16 batch rows,
+// bf16 hi/lo planes, a 1-bit epoch tag in every element, sc1 stores / sc0 sc1 polls).  Differences from the LSTM
+// kernel: the h operands of a stream-step (KS k-steps) do not fit beside the weights, so they move through two
+// rotating register chunks of 5 k-steps; a producer's 10 units straddle the 8-element operand granules, so every
+// (row, unit) element is published on its own (2-byte sc1 stores; the per-element tags make torn granules harmless).
+struct GruP {
+  const float* xproj;          // [steps*N_total][ndir*3H], natural column order (r, z, n), b_ih folded in
+  const unsigned short* whh;   // [ndir][J][plane hi|lo][H/8][32 rows: g*U + u, 30 used][8 bf16]
+  const float* bhh;            // [ndir][3H]
+  const int32_t* lens;         // may be null
+  const float* h0;             // [ndir][N_total][H] or null
+  float* out;                  // [T][N_total][ndir*H]
+  float* hn;                   // [ndir][N_total][H]
+  float* hx;                   // exchange buffer, per direction [stream][plane][parity][H/8][16][8 bf16]
+  unsigned* status;
+  int steps, N, n_base, N_total, ndir, J, poll_sleep;
+};
+
+__device__ __forceinline__ void publish_elem(float hval, unsigned tag, __amdgpu_buffer_rsrc_t rsrc, int off_hi, int off_lo) {
+  const unsigned hi = (bf16_bits(hval) & 0xFFFEu) | tag;
+  const unsigned lo = (bf16_bits(hval - bf16_val(hi)) & 0xFFFEu) | tag;
+  __builtin_amdgcn_raw_buffer_store_b16((unsigned short)hi, rsrc, off_hi, 0, /*aux: sc1*/ 16);
+  __builtin_amdgcn_raw_buffer_store_b16((unsigned short)lo, rsrc, off_lo, 0, /*aux: sc1*/ 16);
+}
+
+template <int KS, int U>
+__global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
+  constexpr int H = 128 * KS, KG = H / 8, CH = 5, NCH = KS / CH;
+  static_assert(KS % CH == 0 && 3 * U <= 32 && 16 * U <= 256, "unsupported GRU tiling");
+  constexpr int RED2 = 4 * 16 * RED_STRIDE;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* red = smem;  // [stream][4 waves][16 rows][RED_STRIDE]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q = lane >> 4;
+  const int d = blockIdx.x / p.J, j = blockIdx.x % p.J;
+  const bool cell_thread = tid < 16 * U;
+  const int nl = cell_thread ? tid / U : 0, u = cell_thread ? tid % U : 0;
+  const int unit = U * j + u;
+  const int N = p.N;
+
+  // this wave's K-quarter of the workgroup's 32 packed gate rows (hi and lo planes): 16*KS VGPRs per lane
+  u32x4 wh0[KS], wh1[KS], wl0[KS], wl1[KS];
+  {
+    const char* wsrc = reinterpret_cast<const char*>(p.whh) + ((size_t)d * p.J + j) * 128 * H;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int kg = wave * (KG / 4) + 4 * ks + q;
+      const char* wp = wsrc + (kg * 32 + c16) * 16;
+      wh0[ks] = *reinterpret_cast<const u32x4*>(wp);
+      wh1[ks] = *reinterpret_cast<const u32x4*>(wp + 256);
+      wl0[ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512);
+      wl1[ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512 + 256);
+    }
+  }
+
+  constexpr int PLANE = 2 * KG * 256;       // bytes: [parity][kg][16][8 bf16]
+  constexpr int STREAM = 2 * PLANE;
+  char* hx_d = reinterpret_cast<char*>(p.hx) + (size_t)d * 2 * STREAM;
+  const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx_d, 0, 2 * STREAM, 0x00020000);
+  const int elem_off = ((unit >> 3) * 16 + nl) * 16 + (unit & 7) * 2;   // this thread's element inside a parity slab
+
+  float h[2] = {0.f, 0.f};
+  int len_n[2] = {0, 0};
+  float bh[3] = {0.f, 0.f, 0.f};
+  if (cell_thread) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bh[g] = p.bhh[(size_t)d * 3 * H + g * H + unit];
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      const int n = sg * 16 + nl;
+      const bool valid = n < N;
+      const size_t sidx = ((size_t)d * p.N_total + p.n_base + n) * H + unit;
+      h[sg] = (valid && p.h0) ? p.h0[sidx] : 0.f;
+      len_n[sg] = valid ? (p.lens ? p.lens[p.n_base + n] : p.steps) : 0;
+      const int off = sg * STREAM + elem_off;  // parity 0
+      publish_elem(h[sg], 0u, hx_rsrc, off, PLANE + off);
+    }
+  }
+  __syncthreads();
+
+  const int kg_base = wave * (KG / 4);
+  const int xcols = p.ndir * 3 * H;
+  bool alive = true;
+
+  for (int s = 0; s < p.steps; ++s) {
+    const int t = d ? (p.steps - 1 - s) : s;
+    const int par = s & 1;
+    const unsigned em = ((s >> 1) & 1) ? 0x00010001u : 0u;
+    const unsigned wtag = (unsigned)(((s + 1) >> 1) & 1);
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      float xg[3] = {0.f, 0.f, 0.f};
+      const int n = sg * 16 + nl;
+      if (cell_thread && n < N) {
+        const float* xp = p.xproj + ((size_t)t * p.N_total + p.n_base + n) * xcols + d * 3 * H + unit;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) xg[g] = xp[g * H];
+      }
+      const int base = sg * STREAM + par * KG * 256 + c16 * 16;
+      u32x4 ah[2][CH], al[2][CH];
+      auto issue = [&](int buf, int c) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int kg = kg_base + 4 * (c * CH + i) + q;
+          ah[buf][i] = load_sc1_u128(hx_rsrc, base + kg * 256);
+          al[buf][i] = load_sc1_u128(hx_rsrc, PLANE + base + kg * 256);
+        }
+      };
+      f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      issue(0, 0);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < NCH) issue(buf ^ 1, c + 1);
+        // wait until every element of this chunk carries the step's tag (stale or torn -> load the chunk again)
+        const unsigned long long t_wait0 = wall_clock64();
+        unsigned spins = 0;
+        for (;;) {
+          unsigned bad = 0;
+#pragma unroll
+          for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bad |= (ah[buf][i][e] ^ em) | (al[buf][i][e] ^ em);
+          if (!alive || !__any((bad & 0x00010001u) != 0)) break;
+          if ((++spins & 63u) == 0) {
+            const unsigned dead = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (dead != 0 || wall_clock64() - t_wait0 > SPIN_LIMIT_TICKS) {
+              if (lane == 0) __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              alive = false;
+              break;
+            }
+          }
+          for (int z = 0; z < p.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+          issue(buf, c);
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int ks = c * CH + i;
+          const bf16x8 bh0 = __builtin_bit_cast(bf16x8, wh0[ks]);
+          const bf16x8 bh1 = __builtin_bit_cast(bf16x8, wh1[ks]);
+          const bf16x8 bl0 = __builtin_bit_cast(bf16x8, wl0[ks]);
+          const bf16x8 bl1 = __builtin_bit_cast(bf16x8, wl1[ks]);
+          const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[buf][i]);
+          const bf16x8 xl = __builtin_bit_cast(bf16x8, al[buf][i]);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh1, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh1, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl1, acc1, 0, 0, 0);
+        }
+      }
+
+      // reduce the 4 K-quarters (LDS, double-buffered by stream: one barrier), cell update, publish
+      float* redb = red + sg * RED2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        redb[(wave * 16 + 4 * q + i) * RED_STRIDE + c16] = acc0[i];
+        redb[(wave * 16 + 4 * q + i) * RED_STRIDE + 16 + c16] = acc1[i];
+      }
+      __syncthreads();
+      if (cell_thread) {
+        float hs[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          float v = 0.f;
+#pragma unroll
+          for (int w2 = 0; w2 < 4; ++w2) v += redb[(w2 * 16 + nl) * RED_STRIDE + g * U + u];
+          hs[g] = v + bh[g];
+        }
+        const float r = fast_sigmoid(xg[0] + hs[0]);
+        const float z = fast_sigmoid(xg[1] + hs[1]);
+        const float nn = fast_tanh(xg[2] + r * hs[2]);
+        const float hnew = (1.0f - z) * nn + z * h[sg];
+        const bool active = t < len_n[sg];
+        h[sg] = active ? hnew : h[sg];
+        const int off = sg * STREAM + (par ^ 1) * KG * 256 + elem_off;
+        publish_elem(h[sg], wtag, hx_rsrc, off, PLANE + off);
+        if (n < N) p.out[((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit] = active ? hnew : 0.f;
+      }
+    }
+  }
+  if (cell_thread) {
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      const int n = sg * 16 + nl;
+      if (n < N) p.hn[((size_t)d * p.N_total + p.n_base + n) * H + unit] = h[sg];
+    }
+  }
+}
+
+// [d][j][plane][kg][32 rows][8]: row r < 3U is gate r / U of unit U*j + r % U, rows 3U..31 are zero
+__global__ void pack_whh_gru_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int H, int U) {
+  const int KG = H / 8, J = H / U;
+  const size_t total = (size_t)J * KG * 256;  // elements per plane
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = i & 7;
+    const int r = (i >> 3) & 31;
+    const int kg = (i >> 8) % KG;
+    const int j = (i >> 8) / KG;
+    float x = 0.f;
+    if (r < 3 * U) x = w[(size_t)((r / U) * H + U * j + r % U) * H + 8 * kg + e];
+    const size_t base = (size_t)j * 2 * KG * 256 + ((size_t)kg * 32 + r) * 8 + e;
+    const __bf16 hi = (__bf16)x;
+    const __bf16 lo = (__bf16)(x - (float)hi);
+    dst[base] = __builtin_bit_cast(unsigned short, hi);
+    dst[base + (size_t)KG * 256] = __builtin_bit_cast(unsigned short, lo);
+  }
+}
+
 }  // namespace
 
 // ================================================================================================ launch timing
@@ -1271,7 +1503,13 @@ extern "C" int ms_rnn_pack(int cell, int In, int H, int ndir, const float* const
         hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH * In)), dim3(256), 0, stream, w_ih[d], wih_d, GH * In);
       }
       hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH)), dim3(256), 0, stream, bi, bx_d, GH);
-      hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d], whh_d, GH * H);
+      if (use_gru_persistent(cell, H, ndir)) {
+        unsigned short* dst = (unsigned short*)(base + L.whh) + (size_t)d * (H / GRU_U) * 64 * H;
+        hipLaunchKernelGGL(pack_whh_gru_kernel, dim3(blocks_for((size_t)(H / GRU_U) * (H / 8) * 256)), dim3(256), 0, stream,
+                           w_hh[d], dst, H, GRU_U);
+      } else {
+        hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d], whh_d, GH * H);
+      }
       hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH)), dim3(256), 0, stream, bh, bhh_d, GH);
     }
     MS_LAUNCH_CHECK();
@@ -1450,6 +1688,33 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
         else rc = hard ? launch_persistent<2, true, false>(p, stream) : launch_persistent<2, false, false>(p, stream);
       }
       if (rc != MS_OK) return rc;
+    }
+    return MS_OK;
+  }
+
+  if (use_gru_persistent(cell, H, ndir)) {
+    // one persistent launch per group of 32 sequences (two interleaved streams of 16)
+    for (int n0 = 0; n0 < N; n0 += 32) {
+      MS_HIP(hipMemsetAsync(ws + W.hx, 0xFF, W.state_h - W.hx, stream));  // tag 1 everywhere = "not yet written"
+      GruP g;
+      g.xproj = xproj;
+      g.whh = (const unsigned short*)(pk + L.whh);
+      g.bhh = (const float*)(pk + L.bhh);
+      g.lens = lens;
+      g.h0 = h0; g.out = out; g.hn = hn;
+      g.hx = (float*)(ws + W.hx);
+      g.status = (unsigned*)(ws + W.status);
+      g.steps = steps; g.N = std::min(32, N - n0); g.n_base = n0; g.N_total = N; g.ndir = ndir; g.J = H / GRU_U;
+      {
+        static const int ps = getenv("MS_LSTM_POLL_SLEEP") ? atoi(getenv("MS_LSTM_POLL_SLEEP")) : 1;
+        g.poll_sleep = ps > 0 ? ps : 1;
+      }
+      const size_t lds = (size_t)RED_FLOATS * sizeof(float);
+      if (H == 2560)
+        hipLaunchKernelGGL((gru_persistent_kernel<20, GRU_U>), dim3(ndir * g.J), dim3(256), lds, stream, g);
+      else
+        hipLaunchKernelGGL((gru_persistent_kernel<10, GRU_U>), dim3(ndir * g.J), dim3(256), lds, stream, g);
+      MS_LAUNCH_CHECK();
     }
     return MS_OK;
   }

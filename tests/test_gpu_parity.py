@@ -102,11 +102,13 @@ def test_lstm_persistent_vs_oracle(H, N, T_, bidir):
 @pytest.mark.parametrize("kind,H,N,T_,bidir,In", [("GRU", 64, 32, 7, False, 32), ("GRU", 128, 17, 5, True, 48),
                                                   ("GRU", 256, 70, 4, False, 64), ("BASIC_RNN", 64, 5, 6, True, 20),
                                                   ("BASIC_RNN", 192, 33, 3, False, 32), ("LSTM", 1280, 9, 3, False, 32),
-                                                  ("GRU", 2560, 32, 3, False, 96)])
+                                                  ("GRU", 2560, 32, 3, False, 96), ("GRU", 1280, 40, 5, True, 64),
+                                                  ("GRU", 2560, 7, 4, False, 32)])
 def test_streamed_weights_step_kernel_vs_oracle(kind, H, N, T_, bidir, In):
-    """Cells / sizes whose recurrent weights are streamed per step through the MFMA step kernel (H % 64 == 0: GRU,
-    tanh-RNN, LSTM wider than the persistent kernel, incl. the shipped DS2 config's GRU-2560): 1, 2 and 4 batch tiles,
-    a batch beyond 64, ragged lengths, random initial state, both directions, split-bf16 input projection."""
+    """Cells / sizes outside the persistent LSTM: the MFMA step kernel that streams W_hh per step (H % 64 == 0: GRU,
+    tanh-RNN, wide LSTM; 1, 2 and 4 batch tiles, a batch beyond 64) and the persistent register-resident GRU
+    (H = 1280 / 2560, the shipped DS2 config's width: one and two batch groups, a partial group, both directions);
+    ragged lengths, random initial state, split-bf16 input projection."""
     from myrtlespeech_amd.model.rnn import RNN, RNNType
     torch.manual_seed(H + N)
     layers = 2 if H <= 256 else 1
