@@ -150,12 +150,24 @@ def main():
     x = torch.randn(BATCH_PER_GPU, 1, FEATURES, FRAMES, generator=g).cuda()
     lens = torch.full((BATCH_PER_GPU,), FRAMES, dtype=torch.int64)
 
-    def step():
+    ev = []  # (encoder start, encoder end = decode start, decode end) events of the timed steps
+
+    def step(timed=False):
+        e0 = e1 = e2 = None
+        if timed:
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
         (logits, out_lens), _ = model((x, lens))
+        if timed:
+            e1.record()
         if args.gather_logits and dist is not None:
             from myrtlespeech_amd.parallel import gather_logits
             logits, out_lens = gather_logits(logits, out_lens)
-        return decoder(logits, out_lens)
+        hyp = decoder(logits, out_lens)
+        if timed:
+            e2.record()
+            ev.append((e0, e1, e2))
+        return hyp
 
     def barrier():
         if dist is not None:
@@ -171,7 +183,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(timed=True)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -202,7 +214,9 @@ def main():
                        "global_batch": world * BATCH_PER_GPU, "frames": FRAMES, "parallelism": f"utterance-shard x{world}",
                        "decode": "all-gather logits, batched decode on every rank" if args.gather_logits else
                                  "per-shard decode (no data-path collective)"},
-            "encoder_ms_per_rnn_step": round(ms_per_step / t_out, 4),
+            "encoder_ms": round(sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev), 3),
+            "decode_ms": round(sum(b.elapsed_time(c) for _, b, c in ev) / len(ev), 3),
+            "encoder_ms_per_rnn_step": round(sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev) / t_out, 4),
             "kernel_ms": {"lstm_recurrent_per_layer": round(rec_ms, 3), "lstm_input_projection_per_layer":
                           round(ms[0] / max(cnt[0], 1), 3)},
             "roofline": {"bound": "hbm", "kernel": "lstm_persistent_split2_kernel (one launch = 1 layer x 2 directions x 501 steps)",
