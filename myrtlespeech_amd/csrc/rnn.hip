@@ -680,6 +680,45 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_kernel(LstmP p) {
 }
 
 
+// Epoch clock of the tagged exchange.  The 1-bit tag replaces the LSB of the published bf16 hi and lo words, so the
+// value a consumer reconstructs depends (at the 2^-17 level) on the tag.  The clock is therefore the SEQUENCE time t of
+// the step, not the launch's step index: forward u = s = t, backward u = steps-1-s = t.  Slot u & 1 is read expecting
+// tag (u >> 1) & 1, h of the next step is written to the other slot with that step's tag.  A sequence's outputs are
+// then bit-identical whatever the longest sequence of its batch is (utterance shards reproduce the whole batch).
+struct EpochClock {
+  int par;        // slot read at this step
+  unsigned em;    // expected tag replicated to both 16-bit halves of a dword
+  unsigned wtag;  // tag of the h written for the next step
+};
+__device__ __forceinline__ EpochClock epoch_clock(int d, int s, int steps) {
+  const int u = d ? (steps - 1 - s) : s;
+  const int un = d ? (u - 1) : (u + 1);
+  EpochClock c;
+  c.par = u & 1;
+  c.em = ((u >> 1) & 1) ? 0x00010001u : 0u;
+  c.wtag = (unsigned)((un >> 1) & 1);
+  return c;
+}
+// slot and tag of the initial state (the h read by the first step)
+__device__ __forceinline__ int epoch_par0(int d, int steps) { return d ? ((steps - 1) & 1) : 0; }
+__device__ __forceinline__ unsigned epoch_tag0(int d, int steps) { return d ? (unsigned)(((steps - 1) >> 1) & 1) : 0u; }
+
+// Exchange-buffer initialisation: every 16-bit word of slot p of direction d gets the tag that is NOT the first one
+// expected there (all-ones or all-zeros words), so a poll that runs ahead of the producers never validates.
+// Layout of a direction: ... [parity][slab_bytes] ..., i.e. parity = (byte offset / slab_bytes) & 1.
+__global__ void hx_init_kernel(unsigned* __restrict__ hx, size_t words_per_dir, size_t slab_words, int ndir, int steps) {
+  const size_t total = words_per_dir * ndir;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i / words_per_dir);
+    const int par = (int)(((i % words_per_dir) / slab_words) & 1);
+    int first_u;  // first clock value at which slot `par` is read
+    if (d == 0) first_u = par;
+    else first_u = ((steps - 1) & 1) == par ? steps - 1 : steps - 2;
+    const unsigned expected = (unsigned)((first_u >> 1) & 1);
+    hx[i] = expected ? 0u : 0xFFFFFFFFu;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ persistent LSTM, split-bf16
 //
 // Same decomposition as lstm_persistent_kernel, two changes:
@@ -779,8 +818,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) 
     h[b] = (valid && p.h0) ? p.h0[sidx] : 0.f;
     c[b] = (valid && p.c0) ? p.c0[sidx] : 0.f;
     len_n[b] = valid ? (p.lens ? p.lens[p.n_base + n] : p.steps) : 0;
-    const int off = (j * p.NPAD + n) * 16;  // parity 0
-    publish_split(h[b], 0u, hx_rsrc, off, plane_bytes + off, lane);
+    const int off = epoch_par0(d, p.steps) * KG * p.NPAD * 16 + (j * p.NPAD + n) * 16;  // slot read by the first step
+    publish_split(h[b], epoch_tag0(d, p.steps), hx_rsrc, off, plane_bytes + off, lane);
   }
   __syncthreads();  // weights are in LDS
 
@@ -804,8 +843,9 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) 
 
   for (int s = 0; s < p.steps; ++s) {
     const int t = d ? (p.steps - 1 - s) : s;
-    const int par = s & 1;
-    const unsigned em = ((s >> 1) & 1) ? 0x00010001u : 0u;  // expected tag, replicated to both halves
+    const EpochClock ec = epoch_clock(d, s, p.steps);
+    const int par = ec.par;
+    const unsigned em = ec.em;  // expected tag, replicated to both halves
 
     float xg[NB][4];
 #pragma unroll
@@ -922,7 +962,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) 
     }
     if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[1] += now - st_prev; st_prev = now; }
 
-    const unsigned wtag = (unsigned)(((s + 1) >> 1) & 1);
+    const unsigned wtag = ec.wtag;
     float hout[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -1035,8 +1075,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
       h[sg] = (valid && p.h0) ? p.h0[sidx] : 0.f;
       c[sg] = (valid && p.c0) ? p.c0[sidx] : 0.f;
       len_n[sg] = valid ? (p.lens ? p.lens[p.n_base + n] : p.steps) : 0;
-      const int off = sg * STREAM + j * 256 + nl * 16;  // parity 0
-      publish_split<F16>(h[sg], 0u, hx_rsrc, off, PLANE + off, lane);
+      const int off = sg * STREAM + epoch_par0(d, p.steps) * KG * 256 + j * 256 + nl * 16;  // slot read by the first step
+      publish_split<F16>(h[sg], epoch_tag0(d, p.steps), hx_rsrc, off, PLANE + off, lane);
     }
   }
   __syncthreads();
@@ -1049,9 +1089,10 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
 
   for (int s = 0; s < p.steps; ++s) {
     const int t = d ? (p.steps - 1 - s) : s;
-    const int par = s & 1;
-    const unsigned em = ((s >> 1) & 1) ? 0x00010001u : 0u;
-    const unsigned wtag = (unsigned)(((s + 1) >> 1) & 1);
+    const EpochClock ec = epoch_clock(d, s, p.steps);
+    const int par = ec.par;
+    const unsigned em = ec.em;
+    const unsigned wtag = ec.wtag;
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg) {
       float xg[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1254,8 +1295,8 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
       const size_t sidx = ((size_t)d * p.N_total + p.n_base + n) * H + unit;
       h[sg] = (valid && p.h0) ? p.h0[sidx] : 0.f;
       len_n[sg] = valid ? (p.lens ? p.lens[p.n_base + n] : p.steps) : 0;
-      const int off = sg * STREAM + elem_off;  // parity 0
-      publish_elem(h[sg], 0u, hx_rsrc, off, PLANE + off);
+      const int off = sg * STREAM + epoch_par0(d, p.steps) * KG * 256 + elem_off;  // slot read by the first step
+      publish_elem(h[sg], epoch_tag0(d, p.steps), hx_rsrc, off, PLANE + off);
     }
   }
   __syncthreads();
@@ -1266,9 +1307,10 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
 
   for (int s = 0; s < p.steps; ++s) {
     const int t = d ? (p.steps - 1 - s) : s;
-    const int par = s & 1;
-    const unsigned em = ((s >> 1) & 1) ? 0x00010001u : 0u;
-    const unsigned wtag = (unsigned)(((s + 1) >> 1) & 1);
+    const EpochClock ec = epoch_clock(d, s, p.steps);
+    const int par = ec.par;
+    const unsigned em = ec.em;
+    const unsigned wtag = ec.wtag;
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg) {
       float xg[3] = {0.f, 0.f, 0.f};
@@ -1656,12 +1698,19 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
       const bool pipe = (H % 256 == 0);
       static const bool stamps = getenv("MS_LSTM_STAMPS") && getenv("MS_LSTM_STAMPS")[0] == '1';
       if (use_split(cell, H, ndir)) {
-        // tag 1 everywhere = "not yet written" for the first epoch of either parity
-        MS_HIP(hipMemsetAsync(ws + W.hx, 0xFF, W.state_h - W.hx, stream));
         const bool hard_ = (cell == MS_CELL_HARD_LSTM);
         if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.total - W.dbg, stream));
         static const bool one_stream = getenv("MS_LSTM_ONE_STREAM") && getenv("MS_LSTM_ONE_STREAM")[0] == '1';
-        if (p.NPAD == 32 && two_stream_shape(H) && (!one_stream || use_f16(cell, H, ndir))) {
+        const bool two_stream = p.NPAD == 32 && two_stream_shape(H) && (!one_stream || use_f16(cell, H, ndir));
+        {
+          // every word of every slot starts with the tag that is NOT the first one expected there
+          const size_t slab_words = two_stream ? (size_t)8 * H : (size_t)H * p.NPAD / 2;
+          const size_t words_per_dir = two_stream ? (size_t)64 * H : (size_t)2 * H * p.NPAD;
+          hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir)), dim3(256), 0, stream,
+                             (unsigned*)(ws + W.hx), words_per_dir, slab_words, ndir, steps);
+          MS_LAUNCH_CHECK();
+        }
+        if (two_stream) {
           rc = launch_split2_any(p, hard_, stamps, use_f16(cell, H, ndir), stream);
         } else if (p.NPAD == 32 && H == 1024) {
           if (stamps && !hard_) rc = launch_split<1, 4, false, true>(p, stream);
@@ -1695,7 +1744,9 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
   if (use_gru_persistent(cell, H, ndir)) {
     // one persistent launch per group of 32 sequences (two interleaved streams of 16)
     for (int n0 = 0; n0 < N; n0 += 32) {
-      MS_HIP(hipMemsetAsync(ws + W.hx, 0xFF, W.state_h - W.hx, stream));  // tag 1 everywhere = "not yet written"
+      hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for((size_t)64 * H * ndir)), dim3(256), 0, stream,
+                         (unsigned*)(ws + W.hx), (size_t)64 * H, (size_t)8 * H, ndir, steps);
+      MS_LAUNCH_CHECK();
       GruP g;
       g.xproj = xproj;
       g.whh = (const unsigned short*)(pk + L.whh);

@@ -1,0 +1,73 @@
+"""Size-independent properties at BASELINE.json's full sizes, on the GPU: what the utterance-sharded
+multi-GPU path relies on, checked on one card.  DS2 config 2 (2 x conv2d, 5 x BiLSTM-1024, FC), 80 features x 1001
+frames, ragged sorted batch of 32."""
+import numpy as np
+import pytest
+import torch
+
+import bench
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    model = bench.build_model()
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(32, 1, 80, 1001, generator=g)
+    lens = torch.sort(torch.randint(501, 1002, (32,), generator=g), descending=True).values
+    lens[0] = 1001
+    (y, ol), _ = model((x.clone(), lens))
+    return model, CTCGreedyDecoder(28), x, lens, y, ol
+
+
+def test_shards_reproduce_the_whole_batch_bit_for_bit(setup):
+    """Contiguous shards of the sorted batch (what each rank of an N-GPU job runs) give exactly the rows of the
+    single-GPU result -- logits, lengths and transcripts -- for 2, 4 and 8 ranks: no utterance sees another."""
+    from myrtlespeech_amd.parallel import shard_batch
+    model, dec, x, lens, y, ol = setup
+    whole = dec(y, ol)
+    for world in (2, 4, 8):
+        hyps, row = [], 0
+        for rank in range(world):
+            xs, ls = shard_batch(x, lens, world, rank)
+            (ys, ols), _ = model((xs.clone(), ls))
+            t = ys.shape[0]
+            diff = (ys - y[:t, row:row + ls.numel()]).abs()
+            assert torch.equal(ys, y[:t, row:row + ls.numel()]), (world, rank, float(diff.max()), (diff.amax(dim=(0, 2)) > 0).nonzero().flatten().tolist(), (diff.amax(dim=(1, 2)) > 0).nonzero().flatten().tolist()[:5])
+            assert torch.equal(ols.cpu(), ol[row:row + ls.numel()].cpu())
+            hyps += dec(ys, ols)
+            row += ls.numel()
+        assert hyps == whole
+
+
+def test_padding_content_is_ignored(setup):
+    """Whatever lies in the padded frames of the input (t >= len) cannot reach the output: MaskConv zeroes it
+    (cnn.py:425-443) and the packed recurrence never reads it."""
+    model, dec, x, lens, y, ol = setup
+    noisy = x.clone()
+    for n, l in enumerate(lens.tolist()):
+        noisy[n, :, :, l:] = 1e3 * torch.randn(1, 80, 1001 - l)
+    (y2, ol2), _ = model((noisy, lens))
+    assert torch.equal(y2, y) and torch.equal(ol2.cpu(), ol.cpu())
+
+
+def test_output_rows_past_each_length_are_zero_before_the_fc_bias(setup):
+    """Packed-sequence semantics (rnn.py:170-183): recurrent outputs at t >= len are exactly zero, so past its length
+    every utterance's logits equal the constant FC response to a zero vector."""
+    model, dec, x, lens, y, ol = setup
+    const = y[ol[-1].item():, -1]            # the shortest utterance's padded tail
+    assert const.shape[0] > 0 and torch.equal(const, const[:1].expand_as(const))
+    for n in (0, 7, 20, 31):
+        tail = y[ol[n].item():, n]
+        if tail.shape[0]:
+            assert torch.equal(tail, const[:1].expand_as(tail))
+
+
+def test_decode_is_deterministic_and_idempotent(setup):
+    model, dec, x, lens, y, ol = setup
+    a, b = dec(y, ol), dec(y.clone(), ol.clone())
+    assert a == b
+    (y2, ol2), _ = model((x.clone(), lens))
+    assert torch.equal(y2, y)
