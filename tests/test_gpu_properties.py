@@ -71,3 +71,28 @@ def test_decode_is_deterministic_and_idempotent(setup):
     assert a == b
     (y2, ol2), _ = model((x.clone(), lens))
     assert torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("kind,H,bidir", [("GRU", 2560, False), ("GRU", 1280, True), ("GRU", 256, True), ("LSTM", 512, True)])
+def test_recurrent_layers_do_not_mix_utterances(kind, H, bidir):
+    """The persistent GRU (H = 2560 / 1280), the streamed-weights step kernel (GRU-256) and another persistent LSTM
+    width: rows of a ragged batch equal the same rows run as 2 and 4 contiguous shards, bit for bit (outputs and the
+    final states), including the backward direction whose step index depends on the batch's longest sequence."""
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    torch.manual_seed(H)
+    m = RNN(getattr(RNNType, kind), 64, H, num_layers=2, bidirectional=bidir).eval()
+    g = torch.Generator().manual_seed(H + 1)
+    T_, N = 40, 32
+    x = torch.randn(T_, N, 64, generator=g)
+    lens = torch.sort(torch.randint(5, T_ + 1, (N,), generator=g), descending=True).values
+    lens[0] = T_
+    (yw, _), hw = m((x, lens))
+    hw = hw[0] if isinstance(hw, tuple) else hw
+    for world in (2, 4):
+        per = N // world
+        for r in range(world):
+            sl = slice(r * per, (r + 1) * per)
+            (ys, _), hs = m((x[:, sl].contiguous(), lens[sl]))
+            hs = hs[0] if isinstance(hs, tuple) else hs
+            assert torch.equal(ys, yw[:, sl]), (kind, H, world, r, float((ys - yw[:, sl]).abs().max()))
+            assert torch.equal(hs, hw[:, sl])
