@@ -443,11 +443,6 @@ __global__ __launch_bounds__(256) void rnn_step_mfma_kernel(StepP p) {
 template <int CELL>
 static void launch_step_mfma(const StepP& p, hipStream_t stream) {
   const int tiles = ms::cdiv(p.N, 16);
-  static const int nt_env = getenv("MS_RNN_STEP_NT") ? atoi(getenv("MS_RNN_STEP_NT")) : 0;
-  if (nt_env == 1) {
-    hipLaunchKernelGGL((rnn_step_mfma_kernel<CELL, 1>), dim3(p.H / 16, p.ndir, tiles), dim3(256), 0, stream, p);
-    return;
-  }
   if (tiles == 1)
     hipLaunchKernelGGL((rnn_step_mfma_kernel<CELL, 1>), dim3(p.H / 16, p.ndir, 1), dim3(256), 0, stream, p);
   else if (tiles == 2)

@@ -31,7 +31,7 @@ namespace {
 
 struct DecLayout {
   // hypothesis lists
-  size_t A_cnt, A_node, A_score, A_slot, oldA_dummy;
+  size_t A_cnt, A_node, A_score, A_slot;
   size_t B_cnt, B_node, B_score, B_slot;
   size_t ext_label, ext_src, ext_dst;
   size_t live, out_cnt;
