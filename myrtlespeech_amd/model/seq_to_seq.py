@@ -71,3 +71,15 @@ class SpeechToText(SeqToSeq):
 
     def extra_repr(self) -> str:
         return f"(alphabet): {self.alphabet}"
+
+    @torch.no_grad()
+    def transcribe(self, waves: torch.Tensor, sample_counts: torch.Tensor):
+        """Waveforms to text, entirely on the device until the label lists come back: ``waves [N, samples]``
+        zero-padded and sorted longest first, ``sample_counts [N]`` -> ``(sentences, label lists)``.  Runs the
+        active pre-processing steps batched (``pre_process_batch``), the encoder, the decoder and the alphabet."""
+        if self.post_process is None:
+            raise ValueError("this SpeechToText has no post_process decoder")
+        x, lens = self.pre_process_batch(waves, sample_counts)
+        (logits, out_lens), _ = self.model((x, lens))
+        labels = self.post_process(logits, out_lens)
+        return ["".join(self.alphabet.get_symbols(seq)) for seq in labels], labels

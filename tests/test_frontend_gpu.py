@@ -279,3 +279,20 @@ def test_ds2_pipeline_feeds_the_encoder():
     assert out_lens.tolist() == list(want_l)
     np.testing.assert_allclose(cpu(y), want_y, rtol=1e-3, atol=1e-3)
     assert stt.post_process(y, out_lens) == O.ctc_greedy_decode(want_y, want_l, 28)
+
+
+def test_transcribe_waveforms_to_text():
+    """SpeechToText.transcribe = pre_process_batch -> encoder -> decoder -> alphabet, nothing else."""
+    from myrtlespeech_amd import protos as P
+    from myrtlespeech_amd.builders.speech_to_text import build as build_stt
+    from tests.test_checkpoint_cpu import DS2_TINY
+    torch.manual_seed(3)
+    stt = build_stt(P.parse(DS2_TINY, P.SpeechToText)).eval()
+    rng = np.random.default_rng(14)
+    lens = [16000, 9000, 4000]
+    w = torch.from_numpy(ragged_waves(rng, lens))
+    text, labels = stt.transcribe(w, torch.tensor(lens))
+    x, fl = stt.pre_process_batch(w, torch.tensor(lens))
+    (y, ol), _ = stt.model((x, fl))
+    assert labels == stt.post_process(y, ol)
+    assert text == ["".join(stt.alphabet.get_symbols(s)) for s in labels] and len(text) == 3
