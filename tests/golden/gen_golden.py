@@ -579,3 +579,40 @@ def gen_ctc_grad():
 
 if __name__ == "__main__" and "ctcgrad" in sys.argv[1:]:
     gen_ctc_grad()
+
+
+# ----------------------------------------------------------------------------- shipped DS2 config at full width
+def gen_ds2_shipped_summary():
+    """The architecture of the reference's SHIPPED config (configs/deep_speech_2_en.config:19-93: 2 x conv2d,
+    3 x GRU-2560 unidirectional, lookahead 80, FC 1 x 1024) at full width on a short ragged batch (8 x up to 4 s),
+    reduced like the config-2 summary: weights / inputs are regenerated from the seeds (checksums stored), logits on
+    a sub-grid, final hidden state on a sub-grid, greedy transcripts."""
+    torch.manual_seed(7)
+    cnn = torch.nn.Sequential(
+        MaskConv2d(1, 32, [41, 11], [2, 2], PaddingMode.SAME), act_wrap(0.0, 20.0),
+        MaskConv2d(32, 32, [21, 11], [2, 1], PaddingMode.SAME), act_wrap(0.0, 20.0),
+    )
+    rnn = RNN(RNNType.GRU, 640, 2560, num_layers=3, bidirectional=False)
+    la = torch.nn.Sequential(Lookahead(2560, 80), SeqLenWrapper(torch.nn.Identity(), torch.nn.Identity()))
+    fc = FullyConnected(2560, 29, 1, 1024, torch.nn.Hardtanh(0.0, 20.0))
+    m = DeepSpeech2(cnn, rnn, la, fc).eval()
+    g = torch.Generator().manual_seed(4321)
+    N, T = 8, 401
+    x = torch.randn(N, 1, 80, T, generator=g)
+    lens = torch.sort(torch.randint(150, T + 1, (N,), generator=g), descending=True).values
+    lens[0] = T
+    import time
+    t0 = time.time()
+    (y, ol), hid = m((x.clone(), lens))
+    print(f"reference shipped-DS2 forward: {time.time() - t0:.1f} s on {torch.get_num_threads()} threads")
+    dec = CTCGreedyDecoder(28)(y, ol)
+    flat, dl = ragged(dec)
+    chk = {k: float(v.double().abs().sum()) for k, v in m.state_dict().items()}
+    arrays = {"in/lens": npy(lens), "in/x_abs_sum": np.array(float(x.double().abs().sum())),
+              "out/lens": npy(ol), "out/y_sub": npy(y[::10, ::2, :]), "out/y_abs_mean": np.array(float(y.abs().mean())),
+              "out/hn_sub": npy(hid[:, :, ::64]), "out/greedy_flat": flat, "out/greedy_lens": dl}
+    save("ds2_shipped_summary", dict(weight_abs_sums=chk, seed_weights=7, seed_input=4321, N=N, T=T), arrays)
+
+
+if __name__ == "__main__" and "shipped" in sys.argv[1:]:
+    gen_ds2_shipped_summary()

@@ -384,6 +384,47 @@ def test_ds2_cfg2_full_size_vs_reference_summary():
     print(f"cfg2 full-size max |logit err| on the sub-grid: {err:.3e} (mean |logit| {float(g['out/y_abs_mean']):.3e})")
 
 
+def test_ds2_shipped_architecture_full_width_vs_reference_summary():
+    """The reference's SHIPPED config shape (2 x conv2d, 3 x GRU-2560 unidirectional, lookahead 80, FC 1 x 1024) at full
+    width: weights and inputs regenerated from the golden generator's seeds (checksums pinned), logits on the stored
+    sub-grid and the final hidden state within 1e-3 of the reference, greedy transcripts bit-exact.  Exercises the
+    persistent register-resident GRU and the register-tiled lookahead against the reference itself."""
+    from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+    from myrtlespeech_amd.model.deep_speech_2 import DeepSpeech2
+    from myrtlespeech_amd.model.fully_connected import FullyConnected
+    from myrtlespeech_amd.model.lookahead import Lookahead
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    from myrtlespeech_amd.model.seq_len_wrapper import SeqLenWrapper
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    g = Golden("ds2_shipped_summary")
+
+    def act():
+        return SeqLenWrapper(torch.nn.Hardtanh(0.0, 20.0), torch.nn.Identity())
+    torch.manual_seed(g.cfg["seed_weights"])
+    cnn = torch.nn.Sequential(MaskConv2d(1, 32, [41, 11], [2, 2], PaddingMode.SAME), act(),
+                              MaskConv2d(32, 32, [21, 11], [2, 1], PaddingMode.SAME), act())
+    rnn = RNN(RNNType.GRU, 640, 2560, num_layers=3, bidirectional=False)
+    la = torch.nn.Sequential(Lookahead(2560, 80), SeqLenWrapper(torch.nn.Identity(), torch.nn.Identity()))
+    fc = FullyConnected(2560, 29, 1, 1024, torch.nn.Hardtanh(0.0, 20.0))
+    model = DeepSpeech2(cnn, rnn, la, fc).eval()
+    for k, v in model.state_dict().items():
+        assert abs(float(v.double().abs().sum()) - g.cfg["weight_abs_sums"][k]) <= 1e-6 * max(1.0, g.cfg["weight_abs_sums"][k]), k
+    gen = torch.Generator().manual_seed(g.cfg["seed_input"])
+    N, Tn = g.cfg["N"], g.cfg["T"]
+    x = torch.randn(N, 1, 80, Tn, generator=gen)
+    lens = torch.sort(torch.randint(150, Tn + 1, (N,), generator=gen), descending=True).values
+    lens[0] = Tn
+    assert abs(float(x.double().abs().sum()) - float(g["in/x_abs_sum"])) < 1e-3
+    np.testing.assert_array_equal(lens.numpy(), g["in/lens"])
+    (y, ol), hn = model((x, lens))
+    np.testing.assert_array_equal(cpu(ol), g["out/lens"])
+    np.testing.assert_allclose(cpu(y[::10, ::2, :]), g["out/y_sub"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(cpu(hn[:, :, ::64]), g["out/hn_sub"], rtol=0, atol=1e-3)
+    assert CTCGreedyDecoder(28)(y, ol) == unragged(g["out/greedy_flat"], g["out/greedy_lens"])
+    err = float(np.abs(cpu(y[::10, ::2, :]) - g["out/y_sub"]).max())
+    print(f"shipped-architecture max |logit err| on the sub-grid: {err:.3e} (mean |logit| {float(g['out/y_abs_mean']):.3e})")
+
+
 # ----------------------------------------------------------------------------- CTC beam search
 def test_beam_reference_kats():
     """tests/post_process/test_ctc_beam_decoder.py:17-102 (the reference's own known answers)."""
