@@ -616,3 +616,32 @@ def gen_ds2_shipped_summary():
 
 if __name__ == "__main__" and "shipped" in sys.argv[1:]:
     gen_ds2_shipped_summary()
+
+
+# ----------------------------------------------------------------------------- DS1 at the shipped width (BASELINE configs[0])
+def gen_ds1_cfg1_summary():
+    """configs/deep_speech_1_en.config:30-35 (n_hidden 1024, 26 MFCC x 19 context channels, 29 symbols) on the
+    BASELINE configs[0] input shape [1, 19, 26, 201] plus a ragged batch of 3; weights / inputs regenerated from the
+    seeds in the test (checksums stored); both the torch-LSTM and the HardLSTM flavour."""
+    for hard in (False, True):
+        torch.manual_seed(11 + hard)
+        m = DeepSpeech1(input_features=26, input_channels=19, n_hidden=1024, out_features=29, drop_prob=0.25,
+                        relu_clip=20.0, forget_gate_bias=1.0, hard_lstm=hard).eval()
+        g = torch.Generator().manual_seed(99 + hard)
+        x1 = torch.randn(1, 19, 26, 201, generator=g)
+        x3 = torch.randn(3, 19, 26, 120, generator=g)
+        l3 = torch.tensor([120, 120, 120] if hard else [120, 77, 31], dtype=torch.int64)
+        (y1, o1), h1 = m((x1.clone(), torch.tensor([201])))
+        (y3, o3), h3 = m((x3.clone(), l3))
+        f1, d1 = ragged(CTCGreedyDecoder(28)(y1, o1))
+        f3, d3 = ragged(CTCGreedyDecoder(28)(y3, o3))
+        chk = {k: float(v.double().abs().sum()) for k, v in m.state_dict().items()}
+        arrays = {"in/l3": npy(l3), "out/y1_sub": npy(y1[::5]), "out/y3_sub": npy(y3[::4]), "out/o3": npy(o3),
+                  "out/hn1_sub": npy(h1[0][:, :, ::32]), "out/cn3_sub": npy(h3[1][:, :, ::32]),
+                  "out/g1_flat": f1, "out/g1_lens": d1, "out/g3_flat": f3, "out/g3_lens": d3}
+        save("ds1_cfg1_hard_summary" if hard else "ds1_cfg1_summary",
+             dict(weight_abs_sums=chk, seed_weights=11 + hard, seed_input=99 + hard, hard_lstm=hard), arrays)
+
+
+if __name__ == "__main__" and "ds1full" in sys.argv[1:]:
+    gen_ds1_cfg1_summary()

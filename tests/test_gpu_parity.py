@@ -304,6 +304,37 @@ def test_ds1_tiny_golden(name):
     np.testing.assert_allclose(cpu(hid[1]), g["out/cn"], **TOL)
 
 
+@pytest.mark.parametrize("name", ["ds1_cfg1_summary", "ds1_cfg1_hard_summary"])
+def test_ds1_shipped_width_vs_reference_summary(name):
+    """BASELINE.json configs[0]: DS1 at the shipped width (n_hidden 1024, input [1, 19, 26, 201]) and a ragged batch of
+    3, torch-LSTM and HardLSTM flavours; weights and inputs regenerated from the generator's seeds (checksums pinned),
+    logits / states on the stored sub-grids within 1e-3 of the reference, greedy transcripts bit-exact."""
+    from myrtlespeech_amd.model.deep_speech_1 import DeepSpeech1
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    g = Golden(name)
+    hard = g.cfg["hard_lstm"]
+    torch.manual_seed(g.cfg["seed_weights"])
+    m = DeepSpeech1(input_features=26, input_channels=19, n_hidden=1024, out_features=29, drop_prob=0.25,
+                    relu_clip=20.0, forget_gate_bias=1.0, hard_lstm=hard).eval()
+    for k, v in m.state_dict().items():
+        assert abs(float(v.double().abs().sum()) - g.cfg["weight_abs_sums"][k]) <= 1e-6 * max(1.0, g.cfg["weight_abs_sums"][k]), k
+    gen = torch.Generator().manual_seed(g.cfg["seed_input"])
+    x1 = torch.randn(1, 19, 26, 201, generator=gen)
+    x3 = torch.randn(3, 19, 26, 120, generator=gen)
+    l3 = T(g["in/l3"])
+    (y1, o1), h1 = m((x1, torch.tensor([201])))
+    (y3, o3), h3 = m((x3, l3))
+    np.testing.assert_allclose(cpu(y1[::5]), g["out/y1_sub"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(cpu(y3[::4]), g["out/y3_sub"], rtol=0, atol=1e-3)
+    np.testing.assert_array_equal(cpu(o3), g["out/o3"])
+    np.testing.assert_allclose(cpu(h1[0][:, :, ::32]), g["out/hn1_sub"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(cpu(h3[1][:, :, ::32]), g["out/cn3_sub"], rtol=0, atol=1e-3)
+    dec = CTCGreedyDecoder(28)
+    assert dec(y1, o1) == unragged(g["out/g1_flat"], g["out/g1_lens"])
+    assert dec(y3, o3) == unragged(g["out/g3_flat"], g["out/g3_lens"])
+    print(f"{name}: max |logit err| {float(np.abs(cpu(y1[::5]) - g['out/y1_sub']).max()):.3e}")
+
+
 # ----------------------------------------------------------------------------- CTC loss / greedy
 def test_ctc_loss_golden():
     from myrtlespeech_amd.loss.ctc_loss import CTCLoss
