@@ -645,3 +645,25 @@ def gen_ds1_cfg1_summary():
 
 if __name__ == "__main__" and "ds1full" in sys.argv[1:]:
     gen_ds1_cfg1_summary()
+
+
+# ----------------------------------------------------------------------------- beam search at the config-2 decode size
+def gen_beam_cfg2():
+    """The reference CTCBeamDecoder on BASELINE-size inputs (T = 501, V = 29, beam 8, prune 1e-3): peaky synthetic
+    posteriors softmax(12 * randn) (otherwise the float32 linear-space scores underflow), 4 ragged
+    utterances; plain, and with separator / word_weight.  Inputs are regenerated from the seed in the test."""
+    torch.manual_seed(808)
+    x = torch.softmax(torch.randn(501, 4, 29) * 12, dim=2)
+    lens = torch.tensor([501, 433, 250, 77], dtype=torch.int64)
+    arrays = {"in/lens": npy(lens), "in/x_abs_sum": np.array(float(x.double().sum())), "in/x_probe": npy(x[::50, :, ::7])}
+    import time
+    for name, kw in (("plain", dict()), ("words", dict(separator_index=0, word_weight=1.3))):
+        t0 = time.time()
+        out = CTCBeamDecoder(blank_index=28, beam_width=8, prune_threshold=0.001, **kw)(x, lens)
+        print(f"reference beam ({name}): {time.time() - t0:.1f} s")
+        arrays[f"out/{name}_flat"], arrays[f"out/{name}_lens"] = ragged(out)
+    save("beam_cfg2", dict(seed=808, scale=12, T=501, N=4, V=29, beam_width=8, prune=0.001, sep=0, word_weight=1.3), arrays)
+
+
+if __name__ == "__main__" and "beamfull" in sys.argv[1:]:
+    gen_beam_cfg2()

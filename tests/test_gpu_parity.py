@@ -457,6 +457,26 @@ def test_ds2_shipped_architecture_full_width_vs_reference_summary():
 
 
 # ----------------------------------------------------------------------------- CTC beam search
+def test_beam_config_size_vs_reference():
+    """The reference CTCBeamDecoder at the BASELINE decode size (T = 501, V = 29, beam 8, prune 1e-3; 4 ragged utterances
+    of peaky posteriors, regenerated from the generator's seed): transcripts bit-exact, plain and with
+    separator / word_weight; the oracle agrees as well."""
+    from myrtlespeech_amd.post_process.ctc_beam_decoder import CTCBeamDecoder
+    g = Golden("beam_cfg2")
+    c = g.cfg
+    torch.manual_seed(c["seed"])
+    x = torch.softmax(torch.randn(c["T"], c["N"], c["V"]) * c["scale"], dim=2)
+    assert abs(float(x.double().sum()) - float(g["in/x_abs_sum"])) < 1e-6 * c["T"] * c["N"]
+    np.testing.assert_array_equal(x[::50, :, ::7].numpy(), g["in/x_probe"])
+    lens = T(g["in/lens"])
+    plain = CTCBeamDecoder(blank_index=28, beam_width=c["beam_width"], prune_threshold=c["prune"])(x, lens)
+    assert plain == unragged(g["out/plain_flat"], g["out/plain_lens"])
+    words = CTCBeamDecoder(blank_index=28, beam_width=c["beam_width"], prune_threshold=c["prune"],
+                           separator_index=c["sep"], word_weight=c["word_weight"])(x, lens)
+    assert words == unragged(g["out/words_flat"], g["out/words_lens"])
+    assert sum(map(len, plain)) > 100   # the search survived (no float32 underflow to empty beams)
+
+
 def test_beam_reference_kats():
     """tests/post_process/test_ctc_beam_decoder.py:17-102 (the reference's own known answers)."""
     from myrtlespeech_amd.post_process.ctc_beam_decoder import CTCBeamDecoder

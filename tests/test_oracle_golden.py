@@ -2,6 +2,7 @@
 the reference itself (tests/golden/gen_golden.py) and the reference's own KATs.
 CPU only."""
 import numpy as np
+import torch
 import pytest
 
 from oracle import ds_oracle as O
@@ -259,3 +260,16 @@ def test_ctc_grad_oracle_matches_reference_autograd(name):
             gn = g.cfg["scale"] / (np.maximum(yl.astype(np.float32), 1.0) * n)
         got = O.ctc_grad(x, xl, y, yl, gn, g.cfg["blank"], bool(int(zi)))
         np.testing.assert_allclose(got, g[key], rtol=1e-4, atol=2e-5)  # the reference subtracts two float32 exponentials
+
+
+def test_beam_oracle_config_size_vs_reference():
+    """The numpy beam search against the reference at T = 501, V = 29, beam 8 (one of the four utterances; the pure-Python
+    oracle takes ~1.5 s per utterance like the reference)."""
+    g = Golden("beam_cfg2")
+    c = g.cfg
+    torch.manual_seed(c["seed"])
+    x = torch.softmax(torch.randn(c["T"], c["N"], c["V"]) * c["scale"], dim=2).numpy()
+    lens = g["in/lens"]
+    want = unragged(g["out/plain_flat"], g["out/plain_lens"])
+    got = O.ctc_beam_decode(x[:, 2:3], lens[2:3], 28, c["beam_width"], c["prune"])
+    assert got == want[2:3]
