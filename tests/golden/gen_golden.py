@@ -667,3 +667,29 @@ def gen_beam_cfg2():
 
 if __name__ == "__main__" and "beamfull" in sys.argv[1:]:
     gen_beam_cfg2()
+
+
+# ----------------------------------------------------------------------------- CTC loss + gradient at the config-2 size
+def gen_ctc_cfg2():
+    """loss/ctc_loss.py on [501, 32, 29] logits, ragged input lengths, targets of 60..120 labels: per-utterance
+    losses, both reductions, and x.grad (reduction sum) on a sub-grid.  Inputs regenerated from the seed in the test."""
+    torch.manual_seed(909)
+    x0 = torch.randn(501, 32, 29)
+    xl = torch.sort(torch.randint(300, 502, (32,)), descending=True).values.to(torch.int32)
+    yl = torch.randint(60, 121, (32,), dtype=torch.int32)
+    y = torch.randint(0, 28, (32, 120), dtype=torch.int32)
+    arrays = {"in/x_lens": npy(xl), "in/y": npy(y), "in/y_lens": npy(yl), "in/x_probe": npy(x0[::100, ::8, ::7])}
+    for red in ("none", "mean", "sum"):
+        arrays[f"out/{red}"] = npy(CTCLoss(blank=28, reduction=red)((x0, xl), (y, yl)))
+    torch.set_grad_enabled(True)
+    try:
+        x = x0.clone().requires_grad_(True)
+        CTCLoss(blank=28, reduction="sum")((x, xl), (y, yl)).backward()
+        arrays["grad/sum_sub"] = npy(x.grad[::25, ::4, :])
+    finally:
+        torch.set_grad_enabled(False)
+    save("ctc_cfg2", dict(seed=909, blank=28), arrays)
+
+
+if __name__ == "__main__" and "ctcfull" in sys.argv[1:]:
+    gen_ctc_cfg2()

@@ -568,6 +568,26 @@ def test_ctc_loss_backward_matches_reference_autograd(name):
         np.testing.assert_allclose(cpu(x.grad), g[key], rtol=1e-4, atol=2e-5)
 
 
+def test_ctc_loss_and_gradient_config_size_vs_reference():
+    """loss/ctc_loss.py at the config-2 logits shape [501, 32, 29] (ragged input lengths, 60..120 labels), inputs
+    regenerated from the generator's seed: per-utterance losses and both reductions against the reference, x.grad
+    (reduction sum) on the stored sub-grid."""
+    from myrtlespeech_amd.loss.ctc_loss import CTCLoss
+    g = Golden("ctc_cfg2")
+    torch.manual_seed(g.cfg["seed"])
+    x0 = torch.randn(501, 32, 29)
+    xl = torch.sort(torch.randint(300, 502, (32,)), descending=True).values.to(torch.int32)
+    np.testing.assert_array_equal(xl.numpy(), g["in/x_lens"])
+    np.testing.assert_array_equal(x0[::100, ::8, ::7].numpy(), g["in/x_probe"])
+    y, yl = T(g["in/y"]), T(g["in/y_lens"])
+    for red in ("none", "mean", "sum"):
+        got = CTCLoss(blank=28, reduction=red)((x0, xl), (y, yl))
+        np.testing.assert_allclose(cpu(got), g[f"out/{red}"], rtol=2e-5, atol=1e-3)
+    x = x0.clone().cuda().requires_grad_(True)
+    CTCLoss(blank=28, reduction="sum")((x, xl), (y, yl)).backward()
+    np.testing.assert_allclose(cpu(x.grad)[::25, ::4, :], g["grad/sum_sub"], rtol=2e-3, atol=1e-3)
+
+
 def test_ctc_loss_backward_full_size_vs_oracle_rows_and_properties():
     """Config-2 logits shape [501, 32, 29], targets of 120: gradient rows of two utterances against the float64 oracle,
     and for all of them the CTC posterior identity: every valid frame's gradient sums to zero (softmax mass 1 minus
