@@ -693,3 +693,46 @@ def gen_ctc_cfg2():
 
 if __name__ == "__main__" and "ctcfull" in sys.argv[1:]:
     gen_ctc_cfg2()
+
+
+# ----------------------------------------------------------------------------- chunked streaming at the config-5 width
+def gen_streaming_full():
+    """BASELINE configs[4] shape in the reference's arithmetic: the config-2 network (5 x BiLSTM-1024, weights from seed
+    0) run on consecutive 32-frame chunks with the returned state threaded into the next call (the definition of
+    gen_streaming above), 4 ragged utterances of up to 96 frames; logits on a sub-grid + final states on a sub-grid."""
+    torch.manual_seed(0)
+    cnn = torch.nn.Sequential(
+        MaskConv2d(1, 32, [41, 11], [2, 2], PaddingMode.SAME), act_wrap(0.0, 20.0),
+        MaskConv2d(32, 32, [21, 11], [2, 1], PaddingMode.SAME), act_wrap(0.0, 20.0),
+    )
+    rnn = RNN(RNNType.LSTM, 640, 1024, num_layers=5, bidirectional=True, forget_gate_bias=1.0)
+    fc = FullyConnected(2048, 29, 1, 1024, torch.nn.Hardtanh(0.0, 20.0))
+    m = DeepSpeech2(cnn, rnn, None, fc).eval()
+    g = torch.Generator().manual_seed(555)
+    N, T, chunk = 4, 96, 32
+    x = torch.randn(N, 1, 80, T, generator=g)
+    lens = torch.tensor([96, 80, 50, 20], dtype=torch.int64)
+    outs, out_lens = [], torch.zeros(N, dtype=torch.int64)
+    hid, t0 = None, 0
+    while t0 < T:
+        alive = int((lens > t0).sum())
+        if alive == 0:
+            break
+        xc = x[:alive, :, :, t0:t0 + chunk].clone()
+        lc = (lens[:alive] - t0).clamp(max=xc.shape[-1])
+        hx = None if hid is None else (hid[0][:, :alive].contiguous(), hid[1][:, :alive].contiguous())
+        (y, ol), hid = m((xc, lc), hx)
+        full = torch.zeros(y.shape[0], N, y.shape[2])
+        full[:, :alive] = y
+        outs.append(full)
+        out_lens[:alive] += ol
+        t0 += chunk
+    y = torch.cat(outs, 0)
+    chk = {k: float(v.double().abs().sum()) for k, v in m.state_dict().items()}
+    arrays = {"in/lens": npy(lens), "out/y_sub": npy(y[::3, :, ::2]), "out/lens": npy(out_lens),
+              "out/hn_last_sub": npy(hid[0][:, :, ::64]), "out/cn_last_sub": npy(hid[1][:, :, ::64])}
+    save("stream_cfg5_summary", dict(weight_abs_sums=chk, seed_input=555, N=N, T=T, chunk_frames=chunk), arrays)
+
+
+if __name__ == "__main__" and "streamfull" in sys.argv[1:]:
+    gen_streaming_full()

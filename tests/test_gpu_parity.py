@@ -664,6 +664,26 @@ def test_chunked_streaming_matches_reference_hx_threading(name):
     np.testing.assert_allclose(cpu(cn)[:, :alive_last], g["out/cn_last"], **TOL)
 
 
+def test_chunked_streaming_full_width_vs_reference_summary():
+    """BASELINE configs[4] shape: the config-2 network (5 x BiLSTM-1024, bench.build_model's seed-0 weights, checksums
+    pinned) on 32-frame chunks with the state carried, 4 ragged utterances -- against the reference run chunk by chunk
+    with hx threaded (tests/golden/stream_cfg5_summary.npz): logits on the stored sub-grid and the last chunk's states."""
+    import bench
+    from myrtlespeech_amd.streaming import ChunkedDeepSpeech2
+    g = Golden("stream_cfg5_summary")
+    model = bench.build_model()
+    for k, v in model.state_dict().items():
+        assert abs(float(v.double().abs().sum()) - g.cfg["weight_abs_sums"][k]) <= 1e-6 * max(1.0, g.cfg["weight_abs_sums"][k]), k
+    gen = torch.Generator().manual_seed(g.cfg["seed_input"])
+    x = torch.randn(g.cfg["N"], 1, 80, g.cfg["T"], generator=gen)
+    (y, lens), (hn, cn) = ChunkedDeepSpeech2(model, g.cfg["chunk_frames"])(x, T(g["in/lens"]))
+    np.testing.assert_array_equal(cpu(lens), g["out/lens"])
+    np.testing.assert_allclose(cpu(y)[::3, :, ::2], g["out/y_sub"], rtol=0, atol=1e-3)
+    alive_last = g["out/hn_last_sub"].shape[1]
+    np.testing.assert_allclose(cpu(hn)[:, :alive_last, ::64], g["out/hn_last_sub"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(cpu(cn)[:, :alive_last, ::64], g["out/cn_last_sub"], rtol=0, atol=1e-3)
+
+
 # ----------------------------------------------------------------------------- RNN-T (own spec, a15)
 def _rnnt_parts(V=11, E=40, D=16, P=96, J=48, seed=3):
     from myrtlespeech_amd.model.rnnt import RNNTJoint, RNNTPredictor
