@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Randomised soak on the GPU box: many small seeded cases of the index-producing paths against the numpy oracle
+(CTC prefix beam search with separators / word weights / a toy LM, RNN-T greedy + beam, CTC greedy), plus ragged
+LSTM / GRU layers against the oracle within 1e-4.  Prints one line per family; exits non-zero on the first mismatch.
+    python tools/soak.py [seconds per family, default 40]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import ds_oracle as O  # noqa: E402
+from oracle import rnnt_oracle as RO  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
+
+
+def family(name, one_case):
+    t0, n = time.time(), 0
+    while time.time() - t0 < budget:
+        one_case(n)
+        n += 1
+    print(f"{name:28s} {n:5d} cases ok", flush=True)
+
+
+def beam_case(seed):
+    from myrtlespeech_amd.post_process.ctc_beam_decoder import CTCBeamDecoder
+    rng = np.random.default_rng(seed)
+    T_, N, V = int(rng.integers(1, 40)), int(rng.integers(1, 5)), int(rng.integers(2, 9))
+    x = torch.softmax(torch.from_numpy(rng.normal(size=(T_, N, V)).astype(np.float32)) * float(rng.uniform(0.5, 6)), dim=2)
+    lens = np.sort(rng.integers(0, T_ + 1, size=N))[::-1].copy()
+    blank = int(rng.integers(0, V))
+    w = int(rng.integers(1, 10))
+    prune = float(rng.choice([0.0, 0.001, 0.05]))
+    kw = {}
+    if V > 2 and rng.random() < 0.5:
+        sep = int(rng.choice([v for v in range(V) if v != blank]))
+        kw = dict(separator_index=sep, word_weight=float(rng.uniform(0.5, 2.0)))
+        if rng.random() < 0.5:
+            kw.update(language_model=O.toy_language_model, lm_weight=float(rng.uniform(0.5, 2.0)))
+    got = CTCBeamDecoder(blank_index=blank, beam_width=w, prune_threshold=prune, **kw)(x, torch.from_numpy(lens))
+    want = O.ctc_beam_decode(x.numpy(), lens, blank, w, prune, kw.get("language_model"), kw.get("lm_weight"),
+                             kw.get("separator_index"), kw.get("word_weight", 1.0))
+    assert got == want, ("beam", seed, got, want)
+
+
+def greedy_case(seed):
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    rng = np.random.default_rng(seed)
+    T_, N, V = int(rng.integers(1, 700)), int(rng.integers(1, 9)), int(rng.integers(1, 40))
+    x = (rng.normal(size=(T_, N, V)) * 2).round(1).astype(np.float32)   # rounded: many exact ties
+    lens = rng.integers(0, T_ + 1, size=N)
+    blank = int(rng.integers(0, V))
+    assert CTCGreedyDecoder(blank)(torch.from_numpy(x), torch.from_numpy(lens)) == O.ctc_greedy_decode(x, lens, blank), ("greedy", seed)
+
+
+_rnnt = {}
+
+
+def rnnt_case(seed):
+    from myrtlespeech_amd.model.rnnt import RNNTJoint, RNNTPredictor
+    from myrtlespeech_amd.post_process.rnnt_decoder import RNNTBeamDecoder, RNNTGreedyDecoder
+    rng = np.random.default_rng(seed)
+    V = int(rng.choice([3, 5, 11]))
+    if V not in _rnnt:
+        torch.manual_seed(V)
+        pred, joint = RNNTPredictor(V, 8, 64, num_layers=2).eval(), RNNTJoint(24, 64, 32, V).eval()
+        _rnnt[V] = (pred, joint, {k: v.detach().cpu().numpy() for k, v in pred.state_dict().items()},
+                    {k: v.detach().cpu().numpy() for k, v in joint.state_dict().items()})
+    pred, joint, psd, jsd = _rnnt[V]
+    T_, N = int(rng.integers(1, 14)), int(rng.integers(1, 4))
+    enc = (rng.normal(size=(T_, N, 24)) * float(rng.uniform(0.5, 3))).astype(np.float32)
+    lens = np.sort(rng.integers(0, T_ + 1, size=N))[::-1].copy()
+    lens[0] = T_
+    w, ms = int(rng.integers(1, 9)), int(rng.integers(1, 4))
+    got = RNNTBeamDecoder(pred, joint, beam_width=w, max_symbols=ms)(torch.from_numpy(enc), torch.from_numpy(lens))
+    want, _ = RO.beam_decode(enc, lens, psd, jsd, 64, 2, V, w, ms)
+    assert got == want, ("rnnt beam", seed, got, want)
+    got = RNNTGreedyDecoder(pred, joint, max_symbols=ms)(torch.from_numpy(enc), torch.from_numpy(lens))
+    assert got == RO.greedy_decode(enc, lens, psd, jsd, 64, 2, V, ms), ("rnnt greedy", seed)
+
+
+_rnn = {}
+
+
+def rnn_case(seed):
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    rng = np.random.default_rng(seed)
+    kind, H, bidir = [("LSTM", 64, True), ("LSTM", 256, False), ("GRU", 64, True), ("GRU", 128, False), ("BASIC_RNN", 64, True),
+                      ("LSTM", 96, True)][seed % 6]
+    key = (kind, H, bidir)
+    if key not in _rnn:
+        torch.manual_seed(seed)
+        m = RNN(getattr(RNNType, kind), 32, H, num_layers=2, bidirectional=bidir).eval()
+        _rnn[key] = (m, {k[len("rnn."):]: v.detach().cpu().numpy() for k, v in m.state_dict().items()})
+    m, sd = _rnn[key]
+    T_, N = int(rng.integers(1, 12)), int(rng.integers(1, 70))
+    lens = np.sort(rng.integers(1, T_ + 1, size=N))[::-1].copy()
+    lens[0] = T_
+    x = rng.normal(size=(T_, N, 32)).astype(np.float32)
+    (out, _), hid = m((torch.from_numpy(x), torch.from_numpy(lens)))
+    want, whid = O.rnn_forward(getattr(O, kind), x, lens, sd, H, 2, bidir, None)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    h = hid[0] if isinstance(hid, tuple) else hid
+    np.testing.assert_allclose(h.cpu().numpy(), whid[0] if isinstance(whid, tuple) else whid, rtol=1e-4, atol=1e-4)
+
+
+def ctc_case(seed):
+    from myrtlespeech_amd.loss.ctc_loss import CTCLoss
+    rng = np.random.default_rng(seed)
+    T_, N, V = int(rng.integers(1, 30)), int(rng.integers(1, 5)), int(rng.integers(2, 8))
+    blank = int(rng.integers(0, V))
+    labels = [v for v in range(V) if v != blank]
+    x = (rng.normal(size=(T_, N, V)) * 2).astype(np.float32)
+    xl = rng.integers(1, T_ + 1, size=N)
+    S = int(rng.integers(1, 8))
+    y = rng.choice(labels, size=(N, S)).astype(np.int32)
+    yl = rng.integers(0, S + 1, size=N).astype(np.int32)
+    red = ["none", "mean", "sum"][seed % 3]
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    out = CTCLoss(blank=blank, reduction=red, zero_infinity=True)((xt, torch.from_numpy(xl)), (torch.from_numpy(y), torch.from_numpy(yl)))
+    want = O.ctc_loss(x, xl, y, yl, blank, red, True)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    wts = rng.uniform(0.5, 1.5, size=N).astype(np.float32)
+    (out * torch.from_numpy(wts).cuda()).sum().backward() if red == "none" else out.backward()
+    gn = wts if red == "none" else (np.ones(N, np.float32) if red == "sum" else 1.0 / (np.maximum(yl.astype(np.float32), 1.0) * N))
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), O.ctc_grad(x, xl, y, yl, gn, blank, True), rtol=1e-3, atol=1e-4)
+
+
+def frontend_case(seed):
+    from oracle import frontend_oracle as FO
+    from myrtlespeech_amd.data.preprocess import AddContextFrames, MFCC, MFCCLegacy, Standardize
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(1, 5))
+    lens = np.sort(rng.integers(201, 6000, size=N))[::-1].copy()
+    w = np.zeros((N, lens[0]), np.float32)
+    for i, l in enumerate(lens):
+        w[i, :l] = (rng.normal(size=l) * 0.2).clip(-1, 1)
+    n_mfcc, hop = int(rng.integers(1, 129)), int(rng.choice([80, 160, 200, 320]))
+    y, fl = MFCC(n_mfcc=n_mfcc, melkwargs={"win_length": 400, "hop_length": hop}).batch(torch.from_numpy(w), torch.from_numpy(lens))
+    want = FO.pad_sequence([FO.mfcc(w[i:i + 1, :l], n_mfcc, 400, hop) for i, l in enumerate(lens)])
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-4, atol=3e-3)
+    s, _ = Standardize().batch(y, fl)
+    wants = FO.pad_sequence([FO.standardize(want[i][..., :int(f)]) for i, f in enumerate(fl.tolist())])
+    if int(fl.min()) * n_mfcc > 1:
+        np.testing.assert_allclose(s.cpu().numpy(), wants, rtol=1e-3, atol=1e-3)
+    c = int(rng.integers(0, 6))
+    ctx, _ = AddContextFrames(c).batch(y, fl)
+    wantc = FO.pad_sequence([FO.add_context_frames(y[i, :, :, :int(f)].cpu().numpy(), c) for i, f in enumerate(fl.tolist())])
+    assert np.array_equal(ctx.cpu().numpy(), wantc)
+    nm = int(rng.integers(1, 27))
+    ly, lf = MFCCLegacy(nm, {"win_length": 400, "hop_length": hop}).batch(torch.from_numpy(w), torch.from_numpy(lens))
+    wantl = FO.pad_sequence([FO.mfcc_legacy(w[i:i + 1, :l], nm, 400, hop) for i, l in enumerate(lens)])
+    np.testing.assert_allclose(ly.cpu().numpy(), wantl, rtol=1e-5, atol=1e-5)
+
+
+family("ctc loss+grad vs oracle", ctc_case)
+family("front-end vs oracle", frontend_case)
+family("ctc beam vs oracle", beam_case)
+family("ctc greedy vs oracle", greedy_case)
+family("rnn-t greedy+beam vs oracle", rnnt_case)
+family("lstm/gru/rnn vs oracle", rnn_case)
+print("soak ok")
