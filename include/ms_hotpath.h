@@ -84,6 +84,17 @@ int ms_maskconv_cl_forward(const float* x, const int32_t* lens, const void* pack
                            int ST, int DF, int DT, int pad_f_l, int pad_t_l, int act, float act_lo, float act_hi,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* MaskConv1d with many input channels as im2col + split-bf16 GEMM (model/cnn.py:295-333, the conv1d flavour of the DS2
+ * builder): x [N, Cin, Tin] -> y [N, Cout, Tout]; frames t >= lens[n] read as zero (cnn.py:280-293), pad_l zero
+ * frames on the left (cnn.py:252-278); packed = ms_maskconv1d_gemm_pack of weight [Cout, Cin, KT]; bias may be NULL;
+ * groups = 1.  Products carry the split-bf16 error (~2^-17 relative, like ms_linear_split_forward). */
+size_t ms_maskconv1d_gemm_packed_bytes(int Cout, int Cin, int KT);
+int ms_maskconv1d_gemm_pack(const float* w, void* packed, int Cout, int Cin, int KT, void* stream);
+size_t ms_maskconv1d_gemm_workspace_bytes(int N, int Cin, int Tout, int Cout, int KT);
+int ms_maskconv1d_gemm_forward(const float* x, const int32_t* lens, const void* packed, const float* bias, float* y, int N,
+                               int Cin, int Tin, int Cout, int Tout, int KT, int ST, int DT, int pad_l, int act,
+                               float act_lo, float act_hi, void* workspace, size_t workspace_bytes, void* stream);
+
 /* DeepSpeech2._conv_to_rnn_size (deep_speech_2.py:114-117): [N, CF, T] -> [T, N, CF]. */
 int ms_nct_to_tnc(const float* x, float* y, int N, int CF, int T, void* stream);
 

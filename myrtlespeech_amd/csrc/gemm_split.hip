@@ -376,7 +376,11 @@ int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const
   }
   static const bool small_tile = getenv("MS_GEMM_TILE128") && getenv("MS_GEMM_TILE128")[0] == '1';
   const bool f16 = prec == PREC_F16;
-  if (f16 || (!small_tile && (long)M * N >= 4L * 1024 * 1024)) {
+  // 256 x 256 tiles unless they would leave a quarter of the CUs without a workgroup while 256 x 128 tiles would not
+  // (narrow outputs, e.g. N = 512: 2 column tiles); both kernels accumulate in the same order, results are identical
+  const long tiles256 = (long)cdiv(M, S2_M) * cdiv(N, S2_N);
+  const bool starved = tiles256 * 4 < (long)num_cus() * 3 && (long)cdiv(M, SB_M) * cdiv(N, SB_N) > tiles256;
+  if (f16 || (!small_tile && !starved && (long)M * N >= 4L * 1024 * 1024)) {
     const int nwg2 = cdiv(M, S2_M) * cdiv(N, S2_N);
     auto kern = f16 ? gemm_nt_bf16x3_kernel2<true> : gemm_nt_bf16x3_kernel2<false>;
     hipLaunchKernelGGL(kern, dim3(nwg2), dim3(512), SPLIT2_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);

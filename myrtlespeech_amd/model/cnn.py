@@ -68,6 +68,19 @@ class _PackedFilters:
             self.key_cl = key
         return self.buf_cl
 
+    def get_gemm1d(self, weight: torch.Tensor) -> torch.Tensor:
+        """bf16 hi / lo planes [Cout, Cin*KT padded to 32] for the im2col + split-GEMM conv1d path (conv1d_gemm.hip)."""
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape), "gemm1d")
+        if key != self.key_cl:
+            lib = _lib.load()
+            cout, cin, _, kt = weight.shape
+            self.buf_cl = torch.empty(lib.ms_maskconv1d_gemm_packed_bytes(cout, cin, kt), dtype=torch.uint8, device="cuda")
+            w = _lib.f32c(weight.detach())
+            _lib.check(lib.ms_maskconv1d_gemm_pack(_lib.ptr(w), _lib.ptr(self.buf_cl), cout, cin, kt, _lib.stream_ptr()),
+                       "ms_maskconv1d_gemm_pack")
+            self.key_cl = key
+        return self.buf_cl
+
     def get(self, weight: torch.Tensor, groups: int) -> torch.Tensor:
         key = (weight.data_ptr(), weight._version, tuple(weight.shape), groups)
         if key != self.key:
@@ -104,7 +117,17 @@ def _conv_forward(x4: torch.Tensor, seq_lens: torch.Tensor, weight4: torch.Tenso
     lens_dev = _lib.lens_i32(seq_lens)
     a, lo, hi = (_lib.ACT_NONE, 0.0, 0.0) if act is None else (_lib.ACT_CLAMP, act[0], act[1])
     b = None if bias is None else _lib.f32c(bias.detach())
-    if _lib.split_precision() and groups == 1 and cin % 16 == 0 and 2.0 * y.numel() * cin * kf * kt >= 1e9:
+    big = 2.0 * y.numel() * cin * kf * kt >= 1e9
+    if _lib.split_precision() and groups == 1 and fin == 1 and kf == 1 and cin * kt >= 64 and big:
+        # conv1d with many input channels: im2col (mask and padding as load predicates) + split-bf16 GEMM (conv1d_gemm.hip)
+        pk = packed.get_gemm1d(weight4)
+        nbytes = lib.ms_maskconv1d_gemm_workspace_bytes(n, cin, tout, cout, kt)
+        ws = packed.workspace.get(nbytes)
+        _lib.check(lib.ms_maskconv1d_gemm_forward(_lib.ptr(x4), _lib.ptr(lens_dev), _lib.ptr(pk), _lib.ptr(b), _lib.ptr(y), n,
+                                                  cin, tin, cout, tout, kt, st, dt, pt[0], a, lo, hi, _lib.ptr(ws), nbytes,
+                                                  _lib.stream_ptr()), "ms_maskconv1d_gemm_forward")
+        return y, new_lens
+    if _lib.split_precision() and groups == 1 and cin % 16 == 0 and big:
         # many input channels: split-bf16 implicit GEMM over channels (conv_cl.hip)
         pk = packed.get_cl(weight4)
         ws = packed.workspace.get(lib.ms_maskconv_cl_workspace_bytes(n, cin, fin, tin))

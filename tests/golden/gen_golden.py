@@ -731,7 +731,7 @@ def gen_streaming_full():
     chk = {k: float(v.double().abs().sum()) for k, v in m.state_dict().items()}
     arrays = {"in/lens": npy(lens), "out/y_sub": npy(y[::3, :, ::2]), "out/lens": npy(out_lens),
               "out/hn_last_sub": npy(hid[0][:, :, ::64]), "out/cn_last_sub": npy(hid[1][:, :, ::64])}
-    save("stream_cfg5_summary", dict(weight_abs_sums=chk, seed_input=555, N=N, T=T, chunk_frames=chunk), arrays)
+    save("cfg5_stream_summary", dict(weight_abs_sums=chk, seed_input=555, N=N, T=T, chunk_frames=chunk), arrays)
 
 
 if __name__ == "__main__" and "streamfull" in sys.argv[1:]:

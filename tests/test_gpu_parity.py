@@ -132,6 +132,26 @@ def test_streamed_weights_step_kernel_vs_oracle(kind, H, N, T_, bidir, In):
     np.testing.assert_allclose(cpu(hn), whn, **TOL)
 
 
+@pytest.mark.parametrize("cin,cout,k,s,d,T_", [(80, 512, 11, 2, 1, 1001), (512, 256, 11, 1, 1, 501), (96, 64, 5, 3, 2, 700),
+                                               (33, 128, 7, 1, 1, 900)])
+def test_maskconv1d_gemm_lowering_vs_oracle(cin, cout, k, s, d, T_):
+    """Conv1d stacks with many input channels take the im2col + split-bf16 GEMM path (conv1d_gemm.hip): SAME padding,
+    stride, dilation, ragged lengths (masked input frames), bias + clamp epilogue, odd channel counts (K padding)."""
+    from myrtlespeech_amd.model.cnn import MaskConv1d, PaddingMode
+    torch.manual_seed(cin + k)
+    m = MaskConv1d(cin, cout, k, s, PaddingMode.SAME, dilation=d).eval()
+    rng = np.random.default_rng(cout)
+    N = 24
+    x = rng.normal(size=(N, cin, T_)).astype(np.float32)
+    lens = np.sort(rng.integers(T_ // 3, T_ + 1, size=N))[::-1].copy()
+    lens[0] = T_
+    y, ol = m((T(x), T(lens)))
+    want, wl = O.mask_conv1d(x.copy(), lens, cpu(m.weight), cpu(m.bias), s, True, d)
+    np.testing.assert_array_equal(cpu(ol), wl)
+    scale = float(np.abs(want).max())
+    np.testing.assert_allclose(cpu(y), want, rtol=1e-4, atol=1e-5 * max(1.0, scale))
+
+
 @pytest.mark.parametrize("name", golden_names("hard_lstm_"))
 def test_hard_lstm_golden(name):
     from myrtlespeech_amd.model.hard_lstm import HardLSTM
@@ -667,10 +687,10 @@ def test_chunked_streaming_matches_reference_hx_threading(name):
 def test_chunked_streaming_full_width_vs_reference_summary():
     """BASELINE configs[4] shape: the config-2 network (5 x BiLSTM-1024, bench.build_model's seed-0 weights, checksums
     pinned) on 32-frame chunks with the state carried, 4 ragged utterances -- against the reference run chunk by chunk
-    with hx threaded (tests/golden/stream_cfg5_summary.npz): logits on the stored sub-grid and the last chunk's states."""
+    with hx threaded (tests/golden/cfg5_stream_summary.npz): logits on the stored sub-grid and the last chunk's states."""
     import bench
     from myrtlespeech_amd.streaming import ChunkedDeepSpeech2
-    g = Golden("stream_cfg5_summary")
+    g = Golden("cfg5_stream_summary")
     model = bench.build_model()
     for k, v in model.state_dict().items():
         assert abs(float(v.double().abs().sum()) - g.cfg["weight_abs_sums"][k]) <= 1e-6 * max(1.0, g.cfg["weight_abs_sums"][k]), k
