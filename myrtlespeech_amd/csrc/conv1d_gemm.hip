@@ -28,23 +28,41 @@ __global__ void conv1d_pack_kernel(const float* __restrict__ w, unsigned short* 
     split_store(k < K ? w[(size_t)row * K + k] : 0.f, hi, lo, (size_t)row * Kp + k);
 }
 
-// patches: row (n, t_out), column ci*KT + k  <-  x[n, ci, t_out*ST + k*DT - pad_l] if that frame exists and is < lens[n]
+// patches: row (n, t_out), column ci*KT + k  <-  x[n, ci, t_out*ST + k*DT - pad_l] if that frame exists and is < lens[n].
+// A thread builds 8 consecutive columns (one 16-byte store per plane; Kp % 32 == 0 keeps the groups aligned).
 __global__ __launch_bounds__(256) void conv1d_im2col_kernel(const float* __restrict__ x, const int32_t* __restrict__ lens,
                                                             unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
                                                             int Cin, int Tin, int Tout, int KT, int ST, int DT, int pad_l,
                                                             int K, int Kp) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const int n = blockIdx.z, t_out = blockIdx.y;
   const int len = min(lens[n], Tin);
   const size_t row = (size_t)n * Tout + t_out;
   const float* xn = x + (size_t)n * Cin * Tin;
-  for (int c = blockIdx.x * 256 + threadIdx.x; c < Kp; c += gridDim.x * 256) {
-    float v = 0.f;
-    if (c < K) {
-      const int ci = c / KT, k = c - ci * KT;
-      const int t = t_out * ST + k * DT - pad_l;
-      if (t >= 0 && t < len) v = xn[(size_t)ci * Tin + t];
+  const int t_base = t_out * ST - pad_l;
+  for (int c0 = (blockIdx.x * 256 + threadIdx.x) * 8; c0 < Kp; c0 += gridDim.x * 256 * 8) {
+    unsigned h16[8], l16[8];
+    int ci = c0 / KT, k = c0 - ci * KT;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = 0.f;
+      if (c0 + e < K) {
+        const int t = t_base + k * DT;
+        if (t >= 0 && t < len) v = xn[(size_t)ci * Tin + t];
+      }
+      const __bf16 hb = (__bf16)v;
+      h16[e] = __builtin_bit_cast(unsigned short, hb);
+      l16[e] = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)hb));
+      if (++k == KT) { k = 0; ++ci; }
     }
-    split_store(v, hi, lo, row * Kp + c);
+    u32x4 ph, pl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ph[e] = h16[2 * e] | (h16[2 * e + 1] << 16);
+      pl[e] = l16[2 * e] | (l16[2 * e + 1] << 16);
+    }
+    *reinterpret_cast<u32x4*>(hi + row * Kp + c0) = ph;
+    *reinterpret_cast<u32x4*>(lo + row * Kp + c0) = pl;
   }
 }
 
@@ -109,7 +127,7 @@ extern "C" int ms_maskconv1d_gemm_forward(const float* x, const int32_t* lens, c
   float* yt = (float*)((char*)workspace + ms::align_up(rows * Kp * 2 * sizeof(unsigned short), 256));
   const unsigned short* wh = (const unsigned short*)packed;
   const unsigned short* wl = wh + (size_t)Cout * Kp;
-  hipLaunchKernelGGL(conv1d_im2col_kernel, dim3(std::min(ms::cdiv(Kp, 256), 8), Tout, N), dim3(256), 0, stream, x, lens, ph,
+  hipLaunchKernelGGL(conv1d_im2col_kernel, dim3(std::min(ms::cdiv(Kp, 2048), 4), Tout, N), dim3(256), 0, stream, x, lens, ph,
                      pl, Cin, Tin, Tout, KT, ST, DT, pad_l, K, Kp);
   MS_LAUNCH_CHECK();
   int rc = ms::gemm_bf16x3_launch(ph, pl, wh, wl, bias, yt, (int)rows, Kp, Cout, act, act_lo, act_hi, ms::PREC_BF16X3, stream);
