@@ -29,40 +29,43 @@ __global__ void conv1d_pack_kernel(const float* __restrict__ w, unsigned short* 
 }
 
 // patches: row (n, t_out), column ci*KT + k  <-  x[n, ci, t_out*ST + k*DT - pad_l] if that frame exists and is < lens[n].
-// A thread builds 8 consecutive columns (one 16-byte store per plane; Kp % 32 == 0 keeps the groups aligned).
+// A workgroup builds a 32-row x 64-column tile through LDS: the gather runs with lanes along t_out (consecutive lanes read
+// consecutive frames of one channel: coalesced), the scatter with 8 lanes per row (one 16-byte store per plane each).
 __global__ __launch_bounds__(256) void conv1d_im2col_kernel(const float* __restrict__ x, const int32_t* __restrict__ lens,
                                                             unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
                                                             int Cin, int Tin, int Tout, int KT, int ST, int DT, int pad_l,
                                                             int K, int Kp) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  const int n = blockIdx.z, t_out = blockIdx.y;
+  __shared__ __attribute__((aligned(16))) unsigned short th[32][72], tl[32][72];  // +8 pad: row stride 144 B
+  const int n = blockIdx.z, t0 = blockIdx.y * 32, c_base = blockIdx.x * 64, tid = threadIdx.x;
   const int len = min(lens[n], Tin);
-  const size_t row = (size_t)n * Tout + t_out;
   const float* xn = x + (size_t)n * Cin * Tin;
-  const int t_base = t_out * ST - pad_l;
-  for (int c0 = (blockIdx.x * 256 + threadIdx.x) * 8; c0 < Kp; c0 += gridDim.x * 256 * 8) {
-    unsigned h16[8], l16[8];
-    int ci = c0 / KT, k = c0 - ci * KT;
+  {
+    const int tr = tid & 31, cg = tid >> 5;
+    const int t_out = t0 + tr;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
+      const int cl = cg * 8 + e, c = c_base + cl;
       float v = 0.f;
-      if (c0 + e < K) {
-        const int t = t_base + k * DT;
+      if (c < K && t_out < Tout) {
+        const int ci = c / KT, k = c - ci * KT;
+        const int t = t_out * ST + k * DT - pad_l;
         if (t >= 0 && t < len) v = xn[(size_t)ci * Tin + t];
       }
       const __bf16 hb = (__bf16)v;
-      h16[e] = __builtin_bit_cast(unsigned short, hb);
-      l16[e] = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)hb));
-      if (++k == KT) { k = 0; ++ci; }
+      th[tr][cl] = __builtin_bit_cast(unsigned short, hb);
+      tl[tr][cl] = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)hb));
     }
-    u32x4 ph, pl;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      ph[e] = h16[2 * e] | (h16[2 * e + 1] << 16);
-      pl[e] = l16[2 * e] | (l16[2 * e + 1] << 16);
+  }
+  __syncthreads();
+  {
+    const int tr = tid >> 3, ch = tid & 7;
+    const int t_out = t0 + tr;
+    if (t_out < Tout && c_base + ch * 8 < Kp) {
+      const size_t at = ((size_t)n * Tout + t_out) * Kp + c_base + ch * 8;
+      *reinterpret_cast<u32x4*>(hi + at) = *reinterpret_cast<const u32x4*>(&th[tr][ch * 8]);
+      *reinterpret_cast<u32x4*>(lo + at) = *reinterpret_cast<const u32x4*>(&tl[tr][ch * 8]);
     }
-    *reinterpret_cast<u32x4*>(hi + row * Kp + c0) = ph;
-    *reinterpret_cast<u32x4*>(lo + row * Kp + c0) = pl;
   }
 }
 
@@ -117,7 +120,7 @@ extern "C" int ms_maskconv1d_gemm_forward(const float* x, const int32_t* lens, c
   MS_REQUIRE(x && lens && packed && y && workspace, "null pointer");
   MS_REQUIRE(N > 0 && Cin > 0 && Tin > 0 && Cout > 0 && Tout > 0 && KT > 0 && ST > 0 && DT > 0 && pad_l >= 0, "bad shape");
   MS_REQUIRE(act == MS_ACT_NONE || act == MS_ACT_CLAMP, "bad act");
-  MS_REQUIRE(N <= 65535 && Tout <= 65535 && (long long)N * Tout <= 2147483647LL, "N / Tout exceed grid limits");
+  MS_REQUIRE(N <= 65535 && Tout <= 65535 * 32 && (long long)N * Tout <= 2147483647LL, "N / Tout exceed grid limits");
   MS_REQUIRE(workspace_bytes >= ms_maskconv1d_gemm_workspace_bytes(N, Cin, Tout, Cout, KT), "workspace too small");
   hipStream_t stream = (hipStream_t)stream_;
   const int K = Cin * KT, Kp = padded_k(Cin, KT);
@@ -127,7 +130,7 @@ extern "C" int ms_maskconv1d_gemm_forward(const float* x, const int32_t* lens, c
   float* yt = (float*)((char*)workspace + ms::align_up(rows * Kp * 2 * sizeof(unsigned short), 256));
   const unsigned short* wh = (const unsigned short*)packed;
   const unsigned short* wl = wh + (size_t)Cout * Kp;
-  hipLaunchKernelGGL(conv1d_im2col_kernel, dim3(std::min(ms::cdiv(Kp, 2048), 4), Tout, N), dim3(256), 0, stream, x, lens, ph,
+  hipLaunchKernelGGL(conv1d_im2col_kernel, dim3(ms::cdiv(Kp, 64), ms::cdiv(Tout, 32), N), dim3(256), 0, stream, x, lens, ph,
                      pl, Cin, Tin, Tout, KT, ST, DT, pad_l, K, Kp);
   MS_LAUNCH_CHECK();
   int rc = ms::gemm_bf16x3_launch(ph, pl, wh, wl, bias, yt, (int)rows, Kp, Cout, act, act_lo, act_hi, ms::PREC_BF16X3, stream);
