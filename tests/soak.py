@@ -2,12 +2,12 @@
 """Randomised soak on the GPU box: many small seeded cases of the index-producing paths against the numpy oracle
 (CTC prefix beam search with separators / word weights / a toy LM, RNN-T greedy + beam, CTC greedy), plus ragged
 LSTM / GRU layers against the oracle within 1e-4.  Prints one line per family; exits non-zero on the first mismatch.
-    python tools/soak.py [seconds per family, default 40]"""
+    python tests/soak.py [seconds per family, default 40]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
