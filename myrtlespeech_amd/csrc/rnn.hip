@@ -94,6 +94,19 @@ bool use_gru_persistent(int cell, int H, int ndir) {
   return ndir * (H / GRU_U) <= ms::num_cus();
 }
 
+// MS_LSTM_RING=<slots> (power of two, 2..128; default 8): exchange slots per (stream, plane) of the two-stream LSTM kernel
+// and of the persistent GRU -- with only two slots the step that writes a slot follows its last readers by one step, with four
+// or more the recurrence measured 5 % faster (any ring from 4 to 128 the same);
+int lstm_ring_shift() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MS_LSTM_RING");
+    int slots = e ? atoi(e) : 8;
+    v = 1;
+    while ((1 << v) < slots && v < 7) ++v;
+  }
+  return v;
+}
 struct PackLayout {
   size_t wih, bias_x, whh, bhh, total;  // byte offsets
 };
@@ -122,7 +135,8 @@ WsLayout ws_layout(int cell, int T, int N, int H, int ndir, int In) {
   L.status = o; o += STATUS_BYTES;
   L.flags = o; o += ms::align_up((size_t)ndir * std::max(H / 8, 1) * sizeof(unsigned), 256);
   L.xproj = o; o += ms::align_up((size_t)T * N * ndir * GH * sizeof(float), 256);
-  L.hx = o; o += ms::align_up((size_t)ndir * 2 * H * std::min(npad, 64) * sizeof(float), 256);
+  // two slots per (stream, plane) by default; the two-stream kernel may use a ring of 2^lstm_ring_shift() slots
+  L.hx = o; o += ms::align_up(((size_t)ndir * 2 * H * std::min(npad, 64) * sizeof(float)) << (lstm_ring_shift() - 1), 256);
   L.state_h = o; o += ms::align_up((size_t)2 * ndir * N * H * sizeof(float), 256);
   L.state_c = o; o += ms::align_up((size_t)ndir * N * H * sizeof(float), 256);
   L.dbg = o; o += ms::align_up((size_t)ndir * std::max(H / 8, 1) * 8 * sizeof(unsigned long long), 256);
@@ -468,6 +482,7 @@ struct LstmP {
   unsigned long long* dbg;  // [ndir*J][8] stamp sums (diagnostic build only)
   int steps, N, n_base, N_total, H, ndir, J, NPAD;
   int poll_sleep;  // s_sleep(1) repetitions between polls of the exchange buffer
+  int ring_shift;  // two-stream kernel: log2 of the number of exchange slots per (stream, plane) (1 = two slots)
 };
 
 __device__ __forceinline__ f32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
@@ -683,33 +698,42 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_kernel(LstmP p) {
 struct EpochClock {
   int par;        // slot read at this step
   unsigned em;    // expected tag replicated to both 16-bit halves of a dword
+  int wpar;       // slot the next step's h is written to
   unsigned wtag;  // tag of the h written for the next step
 };
-__device__ __forceinline__ EpochClock epoch_clock(int d, int s, int steps) {
+// rs = log2 of the number of slots (1: the two-slot scheme; larger: a ring, so that a slot's address is not touched
+// again for 2^rs steps and a cached copy of it is long evicted before it could alias)
+__device__ __forceinline__ EpochClock epoch_clock(int d, int s, int steps, int rs = 1) {
   const int u = d ? (steps - 1 - s) : s;
   const int un = d ? (u - 1) : (u + 1);
+  const int mask = (1 << rs) - 1;
   EpochClock c;
-  c.par = u & 1;
-  c.em = ((u >> 1) & 1) ? 0x00010001u : 0u;
-  c.wtag = (unsigned)((un >> 1) & 1);
+  c.par = u & mask;
+  c.em = ((u >> rs) & 1) ? 0x00010001u : 0u;
+  c.wpar = un & mask;                      // two's complement: -1 & mask = last slot (written by the final step, never read)
+  c.wtag = (unsigned)((un >> rs) & 1);
   return c;
 }
 // slot and tag of the initial state (the h read by the first step)
-__device__ __forceinline__ int epoch_par0(int d, int steps) { return d ? ((steps - 1) & 1) : 0; }
-__device__ __forceinline__ unsigned epoch_tag0(int d, int steps) { return d ? (unsigned)(((steps - 1) >> 1) & 1) : 0u; }
+__device__ __forceinline__ int epoch_par0(int d, int steps, int rs = 1) { return d ? ((steps - 1) & ((1 << rs) - 1)) : 0; }
+__device__ __forceinline__ unsigned epoch_tag0(int d, int steps, int rs = 1) {
+  return d ? (unsigned)(((steps - 1) >> rs) & 1) : 0u;
+}
 
 // Exchange-buffer initialisation: every 16-bit word of slot p of direction d gets the tag that is NOT the first one
 // expected there (all-ones or all-zeros words), so a poll that runs ahead of the producers never validates.
 // Layout of a direction: ... [parity][slab_bytes] ..., i.e. parity = (byte offset / slab_bytes) & 1.
-__global__ void hx_init_kernel(unsigned* __restrict__ hx, size_t words_per_dir, size_t slab_words, int ndir, int steps) {
+__global__ void hx_init_kernel(unsigned* __restrict__ hx, size_t words_per_dir, size_t slab_words, int ndir, int steps,
+                               int rs) {
   const size_t total = words_per_dir * ndir;
+  const int mask = (1 << rs) - 1;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int d = (int)(i / words_per_dir);
-    const int par = (int)(((i % words_per_dir) / slab_words) & 1);
-    int first_u;  // first clock value at which slot `par` is read
+    const int par = (int)(((i % words_per_dir) / slab_words) & mask);
+    int first_u;  // first clock value at which slot `par` is read (forward: counting up from 0; backward: down from steps-1)
     if (d == 0) first_u = par;
-    else first_u = ((steps - 1) & 1) == par ? steps - 1 : steps - 2;
-    const unsigned expected = (unsigned)((first_u >> 1) & 1);
+    else first_u = (steps - 1) - (((steps - 1) - par) & mask);
+    const unsigned expected = (unsigned)((first_u >> rs) & 1);   // arithmetic shift: a slot never read gives any value
     hx[i] = expected ? 0u : 0xFFFFFFFFu;
   }
 }
@@ -1054,8 +1078,9 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
     }
   }
 
-  constexpr int PLANE = 2 * KG * 256;       // bytes: [parity][kg][16][8 bf16]
-  constexpr int STREAM = 2 * PLANE;
+  const int rs = p.ring_shift;
+  const int PLANE = (KG * 256) << rs;       // bytes: [slot][kg][16][8 bf16]
+  const int STREAM = 2 * PLANE;
   char* hx_d = reinterpret_cast<char*>(p.hx) + (size_t)d * 2 * STREAM;
   const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx_d, 0, 2 * STREAM, 0x00020000);
 
@@ -1070,8 +1095,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
       h[sg] = (valid && p.h0) ? p.h0[sidx] : 0.f;
       c[sg] = (valid && p.c0) ? p.c0[sidx] : 0.f;
       len_n[sg] = valid ? (p.lens ? p.lens[p.n_base + n] : p.steps) : 0;
-      const int off = sg * STREAM + epoch_par0(d, p.steps) * KG * 256 + j * 256 + nl * 16;  // slot read by the first step
-      publish_split<F16>(h[sg], epoch_tag0(d, p.steps), hx_rsrc, off, PLANE + off, lane);
+      const int off = sg * STREAM + epoch_par0(d, p.steps, rs) * KG * 256 + j * 256 + nl * 16;  // slot read by the first step
+      publish_split<F16>(h[sg], epoch_tag0(d, p.steps, rs), hx_rsrc, off, PLANE + off, lane);
     }
   }
   __syncthreads();
@@ -1084,7 +1109,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
 
   for (int s = 0; s < p.steps; ++s) {
     const int t = d ? (p.steps - 1 - s) : s;
-    const EpochClock ec = epoch_clock(d, s, p.steps);
+    const EpochClock ec = epoch_clock(d, s, p.steps, rs);
     const int par = ec.par;
     const unsigned em = ec.em;
     const unsigned wtag = ec.wtag;
@@ -1183,7 +1208,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
         const bool active = t < len_n[sg];
         c[sg] = active ? cnew : c[sg];
         h[sg] = active ? hnew : h[sg];
-        const int off = sg * STREAM + (par ^ 1) * KG * 256 + j * 256 + nl * 16;
+        const int off = sg * STREAM + ec.wpar * KG * 256 + j * 256 + nl * 16;
         publish_split<F16>(h[sg], wtag, hx_rsrc, off, PLANE + off, lane);
         if (n < N) p.out[((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit] = active ? hnew : 0.f;
       }
@@ -1230,7 +1255,7 @@ struct GruP {
   float* hn;                   // [ndir][N_total][H]
   float* hx;                   // exchange buffer, per direction [stream][plane][parity][H/8][16][8 bf16]
   unsigned* status;
-  int steps, N, n_base, N_total, ndir, J, poll_sleep;
+  int steps, N, n_base, N_total, ndir, J, poll_sleep, ring_shift;
 };
 
 __device__ __forceinline__ void publish_elem(float hval, unsigned tag, __amdgpu_buffer_rsrc_t rsrc, int off_hi, int off_lo) {
@@ -1271,8 +1296,9 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
     }
   }
 
-  constexpr int PLANE = 2 * KG * 256;       // bytes: [parity][kg][16][8 bf16]
-  constexpr int STREAM = 2 * PLANE;
+  const int rs = p.ring_shift;
+  const int PLANE = (KG * 256) << rs;       // bytes: [slot][kg][16][8 bf16]
+  const int STREAM = 2 * PLANE;
   char* hx_d = reinterpret_cast<char*>(p.hx) + (size_t)d * 2 * STREAM;
   const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx_d, 0, 2 * STREAM, 0x00020000);
   const int elem_off = ((unit >> 3) * 16 + nl) * 16 + (unit & 7) * 2;   // this thread's element inside a parity slab
@@ -1290,8 +1316,8 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
       const size_t sidx = ((size_t)d * p.N_total + p.n_base + n) * H + unit;
       h[sg] = (valid && p.h0) ? p.h0[sidx] : 0.f;
       len_n[sg] = valid ? (p.lens ? p.lens[p.n_base + n] : p.steps) : 0;
-      const int off = sg * STREAM + epoch_par0(d, p.steps) * KG * 256 + elem_off;  // slot read by the first step
-      publish_elem(h[sg], epoch_tag0(d, p.steps), hx_rsrc, off, PLANE + off);
+      const int off = sg * STREAM + epoch_par0(d, p.steps, rs) * KG * 256 + elem_off;  // slot read by the first step
+      publish_elem(h[sg], epoch_tag0(d, p.steps, rs), hx_rsrc, off, PLANE + off);
     }
   }
   __syncthreads();
@@ -1302,7 +1328,7 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
 
   for (int s = 0; s < p.steps; ++s) {
     const int t = d ? (p.steps - 1 - s) : s;
-    const EpochClock ec = epoch_clock(d, s, p.steps);
+    const EpochClock ec = epoch_clock(d, s, p.steps, rs);
     const int par = ec.par;
     const unsigned em = ec.em;
     const unsigned wtag = ec.wtag;
@@ -1393,7 +1419,7 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
         const float hnew = (1.0f - z) * nn + z * h[sg];
         const bool active = t < len_n[sg];
         h[sg] = active ? hnew : h[sg];
-        const int off = sg * STREAM + (par ^ 1) * KG * 256 + elem_off;
+        const int off = sg * STREAM + ec.wpar * KG * 256 + elem_off;
         publish_elem(h[sg], wtag, hx_rsrc, off, PLANE + off);
         if (n < N) p.out[((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit] = active ? hnew : 0.f;
       }
@@ -1699,10 +1725,12 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
         const bool two_stream = p.NPAD == 32 && two_stream_shape(H) && (!one_stream || use_f16(cell, H, ndir));
         {
           // every word of every slot starts with the tag that is NOT the first one expected there
+          const int rs = two_stream ? lstm_ring_shift() : 1;
           const size_t slab_words = two_stream ? (size_t)8 * H : (size_t)H * p.NPAD / 2;
-          const size_t words_per_dir = two_stream ? (size_t)64 * H : (size_t)2 * H * p.NPAD;
+          const size_t words_per_dir = two_stream ? ((size_t)32 * H << rs) : (size_t)2 * H * p.NPAD;
+          p.ring_shift = rs;
           hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir)), dim3(256), 0, stream,
-                             (unsigned*)(ws + W.hx), words_per_dir, slab_words, ndir, steps);
+                             (unsigned*)(ws + W.hx), words_per_dir, slab_words, ndir, steps, rs);
           MS_LAUNCH_CHECK();
         }
         if (two_stream) {
@@ -1739,8 +1767,9 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
   if (use_gru_persistent(cell, H, ndir)) {
     // one persistent launch per group of 32 sequences (two interleaved streams of 16)
     for (int n0 = 0; n0 < N; n0 += 32) {
-      hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for((size_t)64 * H * ndir)), dim3(256), 0, stream,
-                         (unsigned*)(ws + W.hx), (size_t)64 * H, (size_t)8 * H, ndir, steps);
+      const int rs = lstm_ring_shift();
+      hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(((size_t)32 * H << rs) * ndir)), dim3(256), 0, stream,
+                         (unsigned*)(ws + W.hx), (size_t)32 * H << rs, (size_t)8 * H, ndir, steps, rs);
       MS_LAUNCH_CHECK();
       GruP g;
       g.xproj = xproj;
@@ -1751,6 +1780,7 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
       g.hx = (float*)(ws + W.hx);
       g.status = (unsigned*)(ws + W.status);
       g.steps = steps; g.N = std::min(32, N - n0); g.n_base = n0; g.N_total = N; g.ndir = ndir; g.J = H / GRU_U;
+      g.ring_shift = rs;
       {
         static const int ps = getenv("MS_LSTM_POLL_SLEEP") ? atoi(getenv("MS_LSTM_POLL_SLEEP")) : 1;
         g.poll_sleep = ps > 0 ? ps : 1;
