@@ -94,14 +94,14 @@ bool use_gru_persistent(int cell, int H, int ndir) {
   return ndir * (H / GRU_U) <= ms::num_cus();
 }
 
-// MS_LSTM_RING=<slots> (power of two, 2..128; default 8): exchange slots per (stream, plane) of the two-stream LSTM kernel
-// and of the persistent GRU -- with only two slots the step that writes a slot follows its last readers by one step, with four
-// or more the recurrence measured 5 % faster (any ring from 4 to 128 the same);
+// MS_LSTM_RING=<slots> (power of two, 2..128; default 2): exchange slots per (stream, plane) of the two-stream LSTM kernel
+// and of the persistent GRU.  Same-box A/B runs show no difference between 2 and 8..128 slots beyond the +-2 % run-to-run
+// noise, so the default stays at two; the switch remains for experiments.
 int lstm_ring_shift() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("MS_LSTM_RING");
-    int slots = e ? atoi(e) : 8;
+    int slots = e ? atoi(e) : 2;
     v = 1;
     while ((1 << v) < slots && v < 7) ++v;
   }
