@@ -1128,14 +1128,21 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
       u32x4 ah[KS], al[KS];
       const unsigned long long t_wait0 = wall_clock64();
       unsigned spins = 0;
-      for (;;) {
-        unsigned bad = 0;
+      // The first request is issued in straight-line code, the loop only re-requests.  With the loads at the loop header
+      // the compiler must assume a previous iteration's load into the same registers is still in flight and emits
+      // `s_waitcnt vmcnt(1)` there -- which on the first pass waits for the x-projection loads above (HBM latency) before
+      // the h loads are even issued.
+      auto request = [&]() {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int kg = kg_base + 4 * ks + q;
           ah[ks] = load_sc1_u128(hx_rsrc, base + kg * 256);
           if (!F16) al[ks] = load_sc1_u128(hx_rsrc, PLANE + base + kg * 256);
         }
+      };
+      request();
+      for (;;) {
+        unsigned bad = 0;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -1150,6 +1157,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
           }
         }
         for (int z = 0; z < p.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+        request();
       }
       if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[0] += now - st_prev; st_prev = now; }
 
