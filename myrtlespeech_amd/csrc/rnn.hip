@@ -1140,7 +1140,16 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
           if (!F16) al[ks] = load_sc1_u128(hx_rsrc, PLANE + base + kg * 256);
         }
       };
-      request();
+      {
+        // first request: agent scope (sc1) is what cross-XCD visibility needs and measured 1-2 % faster than the
+        // sc0 sc1 + volatile form, which the re-requests keep (a stale answer fails the tag check like any other)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int kg = kg_base + 4 * ks + q;
+          ah[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, base + kg * 256, 0, /*aux: sc1*/ 16);
+          if (!F16) al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, PLANE + base + kg * 256, 0, /*aux: sc1*/ 16);
+        }
+      }
       for (;;) {
         unsigned bad = 0;
 #pragma unroll
