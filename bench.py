@@ -113,10 +113,15 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["bf16x3", "f32", "fp16"], default=None,
+                    help="operand mode of the recurrence / projection kernels (default: MS_PRECISION or bf16x3); "
+                         "f32 = exact float32 MFMA everywhere")
     ap.add_argument("--gather-logits", action="store_true",
                     help="batched-decode path: all-gather every shard's logits (RCCL over xGMI) and decode the whole "
                          "global batch on every rank instead of decoding per shard")
     args = ap.parse_args()
+    if args.precision is not None:   # read once by the library at its first launch
+        os.environ["MS_PRECISION"] = args.precision
 
     # Anything the runtime libraries print (RCCL's banner goes to stdout) is sent to stderr, so that stdout carries
     # the ONE JSON line and nothing else.
@@ -240,7 +245,9 @@ def main():
                                    "transcripts bit-exact (tests/test_gpu_parity.py::test_ds2_cfg2_full_size_vs_reference_summary)"},
             "kernel_ms": {"lstm_recurrent_per_layer": round(rec_ms, 3), "lstm_input_projection_per_layer":
                           round(ms[0] / max(cnt[0], 1), 3)},
-            "roofline": {"bound": "hbm", "kernel": "lstm_persistent_split2_kernel (one launch = 1 layer x 2 directions x 501 steps)",
+            "roofline": {"bound": "hbm", "kernel": ("lstm_persistent_kernel" if os.environ.get("MS_PRECISION") == "f32" else
+                                                    "lstm_persistent_split2_kernel") +
+                                                   " (one launch = 1 layer x 2 directions x 501 steps)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
                          "algorithmic_bytes_per_launch": launch_bytes},
