@@ -8,14 +8,17 @@ namespace ms {
 static thread_local std::string g_err;
 void set_error(const std::string& s) { g_err = s; }
 int num_cus() {
-  static int cus = -1;
-  if (cus < 0) {
-    int dev = 0;
+  static std::atomic<int> cus[64];  // per device ordinal; 0 = not queried yet
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  int v = cus[dev & 63].load(std::memory_order_relaxed);
+  if (v == 0) {
     hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
-    cus = p.multiProcessorCount;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    v = p.multiProcessorCount;
+    cus[dev & 63].store(v, std::memory_order_relaxed);
   }
-  return cus;
+  return v;
 }
 int precision_mode() {
   static int v = -1;

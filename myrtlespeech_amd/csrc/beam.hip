@@ -358,10 +358,10 @@ extern "C" int ms_ctc_beam_decode(const float* probs, const int32_t* lens, int32
     ms::set_error("ms_ctc_beam_decode: beam_width * (alphabet + 1) too large for the LDS candidate tables");
     return MS_ERR_UNSUPPORTED;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ms::DeviceOnce attr_once;
+  if (attr_once.need()) {
     MS_HIP(hipFuncSetAttribute((const void*)beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    attr_once.done();
   }
   BeamP p;
   p.probs = probs; p.lens = lens; p.out_idx = out_idx; p.out_len = out_len; p.word_factor = word_factor;

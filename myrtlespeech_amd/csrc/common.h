@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/ms_hotpath.h"
@@ -41,6 +42,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 int num_cus();
+
+// "Once per device" guard for hipFuncSetAttribute (function attributes belong to the device the module is loaded on;
+// a process that drives more than one device must set them on each).  A race between two host threads at worst
+// repeats an idempotent call.
+struct DeviceOnce {
+  std::atomic<unsigned long long> done_mask{0};
+  static unsigned long long bit() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    return 1ull << (d & 63);
+  }
+  bool need() const { return !(done_mask.load(std::memory_order_acquire) & bit()); }
+  void done() { done_mask.fetch_or(bit(), std::memory_order_release); }
+};
 
 // Operand precision of the split kernels, from MS_PRECISION: 0 = "f32" (exact float32 MFMA),
 // 1 = "bf16x3" (default: bf16 hi+lo, three MFMAs), 2 = "fp16" (single fp16 pass; ~2^-11 operands).

@@ -175,10 +175,10 @@ extern "C" int ms_maskconv_forward(const float* x, const int32_t* lens, const vo
   const size_t lds = ((size_t)RC_MAX * p.KT2 * CO_T + (size_t)RC_MAX * p.PWS) * sizeof(float);
   MS_REQUIRE(lds <= 160 * 1024, "kernel_time/stride/dilation too large for the LDS patch");
   MS_REQUIRE(Fout <= 65535 && (long)N * p.co_tiles <= 65535, "Fout or N*cout_tiles exceed grid limits");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ms::DeviceOnce attr_once;
+  if (attr_once.need()) {
     MS_HIP(hipFuncSetAttribute((const void*)maskconv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    attr_once.done();
   }
   const size_t per_group_packed = (size_t)p.co_tiles * p.R * p.KT2 * CO_T;
   for (int g = 0; g < groups; ++g) {

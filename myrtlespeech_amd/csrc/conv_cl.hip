@@ -255,11 +255,11 @@ extern "C" int ms_maskconv_cl_forward(const float* x, const int32_t* lens, const
     ms::set_error("ms_maskconv_cl_forward: shape outside the LDS / grid budget");
     return MS_ERR_UNSUPPORTED;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ms::DeviceOnce attr_once;
+  if (attr_once.need()) {
     MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    attr_once.done();
   }
   unsigned short* xh = (unsigned short*)workspace;
   unsigned short* xl = xh + (size_t)N * Cin * Fin * Tin;

@@ -322,10 +322,10 @@ extern "C" int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, 
   }
   const size_t lds = (size_t)3 * S_max * sizeof(float);
   MS_REQUIRE(lds <= 160 * 1024, "target too long for the LDS-resident alpha rows");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ms::DeviceOnce attr_once;
+  if (attr_once.need()) {
     MS_HIP(hipFuncSetAttribute((const void*)ctc_alpha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    attr_once.done();
   }
   hipLaunchKernelGGL(ctc_alpha_kernel, dim3(N), dim3(CTC_THREADS), lds, (hipStream_t)stream, logits, in_lens, targets,
                      tgt_offsets, tgt_lens, nll, (float*)workspace, T, N, V, S_max, blank);
@@ -368,10 +368,10 @@ extern "C" int ms_ctc_loss_backward(const float* logits, const int32_t* in_lens,
   const size_t lds = (size_t)4 * S_max * sizeof(float);
   constexpr size_t GRAD_LDS_MAX = 160 * 1024 - 256;   // the kernel also has a static word
   MS_REQUIRE(lds <= GRAD_LDS_MAX, "target too long for the LDS-resident alpha / beta rows");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ms::DeviceOnce attr_once;
+  if (attr_once.need()) {
     MS_HIP(hipFuncSetAttribute((const void*)ctc_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRAD_LDS_MAX));
-    attr_set = true;
+    attr_once.done();
   }
   float* logz = (float*)workspace;
   float* alpha = (float*)((char*)workspace + ms::align_up((size_t)T * N * sizeof(float), 256));

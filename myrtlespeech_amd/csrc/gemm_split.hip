@@ -367,12 +367,12 @@ int split_planes_launch(const float* x, unsigned short* hi, unsigned short* lo, 
 int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
                        const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
                        float hi, int prec, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ms::DeviceOnce attr_once;
+  if (attr_once.need()) {
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT2_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT2_LDS));
-    attr_set = true;
+    attr_once.done();
   }
   static const bool small_tile = getenv("MS_GEMM_TILE128") && getenv("MS_GEMM_TILE128")[0] == '1';
   const bool f16 = prec == PREC_F16;

@@ -1605,11 +1605,11 @@ extern "C" size_t ms_rnn_workspace_bytes(int cell, int T, int N, int In, int H, 
 template <int NB, bool HARD, bool PIPE, bool STAMP = false>
 static int launch_persistent(const LstmP& p, hipStream_t stream) {
   const size_t lds = ((size_t)p.H * 32 + RED_FLOATS) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ms::DeviceOnce attr_once;
+  if (attr_once.need()) {
     MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_kernel<NB, HARD, PIPE, STAMP>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    attr_once.done();
   }
   hipLaunchKernelGGL((lstm_persistent_kernel<NB, HARD, PIPE, STAMP>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
   MS_LAUNCH_CHECK();
@@ -1619,11 +1619,11 @@ static int launch_persistent(const LstmP& p, hipStream_t stream) {
 template <int NB, int NCH, bool HARD, bool STAMP = false>
 static int launch_split(const LstmP& p, hipStream_t stream) {
   const size_t lds = ((size_t)p.H * 32 + RED_FLOATS) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static ms::DeviceOnce attr_once;
+  if (attr_once.need()) {
     MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_split_kernel<NB, NCH, HARD, STAMP>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    attr_once.done();
   }
   hipLaunchKernelGGL((lstm_persistent_split_kernel<NB, NCH, HARD, STAMP>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
   MS_LAUNCH_CHECK();
