@@ -2,7 +2,7 @@
 """Randomised soak on the GPU box: many small seeded cases of the index-producing paths against the numpy oracle
 (CTC prefix beam search with separators / word weights / a toy LM, RNN-T greedy + beam, CTC greedy), plus ragged
 LSTM / GRU layers against the oracle within 1e-4.  Prints one line per family; exits non-zero on the first mismatch.
-    python tests/soak.py [seconds per family, default 40]"""
+    python tests/soak.py [seconds per family, default 40] [first seed, default 0]"""
 import os
 import sys
 import time
@@ -15,12 +15,13 @@ from oracle import ds_oracle as O  # noqa: E402
 from oracle import rnnt_oracle as RO  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 
 
 def family(name, one_case):
     t0, n = time.time(), 0
     while time.time() - t0 < budget:
-        one_case(n)
+        one_case(seed0 + n)
         n += 1
     print(f"{name:28s} {n:5d} cases ok", flush=True)
 
