@@ -5,7 +5,8 @@
 // The whole decode of a batch is ONE host call that enqueues a fixed launch sequence per frame and never reads anything
 // back: hypothesis lists, the prefix trie, the predictor-state pool and the emission lists all live in the caller's
 // workspace.  Per frame and emission round:
-//   joint_slots_kernel   log P(. | frame t, hypothesis) for every live hypothesis row (one workgroup per row)
+//   joint_slots_kernel   log P(. | frame t, hypothesis) for every live hypothesis row (one workgroup per row); a row whose
+//                        predictor output is fresh adds the pred_proj GEMM's K-slice partial sums itself and commits them
 //   beam_round_kernel    per utterance: blank transitions merge into the next frame's set B (same prefix = same trie node,
 //                        float32 scores joined by logaddexp), the beam_width best label extensions become the live set
 //   greedy_round_kernel  per utterance: argmax; blank ends the frame, a label is emitted
@@ -173,42 +174,90 @@ __global__ void lstm_cell_kernel(const float* __restrict__ gates, const int32_t*
   }
 }
 
-// adds the K-slice partial sums of the pred_proj GEMM (slice order) into the destination slot's row
-__global__ void commit_pp_kernel(const float* __restrict__ pp_tmp, const int32_t* __restrict__ ext_dst, float* __restrict__ pp,
-                                 int J, int R) {
-  const int r = blockIdx.x, dst = ext_dst[r];
-  if (dst < 0) return;
-  const size_t part = (size_t)R * J;
-  for (int k = threadIdx.x; k < J; k += blockDim.x) {
-    float v = pp_tmp[(size_t)r * J + k];
-#pragma unroll
-    for (int z = 1; z < KSPLIT; ++z) v += pp_tmp[z * part + (size_t)r * J + k];
-    pp[(size_t)dst * J + k] = v;
-  }
-}
-
 // log_softmax(W_out . tanh(enc_p[t, i] + pp[slot]) + b_out) for hypothesis row r = i*w + j, if it is live.
+// A row whose predictor state was requested by the previous round (ext_dst[r] >= 0) finds its projected predictor
+// output as KSPLIT partial sums in pp_tmp[.][r]: they are added here in slice order and the sum is also stored in
+// pp[slot] (the copy that survives the frame), which used to be a kernel of its own.
 __global__ __launch_bounds__(256) void joint_slots_kernel(const float* __restrict__ enc_p, const int32_t* __restrict__ lens,
-                                                          const float* __restrict__ pp, const int32_t* __restrict__ A_slot,
+                                                          float* __restrict__ pp, const float* __restrict__ pp_tmp,
+                                                          const int32_t* __restrict__ ext_dst,
+                                                          const int32_t* __restrict__ A_slot,
                                                           const int32_t* __restrict__ A_cnt, const float* __restrict__ w_out,
                                                           const float* __restrict__ b_out, float* __restrict__ logp, int t,
-                                                          int N, int w, int J, int V1) {
+                                                          int N, int w, int J, int V1, int R) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* z = smem;
   float* lg = smem + J;
   const int r = blockIdx.x, i = r / w, j = r - i * w;
-  // three independent loads (one memory round trip), then the test: these words were written by the previous kernel on
-  // another XCD, every dependent global load here costs ~2 us
-  const int len_i = lens[i], cnt_i = A_cnt[i], slot = A_slot[r];
-  if (t >= len_i || j >= cnt_i) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // four independent loads (one memory round trip), then the test: these words were written by the previous kernel on
+  // another XCD, every dependent global load here costs ~2 us
+  const int len_i = lens[i], cnt_i = A_cnt[i], slot = A_slot[r], fresh = ext_dst[r];
+  // Everything that does not depend on those words is requested before they are looked at: this wave's W_out rows
+  // (symbols v = wave, wave + 4, ...) and the frame's encoder projection.
+  constexpr int KMAX = 8, VMAX = 8;  // register tile: J <= 512, V1 <= 32
+  const bool reg_tile = J <= 64 * KMAX && V1 <= 4 * VMAX;
+  float wreg[KMAX][VMAX];
+  if (reg_tile) {
+#pragma unroll
+    for (int kk = 0; kk < KMAX; ++kk)
+#pragma unroll
+      for (int vi = 0; vi < VMAX; ++vi) {
+        const int k = lane + 64 * kk, v = wave + 4 * vi;
+        wreg[kk][vi] = (k < J && v < V1) ? w_out[(size_t)v * J + k] : 0.f;
+      }
+  }
   const float* e = enc_p + ((size_t)t * N + i) * J;
-  const float* p = pp + (size_t)slot * J;
-  for (int k = tid; k < J; k += 256) z[k] = tanhf(e[k] + p[k]);
+  float ereg[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool e_tile = J <= 1024;
+  if (e_tile) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (tid + 256 * m < J) ereg[m] = e[tid + 256 * m];
+  }
+  if (t >= len_i || j >= cnt_i) return;
+  float* p = pp + (size_t)slot * J;
+  const size_t part = (size_t)R * J;
+  auto pred_term = [&](int k) {
+    if (fresh < 0) return p[k];
+    float pv = pp_tmp[(size_t)r * J + k];
+#pragma unroll
+    for (int zz = 1; zz < KSPLIT; ++zz) pv += pp_tmp[zz * part + (size_t)r * J + k];
+    p[k] = pv;
+    return pv;
+  };
+  if (e_tile) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int k = tid + 256 * m;
+      if (k < J) z[k] = tanhf(ereg[m] + pred_term(k));
+    }
+  } else {
+    for (int k = tid; k < J; k += 256) z[k] = tanhf(e[k] + pred_term(k));
+  }
   __syncthreads();
-  // each wave owns symbols v = wave, wave + 4, ...; for V1 <= 64 their dot products run side by side so the loads
-  // of the W_out rows are independent and pipeline (a loop over v pays one L2 round trip per symbol)
-  if (V1 <= 64) {
+  if (reg_tile) {
+    float acc[VMAX];
+#pragma unroll
+    for (int vi = 0; vi < VMAX; ++vi) acc[vi] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KMAX; ++kk) {
+      const int k = lane + 64 * kk;
+      const float zk = k < J ? z[k] : 0.f;
+#pragma unroll
+      for (int vi = 0; vi < VMAX; ++vi) acc[vi] += wreg[kk][vi] * zk;
+    }
+#pragma unroll
+    for (int vi = 0; vi < VMAX; ++vi) {
+      const int v = wave + 4 * vi;
+      if (v < V1) {
+        const float tot = wsum(acc[vi]);
+        if (lane == 0) lg[v] = tot + (b_out ? b_out[v] : 0.f);
+      }
+    }
+  } else if (V1 <= 64) {
+    // each wave owns symbols v = wave, wave + 4, ...; their dot products run side by side so the loads of the W_out
+    // rows are independent and pipeline (a loop over v pays one L2 round trip per symbol)
     float acc[16];
 #pragma unroll
     for (int vi = 0; vi < 16; ++vi) acc[vi] = 0.f;
@@ -243,10 +292,10 @@ __global__ __launch_bounds__(256) void joint_slots_kernel(const float* __restric
     for (int v = lane; v < V1; v += 64) m = fmaxf(m, lg[v]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    float s = 0.f;
-    for (int v = lane; v < V1; v += 64) s += expf(lg[v] - m);
-    s = wsum(s);
-    const float lz = logf(s) + m;
+    float sum = 0.f;
+    for (int v = lane; v < V1; v += 64) sum += expf(lg[v] - m);
+    sum = wsum(sum);
+    const float lz = logf(sum) + m;
     for (int v = lane; v < V1; v += 64) logp[(size_t)r * V1 + v] = lg[v] - lz;
   }
 }
@@ -562,6 +611,7 @@ struct Net {
 };
 
 // One prediction-network step for the R request rows described by ext_label / ext_src / ext_dst.
+// The pred_proj GEMM leaves its K-slice partial sums in pp_tmp; joint_slots_kernel adds and commits them.
 int predictor_step(const Net& n, const DecLayout& W, char* ws, hipStream_t s) {
   const int R = W.R, H = n.H, L = n.L;
   int32_t* ext_label = (int32_t*)(ws + W.ext_label);
@@ -584,12 +634,7 @@ int predictor_step(const Net& n, const DecLayout& W, char* ws, hipStream_t s) {
                        R);
     MS_LAUNCH_CHECK();
   }
-  int rc = ms::linear_splitk_launch(htop, n.w_pred, nullptr, (float*)(ws + W.pp_tmp), R, H, n.J, KSPLIT, s);
-  if (rc != MS_OK) return rc;
-  hipLaunchKernelGGL(commit_pp_kernel, dim3(R), dim3(256), 0, s, (const float*)(ws + W.pp_tmp), ext_dst, (float*)(ws + W.pp),
-                     n.J, R);
-  MS_LAUNCH_CHECK();
-  return MS_OK;
+  return ms::linear_splitk_launch(htop, n.w_pred, nullptr, (float*)(ws + W.pp_tmp), R, H, n.J, KSPLIT, s);
 }
 
 }  // namespace
@@ -643,12 +688,14 @@ extern "C" int ms_rnnt_decode(const float* enc_p, const int32_t* lens, const flo
     MS_LAUNCH_CHECK();
     int rc = predictor_step(net, W, ws, s);
     if (rc != MS_OK) return rc;
+    const float* pp_tmp = (const float*)(ws + W.pp_tmp);
+    const int32_t* ext_dst = (const int32_t*)(ws + W.ext_dst);
     for (int t = 0; t < T; ++t) {
       hipLaunchKernelGGL(greedy_frame_start_kernel, dim3(ms::cdiv(N, 64)), dim3(64), 0, s, lens, live, N, t);
       MS_LAUNCH_CHECK();
       for (int v = 0; v < max_symbols; ++v) {
-        hipLaunchKernelGGL(joint_slots_kernel, dim3(R), dim3(256), joint_lds, s, enc_p, lens, pp, A_slot, live, w_out, b_out,
-                           logp, t, N, 1, J, V1);
+        hipLaunchKernelGGL(joint_slots_kernel, dim3(R), dim3(256), joint_lds, s, enc_p, lens, pp, pp_tmp, ext_dst, A_slot,
+                           live, w_out, b_out, logp, t, N, 1, J, V1, R);
         MS_LAUNCH_CHECK();
         hipLaunchKernelGGL(greedy_round_kernel, dim3(N), dim3(64), 0, s, logp, live, out_idx, out_cnt,
                            (int32_t*)(ws + W.ext_label), (int32_t*)(ws + W.ext_src), (int32_t*)(ws + W.ext_dst), V1, V,
@@ -691,12 +738,13 @@ extern "C" int ms_rnnt_decode(const float* enc_p, const int32_t* lens, const flo
   MS_LAUNCH_CHECK();
   int rc = predictor_step(net, W, ws, s);
   if (rc != MS_OK) return rc;
+  const float* pp_tmp = (const float*)(ws + W.pp_tmp);
   const size_t cand_lds = (size_t)w * V1 * 4;
   for (int t = 0; t < T; ++t) {
     for (int v = 0; v < max_symbols; ++v) {
       const int last = v == max_symbols - 1;
-      hipLaunchKernelGGL(joint_slots_kernel, dim3(R), dim3(256), joint_lds, s, enc_p, lens, pp, A_slot, A_cnt, w_out, b_out,
-                         logp, t, N, w, J, V1);
+      hipLaunchKernelGGL(joint_slots_kernel, dim3(R), dim3(256), joint_lds, s, enc_p, lens, pp, pp_tmp, p.ext_dst, A_slot, A_cnt,
+                         w_out, b_out, logp, t, N, w, J, V1, R);
       MS_LAUNCH_CHECK();
       hipLaunchKernelGGL(beam_round_kernel, dim3(N), dim3(256), cand_lds, s, p, t, 2 + v, v == 0, last);
       MS_LAUNCH_CHECK();

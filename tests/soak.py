@@ -58,6 +58,7 @@ def greedy_case(seed):
 
 
 _rnnt = {}
+_ties = []   # RNN-T beam cases decided by a score difference of a few ulp (reported, not failed)
 
 
 def rnnt_case(seed):
@@ -76,9 +77,15 @@ def rnnt_case(seed):
     lens = np.sort(rng.integers(0, T_ + 1, size=N))[::-1].copy()
     lens[0] = T_
     w, ms = int(rng.integers(1, 9)), int(rng.integers(1, 4))
-    got = RNNTBeamDecoder(pred, joint, beam_width=w, max_symbols=ms)(torch.from_numpy(enc), torch.from_numpy(lens))
-    want, _ = RO.beam_decode(enc, lens, psd, jsd, 64, 2, V, w, ms)
-    assert got == want, ("rnnt beam", seed, got, want)
+    dec = RNNTBeamDecoder(pred, joint, beam_width=w, max_symbols=ms)
+    got = dec(torch.from_numpy(enc), torch.from_numpy(lens))
+    want, want_scores = RO.beam_decode(enc, lens, psd, jsd, 64, 2, V, w, ms)
+    if got != want:
+        # The transducer's matrix products are summed in a different order on the device (MFMA k-order, K slices) than
+        # in numpy's BLAS, so two hypotheses whose total scores differ by a few ulp may swap.  Anything else is a bug.
+        for g, x, gs, xs in zip(got, want, dec.last_scores, want_scores):
+            assert g == x or abs(float(gs) - float(xs)) <= 4 * 1.2e-7 * max(1.0, abs(float(xs))), ("rnnt beam", seed, got, want)
+        _ties.append(seed)
     got = RNNTGreedyDecoder(pred, joint, max_symbols=ms)(torch.from_numpy(enc), torch.from_numpy(lens))
     assert got == RO.greedy_decode(enc, lens, psd, jsd, 64, 2, V, ms), ("rnnt greedy", seed)
 
@@ -162,5 +169,7 @@ family("front-end vs oracle", frontend_case)
 family("ctc beam vs oracle", beam_case)
 family("ctc greedy vs oracle", greedy_case)
 family("rnn-t greedy+beam vs oracle", rnnt_case)
+if _ties:
+    print(f"  rnn-t beam: {len(_ties)} case(s) decided by a <= 4 ulp score difference (summation order): seeds {_ties[:8]}", flush=True)
 family("lstm/gru/rnn vs oracle", rnn_case)
 print("soak ok")
