@@ -72,6 +72,13 @@ bool use_fast(int cell, int H, int ndir) {
 bool want_split() { return ms::precision_mode() != ms::PREC_F32; }
 bool use_split(int cell, int H, int ndir) { return use_fast(cell, H, ndir) && want_split() && H % 64 == 0; }
 bool two_stream_shape(int H) { return H == 256 || H == 512 || H == 768 || H == 1024; }
+// MS_PRECISION=f32 on the two-stream shapes: float32-MFMA two-stream kernel with register-resident W_hh; h crosses
+// workgroups with its mantissa LSB used as the epoch tag (MS_LSTM_F32_ONE_STREAM=1 keeps the one-stream LDS-weights
+// kernel, whose exchange is bit-exact)
+bool use_f32x2(int cell, int H, int ndir) {
+  static const bool off = getenv("MS_LSTM_F32_ONE_STREAM") && getenv("MS_LSTM_F32_ONE_STREAM")[0] == '1';
+  return !off && use_fast(cell, H, ndir) && !want_split() && two_stream_shape(H);
+}
 // MS_PRECISION=fp16: single-pass fp16 operands, only on the two-stream kernel's shapes (elsewhere bf16x3)
 bool use_f16(int cell, int H, int ndir) {
   return ms::precision_mode() == ms::PREC_F16 && use_split(cell, H, ndir) && two_stream_shape(H);
@@ -125,7 +132,7 @@ PackLayout pack_layout(int cell, int In, int H, int ndir) {
 }
 
 struct WsLayout {
-  size_t status, flags, xproj, hx, state_h, state_c, dbg, xsplit, total;
+  size_t status, flags, xproj, hx, hx_bytes, state_h, state_c, dbg, xsplit, total;
 };
 WsLayout ws_layout(int cell, int T, int N, int H, int ndir, int In) {
   const size_t GH = (size_t)gates_of(cell) * H;
@@ -136,7 +143,10 @@ WsLayout ws_layout(int cell, int T, int N, int H, int ndir, int In) {
   L.flags = o; o += ms::align_up((size_t)ndir * std::max(H / 8, 1) * sizeof(unsigned), 256);
   L.xproj = o; o += ms::align_up((size_t)T * N * ndir * GH * sizeof(float), 256);
   // two slots per (stream, plane) by default; the two-stream kernel may use a ring of 2^lstm_ring_shift() slots
-  L.hx = o; o += ms::align_up(((size_t)ndir * 2 * H * std::min(npad, 64) * sizeof(float)) << (lstm_ring_shift() - 1), 256);
+  // (the float32 two-stream kernel: ndir * 2 streams * 2 slots * 16 rows * H floats = the same ndir * 256 * H bytes)
+  L.hx = o;
+  L.hx_bytes = ms::align_up(((size_t)ndir * 2 * H * std::min(npad, 64) * sizeof(float)) << (lstm_ring_shift() - 1), 256);
+  o += L.hx_bytes;
   L.state_h = o; o += ms::align_up((size_t)2 * ndir * N * H * sizeof(float), 256);
   L.state_c = o; o += ms::align_up((size_t)ndir * N * H * sizeof(float), 256);
   L.dbg = o; o += ms::align_up((size_t)ndir * std::max(H / 8, 1) * 8 * sizeof(unsigned long long), 256);
@@ -1250,6 +1260,201 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
 }
 
 
+// ------------------------------------------------------------------------------------------------ persistent LSTM, float32 MFMA, two streams
+//
+// MS_PRECISION=f32 on the two-stream shapes.  The same decomposition as lstm_persistent_split2_kernel -- 8 units per
+// workgroup, each wave one K-quarter, two interleaved streams of 16 batch rows -- with every product in float32:
+// v_mfma_f32_16x16x4_f32 (16 batch rows x 16 gate columns x 4 k, a k-ordered fmaf chain).  A wave's K-quarter x 32 gate
+// columns of W_hh is 32 * H / 4 floats = 128 VGPRs per lane at H = 1024 and stays in registers for the whole sequence
+// (the one-stream kernel above re-reads it from LDS every step and waits for epoch flags before it may load h).
+// h is exchanged as float32 whose mantissa LSB carries the 1-bit epoch tag -- the only place where this mode is not
+// bit-faithful float32: the copy of h that OTHER workgroups multiply is off by at most one ulp (2^-24 relative; each
+// workgroup's own state, the outputs and h_n / c_n are untouched).  Full-size config-2 logits: max error 3.9e-8 against
+// the reference, 3.4e-8 with the exact exchange of the one-stream kernel (MS_LSTM_F32_ONE_STREAM=1).  An untagged
+// alternative was built and measured first: 8-byte {value, step} packets double the bytes every CU pulls per step
+// (128 KB per stream-step at ~65 GB/s) and ran 14 % SLOWER than the one-stream kernel; with 4-byte tagged elements
+// the step drops from 8.2 to 5.9 us (2.97 vs 4.13 ms per layer, 75 % of the algorithmic roofline).
+// Element layout per (direction, stream, slot): [k/16][k%4][row 16][(k%16)/4] floats -- lane (row = lane & 15,
+// kq = lane >> 4) finds the A operands of four consecutive MFMAs (k = 16g + 4j + kq, j = 0..3) in one 16-byte load.
+// Slot s & 1 is read by step s; its elements carry LSB ((s >> 1) & 1) ^ 1, so consecutive uses of a slot alternate and
+// the zero-filled buffer reads as "not yet written".
+
+// dst[d][j][wave][g][c][lane][e] = w_hh[gate*H + 8j + u][wave*H/4 + 16g + 4e + (lane >> 4)],  gate*8 + u = 16c + (lane & 15)
+__global__ void pack_whh_f32x2_kernel(const float* __restrict__ w, float* __restrict__ dst, int H) {
+  const size_t total = (size_t)4 * H * H;
+  const int G = H / 64;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = i & 3, lane = (i >> 2) & 63, c = (i >> 8) & 1;
+    const size_t rest = i >> 9;
+    const int g = rest % G, wave = (rest / G) & 3;
+    const int j = (int)(rest / G / 4);
+    const int r = 16 * c + (lane & 15), gate = r >> 3, u = r & 7;
+    const int k = wave * (H / 4) + 16 * g + 4 * e + (lane >> 4);
+    dst[i] = w[(size_t)(gate * H + 8 * j + u) * H + k];
+  }
+}
+
+template <int G, bool HARD>
+__global__ __launch_bounds__(256, 1) void lstm_persistent_f32x2_kernel(LstmP p) {
+  constexpr int H = 64 * G;
+  constexpr int RED2 = 4 * 16 * RED_STRIDE;
+  constexpr int SLOT = H * 16 * 4;   // bytes of one (stream, slot): H x 16 floats
+  constexpr int STREAM = 2 * SLOT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* red = smem;  // [stream][4 waves][16 rows][RED_STRIDE]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q = lane >> 4;
+  const int d = blockIdx.x / p.J, j = blockIdx.x % p.J;
+  const int nl = (tid >> 3) & 15, u = tid & 7;  // cell threads are waves 0 and 1
+  const int unit = 8 * j + u;
+  const int N = p.N;
+
+  f32x4 w0[G], w1[G];
+  {
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.whh) + ((((size_t)d * p.J + j) * 4 + wave) * G * 2) * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      w0[g] = wsrc[(g * 2 + 0) * 64];
+      w1[g] = wsrc[(g * 2 + 1) * 64];
+    }
+  }
+
+  char* hx_d = reinterpret_cast<char*>(p.hx) + (size_t)d * 2 * STREAM;
+  const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx_d, 0, 2 * STREAM, 0x00020000);
+  const int pk_off = (((unit >> 4) * 4 + (unit & 3)) * 16 + nl) * 16 + ((unit >> 2) & 3) * 4;  // this thread's element
+  auto publish = [&](float hval, unsigned tag, int off) {
+    __builtin_amdgcn_raw_buffer_store_b32((__float_as_uint(hval) & ~1u) | tag, hx_rsrc, off, 0, /*aux: sc1*/ 16);
+  };
+
+  float c[2] = {0.f, 0.f}, h[2] = {0.f, 0.f};
+  int len_n[2] = {0, 0};
+  if (wave < 2) {
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      const int n = sg * 16 + nl;
+      const bool valid = n < N;
+      const size_t sidx = ((size_t)d * p.N_total + p.n_base + n) * H + unit;
+      h[sg] = (valid && p.h0) ? p.h0[sidx] : 0.f;
+      c[sg] = (valid && p.c0) ? p.c0[sidx] : 0.f;
+      len_n[sg] = valid ? (p.lens ? p.lens[p.n_base + n] : p.steps) : 0;
+      publish(h[sg], 1u, sg * STREAM + pk_off);   // slot 0, read by step 0 with tag bit 1
+    }
+  }
+  __syncthreads();
+
+  const int xcols = p.ndir * 4 * H;
+  bool alive = true;
+
+  for (int s = 0; s < p.steps; ++s) {
+    const int t = d ? (p.steps - 1 - s) : s;
+    const unsigned tag = ((unsigned)(s >> 1) & 1u) ^ 1u;          // LSB of every element this step reads (slot s & 1)
+    const unsigned em = tag ? 0xFFFFFFFFu : 0u;
+    const unsigned wtag = ((unsigned)((s + 1) >> 1) & 1u) ^ 1u;
+    const int rslot = (s & 1) * SLOT, wslot = ((s + 1) & 1) * SLOT;
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      float xg[4] = {0.f, 0.f, 0.f, 0.f};
+      const int n = sg * 16 + nl;
+      if (wave < 2 && n < N) {
+        const float* xp = p.xproj + ((size_t)t * p.N_total + p.n_base + n) * xcols + d * 4 * H + j * 32 + u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xg[g] = xp[g * 8];
+      }
+
+      // ---- h_{t-1} of this stream: all G k-groups (16 k each) of the wave's K-quarter requested at once (8 G VGPRs);
+      // the first request in straight-line code, the loop only re-requests (see lstm_persistent_split2_kernel)
+      const int base = sg * STREAM + rslot + (wave * G * 4 * 16 + q * 16 + c16) * 16;
+      u32x4 pa[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        pa[g] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, base + g * 1024, 0, /*aux: sc1*/ 16);
+      }
+      {
+        const unsigned long long t_wait0 = wall_clock64();
+        unsigned spins = 0;
+        for (;;) {
+          unsigned bad = 0;
+#pragma unroll
+          for (int g = 0; g < G; ++g) bad |= (pa[g][0] ^ em) | (pa[g][1] ^ em) | (pa[g][2] ^ em) | (pa[g][3] ^ em);
+          if (!alive || !__any((bad & 1u) != 0)) break;
+          if ((++spins & 63u) == 0) {
+            const unsigned dead = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (dead != 0 || wall_clock64() - t_wait0 > SPIN_LIMIT_TICKS) {
+              if (lane == 0) __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              alive = false;
+              break;
+            }
+          }
+          for (int z = 0; z < p.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            pa[g] = load_sc1_u128(hx_rsrc, base + g * 1024);
+          }
+        }
+      }
+      f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float a0 = __uint_as_float(pa[g][0]), a1 = __uint_as_float(pa[g][1]);
+        const float a2 = __uint_as_float(pa[g][2]), a3 = __uint_as_float(pa[g][3]);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, w0[g][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, w1[g][0], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, w0[g][1], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, w1[g][1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, w0[g][2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, w1[g][2], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, w0[g][3], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, w1[g][3], acc1, 0, 0, 0);
+      }
+
+      // ---- reduce the 4 K-quarters (LDS, double-buffered by stream: one barrier), cell update on waves 0/1, publish
+      float* redb = red + sg * RED2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        redb[(wave * 16 + 4 * q + i) * RED_STRIDE + c16] = acc0[i];
+        redb[(wave * 16 + 4 * q + i) * RED_STRIDE + 16 + c16] = acc1[i];
+      }
+      __syncthreads();
+      if (wave < 2) {
+        float gsum[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v = xg[g];
+#pragma unroll
+          for (int w2 = 0; w2 < 4; ++w2) v += redb[(w2 * 16 + nl) * RED_STRIDE + g * 8 + u];
+          gsum[g] = v;
+        }
+        float cnew, hnew;
+        if (HARD) {
+          cnew = clamp01(0.2f * gsum[1] + 0.5f) * c[sg] + clamp01(0.2f * gsum[0] + 0.5f) * clamp11(gsum[2]);
+          hnew = clamp01(0.2f * gsum[3] + 0.5f) * clamp11(cnew);
+        } else {
+          cnew = fast_sigmoid(gsum[1]) * c[sg] + fast_sigmoid(gsum[0]) * fast_tanh(gsum[2]);
+          hnew = fast_sigmoid(gsum[3]) * fast_tanh(cnew);
+        }
+        const bool active = t < len_n[sg];
+        c[sg] = active ? cnew : c[sg];
+        h[sg] = active ? hnew : h[sg];
+        publish(h[sg], wtag, sg * STREAM + wslot + pk_off);
+        if (n < N) p.out[((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit] = active ? hnew : 0.f;
+      }
+    }
+  }
+  if (wave < 2) {
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      const int n = sg * 16 + nl;
+      if (n < N) {
+        const size_t sidx = ((size_t)d * p.N_total + p.n_base + n) * H + unit;
+        p.hn[sidx] = h[sg];
+        p.cn[sidx] = c[sg];
+      }
+    }
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------------ persistent GRU, split-bf16
 //
 // The reference's SHIPPED DS2 config is 3 x GRU-2560: 78.6 MB of f32 recurrent weights per layer, far beyond the L2, so
@@ -1567,6 +1772,8 @@ extern "C" int ms_rnn_pack(int cell, int In, int H, int ndir, const float* const
         else
           hipLaunchKernelGGL(pack_whh_split_kernel<false>, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d],
                              (unsigned short*)whh_d, H);
+      else if (use_f32x2(cell, H, ndir))
+        hipLaunchKernelGGL(pack_whh_f32x2_kernel, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d], whh_d, H);
       else
         hipLaunchKernelGGL(pack_whh_fast_kernel, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d], whh_d, H);
       hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH)), dim3(256), 0, stream, (const float*)nullptr, bhh_d,
@@ -1636,6 +1843,23 @@ static int launch_split2(const LstmP& p, hipStream_t stream) {
   hipLaunchKernelGGL((lstm_persistent_split2_kernel<KS, HARD, STAMP, F16>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
   MS_LAUNCH_CHECK();
   return MS_OK;
+}
+
+template <int G, bool HARD>
+static int launch_f32x2(const LstmP& p, hipStream_t stream) {
+  const size_t lds = (size_t)RED_FLOATS * sizeof(float);
+  hipLaunchKernelGGL((lstm_persistent_f32x2_kernel<G, HARD>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}
+
+static int launch_f32x2_any(const LstmP& p, bool hard, hipStream_t stream) {
+  switch (p.H) {
+    case 256: return hard ? launch_f32x2<4, true>(p, stream) : launch_f32x2<4, false>(p, stream);
+    case 512: return hard ? launch_f32x2<8, true>(p, stream) : launch_f32x2<8, false>(p, stream);
+    case 768: return hard ? launch_f32x2<12, true>(p, stream) : launch_f32x2<12, false>(p, stream);
+    default: return hard ? launch_f32x2<16, true>(p, stream) : launch_f32x2<16, false>(p, stream);
+  }
 }
 
 static int launch_split2_any(const LstmP& p, bool hard, bool stamps, bool f16, hipStream_t stream) {
@@ -1713,7 +1937,8 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
   if (fast) {
     // batch groups of <= 64 sequences, one persistent launch each (stream-ordered; the epoch
     // flags are re-zeroed in between, the status word is kept so any time-out is reported)
-    const int group = (use_split(cell, H, ndir) && two_stream_shape(H)) ? 32 : 64;
+    const bool f32x2 = use_f32x2(cell, H, ndir);
+    const int group = ((use_split(cell, H, ndir) && two_stream_shape(H)) || f32x2) ? 32 : 64;
     for (int n0 = 0; n0 < N; n0 += group) {
       const int ng = std::min(group, N - n0);
       if (n0 > 0) MS_HIP(hipMemsetAsync(ws + W.flags, 0, W.xproj - W.flags, stream));
@@ -1760,6 +1985,13 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
         } else {
           rc = hard_ ? launch_split<2, 0, true>(p, stream) : launch_split<2, 0, false>(p, stream);
         }
+        if (rc != MS_OK) return rc;
+        continue;
+      }
+      if (f32x2) {
+        // the first tag expected in either slot is 1: a zero-filled buffer reads as "not yet written" (also between groups)
+        MS_HIP(hipMemsetAsync(ws + W.hx, 0, W.hx_bytes, stream));
+        rc = launch_f32x2_any(p, hard, stream);
         if (rc != MS_OK) return rc;
         continue;
       }

@@ -797,8 +797,10 @@ def test_rnnt_decode_validation():
 
 
 def test_exact_f32_mode_in_subprocess():
-    """MS_PRECISION=f32 is read once per process, so the exact-f32 persistent kernel and GEMM at
-    the config-2 width are exercised in one child process (H=1024 and H=256, ragged, 2 layers)."""
+    """MS_PRECISION=f32 is read once per process, so the exact-f32 kernels are exercised in one child process: the
+    two-stream register-resident kernel on each of its shapes (H = 1024 / 768 / 512 / 256; ragged, 2 layers, batch groups
+    of 32 + remainder, 37 steps through both packet slots, a given initial state, the hard cell) and the one-stream
+    kernel on a shape outside that set (H = 96)."""
     import os
     import subprocess
     import sys
@@ -807,17 +809,33 @@ import sys, numpy as np, torch
 sys.path.insert(0, %r)
 from myrtlespeech_amd.model.rnn import RNN, RNNType
 from oracle import ds_oracle as O
-for H, N, T_ in ((1024, 32, 5), (256, 40, 6)):
+from myrtlespeech_amd.model.hard_lstm import HardLSTM
+for H, N, T_, bidir, with_hx in ((1024, 32, 5, True, False), (256, 40, 6, True, False), (512, 33, 9, False, True),
+                                 (768, 16, 37, True, True), (96, 7, 5, True, False)):
     torch.manual_seed(H)
-    m = RNN(RNNType.LSTM, 64, H, num_layers=2, bidirectional=True, forget_gate_bias=1.0).eval()
+    m = RNN(RNNType.LSTM, 64, H, num_layers=2, bidirectional=bidir, forget_gate_bias=1.0).eval()
     rng = np.random.default_rng(H)
     lens = np.sort(rng.integers(1, T_ + 1, size=N))[::-1].copy(); lens[0] = T_
     x = rng.normal(size=(T_, N, 64)).astype(np.float32)
-    (out, _), (hn, cn) = m((torch.from_numpy(x), torch.from_numpy(lens)))
+    D = 2 if bidir else 1
+    hx = None
+    if with_hx:
+        hx = tuple((rng.normal(size=(2 * D, N, H)) * 0.5).astype(np.float32) for _ in range(2))
+    (out, _), (hn, cn) = m((torch.from_numpy(x), torch.from_numpy(lens)),
+                           None if hx is None else tuple(torch.from_numpy(a) for a in hx))
     sd = {k[4:]: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
-    want, (whn, wcn) = O.rnn_forward(O.LSTM, x, lens, sd, H, 2, True)
-    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(cn.cpu().numpy(), wcn, rtol=1e-5, atol=2e-6)
+    want, (whn, wcn) = O.rnn_forward(O.LSTM, x, lens, sd, H, 2, bidir, hx)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(hn.cpu().numpy(), whn, rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(cn.cpu().numpy(), wcn, rtol=1e-5, atol=3e-6)
+torch.manual_seed(9)
+m = HardLSTM(20, 256, num_layers=1, bidirectional=True, forget_gate_bias=1.0).eval()
+x = (np.random.default_rng(9).normal(size=(11, 35, 20)) * 2).astype(np.float32)
+(out, _), (hn, cn) = m((torch.from_numpy(x), torch.tensor([11] * 35)))
+sd = {k[len("rnn."):]: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+want, (whn, wcn) = O.hard_lstm_forward(x, sd, 256, 1, True)
+np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=3e-6)
+np.testing.assert_allclose(cn.cpu().numpy(), wcn, rtol=1e-5, atol=3e-6)
 print("f32 mode ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MS_PRECISION="f32")
