@@ -1276,8 +1276,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
 // the step drops from 8.2 to 5.9 us (2.97 vs 4.13 ms per layer, 75 % of the algorithmic roofline).
 // Element layout per (direction, stream, slot): [k/16][k%4][row 16][(k%16)/4] floats -- lane (row = lane & 15,
 // kq = lane >> 4) finds the A operands of four consecutive MFMAs (k = 16g + 4j + kq, j = 0..3) in one 16-byte load.
-// Slot s & 1 is read by step s; its elements carry LSB ((s >> 1) & 1) ^ 1, so consecutive uses of a slot alternate and
-// the zero-filled buffer reads as "not yet written".
+// Slots and tags follow the EpochClock above (sequence time, two slots); hx_init_kernel pre-sets every word of a slot to
+// the tag that is NOT the first one expected there.
 
 // dst[d][j][wave][g][c][lane][e] = w_hh[gate*H + 8j + u][wave*H/4 + 16g + 4e + (lane >> 4)],  gate*8 + u = 16c + (lane & 15)
 __global__ void pack_whh_f32x2_kernel(const float* __restrict__ w, float* __restrict__ dst, int H) {
@@ -1338,7 +1338,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_f32x2_kernel(LstmP p) 
       h[sg] = (valid && p.h0) ? p.h0[sidx] : 0.f;
       c[sg] = (valid && p.c0) ? p.c0[sidx] : 0.f;
       len_n[sg] = valid ? (p.lens ? p.lens[p.n_base + n] : p.steps) : 0;
-      publish(h[sg], 1u, sg * STREAM + pk_off);   // slot 0, read by step 0 with tag bit 1
+      publish(h[sg], epoch_tag0(d, p.steps), sg * STREAM + epoch_par0(d, p.steps) * SLOT + pk_off);   // read by the first step
     }
   }
   __syncthreads();
@@ -1348,10 +1348,11 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_f32x2_kernel(LstmP p) 
 
   for (int s = 0; s < p.steps; ++s) {
     const int t = d ? (p.steps - 1 - s) : s;
-    const unsigned tag = ((unsigned)(s >> 1) & 1u) ^ 1u;          // LSB of every element this step reads (slot s & 1)
-    const unsigned em = tag ? 0xFFFFFFFFu : 0u;
-    const unsigned wtag = ((unsigned)((s + 1) >> 1) & 1u) ^ 1u;
-    const int rslot = (s & 1) * SLOT, wslot = ((s + 1) & 1) * SLOT;
+    // the clock of the tags is the sequence time (see EpochClock): a sequence's outputs do not depend on the batch's length
+    const EpochClock ec = epoch_clock(d, s, p.steps);
+    const unsigned em = (ec.em & 1u) ? 0xFFFFFFFFu : 0u;      // LSB of every element this step reads
+    const unsigned wtag = ec.wtag;
+    const int rslot = ec.par * SLOT, wslot = ec.wpar * SLOT;
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg) {
       float xg[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1989,8 +1990,10 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
         continue;
       }
       if (f32x2) {
-        // the first tag expected in either slot is 1: a zero-filled buffer reads as "not yet written" (also between groups)
-        MS_HIP(hipMemsetAsync(ws + W.hx, 0, W.hx_bytes, stream));
+        // every word of every slot starts with the tag that is NOT the first one expected there (also between groups)
+        hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for((size_t)64 * H * ndir)), dim3(256), 0, stream,
+                           (unsigned*)(ws + W.hx), (size_t)64 * H, (size_t)16 * H, ndir, steps, 1);
+        MS_LAUNCH_CHECK();
         rc = launch_f32x2_any(p, hard, stream);
         if (rc != MS_OK) return rc;
         continue;

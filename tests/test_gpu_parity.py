@@ -828,6 +828,11 @@ for H, N, T_, bidir, with_hx in ((1024, 32, 5, True, False), (256, 40, 6, True, 
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=3e-6)
     np.testing.assert_allclose(hn.cpu().numpy(), whn, rtol=1e-5, atol=3e-6)
     np.testing.assert_allclose(cn.cpu().numpy(), wcn, rtol=1e-5, atol=3e-6)
+    if hx is None and (lens < T_).any():
+        # an utterance shard (shorter longest sequence => other launch step indices) reproduces the whole batch bit for bit
+        k0 = int(np.argmax(lens < T_)); t0 = int(lens[k0])
+        (out2, _), _ = m((torch.from_numpy(x[:t0, k0:].copy()), torch.from_numpy(lens[k0:].copy())))
+        assert np.array_equal(out.cpu().numpy()[:t0, k0:], out2.cpu().numpy()), ("shard", H)
 torch.manual_seed(9)
 m = HardLSTM(20, 256, num_layers=1, bidirectional=True, forget_gate_bias=1.0).eval()
 x = (np.random.default_rng(9).normal(size=(11, 35, 20)) * 2).astype(np.float32)
