@@ -17,6 +17,20 @@
  *   - return value: MS_OK or an MS_ERR_* code; ms_last_error() describes the
  *     last failure on the calling thread;
  *   - outputs are caller-allocated; nothing is freed or retained.
+ *
+ * Operand precision (environment variable MS_PRECISION, read once per process
+ * at the first launch; it selects kernels inside ms_rnn_pack / ms_rnn_layer_forward,
+ * ms_linear_split_forward and ms_maskconv_cl_*; packed weights are only valid for
+ * the mode they were packed in)
+ *   unset / "bf16x3"  every float32 operand of the large contractions is split into
+ *                     bf16 hi + lo and multiplied as hi*hi + lo*hi + hi*lo with float32
+ *                     accumulation (relative error ~2^-17 per product; full-size DS2
+ *                     logits within 2.5e-7 of the reference);
+ *   "f32"             float32 MFMA everywhere (3.9e-8); the two-stream LSTM hands h to the
+ *                     other workgroups with its mantissa LSB used as an epoch tag;
+ *   "fp16"            one fp16 pass (1.1e-5 on that network; relative, not a parity mode).
+ * Convolutions with few input channels, small GEMMs, CTC loss / gradient and the
+ * decoders are float32 in every mode.
  */
 #ifndef MS_HOTPATH_H
 #define MS_HOTPATH_H
