@@ -98,6 +98,21 @@ int ms_maskconv_cl_forward(const float* x, const int32_t* lens, const void* pack
                            int ST, int DF, int DT, int pad_f_l, int pad_t_l, int act, float act_lo, float act_hi,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* Single-channel MaskConv2d (Cin = 1, groups = 1, feature dilation 1, even feature stride; DS2's first convolution,
+ * cnn.py:445-483 with builders/deep_speech_2.py:198-203 kernel [41, 11] stride [2, 2]) as the same split-bf16 implicit
+ * GEMM: the KF input feature rows under an output feature row take the place of the input channels (padded to a
+ * multiple of 16), the KT time taps stay taps.  x is [N, 1, Fin, Tin]; the workspace holds its feature-contiguous bf16
+ * hi / lo planes [N, Tin, FP] with the SAME feature padding materialised; mask (t >= lens[n]) and time padding are load
+ * predicates; bias + clamp in the epilogue; y is [N, Cout, Fout, Tout] float32.  MS_ERR_UNSUPPORTED when the staged
+ * rows do not fit LDS (the caller then uses ms_maskconv_forward). */
+size_t ms_maskconv_fwin_packed_bytes(int Cout, int KF, int KT);
+int ms_maskconv_fwin_pack(const float* w, void* packed, int Cout, int KF, int KT, void* stream);
+size_t ms_maskconv_fwin_workspace_bytes(int N, int Tin, int KF, int SF, int Fout);
+int ms_maskconv_fwin_forward(const float* x, const int32_t* lens, const void* packed_w, const float* bias, float* y, int N,
+                             int Fin, int Tin, int Cout, int Fout, int Tout, int KF, int KT, int SF, int ST, int DT,
+                             int pad_f_l, int pad_t_l, int act, float act_lo, float act_hi, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* MaskConv1d with many input channels as im2col + split-bf16 GEMM (model/cnn.py:295-333, the conv1d flavour of the DS2
  * builder): x [N, Cin, Tin] -> y [N, Cout, Tout]; frames t >= lens[n] read as zero (cnn.py:280-293), pad_l zero
  * frames on the left (cnn.py:252-278); packed = ms_maskconv1d_gemm_pack of weight [Cout, Cin, KT]; bias may be NULL;

@@ -35,6 +35,10 @@ SIGNATURES = {
     "ms_maskconv_cl_pack": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ms_maskconv_cl_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ms_maskconv_cl_forward": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 16 + [c_float, c_float, _P, c_size_t, _P]),
+    "ms_maskconv_fwin_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ms_maskconv_fwin_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ms_maskconv_fwin_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "ms_maskconv_fwin_forward": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 14 + [c_float, c_float, _P, c_size_t, _P]),
     "ms_maskconv1d_gemm_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ms_maskconv1d_gemm_pack": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ms_maskconv1d_gemm_workspace_bytes": (c_size_t, [c_int] * 5),

@@ -36,6 +36,9 @@ struct ClP {
   int co_tiles;
   int act;
   float lo, hi;
+  // feature-window mode (single-channel input, ms_maskconv_fwin_*): the "channels" of output feature row fo are the
+  // KF input feature rows of its window, read from planes [N][Tin][FP] at element offset fo * SF (KF = 1 in this struct)
+  int win, FP;
 };
 
 __device__ __forceinline__ unsigned bf16b(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
@@ -97,21 +100,32 @@ __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned shor
 
   const int tin0 = t0 * p.ST - p.pad_t;
   const int ngran = p.KG * p.PW;  // granules per staged input row
+  const unsigned plane_bytes = p.win ? (unsigned)((size_t)p.N * p.Tin * p.FP * 2) : 0u;
+  const __amdgpu_buffer_rsrc_t xh_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xh), 0, plane_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xl_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xl), 0, plane_bytes, 0x00020000);
 
   for (int kf = 0; kf < p.KF; ++kf) {
     // ---- stage the two input rows this kf touches (masked, zero padded)
     for (int f = 0; f < CL_F; ++f) {
       const int fin = (fo0 + f) * p.SF - p.pad_f + kf * p.DF;
-      const bool frow = (fo0 + f) < p.Fout && fin >= 0 && fin < p.Fin;
-      const size_t rbase = ((size_t)n * p.Fin + (frow ? fin : 0)) * p.Tin;
+      const bool frow = (fo0 + f) < p.Fout && (p.win || (fin >= 0 && fin < p.Fin));
+      const size_t rbase = ((size_t)n * p.Fin + (frow && !p.win ? fin : 0)) * p.Tin;
       for (int i = tid; i < ngran; i += 256) {
         const int q = i / p.KG, kg = i - q * p.KG;  // frame-major so 4 lanes cover one frame's 64 B
         const int tin = tin0 + q;
         u32x4 vh = {0u, 0u, 0u, 0u}, vl = {0u, 0u, 0u, 0u};
         if (frow && tin >= 0 && tin < len) {
-          const size_t off = (rbase + tin) * p.Cin + kg * 8;
-          vh = *reinterpret_cast<const u32x4*>(xh + off);
-          if (!F16) vl = *reinterpret_cast<const u32x4*>(xl + off);
+          if (p.win) {
+            // window of output row fo: FP-strided frame, element offset fo * SF (even => 4-byte aligned 16-byte loads)
+            // (buffer loads: a 16-byte global load would be split into four dwords at this alignment)
+            const int boff = (int)((((size_t)n * p.Tin + tin) * p.FP + (size_t)(fo0 + f) * p.SF + kg * 8) * 2);
+            vh = __builtin_amdgcn_raw_buffer_load_b128(xh_rsrc, boff, 0, 0);
+            if (!F16) vl = __builtin_amdgcn_raw_buffer_load_b128(xl_rsrc, boff, 0, 0);
+          } else {
+            const size_t off = (rbase + tin) * p.Cin + kg * 8;
+            vh = *reinterpret_cast<const u32x4*>(xh + off);
+            if (!F16) vl = *reinterpret_cast<const u32x4*>(xl + off);
+          }
         }
         *reinterpret_cast<u32x4*>(Ph + f * row_bytes + (kg * p.PW + q) * 16) = vh;
         if (!F16) *reinterpret_cast<u32x4*>(Pl + f * row_bytes + (kg * p.PW + q) * 16) = vl;
@@ -207,7 +221,136 @@ __global__ void nchw_to_cl_split_kernel(const float* __restrict__ x, unsigned sh
   }
 }
 
+// single-channel input x [N][Fin][T] f32 -> bf16 hi / lo planes [N][T][FP], element j = feature j - pad (zeros outside)
+__global__ void ft_to_tf_split_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi,
+                                      unsigned short* __restrict__ lo, int Fin, int T, int FP, int pad, int f16) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int t0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+  const int tx = threadIdx.x, ty = threadIdx.y;  // (32, 8)
+  for (int i = ty; i < 32; i += 8) {
+    const int fidx = j0 + i - pad, t = t0 + tx;
+    tile[i][tx] = (fidx >= 0 && fidx < Fin && t < T) ? x[((size_t)n * Fin + fidx) * T + t] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, j = j0 + tx;
+    if (t < T && j < FP) {
+      const float v = tile[tx][i];
+      const size_t o = ((size_t)n * T + t) * FP + j;
+      if (f16) {
+        hi[o] = (unsigned short)f16b(v);
+      } else {
+        const unsigned h = bf16b(v);
+        hi[o] = (unsigned short)h;
+        lo[o] = (unsigned short)bf16b(v - __uint_as_float(h << 16));
+      }
+    }
+  }
+}
+
+// packed[plane][kt][kg][cout_pad][8] <- w[cout][0][kf = 8 kg + e][kt]  (zero for kf >= KF)
+__global__ void conv_fwin_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int Cout, int KF,
+                                      int KT, int KG, int cout_pad, int f16) {
+  const size_t plane = (size_t)KT * KG * cout_pad * 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = i & 7;
+    const int co = (i >> 3) % cout_pad;
+    const int kg = (i / ((size_t)8 * cout_pad)) % KG;
+    const int kt = i / ((size_t)8 * cout_pad * KG);
+    const int kf = kg * 8 + e;
+    float x = 0.f;
+    if (co < Cout && kf < KF) x = w[((size_t)co * KF + kf) * KT + kt];
+    if (f16) {
+      packed[i] = (unsigned short)f16b(x);
+      packed[plane + i] = 0;
+    } else {
+      const unsigned h = bf16b(x);
+      packed[i] = (unsigned short)h;
+      packed[plane + i] = (unsigned short)bf16b(x - __uint_as_float(h << 16));
+    }
+  }
+}
+
+inline int fwin_kfp(int KF) { return ms::cdiv(KF, 16) * 16; }
+inline int fwin_fp(int KF, int SF, int Fout) { return ms::cdiv((Fout - 1) * SF + fwin_kfp(KF), 32) * 32; }
+
 }  // namespace
+
+// ---- single-channel convolutions (DS2 conv1: 1 -> 32 channels, 41 x 11 taps) as the same split-bf16 implicit GEMM: the
+// KF feature rows under an output row play the role of the input channels (padded to a multiple of 16), the time taps
+// stay taps.  Input planes are [N][Tin][FP] (feature-contiguous, zero feature padding materialised).
+extern "C" size_t ms_maskconv_fwin_packed_bytes(int Cout, int KF, int KT) {
+  if (Cout <= 0 || KF <= 0 || KT <= 0) return 0;
+  return (size_t)2 * KT * (fwin_kfp(KF) / 8) * (ms::cdiv(Cout, 32) * 32) * 8 * sizeof(unsigned short);
+}
+
+extern "C" int ms_maskconv_fwin_pack(const float* w, void* packed, int Cout, int KF, int KT, void* stream) {
+  MS_REQUIRE(w && packed, "null pointer");
+  MS_REQUIRE(Cout > 0 && KF > 0 && KT > 0, "bad shape");
+  const int cout_pad = ms::cdiv(Cout, 32) * 32, KG = fwin_kfp(KF) / 8;
+  const size_t plane = (size_t)KT * KG * cout_pad * 8;
+  const int blocks = (int)std::min<size_t>((plane + 255) / 256, 2048);
+  hipLaunchKernelGGL(conv_fwin_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)packed, Cout,
+                     KF, KT, KG, cout_pad, ms::precision_mode() == ms::PREC_F16 ? 1 : 0);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}
+
+extern "C" size_t ms_maskconv_fwin_workspace_bytes(int N, int Tin, int KF, int SF, int Fout) {
+  if (N <= 0 || Tin <= 0 || KF <= 0 || SF <= 0 || Fout <= 0) return 0;
+  return ms::align_up((size_t)N * Tin * fwin_fp(KF, SF, Fout) * 4, 256);  // hi + lo planes
+}
+
+extern "C" int ms_maskconv_fwin_forward(const float* x, const int32_t* lens, const void* packed_w, const float* bias, float* y,
+                                        int N, int Fin, int Tin, int Cout, int Fout, int Tout, int KF, int KT, int SF, int ST,
+                                        int DT, int pad_f_l, int pad_t_l, int act, float act_lo, float act_hi, void* workspace,
+                                        size_t workspace_bytes, void* stream_) {
+  MS_REQUIRE(x && packed_w && y && workspace, "null pointer");
+  MS_REQUIRE(N > 0 && Fin > 0 && Tin > 0 && Cout > 0 && Fout > 0 && Tout > 0, "bad shape");
+  MS_REQUIRE(KF > 0 && KT > 0 && SF > 0 && ST > 0 && DT > 0 && pad_f_l >= 0 && pad_t_l >= 0, "bad kernel");
+  MS_REQUIRE(SF % 2 == 0, "feature stride must be even (4-byte aligned window loads)");
+  MS_REQUIRE(act == MS_ACT_NONE || act == MS_ACT_CLAMP, "bad act");
+  if (workspace_bytes < ms_maskconv_fwin_workspace_bytes(N, Tin, KF, SF, Fout)) {
+    ms::set_error("ms_maskconv_fwin_forward: workspace too small");
+    return MS_ERR_WORKSPACE;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  ClP p;
+  p.N = N; p.Cin = fwin_kfp(KF); p.Fin = 1; p.Tin = Tin; p.Cout = Cout; p.Fout = Fout; p.Tout = Tout; p.KF = 1; p.KT = KT;
+  p.SF = SF; p.ST = ST; p.DF = 1; p.DT = DT; p.pad_f = 0; p.pad_t = pad_t_l; p.KG = p.Cin / 8;
+  p.PW = (CL_T - 1) * ST + (KT - 1) * DT + 1;
+  p.co_tiles = ms::cdiv(Cout, 32);
+  p.act = act; p.lo = act_lo; p.hi = act_hi;
+  p.win = 1; p.FP = fwin_fp(KF, SF, Fout);
+  const size_t lds = (size_t)2 * CL_F * p.KG * p.PW * 16 + (size_t)2 * ((KT + 1) / 2) * p.KG * 32 * 16;
+  if (lds > 160 * 1024 || (long)N * p.co_tiles > 65535 || ms::cdiv(Fout, CL_F) > 65535 ||
+      (size_t)N * Tin * p.FP * 2 >= ((size_t)1 << 31)) {
+    ms::set_error("ms_maskconv_fwin_forward: shape outside the LDS / grid budget");
+    return MS_ERR_UNSUPPORTED;
+  }
+  static ms::DeviceOnce attr_once;
+  if (attr_once.need()) {
+    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_once.done();
+  }
+  unsigned short* xh = (unsigned short*)workspace;
+  unsigned short* xl = xh + (size_t)N * Tin * p.FP;
+  const bool f16 = ms::precision_mode() == ms::PREC_F16;
+  hipLaunchKernelGGL(ft_to_tf_split_kernel, dim3(ms::cdiv(Tin, 32), ms::cdiv(p.FP, 32), N), dim3(32, 8), 0, stream, x, xh, xl,
+                     Fin, Tin, p.FP, pad_f_l, f16 ? 1 : 0);
+  MS_LAUNCH_CHECK();
+  dim3 grid(ms::cdiv(Tout, CL_T), ms::cdiv(Fout, CL_F), N * p.co_tiles);
+  if (f16)
+    hipLaunchKernelGGL(maskconv_cl_kernel<true>, grid, dim3(256), lds, stream, xh, xl, lens, (const unsigned short*)packed_w,
+                       bias, y, p);
+  else
+    hipLaunchKernelGGL(maskconv_cl_kernel<false>, grid, dim3(256), lds, stream, xh, xl, lens, (const unsigned short*)packed_w,
+                       bias, y, p);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}
 
 extern "C" size_t ms_maskconv_cl_packed_bytes(int Cout, int Cin, int KF, int KT) {
   if (Cout <= 0 || Cin <= 0 || Cin % 16 || KF <= 0 || KT <= 0) return 0;
@@ -250,6 +393,7 @@ extern "C" int ms_maskconv_cl_forward(const float* x, const int32_t* lens, const
   p.PW = (CL_T - 1) * ST + (KT - 1) * DT + 1;
   p.co_tiles = ms::cdiv(Cout, 32);
   p.act = act; p.lo = act_lo; p.hi = act_hi;
+  p.win = 0; p.FP = 0;
   const size_t lds = (size_t)2 * CL_F * p.KG * p.PW * 16 + (size_t)2 * ((KT + 1) / 2) * p.KG * 32 * 16;
   if (lds > 160 * 1024 || (long)N * p.co_tiles > 65535 || ms::cdiv(Fout, CL_F) > 65535) {
     ms::set_error("ms_maskconv_cl_forward: shape outside the LDS / grid budget");

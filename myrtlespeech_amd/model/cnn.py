@@ -5,6 +5,7 @@ Same classes, constructor arguments, ``(acts, seq_lens)`` convention and
 HIP implicit-GEMM kernel (``csrc/conv.hip``) instead of mask + F.pad + cuDNN.
 """
 from enum import Enum
+import os
 from typing import List, Optional, Tuple, TypeVar, Union
 
 import torch
@@ -65,6 +66,19 @@ class _PackedFilters:
             w = _lib.f32c(weight.detach())
             _lib.check(lib.ms_maskconv_cl_pack(_lib.ptr(w), _lib.ptr(self.buf_cl), cout, cin, kf, kt, _lib.stream_ptr()),
                        "ms_maskconv_cl_pack")
+            self.key_cl = key
+        return self.buf_cl
+
+    def get_fwin(self, weight: torch.Tensor) -> torch.Tensor:
+        """Split-bf16 bank of a single-channel filter for the feature-window kernel (conv_cl.hip, ms_maskconv_fwin_*)."""
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape), "fwin")
+        if key != self.key_cl:
+            lib = _lib.load()
+            cout, _, kf, kt = weight.shape
+            self.buf_cl = torch.empty(lib.ms_maskconv_fwin_packed_bytes(cout, kf, kt), dtype=torch.uint8, device="cuda")
+            w = _lib.f32c(weight.detach())
+            _lib.check(lib.ms_maskconv_fwin_pack(_lib.ptr(w), _lib.ptr(self.buf_cl), cout, kf, kt, _lib.stream_ptr()),
+                       "ms_maskconv_fwin_pack")
             self.key_cl = key
         return self.buf_cl
 
@@ -136,6 +150,18 @@ def _conv_forward(x4: torch.Tensor, seq_lens: torch.Tensor, weight4: torch.Tenso
                                         _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
         if rc != 5:  # MS_ERR_UNSUPPORTED -> the exact-f32 kernel below
             _lib.check(rc, "ms_maskconv_cl_forward")
+            return y, new_lens
+    if (_lib.split_precision() and groups == 1 and cin == 1 and df == 1 and sf % 2 == 0 and kf >= 16 and big
+            and os.environ.get("MS_CONV_FWIN") != "0"):
+        # one input channel, tall filter (DS2 conv1): the feature window takes the place of the channels (conv_cl.hip)
+        pk = packed.get_fwin(weight4)
+        nbytes = lib.ms_maskconv_fwin_workspace_bytes(n, tin, kf, sf, fout)
+        ws = packed.workspace.get(nbytes)
+        rc = lib.ms_maskconv_fwin_forward(_lib.ptr(x4), _lib.ptr(lens_dev), _lib.ptr(pk), _lib.ptr(b), _lib.ptr(y), n, fin,
+                                          tin, cout, fout, tout, kf, kt, sf, st, dt, pf[0], pt[0], a, lo, hi, _lib.ptr(ws),
+                                          nbytes, _lib.stream_ptr())
+        if rc != 5:  # MS_ERR_UNSUPPORTED -> the exact-f32 kernel below
+            _lib.check(rc, "ms_maskconv_fwin_forward")
             return y, new_lens
     pk = packed.get(weight4, groups)
     _lib.check(lib.ms_maskconv_forward(_lib.ptr(x4), _lib.ptr(lens_dev), _lib.ptr(pk), _lib.ptr(b), _lib.ptr(y), n, cin,

@@ -866,6 +866,26 @@ def test_conv2d_channels_last_split_vs_oracle(cin, cout, k, s, same, F, Tn, N):
     np.testing.assert_array_equal(cpu(nl), wl)
 
 
+@pytest.mark.parametrize("cout,k,s,same,F,Tn,N", [(32, [41, 11], [2, 2], True, 80, 700, 3),     # DS2 conv1
+                                                  (40, [21, 5], [2, 1], False, 64, 700, 8),    # two cout tiles, no padding
+                                                  (32, [16, 11], [4, 2], True, 30, 2800, 8)])  # window = one k-step
+def test_conv2d_single_channel_feature_window_vs_oracle(cout, k, s, same, F, Tn, N):
+    """Single-channel convolutions with a tall filter take the feature-window form of the split-bf16 kernel
+    (conv_cl.hip, ms_maskconv_fwin_*): ragged lengths, SAME and no padding, bias + clamp epilogue."""
+    from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+    torch.manual_seed(cout + k[0])
+    m = MaskConv2d(1, cout, k, s, PaddingMode.SAME if same else PaddingMode.NONE).eval()
+    rng = np.random.default_rng(cout)
+    x = rng.normal(size=(N, 1, F, Tn)).astype(np.float32)
+    lens = np.sort(rng.integers(Tn // 2, Tn + 1, size=N))[::-1].copy()
+    y, nl = m((T(x), T(lens)), fused_activation=(0.0, 20.0))
+    assert 2.0 * y.numel() * k[0] * k[1] >= 1e9   # large enough to be routed to the MFMA path
+    want, wl = O.mask_conv2d(x, lens, cpu(m.weight), cpu(m.bias), tuple(s), same)
+    want = np.clip(want, 0.0, 20.0)
+    np.testing.assert_allclose(cpu(y), want, rtol=1e-4, atol=2e-4)
+    np.testing.assert_array_equal(cpu(nl), wl)
+
+
 # ----------------------------------------------------------------------------- edge cases
 @pytest.mark.parametrize("kind,H,bidir", [(0, 1024, True), (0, 64, True), (0, 48, False), (1, 256, True), (2, 200, True)])
 def test_rnn_all_lengths_shorter_than_the_buffer(kind, H, bidir):
