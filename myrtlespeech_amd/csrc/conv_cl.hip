@@ -36,9 +36,9 @@ struct ClP {
   int co_tiles;
   int act;
   float lo, hi;
-  // feature-window mode (single-channel input, ms_maskconv_fwin_*): the "channels" of output feature row fo are the
-  // KF input feature rows of its window, read from planes [N][Tin][FP] at element offset fo * SF (KF = 1 in this struct)
-  int win, FP;
+  // feature-window instantiation (single-channel input, ms_maskconv_fwin_*): the "channels" of output feature row fo are
+  // the KF input feature rows of its window, read from planes [N][Tin][FP] at element offset fo * SF (KF = 1 in this struct)
+  int FP;
 };
 
 __device__ __forceinline__ unsigned bf16b(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
@@ -68,7 +68,9 @@ __global__ void conv_cl_pack_kernel(const float* __restrict__ w, unsigned short*
   }
 }
 
-template <bool F16>
+// WIN: feature-window mode (ms_maskconv_fwin_*), a separate instantiation so that the multi-channel kernel's code is
+// untouched by it.
+template <bool F16, bool WIN = false>
 __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned short* __restrict__ xh,
                                                              const unsigned short* __restrict__ xl,
                                                              const int32_t* __restrict__ lens,
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned shor
 
   const int tin0 = t0 * p.ST - p.pad_t;
   const int ngran = p.KG * p.PW;  // granules per staged input row
-  const unsigned plane_bytes = p.win ? (unsigned)((size_t)p.N * p.Tin * p.FP * 2) : 0u;
+  const unsigned plane_bytes = WIN ? (unsigned)((size_t)p.N * p.Tin * p.FP * 2) : 0u;
   const __amdgpu_buffer_rsrc_t xh_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xh), 0, plane_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t xl_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xl), 0, plane_bytes, 0x00020000);
 
@@ -108,14 +110,14 @@ __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned shor
     // ---- stage the two input rows this kf touches (masked, zero padded)
     for (int f = 0; f < CL_F; ++f) {
       const int fin = (fo0 + f) * p.SF - p.pad_f + kf * p.DF;
-      const bool frow = (fo0 + f) < p.Fout && (p.win || (fin >= 0 && fin < p.Fin));
-      const size_t rbase = ((size_t)n * p.Fin + (frow && !p.win ? fin : 0)) * p.Tin;
+      const bool frow = (fo0 + f) < p.Fout && (WIN || (fin >= 0 && fin < p.Fin));
+      const size_t rbase = ((size_t)n * p.Fin + (frow && !WIN ? fin : 0)) * p.Tin;
       for (int i = tid; i < ngran; i += 256) {
         const int q = i / p.KG, kg = i - q * p.KG;  // frame-major so 4 lanes cover one frame's 64 B
         const int tin = tin0 + q;
         u32x4 vh = {0u, 0u, 0u, 0u}, vl = {0u, 0u, 0u, 0u};
         if (frow && tin >= 0 && tin < len) {
-          if (p.win) {
+          if (WIN) {
             // window of output row fo: FP-strided frame, element offset fo * SF (even => 4-byte aligned 16-byte loads)
             // (buffer loads: a 16-byte global load would be split into four dwords at this alignment)
             const int boff = (int)((((size_t)n * p.Tin + tin) * p.FP + (size_t)(fo0 + f) * p.SF + kg * 8) * 2);
@@ -322,7 +324,7 @@ extern "C" int ms_maskconv_fwin_forward(const float* x, const int32_t* lens, con
   p.PW = (CL_T - 1) * ST + (KT - 1) * DT + 1;
   p.co_tiles = ms::cdiv(Cout, 32);
   p.act = act; p.lo = act_lo; p.hi = act_hi;
-  p.win = 1; p.FP = fwin_fp(KF, SF, Fout);
+  p.FP = fwin_fp(KF, SF, Fout);
   const size_t lds = (size_t)2 * CL_F * p.KG * p.PW * 16 + (size_t)2 * ((KT + 1) / 2) * p.KG * 32 * 16;
   if (lds > 160 * 1024 || (long)N * p.co_tiles > 65535 || ms::cdiv(Fout, CL_F) > 65535 ||
       (size_t)N * Tin * p.FP * 2 >= ((size_t)1 << 31)) {
@@ -331,8 +333,8 @@ extern "C" int ms_maskconv_fwin_forward(const float* x, const int32_t* lens, con
   }
   static ms::DeviceOnce attr_once;
   if (attr_once.need()) {
-    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.done();
   }
   unsigned short* xh = (unsigned short*)workspace;
@@ -343,10 +345,10 @@ extern "C" int ms_maskconv_fwin_forward(const float* x, const int32_t* lens, con
   MS_LAUNCH_CHECK();
   dim3 grid(ms::cdiv(Tout, CL_T), ms::cdiv(Fout, CL_F), N * p.co_tiles);
   if (f16)
-    hipLaunchKernelGGL(maskconv_cl_kernel<true>, grid, dim3(256), lds, stream, xh, xl, lens, (const unsigned short*)packed_w,
+    hipLaunchKernelGGL((maskconv_cl_kernel<true, true>), grid, dim3(256), lds, stream, xh, xl, lens, (const unsigned short*)packed_w,
                        bias, y, p);
   else
-    hipLaunchKernelGGL(maskconv_cl_kernel<false>, grid, dim3(256), lds, stream, xh, xl, lens, (const unsigned short*)packed_w,
+    hipLaunchKernelGGL((maskconv_cl_kernel<false, true>), grid, dim3(256), lds, stream, xh, xl, lens, (const unsigned short*)packed_w,
                        bias, y, p);
   MS_LAUNCH_CHECK();
   return MS_OK;
@@ -393,7 +395,7 @@ extern "C" int ms_maskconv_cl_forward(const float* x, const int32_t* lens, const
   p.PW = (CL_T - 1) * ST + (KT - 1) * DT + 1;
   p.co_tiles = ms::cdiv(Cout, 32);
   p.act = act; p.lo = act_lo; p.hi = act_hi;
-  p.win = 0; p.FP = 0;
+  p.FP = 0;
   const size_t lds = (size_t)2 * CL_F * p.KG * p.PW * 16 + (size_t)2 * ((KT + 1) / 2) * p.KG * 32 * 16;
   if (lds > 160 * 1024 || (long)N * p.co_tiles > 65535 || ms::cdiv(Fout, CL_F) > 65535) {
     ms::set_error("ms_maskconv_cl_forward: shape outside the LDS / grid budget");

@@ -131,7 +131,8 @@ def _conv_forward(x4: torch.Tensor, seq_lens: torch.Tensor, weight4: torch.Tenso
     lens_dev = _lib.lens_i32(seq_lens)
     a, lo, hi = (_lib.ACT_NONE, 0.0, 0.0) if act is None else (_lib.ACT_CLAMP, act[0], act[1])
     b = None if bias is None else _lib.f32c(bias.detach())
-    big = 2.0 * y.numel() * cin * kf * kt >= 1e9
+    # below ~1 GFLOP the exact-f32 tap kernel wins (no layout pass); MS_CONV_MFMA_MIN_FLOPS moves the threshold (tests)
+    big = 2.0 * y.numel() * cin * kf * kt >= float(os.environ.get("MS_CONV_MFMA_MIN_FLOPS", "1e9"))
     if _lib.split_precision() and groups == 1 and fin == 1 and kf == 1 and cin * kt >= 64 and big:
         # conv1d with many input channels: im2col (mask and padding as load predicates) + split-bf16 GEMM (conv1d_gemm.hip)
         pk = packed.get_gemm1d(weight4)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised soak on the GPU box: many small seeded cases of the index-producing paths against the numpy oracle
 (CTC prefix beam search with separators / word weights / a toy LM, RNN-T greedy + beam, CTC greedy), plus ragged
-LSTM / GRU layers against the oracle within 1e-4.  Prints one line per family; exits non-zero on the first mismatch.
+LSTM / GRU layers and masked convolutions (all three kernels) against the oracle within 1e-4.  Prints one line per family; exits non-zero on the first mismatch.
     python tests/soak.py [seconds per family, default 40] [first seed, default 0]"""
 import os
 import sys
@@ -164,6 +164,47 @@ def frontend_case(seed):
     np.testing.assert_allclose(ly.cpu().numpy(), wantl, rtol=1e-5, atol=1e-5)
 
 
+def conv_case(seed):
+    """Convolutions large enough for the MFMA paths: single-channel tall filters (feature-window kernel), multi-channel
+    filters (channels-last kernel) and -- every third case -- a small shape on the exact-f32 tap kernel."""
+    from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+    rng = np.random.default_rng(seed)
+    kind = seed % 3
+    if kind == 0:      # Cin = 1, tall filter, even feature stride
+        cin, cout = 1, int(rng.choice([8, 32, 40]))
+        k = [int(rng.integers(16, 49)), int(rng.integers(3, 14))]
+        s = [int(rng.choice([2, 4])), int(rng.choice([1, 2]))]
+        F = int(rng.integers(max(k[0], 32), 97))
+    elif kind == 1:    # Cin % 16 == 0
+        cin, cout = int(rng.choice([16, 32, 48])), int(rng.choice([16, 32, 33]))
+        k = [int(rng.integers(1, 8)), int(rng.integers(1, 12))]
+        s = [int(rng.choice([1, 2])), int(rng.choice([1, 2]))]
+        F = int(rng.integers(max(k[0], 8), 33))
+    else:
+        cin, cout = int(rng.integers(1, 5)), int(rng.integers(1, 20))
+        k = [int(rng.integers(1, 6)), int(rng.integers(1, 8))]
+        s = [int(rng.integers(1, 3)), int(rng.integers(1, 3))]
+        F = int(rng.integers(k[0], 20))
+    same = bool(rng.random() < 0.6)
+    N = int(rng.integers(1, 5))
+    fo = (F + s[0] - 1) // s[0] if same else (F - k[0]) // s[0] + 1
+    # frames: enough for the 1e9-flop routing threshold on the MFMA kinds, small on the tap kernel
+    if kind < 2:
+        per_frame = 2.0 * N * cout * max(fo, 1) * cin * k[0] * k[1] / s[1]
+        Tn = int(min(max(1.05e9 / per_frame, 4 * k[1]), 6000)) + int(rng.integers(0, 40))
+    else:
+        Tn = int(rng.integers(k[1], 60))
+    key = ("conv", cin, cout, tuple(k), tuple(s), same)
+    torch.manual_seed(seed)
+    m = MaskConv2d(cin, cout, k, s, PaddingMode.SAME if same else PaddingMode.NONE).eval()
+    x = rng.normal(size=(N, cin, F, Tn)).astype(np.float32)
+    lens = np.sort(rng.integers(max(Tn // 2, k[1]), Tn + 1, size=N))[::-1].copy()
+    y, nl = m((torch.from_numpy(x), torch.from_numpy(lens)), fused_activation=(0.0, 20.0))
+    want, wl = O.mask_conv2d(x, lens, m.weight.detach().cpu().numpy(), m.bias.detach().cpu().numpy(), tuple(s), same)
+    np.testing.assert_allclose(y.cpu().numpy(), np.clip(want, 0.0, 20.0), rtol=1e-4, atol=3e-4, err_msg=str(key))
+    assert np.array_equal(nl.cpu().numpy(), wl), key
+
+
 family("ctc loss+grad vs oracle", ctc_case)
 family("front-end vs oracle", frontend_case)
 family("ctc beam vs oracle", beam_case)
@@ -172,4 +213,5 @@ family("rnn-t greedy+beam vs oracle", rnnt_case)
 if _ties:
     print(f"  rnn-t beam: {len(_ties)} case(s) decided by a <= 4 ulp score difference (summation order): seeds {_ties[:8]}", flush=True)
 family("lstm/gru/rnn vs oracle", rnn_case)
+family("mask-conv2d vs oracle", conv_case)
 print("soak ok")

@@ -886,6 +886,39 @@ def test_conv2d_single_channel_feature_window_vs_oracle(cout, k, s, same, F, Tn,
     np.testing.assert_array_equal(cpu(nl), wl)
 
 
+def test_conv_mfma_paths_small_shape_sweep(monkeypatch):
+    """Both split-bf16 convolution kernels over a grid of small shapes (MS_CONV_MFMA_MIN_FLOPS=0 routes them there):
+    every (taps, stride, padding, parity of T) combination has its own staging extent, tile tail and SAME offsets.
+    408 cases; written after a randomized soak case exposed a staging fault in an interim build of this kernel."""
+    from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+    monkeypatch.setenv("MS_CONV_MFMA_MIN_FLOPS", "0")
+    rng = np.random.default_rng(0)
+    cases = []
+    for cin in (16, 32):                                    # channels-last kernel
+        for kt in range(1, 8):
+            for st in (1, 2, 3):
+                for same in (True, False):
+                    for tn in (300, 301):
+                        cases.append((cin, [1 + (kt % 2), kt], [1, st], same, 4, tn, 1))
+    for kf in (16, 41):                                     # feature-window kernel
+        for kt in (1, 3, 4, 7, 11):
+            for sf in (2, 4):
+                for st in (1, 2, 3):
+                    for same in (True, False):
+                        for tn, F, N in ((300, 50, 1), (301, 81, 2)):
+                            cases.append((1, [kf, kt], [sf, st], same, F, tn, N))
+    for cin, k, s, same, F, tn, N in cases:
+        torch.manual_seed(1)
+        m = MaskConv2d(cin, 32, k, s, PaddingMode.SAME if same else PaddingMode.NONE).eval()
+        x = rng.normal(size=(N, cin, F, tn)).astype(np.float32)
+        lens = np.array([tn, tn - 37][:N])
+        y, nl = m((T(x), T(lens)))
+        want, wl = O.mask_conv2d(x, lens, cpu(m.weight), cpu(m.bias), tuple(s), same)
+        np.testing.assert_allclose(cpu(y), want, rtol=1e-4, atol=3e-4, err_msg=str((cin, k, s, same, F, tn, N)))
+        np.testing.assert_array_equal(cpu(nl), wl)
+    assert len(cases) == 408
+
+
 # ----------------------------------------------------------------------------- edge cases
 @pytest.mark.parametrize("kind,H,bidir", [(0, 1024, True), (0, 64, True), (0, 48, False), (1, 256, True), (2, 200, True)])
 def test_rnn_all_lengths_shorter_than_the_buffer(kind, H, bidir):
