@@ -205,6 +205,76 @@ def conv_case(seed):
     assert np.array_equal(nl.cpu().numpy(), wl), key
 
 
+def linear_case(seed):
+    """The three GEMM kernels at random shapes: exact-f32 tiles (ms_linear_forward: every tile configuration, ragged edges,
+    K not a multiple of 4), split-bf16 (ms_linear_split_forward: 256 x 256 and 256 x 128 tiles, K % 32 == 0)."""
+    from myrtlespeech_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(seed)
+    big = seed % 4 == 0
+    M = int(rng.integers(1, 3000 if big else 400))
+    N = int(rng.integers(1, 3000 if big else 400))
+    split = seed % 2 == 1
+    K = 32 * int(rng.integers(1, 20)) if split else int(rng.integers(1, 600))
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.normal(size=(N,)).astype(np.float32) if rng.random() < 0.7 else None
+    act = int(rng.random() < 0.5)
+    lo, hi = (0.0, 1.5) if act else (0.0, 0.0)
+    xd, wd = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
+    bd = None if b is None else torch.from_numpy(b).cuda()
+    y = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    if split:
+        ws = torch.empty(lib.ms_linear_split_workspace_bytes(M, K, N), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.ms_linear_split_forward(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), M, K, N, act, lo, hi,
+                                               _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "split")
+    else:
+        _lib.check(lib.ms_linear_forward(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), M, K, N, act, lo, hi,
+                                         _lib.stream_ptr()), "linear")
+    want = x.astype(np.float64) @ w.astype(np.float64).T + (0.0 if b is None else b.astype(np.float64))
+    if act:
+        want = np.clip(want, lo, hi)
+    tol = 1e-4 if split else 2e-5   # bf16x3: ~2^-17 per product; exact f32: summation order only
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=tol, atol=tol, err_msg=str(("linear", seed, M, K, N, split, act)))
+
+
+def lookahead_case(seed):
+    from myrtlespeech_amd.model.lookahead import Lookahead
+    rng = np.random.default_rng(seed)
+    Fd, ctx = int(rng.integers(1, 700)), int(rng.integers(1, 90))
+    N, T_ = int(rng.integers(1, 5)), int(rng.integers(1, 300))
+    torch.manual_seed(seed)
+    m = Lookahead(Fd, ctx).eval()
+    x = rng.normal(size=(N, Fd, T_)).astype(np.float32)
+    y, _ = m((torch.from_numpy(x), torch.full((N,), T_)))
+    want = O.lookahead(x, m.weight.detach().cpu().numpy())
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-4, atol=1e-5, err_msg=str(("lookahead", seed, Fd, ctx, N, T_)))
+
+
+def conv1d_case(seed):
+    """MaskConv1d, small (tap kernel) and large (im2col + split GEMM lowering) shapes."""
+    from myrtlespeech_amd.model.cnn import MaskConv1d, PaddingMode
+    rng = np.random.default_rng(seed)
+    large = seed % 2 == 0
+    cin = int(rng.choice([64, 80, 128, 200])) if large else int(rng.integers(1, 40))
+    cout = int(rng.choice([32, 100, 256])) if large else int(rng.integers(1, 40))
+    k, st = int(rng.integers(1, 12)), int(rng.integers(1, 4))
+    same = bool(rng.random() < 0.6)
+    N = int(rng.integers(1, 5))
+    if large:
+        Tn = int(min(max(1.05e9 * st / (2.0 * N * cout * cin * k), 4 * k), 8000)) + int(rng.integers(0, 30))
+    else:
+        Tn = int(rng.integers(k, 200))
+    torch.manual_seed(seed)
+    m = MaskConv1d(cin, cout, k, st, PaddingMode.SAME if same else PaddingMode.NONE).eval()
+    x = rng.normal(size=(N, cin, Tn)).astype(np.float32)
+    lens = np.sort(rng.integers(max(Tn // 2, k), Tn + 1, size=N))[::-1].copy()
+    y, nl = m((torch.from_numpy(x), torch.from_numpy(lens)))
+    want, wl = O.mask_conv1d(x, lens, m.weight.detach().cpu().numpy(), m.bias.detach().cpu().numpy(), st, same)
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-4, atol=3e-4, err_msg=str(("conv1d", seed, cin, cout, k, st, same, N, Tn)))
+    assert np.array_equal(nl.cpu().numpy(), wl), ("conv1d lens", seed)
+
+
 family("ctc loss+grad vs oracle", ctc_case)
 family("front-end vs oracle", frontend_case)
 family("ctc beam vs oracle", beam_case)
@@ -214,4 +284,7 @@ if _ties:
     print(f"  rnn-t beam: {len(_ties)} case(s) decided by a <= 4 ulp score difference (summation order): seeds {_ties[:8]}", flush=True)
 family("lstm/gru/rnn vs oracle", rnn_case)
 family("mask-conv2d vs oracle", conv_case)
+family("mask-conv1d vs oracle", conv1d_case)
+family("linear kernels vs float64", linear_case)
+family("lookahead vs oracle", lookahead_case)
 print("soak ok")
