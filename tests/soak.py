@@ -275,6 +275,56 @@ def conv1d_case(seed):
     assert np.array_equal(nl.cpu().numpy(), wl), ("conv1d lens", seed)
 
 
+_build_ds2 = None
+
+
+def ds2_case(seed):
+    """A whole random DeepSpeech2 (1-2 masked conv2d layers, LSTM / GRU / tanh-RNN, optional lookahead, 0-1 hidden FC
+    layers) against the oracle's forward: the glue between the kernels (layout changes, lengths, fused activations)."""
+    global _build_ds2
+    if _build_ds2 is None:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_gpu_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                                  "test_gpu_parity.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        spec.loader.exec_module(mod)
+        _build_ds2 = mod.build_ds2
+    rng = np.random.default_rng(seed)
+    F, Tn, N = int(rng.integers(8, 25)), int(rng.integers(20, 81)), int(rng.integers(1, 6))
+    convs, cin, f = [], 1, F
+    for i in range(int(rng.integers(1, 3))):
+        cout = int(rng.integers(2, 9))
+        k = [int(rng.integers(1, 6)), int(rng.integers(1, 8))]
+        st = [int(rng.integers(1, 3)), int(rng.integers(1, 3))]
+        convs.append(dict(kind="conv2d", idx=2 * i, in_channels=cin, out_channels=cout, kernel=k, stride=st, same=True,
+                          act=(0.0, 20.0) if rng.random() < 0.7 else None))
+        f, cin = -(-f // st[0]), cout
+    bidir = bool(rng.random() < 0.5)
+    H = int(rng.choice([32, 64, 96]))
+    rnn = dict(kind=int(rng.integers(0, 3)), input=cin * f, hidden=H, layers=int(rng.integers(1, 3)), bidirectional=bidir,
+               forget_gate_bias=1.0 if rng.random() < 0.5 else None)
+    if rnn["kind"] != 0:
+        rnn["forget_gate_bias"] = None
+    la = None
+    if not bidir and rng.random() < 0.6:
+        la = dict(context=int(rng.integers(1, 12)), act=(0.0, 20.0) if rng.random() < 0.5 else None)
+    nh = int(rng.integers(0, 2))
+    fc = dict(in_features=H * (2 if bidir else 1), out_features=int(rng.integers(5, 31)), n_hidden=nh,
+              hidden=int(rng.integers(16, 49)) if nh else None, act=(0.0, 20.0) if nh else None)
+    cfg = dict(convs=convs, rnn=rnn, lookahead=la, fc=fc)
+    torch.manual_seed(seed)
+    m = _build_ds2(cfg).eval()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    x = rng.normal(size=(N, 1, F, Tn)).astype(np.float32)
+    lens = np.sort(rng.integers(Tn // 2, Tn + 1, size=N))[::-1].copy()
+    lens[0] = Tn
+    (y, yl), _ = m((torch.from_numpy(x.copy()), torch.from_numpy(lens)))
+    want, wl, _ = O.deep_speech_2_forward(x, lens, cfg, sd)
+    assert np.array_equal(yl.cpu().numpy(), wl), ("ds2 lens", seed)
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=2e-4, atol=2e-4, err_msg=str(("ds2", seed, cfg)))
+
+
 family("ctc loss+grad vs oracle", ctc_case)
 family("front-end vs oracle", frontend_case)
 family("ctc beam vs oracle", beam_case)
@@ -287,4 +337,5 @@ family("mask-conv2d vs oracle", conv_case)
 family("mask-conv1d vs oracle", conv1d_case)
 family("linear kernels vs float64", linear_case)
 family("lookahead vs oracle", lookahead_case)
+family("whole random DS2 vs oracle", ds2_case)
 print("soak ok")
