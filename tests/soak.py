@@ -325,6 +325,56 @@ def ds2_case(seed):
     np.testing.assert_allclose(y.cpu().numpy(), want, rtol=2e-4, atol=2e-4, err_msg=str(("ds2", seed, cfg)))
 
 
+def ds1_case(seed):
+    """A whole random DeepSpeech1 (torch-LSTM and HardLSTM flavours) against the oracle's forward."""
+    from myrtlespeech_amd.model.deep_speech_1 import DeepSpeech1
+    rng = np.random.default_rng(seed)
+    C, Fd, H = int(rng.integers(1, 6)), int(rng.integers(4, 20)), int(rng.choice([24, 32, 64, 96]))
+    V, N, Tn = int(rng.integers(5, 31)), int(rng.integers(1, 6)), int(rng.integers(1, 60))
+    hard = bool(seed % 2)
+    torch.manual_seed(seed)
+    m = DeepSpeech1(Fd, C, H, V, drop_prob=0.25, relu_clip=20.0, forget_gate_bias=1.0, hard_lstm=hard).eval()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    x = rng.normal(size=(N, C, Fd, Tn)).astype(np.float32)
+    lens = np.sort(rng.integers(1, Tn + 1, size=N))[::-1].copy()
+    lens[0] = Tn
+    (y, yl), _ = m((torch.from_numpy(x.copy()), torch.from_numpy(lens)))
+    want, wl, _ = O.deep_speech_1_forward(x, lens, sd, H, 20.0, hard)
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=2e-4, atol=2e-4, err_msg=str(("ds1", seed, C, Fd, H, V, N, Tn, hard)))
+
+
+def stream_case(seed):
+    """Chunked streaming against the unchunked run of the same network on the device: unidirectional recurrences, time
+    kernel 1 (no conv context to carry), so feeding the state back chunk by chunk must reproduce the whole utterance."""
+    global _build_ds2
+    from myrtlespeech_amd.streaming import ChunkedDeepSpeech2
+    if _build_ds2 is None:
+        ds2_case(seed)
+    rng = np.random.default_rng(seed)
+    F, Tn, N = int(rng.integers(8, 25)), int(rng.integers(10, 90)), int(rng.integers(1, 6))
+    cout, kf, sf = int(rng.integers(2, 9)), int(rng.integers(1, 6)), int(rng.integers(1, 3))
+    convs = [dict(kind="conv2d", idx=0, in_channels=1, out_channels=cout, kernel=[kf, 1], stride=[sf, 1], same=True, act=(0.0, 20.0))]
+    H = int(rng.choice([32, 64, 96]))
+    kind = int(rng.integers(0, 3))
+    rnn = dict(kind=kind, input=cout * (-(-F // sf)), hidden=H, layers=int(rng.integers(1, 3)), bidirectional=False,
+               forget_gate_bias=1.0 if kind == 0 else None)
+    fc = dict(in_features=H, out_features=int(rng.integers(5, 31)), n_hidden=0, hidden=None, act=None)
+    torch.manual_seed(seed)
+    m = _build_ds2(dict(convs=convs, rnn=rnn, lookahead=None, fc=fc)).eval()
+    x = rng.normal(size=(N, 1, F, Tn)).astype(np.float32)
+    lens = np.sort(rng.integers(1, Tn + 1, size=N))[::-1].copy()
+    lens[0] = Tn
+    (y, yl), hid = m((torch.from_numpy(x.copy()), torch.from_numpy(lens)))
+    (ys, ysl), hids = ChunkedDeepSpeech2(m, int(rng.integers(3, 18)))(torch.from_numpy(x.copy()), torch.from_numpy(lens))
+    assert yl.tolist() == ysl.tolist(), ("stream lens", seed)
+    yw, yc = y.cpu().numpy(), ys.cpu().numpy()
+    for n in range(N):   # frames past an utterance's length hold the FC bias in one run and may be absent in the other
+        np.testing.assert_allclose(yc[:lens[n], n], yw[:lens[n], n], rtol=1e-4, atol=1e-4, err_msg=str(("stream", seed, n)))
+    h_w = hid[0] if isinstance(hid, tuple) else hid
+    h_c = hids[0] if isinstance(hids, tuple) else hids
+    np.testing.assert_allclose(h_c.cpu().numpy(), h_w.cpu().numpy(), rtol=1e-4, atol=1e-4, err_msg=str(("stream state", seed)))
+
+
 family("ctc loss+grad vs oracle", ctc_case)
 family("front-end vs oracle", frontend_case)
 family("ctc beam vs oracle", beam_case)
@@ -338,4 +388,6 @@ family("mask-conv1d vs oracle", conv1d_case)
 family("linear kernels vs float64", linear_case)
 family("lookahead vs oracle", lookahead_case)
 family("whole random DS2 vs oracle", ds2_case)
+family("whole random DS1 vs oracle", ds1_case)
+family("chunked streaming vs whole", stream_case)
 print("soak ok")
