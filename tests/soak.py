@@ -97,7 +97,8 @@ def rnn_case(seed):
     from myrtlespeech_amd.model.rnn import RNN, RNNType
     rng = np.random.default_rng(seed)
     kind, H, bidir = [("LSTM", 64, True), ("LSTM", 256, False), ("GRU", 64, True), ("GRU", 128, False), ("BASIC_RNN", 64, True),
-                      ("LSTM", 96, True)][seed % 6]
+                      ("LSTM", 96, True), ("LSTM", 512, True), ("LSTM", 1024, False), ("LSTM", 768, True),
+                      ("LSTM", 1024, True)][seed % 10]
     key = (kind, H, bidir)
     if key not in _rnn:
         torch.manual_seed(seed)
