@@ -138,9 +138,57 @@ def f32c(t):
     return t.contiguous()
 
 
+# MS_ASYNC_LENS=0: blocking uploads and read-backs of the lengths (the behaviour before the side channel; for A/B runs)
+_ASYNC_LENS = os.environ.get("MS_ASYNC_LENS") != "0"
+
+
+def upload(host: torch.Tensor, dtype=None) -> torch.Tensor:
+    """Small host tensor -> device without stalling the host: a pageable ``.cuda()`` is stream-ordered AND blocks the host
+    until the device gets there, i.e. it drains the launch queue in the middle of a forward.  Pinned + non_blocking does
+    neither (torch's caching host allocator keeps the staging block alive until the copy has run)."""
+    h = host.detach()
+    if dtype is not None and h.dtype != dtype:
+        h = h.to(dtype)
+    h = h.contiguous()
+    if not _ASYNC_LENS:
+        return h.cuda()
+    try:
+        h = h.pin_memory()
+    except RuntimeError:
+        return h.cuda()
+    return h.to("cuda", non_blocking=True)
+
+
+def attach_host(dev: torch.Tensor, host: torch.Tensor) -> torch.Tensor:
+    """Lengths travel between modules on the device (the reference's convention) but drive host control flow (step
+    counts, validation): the device tensor a module returns remembers the host values it was made from, so the next
+    module does not read them back (a blocking copy = another drain of the launch queue)."""
+    dev._ms_host = host
+    return dev
+
+
+def host_lens(lens: torch.Tensor) -> torch.Tensor:
+    """Host int64 values of a lengths tensor (from the side channel of ``attach_host`` when there is one)."""
+    if not lens.is_cuda:
+        return lens.detach().to(torch.int64)
+    h = getattr(lens, "_ms_host", None) if _ASYNC_LENS else None
+    if h is not None and h.shape == lens.shape:
+        return h.to(torch.int64)
+    return lens.detach().to("cpu", torch.int64)
+
+
+def lens_to_device(lens: torch.Tensor) -> torch.Tensor:
+    """The reference's ``seq_lens.cuda()`` at the end of every module, without the blocking upload."""
+    if lens.is_cuda:
+        return lens
+    return attach_host(upload(lens), lens.detach())
+
+
 def lens_i32(lens):
     """int32 device copy of a lengths tensor."""
-    return lens.to(device="cuda", dtype=torch.int32).contiguous()
+    if lens.is_cuda:
+        return lens.to(torch.int32).contiguous()
+    return upload(lens, torch.int32)
 
 
 def split_precision():

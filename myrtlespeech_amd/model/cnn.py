@@ -126,7 +126,10 @@ def _conv_forward(x4: torch.Tensor, seq_lens: torch.Tensor, weight4: torch.Tenso
     tout = (tin + sum(pt) - (dt * (kt - 1) + 1)) // st + 1
     if fout <= 0 or tout <= 0:
         raise RuntimeError("convolution output would be empty")
-    new_lens = out_lens(seq_lens, kt, st, dt, sum(pt))
+    # lengths arithmetic on the host values (same float32 formula, same dtype as the input), uploaded without blocking
+    host_in = _lib.host_lens(seq_lens).to(seq_lens.dtype)
+    new_host = out_lens(host_in, kt, st, dt, sum(pt))
+    new_lens = _lib.attach_host(_lib.upload(new_host), new_host)
     y = torch.empty((n, cout, fout, tout), dtype=torch.float32, device="cuda")
     lens_dev = _lib.lens_i32(seq_lens)
     a, lo, hi = (_lib.ACT_NONE, 0.0, 0.0) if act is None else (_lib.ACT_CLAMP, act[0], act[1])
@@ -209,7 +212,7 @@ class MaskConv1d(torch.nn.Conv1d):
         y, new_lens = _conv_forward(x4, seq_lens, self.weight.unsqueeze(2), self.bias, self._packed,
                                     (1, self.stride[0]), (1, self.dilation[0]), self.groups,
                                     self._padding_mode == PaddingMode.SAME, fused_activation)
-        return y.squeeze(2), new_lens.cuda()
+        return y.squeeze(2), new_lens
 
     def extra_repr(self) -> str:
         return super().extra_repr() + f", padding_mode={self._padding_mode}"
@@ -245,7 +248,7 @@ class MaskConv2d(torch.nn.Conv2d):
         y, new_lens = _conv_forward(x4, seq_lens, self.weight, self.bias, self._packed, _pair(self.stride),
                                     _pair(self.dilation), self.groups, self._padding_mode == PaddingMode.SAME,
                                     fused_activation)
-        return y, new_lens.cuda()
+        return y, new_lens
 
     def extra_repr(self) -> str:
         return super().extra_repr() + f", padding_mode={self._padding_mode}"

@@ -66,4 +66,4 @@ class DeepSpeech1(torch.nn.Module):
         plan = linear_stack_plan(self.fc4, self.training) + linear_stack_plan(self.out, self.training)
         h = _lib.f32c(h)
         out = run_linear_stack(h.reshape(t * n, h.shape[-1]), plan).reshape(t, n, -1)
-        return (out, seq_lens.cuda()), hid
+        return (out, _lib.lens_to_device(seq_lens)), hid

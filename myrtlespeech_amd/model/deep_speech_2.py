@@ -106,6 +106,6 @@ class DeepSpeech2(torch.nn.Module):
         if fused_fc:
             t, n, f = seq.shape
             y = run_linear_stack(_lib.f32c(seq).reshape(t * n, f), linear_stack_plan(fc.fully_connected, fc.training))
-            return (y.reshape(t, n, -1), lens.cuda()), hid
+            return (y.reshape(t, n, -1), _lib.lens_to_device(lens)), hid
         out, lens = fc((seq.transpose(0, 1), lens))
         return (out.transpose(0, 1), lens), hid

@@ -111,4 +111,4 @@ class FullyConnected(torch.nn.Module):
         h = _lib.f32c(x_inp)
         lead = h.shape[:-1]
         y = run_linear_stack(h.reshape(-1, h.shape[-1]), linear_stack_plan(self.fully_connected, self.training))
-        return y.reshape(*lead, y.shape[-1]), x_len.cuda()
+        return y.reshape(*lead, y.shape[-1]), _lib.lens_to_device(x_len)

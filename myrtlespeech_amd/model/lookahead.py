@@ -55,7 +55,7 @@ class Lookahead(torch.nn.Module):
         if f != self.in_features:
             raise RuntimeError(f"expected {self.in_features} features, got {f}")
         y = lookahead_apply(acts, self.weight, acts.stride(), n, f, t)
-        return y, lens.cuda()
+        return y, _lib.lens_to_device(lens)
 
     def extra_repr(self) -> str:
         return f"in_features={self.in_features}, context={self.context}"

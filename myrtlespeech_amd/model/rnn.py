@@ -146,7 +146,7 @@ class RNN(torch.nn.Module):
         inp, lengths = x
         if self.training and self.rnn.dropout > 0 and self.rnn.num_layers > 1:
             raise RuntimeError("inter-layer dropout in training mode is outside the inference hot path")
-        lens_cpu = lengths.detach().to("cpu", torch.int64)
+        lens_cpu = _lib.host_lens(lengths)
         if lens_cpu.numel() > 1 and bool((lens_cpu[:-1] < lens_cpu[1:]).any()):
             # pack_padded_sequence(enforce_sorted=True), rnn.py:170-175
             raise RuntimeError("`lengths` array must be sorted in decreasing order when `enforce_sorted` is True")

@@ -12,7 +12,8 @@ def check_decoder_args(x: torch.Tensor, lengths: torch.Tensor):
     l_batch = len(lengths)
     if x_batch != l_batch:
         raise ValueError(f"batch size of x ({x_batch}) and lengths {l_batch} must be equal")
-    if not (lengths <= seq_len).all():
+    from myrtlespeech_amd import _lib
+    if not bool((_lib.host_lens(lengths) <= seq_len).all()):   # host values: no read-back when a module attached them
         raise ValueError("length values must be less than or equal to x seq_len")
     return seq_len, x_batch, symbols
 
