@@ -19,7 +19,7 @@ def check_decoder_args(x: torch.Tensor, lengths: torch.Tensor):
 
 
 def ragged_to_lists(idx: torch.Tensor, lens: torch.Tensor):
-    """[N, T] int32 + [N] int32 (device) -> List[List[int]] with ONE D2H copy each."""
-    idx = idx.cpu()
-    lens = lens.cpu().tolist()
-    return [idx[n, :ln].tolist() for n, ln in enumerate(lens)]
+    """[N, T] int32 + [N] int32 (device) -> List[List[int]] with ONE read-back (lengths ride in column 0) and numpy
+    slicing on the host (a torch slice + tolist per utterance costs ~3 us each)."""
+    packed = torch.cat([lens.to(idx.dtype).reshape(-1, 1), idx], dim=1).cpu().numpy()
+    return [packed[n, 1:1 + int(packed[n, 0])].tolist() for n in range(packed.shape[0])]
