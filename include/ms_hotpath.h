@@ -179,8 +179,12 @@ int ms_rnn_layer_forward(int cell, const void* packed, const float* x, const int
                          const float* h0, const float* c0, float* out, float* hn, float* cn, int T, int N, int In,
                          int H, int ndir, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Synchronises `stream` and reports whether the last ms_rnn_layer_forward that
- * used `workspace` completed (MS_OK) or a persistent kernel timed out. */
+/* Synchronises `stream` and reports whether every ms_rnn_layer_forward that used
+ * `workspace` since the previous call of this function completed (MS_OK) or a
+ * persistent kernel timed out (MS_ERR_TIMEOUT, reported once).  The time-out word is
+ * sticky across layer calls -- one check after a whole stack of layers is enough --
+ * and lives in the first 256 bytes of the workspace, which must therefore be ZERO
+ * when a freshly allocated workspace is used for the first time. */
 int ms_rnn_status(const void* workspace, void* stream);
 
 /* Diagnostic: byte offset inside the RNN workspace of the per-workgroup stamp sums

@@ -204,5 +204,6 @@ class Workspace:
 
     def get(self, nbytes):
         if self.buf is None or self.buf.numel() < nbytes:
-            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device="cuda")
+            # zero-filled: the recurrent layers keep a sticky time-out word in the first bytes (ms_rnn_status)
+            self.buf = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device="cuda")
         return self.buf

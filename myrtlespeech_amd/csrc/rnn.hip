@@ -139,7 +139,8 @@ WsLayout ws_layout(int cell, int T, int N, int H, int ndir, int In) {
   const int npad = ms::cdiv(N, 32) * 32;
   WsLayout L;
   size_t o = 0;
-  L.status = o; o += STATUS_BYTES;
+  o += STATUS_BYTES;              // [0]: sticky time-out word (set by the kernels, read and cleared by ms_rnn_status)
+  L.status = o; o += STATUS_BYTES;  // per-call word, zeroed by every layer call
   L.flags = o; o += ms::align_up((size_t)ndir * std::max(H / 8, 1) * sizeof(unsigned), 256);
   L.xproj = o; o += ms::align_up((size_t)T * N * ndir * GH * sizeof(float), 256);
   // two slots per (stream, plane) by default; the two-stream kernel may use a ring of 2^lstm_ring_shift() slots
@@ -504,6 +505,13 @@ __device__ __forceinline__ void store_sc1_f32(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A wait gave up: raise the per-call word (peers stop waiting too) and the sticky word one STATUS block below it, which
+// no launch clears -- ms_rnn_status reads that one, so a caller may check once after several layer calls.
+__device__ __forceinline__ void flag_timeout(unsigned* status) {
+  __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(status - STATUS_BYTES / sizeof(unsigned), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Wave-level wait until every producer flag this wave depends on has reached `epoch`.
 // Returns false when it gave up (peer not resident / dead): the caller stops waiting for
 // the rest of the launch and the host reports MS_ERR_TIMEOUT.
@@ -517,7 +525,7 @@ __device__ __forceinline__ bool wait_flags(const unsigned* flags, int count, uns
     if ((++spins & 63u) == 0) {
       const unsigned dead = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (dead != 0 || wall_clock64() - t0 > SPIN_LIMIT_TICKS) {
-        if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) flag_timeout(status);
         return false;
       }
     }
@@ -910,7 +918,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) 
       if ((++spins & 63u) != 0) { __builtin_amdgcn_s_sleep(1); return false; }
       const unsigned dead = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (dead != 0 || wall_clock64() - t_wait0 > SPIN_LIMIT_TICKS) {
-        if (lane == 0) __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) flag_timeout(p.status);
         return true;
       }
       return false;
@@ -1170,7 +1178,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
         if ((++spins & 63u) == 0) {
           const unsigned dead = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (dead != 0 || wall_clock64() - t_wait0 > SPIN_LIMIT_TICKS) {
-            if (lane == 0) __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) flag_timeout(p.status);
             alive = false;
             break;
           }
@@ -1382,7 +1390,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_f32x2_kernel(LstmP p) 
           if ((++spins & 63u) == 0) {
             const unsigned dead = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (dead != 0 || wall_clock64() - t_wait0 > SPIN_LIMIT_TICKS) {
-              if (lane == 0) __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (lane == 0) flag_timeout(p.status);
               alive = false;
               break;
             }
@@ -1593,7 +1601,7 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
           if ((++spins & 63u) == 0) {
             const unsigned dead = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (dead != 0 || wall_clock64() - t_wait0 > SPIN_LIMIT_TICKS) {
-              if (lane == 0) __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (lane == 0) flag_timeout(p.status);
               alive = false;
               break;
             }
@@ -2092,6 +2100,7 @@ extern "C" int ms_rnn_status(const void* workspace, void* stream) {
   unsigned st = 0;
   MS_HIP(hipMemcpy(&st, workspace, sizeof(st), hipMemcpyDeviceToHost));
   if (st != 0) {
+    MS_HIP(hipMemset(const_cast<void*>(workspace), 0, sizeof(st)));  // reported once
     ms::set_error("ms_rnn_status: persistent LSTM kernel timed out waiting for a peer workgroup");
     return MS_ERR_TIMEOUT;
   }

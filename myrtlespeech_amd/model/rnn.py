@@ -73,10 +73,13 @@ def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max
     hn = torch.empty((nl * ndir, n, hidden), dtype=torch.float32, device="cuda")
     cn = torch.empty_like(hn) if lstm_like else None
     inp = x
+    # one workspace for the whole stack (the time-out word in it is sticky, so ONE status check -- a host sync -- after
+    # the last layer covers all of them)
+    in_sizes = [x.shape[2]] + [ndir * hidden] * (nl - 1)
+    ws = workspace.get(max(lib.ms_rnn_workspace_bytes(cell, t, n, k, hidden, ndir) for k in in_sizes))
     for layer in range(nl):
         in_size = inp.shape[2]
         pk = packed[layer].get(cell, in_size, hidden, layer_params[layer])
-        ws = workspace.get(lib.ms_rnn_workspace_bytes(cell, t, n, in_size, hidden, ndir))
         out = torch.empty((t, n, ndir * hidden), dtype=torch.float32, device="cuda")
         sl = slice(layer * ndir, (layer + 1) * ndir)
         h0l = None if h0 is None else h0[sl].contiguous()
@@ -87,9 +90,9 @@ def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max
                                             _lib.ptr(h0l), _lib.ptr(c0l), _lib.ptr(out), _lib.ptr(hnl), _lib.ptr(cnl), t,
                                             n, in_size, hidden, ndir, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
                    "ms_rnn_layer_forward")
-        if check:
-            _lib.check(lib.ms_rnn_status(_lib.ptr(ws), _lib.stream_ptr()), "ms_rnn_layer_forward")
         inp = out
+    if check:
+        _lib.check(lib.ms_rnn_status(_lib.ptr(ws), _lib.stream_ptr()), "ms_rnn_layer_forward")
     return inp, hn, cn
 
 

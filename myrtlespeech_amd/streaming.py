@@ -63,6 +63,6 @@ class ChunkedDeepSpeech2:
             block = torch.zeros((y.shape[0], n, y.shape[2]), dtype=y.dtype, device=y.device)
             block[:, :alive] = y
             outs.append(block)
-            out_lens[:alive] += ol.detach().to("cpu", torch.int64)
+            out_lens[:alive] += _lib.host_lens(ol)   # host values ride along with the device tensor: no read-back
             t0 += self.chunk_frames
         return (torch.cat(outs, 0), out_lens.to(lens.dtype)), full_state

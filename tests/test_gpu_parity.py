@@ -919,6 +919,28 @@ def test_conv_mfma_paths_small_shape_sweep(monkeypatch):
     assert len(cases) == 408
 
 
+def test_rnn_status_word_is_sticky_and_reported_once():
+    """ms_rnn_status reads the sticky time-out word at the head of the workspace (set by the kernels, never cleared by a
+    layer call), reports it once and clears it; a layer call in between leaves it alone."""
+    from myrtlespeech_amd import _lib
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    lib = _lib.load()
+    m = RNN(RNNType.LSTM, 16, 64, num_layers=2, bidirectional=True).eval()
+    m.check_status = False
+    x, lens = torch.randn(5, 3, 16), torch.tensor([5, 4, 2])
+    m((x, lens))
+    ws = m._workspace.buf
+    assert lib.ms_rnn_status(_lib.ptr(ws), _lib.stream_ptr()) == 0
+    ws[:4] = torch.tensor([1, 0, 0, 0], dtype=torch.uint8)           # what a timed-out kernel leaves behind
+    m((x, lens))                                                     # later layer calls do not clear it
+    assert lib.ms_rnn_status(_lib.ptr(ws), _lib.stream_ptr()) == 4   # MS_ERR_TIMEOUT
+    assert lib.ms_rnn_status(_lib.ptr(ws), _lib.stream_ptr()) == 0   # reported once
+    m.check_status = True
+    ws[:4] = torch.tensor([1, 0, 0, 0], dtype=torch.uint8)
+    with pytest.raises(RuntimeError, match="TIMEOUT"):
+        m((x, lens))
+
+
 # ----------------------------------------------------------------------------- edge cases
 @pytest.mark.parametrize("kind,H,bidir", [(0, 1024, True), (0, 64, True), (0, 48, False), (1, 256, True), (2, 200, True)])
 def test_rnn_all_lengths_shorter_than_the_buffer(kind, H, bidir):
