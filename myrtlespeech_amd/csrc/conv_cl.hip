@@ -26,13 +26,12 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int CL_T = 128;  // output frames per workgroup
-constexpr int CL_F = 2;    // output feature rows per workgroup
+constexpr int CL_F = 2;    // output feature rows per wave (accumulator tiles)
 
 struct ClP {
   int N, Cin, Fin, Tin, Cout, Fout, Tout, KF, KT, SF, ST, DF, DT, pad_f, pad_t;
   int KG;        // Cin / 8
-  int PW;        // staged frames per input row = (CL_T-1)*ST + (KT-1)*DT + 1
+  int PW;        // staged frames per input row = (frames per workgroup - 1)*ST + (KT-1)*DT + 1
   int co_tiles;
   int act;
   float lo, hi;
@@ -70,25 +69,32 @@ __global__ void conv_cl_pack_kernel(const float* __restrict__ w, unsigned short*
 
 // WIN: feature-window mode (ms_maskconv_fwin_*), a separate instantiation so that the multi-channel kernel's code is
 // untouched by it.
-template <bool F16, bool WIN = false>
+// WF: waves along the feature axis.  WF = 1: the four waves own four consecutive 32-frame blocks (128 frames x CL_F rows
+// per workgroup).  WF = 4: they own the SAME 32 frames of four consecutive row groups (32 frames x 4 CL_F rows) -- for short
+// inputs (a 320 ms streaming chunk is 16 output frames) a 128-frame tile would be seven-eighths padding.
+template <bool F16, bool WIN = false, int WF = 1>
 __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned short* __restrict__ xh,
                                                              const unsigned short* __restrict__ xl,
                                                              const int32_t* __restrict__ lens,
                                                              const unsigned short* __restrict__ wp,
                                                              const float* __restrict__ bias, float* __restrict__ y, ClP p) {
+  constexpr int WT = 4 / WF;        // waves along time
+  constexpr int TT = 32 * WT;       // output frames per workgroup
+  constexpr int RF = CL_F * WF;     // output feature rows per workgroup
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  // [plane 2][row CL_F][kg][PW][16 B]  then filters [plane 2][KT][kg][32][16 B]
+  // [plane 2][row RF][kg][PW][16 B]  then filters [plane 2][KT][kg][32][16 B]
   const int row_bytes = p.KG * p.PW * 16;
   char* Ph = lds;
-  char* Pl = lds + CL_F * row_bytes;
-  char* Wh = lds + 2 * CL_F * row_bytes;
+  char* Pl = lds + RF * row_bytes;
+  char* Wh = lds + 2 * RF * row_bytes;
   const int wtap = p.KG * 32 * 16;            // bytes of one tap's filters (one plane)
   char* Wl = Wh + ((p.KT + 1) / 2) * wtap;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
-  const int t0 = blockIdx.x * CL_T;
-  const int fo0 = blockIdx.y * CL_F;
+  const int wt = wave % WT, wf = wave / WT;   // this wave's frame block and row group
+  const int t0 = blockIdx.x * TT;
+  const int fo0 = blockIdx.y * RF;
   const int n = blockIdx.z / p.co_tiles, tile = blockIdx.z % p.co_tiles;
   const int len = lens ? min(lens[n], p.Tin) : p.Tin;
   const int cout_pad = p.co_tiles * 32;
@@ -107,8 +113,8 @@ __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned shor
   const __amdgpu_buffer_rsrc_t xl_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xl), 0, plane_bytes, 0x00020000);
 
   for (int kf = 0; kf < p.KF; ++kf) {
-    // ---- stage the two input rows this kf touches (masked, zero padded)
-    for (int f = 0; f < CL_F; ++f) {
+    // ---- stage the input rows this kf touches (masked, zero padded)
+    for (int f = 0; f < RF; ++f) {
       const int fin = (fo0 + f) * p.SF - p.pad_f + kf * p.DF;
       const bool frow = (fo0 + f) < p.Fout && (WIN || (fin >= 0 && fin < p.Fin));
       const size_t rbase = ((size_t)n * p.Fin + (frow && !WIN ? fin : 0)) * p.Tin;
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned shor
       }
       __syncthreads();
       for (int ktl = 0; ktl < ntap; ++ktl) {
-        const int tq = (wave * 32 + l31) * p.ST + (kt0 + ktl) * p.DT;
+        const int tq = (wt * 32 + l31) * p.ST + (kt0 + ktl) * p.DT;
         for (int s = 0; s < p.KG / 2; ++s) {
           const int kg = 2 * s + half;
           const int woff = ((ktl * p.KG + kg) * 32 + l31) * 16;
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned shor
           if (!F16) al = *reinterpret_cast<const u32x4*>(Wl + woff);
 #pragma unroll
           for (int f = 0; f < CL_F; ++f) {
-            const int poff = f * row_bytes + (kg * p.PW + tq) * 16;
+            const int poff = (wf * CL_F + f) * row_bytes + (kg * p.PW + tq) * 16;
             const u32x4 bh = *reinterpret_cast<const u32x4*>(Ph + poff);
             if (F16) {
               acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), acc[f], 0, 0, 0);
@@ -176,11 +182,11 @@ __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned shor
     __syncthreads();
   }
 
-  const int t = t0 + wave * 32 + l31;
+  const int t = t0 + wt * 32 + l31;
   if (t < p.Tout) {
 #pragma unroll
     for (int f = 0; f < CL_F; ++f) {
-      const int fo = fo0 + f;
+      const int fo = fo0 + wf * CL_F + f;
       if (fo >= p.Fout) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -274,6 +280,46 @@ __global__ void conv_fwin_pack_kernel(const float* __restrict__ w, unsigned shor
   }
 }
 
+// Tile shape of maskconv_cl_kernel for this problem: 4 = 32 frames x 8 rows per workgroup (short inputs), 1 = 128 frames x 2
+// rows, 0 = neither fits LDS / the grid.  Fills p.PW and *lds.
+int conv_cl_plan(ClP& p, size_t* lds) {
+  const size_t wbytes = (size_t)2 * ((p.KT + 1) / 2) * p.KG * 32 * 16;
+  if ((long)p.N * p.co_tiles > 65535) return 0;
+  for (int wf : {p.Tout <= 48 ? 4 : 1, 1}) {
+    const int tt = 128 / wf, rf = CL_F * wf;
+    p.PW = (tt - 1) * p.ST + (p.KT - 1) * p.DT + 1;
+    *lds = (size_t)2 * rf * p.KG * p.PW * 16 + wbytes;
+    if (*lds <= 160 * 1024 && ms::cdiv(p.Fout, rf) <= 65535) return wf;
+  }
+  return 0;
+}
+
+template <bool WIN>
+int conv_cl_launch(const ClP& p, int wf, size_t lds, const unsigned short* xh, const unsigned short* xl, const int32_t* lens,
+                   const void* packed_w, const float* bias, float* y, hipStream_t stream) {
+  static ms::DeviceOnce attr_once;
+  if (attr_once.need()) {
+    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<false, WIN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<true, WIN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<false, WIN, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<true, WIN, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_once.done();
+  }
+  const bool f16 = ms::precision_mode() == ms::PREC_F16;
+  const int tt = 128 / wf, rf = CL_F * wf;
+  dim3 grid(ms::cdiv(p.Tout, tt), ms::cdiv(p.Fout, rf), p.N * p.co_tiles);
+  const unsigned short* wq = (const unsigned short*)packed_w;
+  if (wf == 4) {
+    if (f16) hipLaunchKernelGGL((maskconv_cl_kernel<true, WIN, 4>), grid, dim3(256), lds, stream, xh, xl, lens, wq, bias, y, p);
+    else hipLaunchKernelGGL((maskconv_cl_kernel<false, WIN, 4>), grid, dim3(256), lds, stream, xh, xl, lens, wq, bias, y, p);
+  } else {
+    if (f16) hipLaunchKernelGGL((maskconv_cl_kernel<true, WIN, 1>), grid, dim3(256), lds, stream, xh, xl, lens, wq, bias, y, p);
+    else hipLaunchKernelGGL((maskconv_cl_kernel<false, WIN, 1>), grid, dim3(256), lds, stream, xh, xl, lens, wq, bias, y, p);
+  }
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}
+
 inline int fwin_kfp(int KF) { return ms::cdiv(KF, 16) * 16; }
 inline int fwin_fp(int KF, int SF, int Fout) { return ms::cdiv((Fout - 1) * SF + fwin_kfp(KF), 32) * 32; }
 
@@ -321,21 +367,14 @@ extern "C" int ms_maskconv_fwin_forward(const float* x, const int32_t* lens, con
   ClP p;
   p.N = N; p.Cin = fwin_kfp(KF); p.Fin = 1; p.Tin = Tin; p.Cout = Cout; p.Fout = Fout; p.Tout = Tout; p.KF = 1; p.KT = KT;
   p.SF = SF; p.ST = ST; p.DF = 1; p.DT = DT; p.pad_f = 0; p.pad_t = pad_t_l; p.KG = p.Cin / 8;
-  p.PW = (CL_T - 1) * ST + (KT - 1) * DT + 1;
   p.co_tiles = ms::cdiv(Cout, 32);
   p.act = act; p.lo = act_lo; p.hi = act_hi;
   p.FP = fwin_fp(KF, SF, Fout);
-  const size_t lds = (size_t)2 * CL_F * p.KG * p.PW * 16 + (size_t)2 * ((KT + 1) / 2) * p.KG * 32 * 16;
-  if (lds > 160 * 1024 || (long)N * p.co_tiles > 65535 || ms::cdiv(Fout, CL_F) > 65535 ||
-      (size_t)N * Tin * p.FP * 2 >= ((size_t)1 << 31)) {
+  size_t lds = 0;
+  const int wf = conv_cl_plan(p, &lds);
+  if (wf == 0 || (size_t)N * Tin * p.FP * 2 >= ((size_t)1 << 31)) {
     ms::set_error("ms_maskconv_fwin_forward: shape outside the LDS / grid budget");
     return MS_ERR_UNSUPPORTED;
-  }
-  static ms::DeviceOnce attr_once;
-  if (attr_once.need()) {
-    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_once.done();
   }
   unsigned short* xh = (unsigned short*)workspace;
   unsigned short* xl = xh + (size_t)N * Tin * p.FP;
@@ -343,15 +382,7 @@ extern "C" int ms_maskconv_fwin_forward(const float* x, const int32_t* lens, con
   hipLaunchKernelGGL(ft_to_tf_split_kernel, dim3(ms::cdiv(Tin, 32), ms::cdiv(p.FP, 32), N), dim3(32, 8), 0, stream, x, xh, xl,
                      Fin, Tin, p.FP, pad_f_l, f16 ? 1 : 0);
   MS_LAUNCH_CHECK();
-  dim3 grid(ms::cdiv(Tout, CL_T), ms::cdiv(Fout, CL_F), N * p.co_tiles);
-  if (f16)
-    hipLaunchKernelGGL((maskconv_cl_kernel<true, true>), grid, dim3(256), lds, stream, xh, xl, lens, (const unsigned short*)packed_w,
-                       bias, y, p);
-  else
-    hipLaunchKernelGGL((maskconv_cl_kernel<false, true>), grid, dim3(256), lds, stream, xh, xl, lens, (const unsigned short*)packed_w,
-                       bias, y, p);
-  MS_LAUNCH_CHECK();
-  return MS_OK;
+  return conv_cl_launch<true>(p, wf, lds, xh, xl, lens, packed_w, bias, y, stream);
 }
 
 extern "C" size_t ms_maskconv_cl_packed_bytes(int Cout, int Cin, int KF, int KT) {
@@ -392,20 +423,14 @@ extern "C" int ms_maskconv_cl_forward(const float* x, const int32_t* lens, const
   ClP p;
   p.N = N; p.Cin = Cin; p.Fin = Fin; p.Tin = Tin; p.Cout = Cout; p.Fout = Fout; p.Tout = Tout; p.KF = KF; p.KT = KT;
   p.SF = SF; p.ST = ST; p.DF = DF; p.DT = DT; p.pad_f = pad_f_l; p.pad_t = pad_t_l; p.KG = Cin / 8;
-  p.PW = (CL_T - 1) * ST + (KT - 1) * DT + 1;
   p.co_tiles = ms::cdiv(Cout, 32);
   p.act = act; p.lo = act_lo; p.hi = act_hi;
   p.FP = 0;
-  const size_t lds = (size_t)2 * CL_F * p.KG * p.PW * 16 + (size_t)2 * ((KT + 1) / 2) * p.KG * 32 * 16;
-  if (lds > 160 * 1024 || (long)N * p.co_tiles > 65535 || ms::cdiv(Fout, CL_F) > 65535) {
+  size_t lds = 0;
+  const int wf = conv_cl_plan(p, &lds);
+  if (wf == 0) {
     ms::set_error("ms_maskconv_cl_forward: shape outside the LDS / grid budget");
     return MS_ERR_UNSUPPORTED;
-  }
-  static ms::DeviceOnce attr_once;
-  if (attr_once.need()) {
-    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_once.done();
   }
   unsigned short* xh = (unsigned short*)workspace;
   unsigned short* xl = xh + (size_t)N * Cin * Fin * Tin;
@@ -414,13 +439,5 @@ extern "C" int ms_maskconv_cl_forward(const float* x, const int32_t* lens, const
   hipLaunchKernelGGL(nchw_to_cl_split_kernel, dim3(ms::cdiv(Tin, 32), ms::cdiv(Cin, 32), N * Fin), dim3(32, 8), 0, stream, x,
                      xh, xl, Cin, Fin, Tin, f16 ? 1 : 0);
   MS_LAUNCH_CHECK();
-  dim3 grid(ms::cdiv(Tout, CL_T), ms::cdiv(Fout, CL_F), N * p.co_tiles);
-  if (f16)
-    hipLaunchKernelGGL(maskconv_cl_kernel<true>, grid, dim3(256), lds, stream, xh, xl, lens, (const unsigned short*)packed_w,
-                       bias, y, p);
-  else
-    hipLaunchKernelGGL(maskconv_cl_kernel<false>, grid, dim3(256), lds, stream, xh, xl, lens, (const unsigned short*)packed_w,
-                       bias, y, p);
-  MS_LAUNCH_CHECK();
-  return MS_OK;
+  return conv_cl_launch<false>(p, wf, lds, xh, xl, lens, packed_w, bias, y, stream);
 }

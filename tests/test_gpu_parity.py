@@ -889,7 +889,7 @@ def test_conv2d_single_channel_feature_window_vs_oracle(cout, k, s, same, F, Tn,
 def test_conv_mfma_paths_small_shape_sweep(monkeypatch):
     """Both split-bf16 convolution kernels over a grid of small shapes (MS_CONV_MFMA_MIN_FLOPS=0 routes them there):
     every (taps, stride, padding, parity of T) combination has its own staging extent, tile tail and SAME offsets.
-    408 cases; written after a randomized soak case exposed a staging fault in an interim build of this kernel."""
+    504 cases; written after a randomized soak case exposed a staging fault in an interim build of this kernel."""
     from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
     monkeypatch.setenv("MS_CONV_MFMA_MIN_FLOPS", "0")
     rng = np.random.default_rng(0)
@@ -907,16 +907,29 @@ def test_conv_mfma_paths_small_shape_sweep(monkeypatch):
                     for same in (True, False):
                         for tn, F, N in ((300, 50, 1), (301, 81, 2)):
                             cases.append((1, [kf, kt], [sf, st], same, F, tn, N))
+    for cin in (16, 32):                                    # short inputs: the 32-frame x 8-row tile of both kernels
+        for kt in (1, 3, 5, 11):
+            for st in (1, 2):
+                for same in (True, False):
+                    for tn in (17, 33):
+                        cases.append((cin, [3, kt], [1, st], same, 19, tn, 2))
+    for kf in (16, 41):
+        for kt in (3, 11):
+            for st in (1, 2):
+                for same in (True, False):
+                    for tn, F, N in ((32, 80, 3), (19, 50, 2)):
+                        cases.append((1, [kf, kt], [2, st], same, F, tn, N))
     for cin, k, s, same, F, tn, N in cases:
         torch.manual_seed(1)
         m = MaskConv2d(cin, 32, k, s, PaddingMode.SAME if same else PaddingMode.NONE).eval()
         x = rng.normal(size=(N, cin, F, tn)).astype(np.float32)
-        lens = np.array([tn, tn - 37][:N])
+        lens = np.array([tn, max(tn - 37, k[1]), max(tn - 5, k[1])][:N])
+        lens = np.sort(lens)[::-1].copy()
         y, nl = m((T(x), T(lens)))
         want, wl = O.mask_conv2d(x, lens, cpu(m.weight), cpu(m.bias), tuple(s), same)
         np.testing.assert_allclose(cpu(y), want, rtol=1e-4, atol=3e-4, err_msg=str((cin, k, s, same, F, tn, N)))
         np.testing.assert_array_equal(cpu(nl), wl)
-    assert len(cases) == 408
+    assert len(cases) == 408 + 64 + 32
 
 
 def test_rnn_status_word_is_sticky_and_reported_once():
