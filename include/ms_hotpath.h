@@ -179,6 +179,21 @@ int ms_rnn_layer_forward(int cell, const void* packed, const float* x, const int
                          const float* h0, const float* c0, float* out, float* hn, float* cn, int T, int N, int In,
                          int H, int ndir, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Layer stacks (rnn.py:112-120 num_layers > 1): the same call with two optional hand-offs through the shared workspace,
+ * for layer kinds where ms_rnn_layer_chains_planes() returns 1 (the two-stream LSTM with split-bf16 / fp16 operands):
+ *   MS_RNN_OUT_PLANES_TO_WS  the layer output is left in the workspace as the NEXT layer's GEMM operand planes
+ *                            ([max_len*N][ndir*H] bf16 hi + lo, or one fp16 plane) instead of float32 `out` (which may
+ *                            then be NULL and is not written); the workspace must also hold
+ *                            ms_rnn_workspace_bytes(cell, T, N, ndir*H, H, ndir);
+ *   MS_RNN_X_PLANES_IN_WS    the input is taken from those planes (left there by the previous layer's call with the
+ *                            same T, N, max_len and workspace); `x` may be NULL.
+ * Same arithmetic as splitting the float32 output afterwards, one pass over the activations less per layer. */
+enum { MS_RNN_X_PLANES_IN_WS = 1, MS_RNN_OUT_PLANES_TO_WS = 2 };
+int ms_rnn_layer_chains_planes(int cell, int H, int ndir);
+int ms_rnn_layer_forward_ex(int cell, const void* packed, const float* x, const int32_t* lens, int max_len,
+                            const float* h0, const float* c0, float* out, float* hn, float* cn, int T, int N, int In,
+                            int H, int ndir, int flags, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Synchronises `stream` and reports whether every ms_rnn_layer_forward that used
  * `workspace` since the previous call of this function completed (MS_OK) or a
  * persistent kernel timed out (MS_ERR_TIMEOUT, reported once).  The time-out word is

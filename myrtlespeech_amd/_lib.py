@@ -53,6 +53,8 @@ SIGNATURES = {
     "ms_rnn_pack": (c_int, [c_int, c_int, c_int, c_int, _PP, _PP, _PP, _PP, _P, _P]),
     "ms_rnn_workspace_bytes": (c_size_t, [c_int] * 6),
     "ms_rnn_layer_forward": (c_int, [c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P] + [c_int] * 5 + [_P, c_size_t, _P]),
+    "ms_rnn_layer_forward_ex": (c_int, [c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P] + [c_int] * 6 + [_P, c_size_t, _P]),
+    "ms_rnn_layer_chains_planes": (c_int, [c_int, c_int, c_int]),
     "ms_rnn_status": (c_int, [_P, _P]),
     "ms_rnn_debug_offset": (c_size_t, [c_int] * 6),
     "ms_prof_enable": (c_int, [c_int]),

@@ -494,6 +494,10 @@ struct LstmP {
   int steps, N, n_base, N_total, H, ndir, J, NPAD;
   int poll_sleep;  // s_sleep(1) repetitions between polls of the exchange buffer
   int ring_shift;  // two-stream kernel: log2 of the number of exchange slots per (stream, plane) (1 = two slots)
+  // two-stream kernel: when set, the layer output goes out as the NEXT layer's GEMM operand planes [T*N][ndir*H] (bf16
+  // hi / lo, or one fp16 plane) instead of float32 `out` -- same bytes, and the separate plane-split pass disappears
+  unsigned short* out_hi;
+  unsigned short* out_lo;
 };
 
 __device__ __forceinline__ f32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
@@ -1245,7 +1249,21 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
         h[sg] = active ? hnew : h[sg];
         const int off = sg * STREAM + ec.wpar * KG * 256 + j * 256 + nl * 16;
         publish_split<F16>(h[sg], wtag, hx_rsrc, off, PLANE + off, lane);
-        if (n < N) p.out[((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit] = active ? hnew : 0.f;
+        if (n < N) {
+          const size_t oidx = ((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit;
+          const float ov = active ? hnew : 0.f;
+          if (p.out_hi) {   // exactly split_planes_kernel's arithmetic
+            if (F16) {
+              p.out_hi[oidx] = __builtin_bit_cast(unsigned short, (_Float16)ov);
+            } else {
+              const unsigned hb = bf16_bits(ov);
+              p.out_hi[oidx] = (unsigned short)hb;
+              p.out_lo[oidx] = (unsigned short)bf16_bits(ov - bf16_val(hb));
+            }
+          } else {
+            p.out[oidx] = ov;
+          }
+        }
       }
       if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[3] += now - st_prev; st_prev = now; }
     }
@@ -1890,12 +1908,32 @@ static int launch_split2_any(const LstmP& p, bool hard, bool stamps, bool f16, h
   }
 }
 
+// Does a layer of this kind hand its output to the next layer as GEMM operand planes inside the shared workspace
+// (MS_RNN_X_PLANES_IN_WS / MS_RNN_OUT_PLANES_TO_WS)?  Only the two-stream LSTM kernel writes planes.
+extern "C" int ms_rnn_layer_chains_planes(int cell, int H, int ndir) {
+  static const bool off = getenv("MS_RNN_CHAIN_PLANES") && getenv("MS_RNN_CHAIN_PLANES")[0] == '0';
+  if (off || cell < 0 || cell > MS_CELL_HARD_LSTM) return 0;
+  return use_split(cell, H, ndir) && two_stream_shape(H) && use_split_gemm(cell, H, ndir, ndir * H) &&
+         !(getenv("MS_LSTM_ONE_STREAM") && getenv("MS_LSTM_ONE_STREAM")[0] == '1') ? 1 : 0;
+}
+
 extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x, const int32_t* lens, int max_len,
                                     const float* h0, const float* c0, float* out, float* hn, float* cn, int T, int N,
                                     int In, int H, int ndir, void* workspace, size_t workspace_bytes, void* stream_) {
+  return ms_rnn_layer_forward_ex(cell, packed, x, lens, max_len, h0, c0, out, hn, cn, T, N, In, H, ndir, 0, workspace,
+                                 workspace_bytes, stream_);
+}
+
+extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float* x, const int32_t* lens, int max_len,
+                                       const float* h0, const float* c0, float* out, float* hn, float* cn, int T, int N,
+                                       int In, int H, int ndir, int flags, void* workspace, size_t workspace_bytes,
+                                       void* stream_) {
   MS_REQUIRE(cell >= 0 && cell <= MS_CELL_HARD_LSTM, "unknown cell");
   MS_REQUIRE(T > 0 && N > 0 && In > 0 && H > 0 && (ndir == 1 || ndir == 2), "bad shape");
-  MS_REQUIRE(packed && x && out && hn && workspace, "null pointer");
+  const bool x_in_ws = (flags & MS_RNN_X_PLANES_IN_WS) != 0, out_to_ws = (flags & MS_RNN_OUT_PLANES_TO_WS) != 0;
+  MS_REQUIRE(!(x_in_ws || out_to_ws) || ms_rnn_layer_chains_planes(cell, H, ndir), "this layer kind does not chain planes");
+  MS_REQUIRE(!x_in_ws || use_split_gemm(cell, H, ndir, In), "input planes need the split GEMM (In % 32 == 0)");
+  MS_REQUIRE(packed && (x || x_in_ws) && (out || out_to_ws) && hn && workspace, "null pointer");
   const bool lstm_like = (cell == MS_CELL_LSTM || cell == MS_CELL_HARD_LSTM);
   MS_REQUIRE(!lstm_like || cn, "cn required for LSTM cells");
   MS_REQUIRE(max_len >= 1 && max_len <= T, "max_len must be in [1, T]");
@@ -1903,7 +1941,9 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
   const int G = gates_of(cell);
   const size_t GH = (size_t)G * H;
   const WsLayout W = ws_layout(cell, T, N, H, ndir, In);
-  if (workspace_bytes < W.total) {
+  // (the next layer's planes are ndir*H wide and share the xsplit region, which is sized for THIS layer's In)
+  const size_t need = out_to_ws ? std::max(W.total, W.xsplit + ms::align_up((size_t)T * N * ndir * H * 4, 256)) : W.total;
+  if (workspace_bytes < need) {
     ms::set_error("ms_rnn_layer_forward: workspace too small");
     return MS_ERR_WORKSPACE;
   }
@@ -1915,8 +1955,8 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
 
   // status + epoch flags are re-zeroed on every call (cdna_hip_programming.md G16)
   MS_HIP(hipMemsetAsync(ws + W.status, 0, W.xproj - W.status, stream));
-  // frames t >= max_len are all padding
-  if (steps < T)
+  // frames t >= max_len are all padding (the planes of a chained layer are only read up to max_len)
+  if (steps < T && out)
     MS_HIP(hipMemsetAsync(out + (size_t)steps * N * ndir * H, 0, (size_t)(T - steps) * N * ndir * H * sizeof(float),
                           stream));
 
@@ -1931,7 +1971,7 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
       const unsigned short* wh = (const unsigned short*)(pk + L.wih);
       const unsigned short* wl = wh + (size_t)ndir * GH * In;
       const int prec = use_f16(cell, H, ndir) ? ms::PREC_F16 : ms::PREC_BF16X3;
-      rc = ms::split_planes_launch(x, xh, xl, (size_t)steps * N * In, prec, stream);
+      rc = x_in_ws ? MS_OK : ms::split_planes_launch(x, xh, xl, (size_t)steps * N * In, prec, stream);
       if (rc == MS_OK)
         rc = ms::gemm_bf16x3_launch(xh, xl, wh, wl, (const float*)(pk + L.bias_x), xproj, steps * N, In, (int)(ndir * GH),
                                     MS_ACT_NONE, 0.f, 0.f, prec, stream);
@@ -1956,6 +1996,11 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
       p.whh = (const float*)(pk + L.whh);
       p.lens = lens;
       p.h0 = h0; p.c0 = c0; p.out = out; p.hn = hn; p.cn = cn;
+      p.out_hi = p.out_lo = nullptr;
+      if (out_to_ws) {   // next layer: [steps*N][ndir*H] hi plane, then the lo plane
+        p.out_hi = (unsigned short*)(ws + W.xsplit);
+        p.out_lo = p.out_hi + (size_t)steps * N * ndir * H;
+      }
       p.hx = (float*)(ws + W.hx);
       p.flags = (unsigned*)(ws + W.flags);
       p.status = (unsigned*)(ws + W.status);

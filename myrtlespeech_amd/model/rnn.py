@@ -77,18 +77,22 @@ def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max
     # the last layer covers all of them)
     in_sizes = [x.shape[2]] + [ndir * hidden] * (nl - 1)
     ws = workspace.get(max(lib.ms_rnn_workspace_bytes(cell, t, n, k, hidden, ndir) for k in in_sizes))
+    # intermediate outputs of a two-stream LSTM stack travel as the next layer's GEMM operand planes inside the workspace
+    chain = nl > 1 and bool(lib.ms_rnn_layer_chains_planes(cell, hidden, ndir)) and (ndir * hidden) % 32 == 0
     for layer in range(nl):
-        in_size = inp.shape[2]
+        in_size = in_sizes[layer]
         pk = packed[layer].get(cell, in_size, hidden, layer_params[layer])
-        out = torch.empty((t, n, ndir * hidden), dtype=torch.float32, device="cuda")
+        flags = (1 if (chain and layer > 0) else 0) | (2 if (chain and layer < nl - 1) else 0)
+        out = None if flags & 2 else torch.empty((t, n, ndir * hidden), dtype=torch.float32, device="cuda")
         sl = slice(layer * ndir, (layer + 1) * ndir)
         h0l = None if h0 is None else h0[sl].contiguous()
         c0l = None if (c0 is None or not lstm_like) else c0[sl].contiguous()
         hnl = hn[sl]
         cnl = cn[sl] if lstm_like else None
-        _lib.check(lib.ms_rnn_layer_forward(cell, _lib.ptr(pk), _lib.ptr(inp), _lib.ptr(lens_dev), max_len,
-                                            _lib.ptr(h0l), _lib.ptr(c0l), _lib.ptr(out), _lib.ptr(hnl), _lib.ptr(cnl), t,
-                                            n, in_size, hidden, ndir, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+        _lib.check(lib.ms_rnn_layer_forward_ex(cell, _lib.ptr(pk), _lib.ptr(None if flags & 1 else inp), _lib.ptr(lens_dev),
+                                               max_len, _lib.ptr(h0l), _lib.ptr(c0l), _lib.ptr(out), _lib.ptr(hnl),
+                                               _lib.ptr(cnl), t, n, in_size, hidden, ndir, flags, _lib.ptr(ws), ws.numel(),
+                                               _lib.stream_ptr()),
                    "ms_rnn_layer_forward")
         inp = out
     if check:

@@ -932,6 +932,40 @@ def test_conv_mfma_paths_small_shape_sweep(monkeypatch):
     assert len(cases) == 408 + 64 + 32
 
 
+@pytest.mark.parametrize("H,bidir,N,Tn", [(256, True, 37, 9), (512, False, 5, 12), (1024, True, 32, 6)])
+def test_lstm_stack_plane_chaining_is_bit_identical_to_single_layers(H, bidir, N, Tn):
+    """A two-stream LSTM stack hands each layer's output to the next layer as GEMM operand planes inside the workspace
+    (MS_RNN_OUT_PLANES_TO_WS / MS_RNN_X_PLANES_IN_WS); the same weights run as single-layer modules (float32 hand-over,
+    split afterwards) must give the same bits."""
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    torch.manual_seed(H)
+    stack = RNN(RNNType.LSTM, 64, H, num_layers=3, bidirectional=bidir, forget_gate_bias=1.0).eval()
+    D = 2 if bidir else 1
+    singles = []
+    for layer in range(3):
+        m = RNN(RNNType.LSTM, 64 if layer == 0 else D * H, H, num_layers=1, bidirectional=bidir).eval()
+        sd = {}
+        for k, v in stack.state_dict().items():
+            if f"_l{layer}" in k:
+                sd[k.replace(f"_l{layer}", "_l0")] = v
+        m.load_state_dict(sd)
+        singles.append(m)
+    rng = np.random.default_rng(H)
+    x = T(rng.normal(size=(Tn, N, 64)).astype(np.float32))
+    lens = np.sort(rng.integers(1, Tn + 1, size=N))[::-1].copy()
+    lens[0] = Tn
+    lens = T(lens)
+    (out, _), (hn, cn) = stack((x, lens))
+    h = x
+    hs, cs = [], []
+    for m in singles:
+        (h, _), (a, b) = m((h, lens))
+        hs.append(a)
+        cs.append(b)
+    assert torch.equal(out, h)
+    assert torch.equal(hn, torch.cat(hs, 0)) and torch.equal(cn, torch.cat(cs, 0))
+
+
 def test_rnn_status_word_is_sticky_and_reported_once():
     """ms_rnn_status reads the sticky time-out word at the head of the workspace (set by the kernels, never cleared by a
     layer call), reports it once and clears it; a layer call in between leaves it alone."""
