@@ -745,10 +745,14 @@ __device__ __forceinline__ unsigned epoch_tag0(int d, int steps, int rs = 1) {
 // Exchange-buffer initialisation: every 16-bit word of slot p of direction d gets the tag that is NOT the first one
 // expected there (all-ones or all-zeros words), so a poll that runs ahead of the producers never validates.
 // Layout of a direction: ... [parity][slab_bytes] ..., i.e. parity = (byte offset / slab_bytes) & 1.
+// The same launch clears the per-call status word and the epoch flags (`zero_words` words at `zero_base`), which used to
+// be a memset of its own before every layer call and between batch groups.
 __global__ void hx_init_kernel(unsigned* __restrict__ hx, size_t words_per_dir, size_t slab_words, int ndir, int steps,
-                               int rs) {
+                               int rs, unsigned* __restrict__ zero_base, int zero_words) {
   const size_t total = words_per_dir * ndir;
   const int mask = (1 << rs) - 1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)zero_words; i += (size_t)gridDim.x * blockDim.x)
+    zero_base[i] = 0u;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int d = (int)(i / words_per_dir);
     const int par = (int)(((i % words_per_dir) / slab_words) & mask);
@@ -1953,8 +1957,12 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
   const int steps = max_len;
   const bool fast = use_fast(cell, H, ndir);
 
-  // status + epoch flags are re-zeroed on every call (cdna_hip_programming.md G16)
-  MS_HIP(hipMemsetAsync(ws + W.status, 0, W.xproj - W.status, stream));
+  // status + epoch flags are re-zeroed on every call (cdna_hip_programming.md G16): by hx_init_kernel on the paths that
+  // launch it anyway, by a memset otherwise
+  const bool hx_path = use_split(cell, H, ndir) || use_f32x2(cell, H, ndir) || use_gru_persistent(cell, H, ndir);
+  if (!hx_path) MS_HIP(hipMemsetAsync(ws + W.status, 0, W.xproj - W.status, stream));
+  auto zero_base = [&](int n0) { return (unsigned*)(ws + (n0 == 0 ? W.status : W.flags)); };
+  auto zero_words = [&](int n0) { return (int)((W.xproj - (n0 == 0 ? W.status : W.flags)) / sizeof(unsigned)); };
   // frames t >= max_len are all padding (the planes of a chained layer are only read up to max_len)
   if (steps < T && out)
     MS_HIP(hipMemsetAsync(out + (size_t)steps * N * ndir * H, 0, (size_t)(T - steps) * N * ndir * H * sizeof(float),
@@ -1990,7 +1998,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
     const int group = ((use_split(cell, H, ndir) && two_stream_shape(H)) || f32x2) ? 32 : 64;
     for (int n0 = 0; n0 < N; n0 += group) {
       const int ng = std::min(group, N - n0);
-      if (n0 > 0) MS_HIP(hipMemsetAsync(ws + W.flags, 0, W.xproj - W.flags, stream));
+      if (n0 > 0 && !hx_path) MS_HIP(hipMemsetAsync(ws + W.flags, 0, W.xproj - W.flags, stream));
       LstmP p;
       p.xproj = xproj;
       p.whh = (const float*)(pk + L.whh);
@@ -2026,7 +2034,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
           const size_t words_per_dir = two_stream ? ((size_t)32 * H << rs) : (size_t)2 * H * p.NPAD;
           p.ring_shift = rs;
           hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir)), dim3(256), 0, stream,
-                             (unsigned*)(ws + W.hx), words_per_dir, slab_words, ndir, steps, rs);
+                             (unsigned*)(ws + W.hx), words_per_dir, slab_words, ndir, steps, rs, zero_base(n0), zero_words(n0));
           MS_LAUNCH_CHECK();
         }
         if (two_stream) {
@@ -2045,7 +2053,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       if (f32x2) {
         // every word of every slot starts with the tag that is NOT the first one expected there (also between groups)
         hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for((size_t)64 * H * ndir)), dim3(256), 0, stream,
-                           (unsigned*)(ws + W.hx), (size_t)64 * H, (size_t)16 * H, ndir, steps, 1);
+                           (unsigned*)(ws + W.hx), (size_t)64 * H, (size_t)16 * H, ndir, steps, 1, zero_base(n0), zero_words(n0));
         MS_LAUNCH_CHECK();
         rc = launch_f32x2_any(p, hard, stream);
         if (rc != MS_OK) return rc;
@@ -2074,7 +2082,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
     for (int n0 = 0; n0 < N; n0 += 32) {
       const int rs = lstm_ring_shift();
       hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(((size_t)32 * H << rs) * ndir)), dim3(256), 0, stream,
-                         (unsigned*)(ws + W.hx), (size_t)32 * H << rs, (size_t)8 * H, ndir, steps, rs);
+                         (unsigned*)(ws + W.hx), (size_t)32 * H << rs, (size_t)8 * H, ndir, steps, rs, zero_base(n0), zero_words(n0));
       MS_LAUNCH_CHECK();
       GruP g;
       g.xproj = xproj;
