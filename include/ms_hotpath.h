@@ -180,7 +180,7 @@ int ms_rnn_layer_forward(int cell, const void* packed, const float* x, const int
                          int H, int ndir, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Layer stacks (rnn.py:112-120 num_layers > 1): the same call with two optional hand-offs through the shared workspace,
- * for layer kinds where ms_rnn_layer_chains_planes() returns 1 (the two-stream LSTM with split-bf16 / fp16 operands):
+ * for layer kinds where ms_rnn_layer_chains_planes() returns 1 (the two-stream LSTM with split-bf16 / fp16 operands, the persistent GRU):
  *   MS_RNN_OUT_PLANES_TO_WS  the layer output is left in the workspace as the NEXT layer's GEMM operand planes
  *                            ([max_len*N][ndir*H] bf16 hi + lo, or one fp16 plane) instead of float32 `out` (which may
  *                            then be NULL and is not written); the workspace must also hold

@@ -1509,6 +1509,8 @@ struct GruP {
   float* hx;                   // exchange buffer, per direction [stream][plane][parity][H/8][16][8 bf16]
   unsigned* status;
   int steps, N, n_base, N_total, ndir, J, poll_sleep, ring_shift;
+  unsigned short* out_hi;      // when set: the next layer's GEMM operand planes instead of float32 `out` (see LstmP)
+  unsigned short* out_lo;
 };
 
 __device__ __forceinline__ void publish_elem(float hval, unsigned tag, __amdgpu_buffer_rsrc_t rsrc, int off_hi, int off_lo) {
@@ -1674,7 +1676,17 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
         h[sg] = active ? hnew : h[sg];
         const int off = sg * STREAM + ec.wpar * KG * 256 + elem_off;
         publish_elem(h[sg], wtag, hx_rsrc, off, PLANE + off);
-        if (n < N) p.out[((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit] = active ? hnew : 0.f;
+        if (n < N) {
+          const size_t oidx = ((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit;
+          const float ov = active ? hnew : 0.f;
+          if (p.out_hi) {   // exactly split_planes_kernel's arithmetic
+            const unsigned hb = bf16_bits(ov);
+            p.out_hi[oidx] = (unsigned short)hb;
+            p.out_lo[oidx] = (unsigned short)bf16_bits(ov - bf16_val(hb));
+          } else {
+            p.out[oidx] = ov;
+          }
+        }
       }
     }
   }
@@ -1913,10 +1925,11 @@ static int launch_split2_any(const LstmP& p, bool hard, bool stamps, bool f16, h
 }
 
 // Does a layer of this kind hand its output to the next layer as GEMM operand planes inside the shared workspace
-// (MS_RNN_X_PLANES_IN_WS / MS_RNN_OUT_PLANES_TO_WS)?  Only the two-stream LSTM kernel writes planes.
+// (MS_RNN_X_PLANES_IN_WS / MS_RNN_OUT_PLANES_TO_WS)?  The two-stream LSTM and the persistent GRU kernels write planes.
 extern "C" int ms_rnn_layer_chains_planes(int cell, int H, int ndir) {
   static const bool off = getenv("MS_RNN_CHAIN_PLANES") && getenv("MS_RNN_CHAIN_PLANES")[0] == '0';
   if (off || cell < 0 || cell > MS_CELL_HARD_LSTM) return 0;
+  if (use_gru_persistent(cell, H, ndir)) return use_split_gemm(cell, H, ndir, ndir * H) ? 1 : 0;
   return use_split(cell, H, ndir) && two_stream_shape(H) && use_split_gemm(cell, H, ndir, ndir * H) &&
          !(getenv("MS_LSTM_ONE_STREAM") && getenv("MS_LSTM_ONE_STREAM")[0] == '1') ? 1 : 0;
 }
@@ -2090,6 +2103,11 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       g.bhh = (const float*)(pk + L.bhh);
       g.lens = lens;
       g.h0 = h0; g.out = out; g.hn = hn;
+      g.out_hi = g.out_lo = nullptr;
+      if (out_to_ws) {
+        g.out_hi = (unsigned short*)(ws + W.xsplit);
+        g.out_lo = g.out_hi + (size_t)steps * N * ndir * H;
+      }
       g.hx = (float*)(ws + W.hx);
       g.status = (unsigned*)(ws + W.status);
       g.steps = steps; g.N = std::min(32, N - n0); g.n_base = n0; g.N_total = N; g.ndir = ndir; g.J = H / GRU_U;

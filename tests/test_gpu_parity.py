@@ -966,6 +966,30 @@ def test_lstm_stack_plane_chaining_is_bit_identical_to_single_layers(H, bidir, N
     assert torch.equal(hn, torch.cat(hs, 0)) and torch.equal(cn, torch.cat(cs, 0))
 
 
+def test_gru_stack_plane_chaining_is_bit_identical_to_single_layers():
+    """The same hand-over in the persistent GRU (H = 1280, the half-width sibling of the shipped config's GRU-2560)."""
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    H, N, Tn = 1280, 9, 7
+    torch.manual_seed(3)
+    stack = RNN(RNNType.GRU, 64, H, num_layers=2, bidirectional=False).eval()
+    singles = []
+    for layer in range(2):
+        m = RNN(RNNType.GRU, 64 if layer == 0 else H, H, num_layers=1, bidirectional=False).eval()
+        m.load_state_dict({k.replace(f"_l{layer}", "_l0"): v for k, v in stack.state_dict().items() if f"_l{layer}" in k})
+        singles.append(m)
+    rng = np.random.default_rng(3)
+    x = T(rng.normal(size=(Tn, N, 64)).astype(np.float32))
+    lens = np.sort(rng.integers(1, Tn + 1, size=N))[::-1].copy()
+    lens[0] = Tn
+    lens = T(lens)
+    (out, _), hn = stack((x, lens))
+    h, hs = x, []
+    for m in singles:
+        (h, _), a = m((h, lens))
+        hs.append(a)
+    assert torch.equal(out, h) and torch.equal(hn, torch.cat(hs, 0))
+
+
 def test_rnn_status_word_is_sticky_and_reported_once():
     """ms_rnn_status reads the sticky time-out word at the head of the workspace (set by the kernels, never cleared by a
     layer call), reports it once and clears it; a layer call in between leaves it alone."""
