@@ -164,8 +164,11 @@ def upload(host: torch.Tensor, dtype=None) -> torch.Tensor:
 def attach_host(dev: torch.Tensor, host: torch.Tensor) -> torch.Tensor:
     """Lengths travel between modules on the device (the reference's convention) but drive host control flow (step
     counts, validation): the device tensor a module returns remembers the host values it was made from, so the next
-    module does not read them back (a blocking copy = another drain of the launch queue)."""
-    dev._ms_host = host
+    module does not read them back (a blocking copy = another drain of the launch queue).  The host copy is keyed on the
+    device tensor's version counter and storage address (like the weight caches in ``model/rnn.py``): an in-place edit of
+    the lengths between two modules (``lens -= k``, a masked update, the reference's float in-place ``out_lens``,
+    ``cnn.py:191-197``) bumps ``_version`` and the stale host values are dropped in ``host_lens``."""
+    dev._ms_host = (host.detach().clone(), dev._version, dev.data_ptr())
     return dev
 
 
@@ -173,10 +176,22 @@ def host_lens(lens: torch.Tensor) -> torch.Tensor:
     """Host int64 values of a lengths tensor (from the side channel of ``attach_host`` when there is one)."""
     if not lens.is_cuda:
         return lens.detach().to(torch.int64)
-    h = getattr(lens, "_ms_host", None) if _ASYNC_LENS else None
-    if h is not None and h.shape == lens.shape:
+    h = cached_host(lens) if _ASYNC_LENS else None
+    if h is not None:
         return h.to(torch.int64)
     return lens.detach().to("cpu", torch.int64)
+
+
+def cached_host(lens: torch.Tensor):
+    """The host values attached to ``lens`` if they still describe it, else None (and the stale record is dropped)."""
+    rec = getattr(lens, "_ms_host", None)
+    if rec is None:
+        return None
+    h, version, address = rec
+    if h.shape == lens.shape and version == lens._version and address == lens.data_ptr():
+        return h
+    lens._ms_host = None  # edited in place (or re-pointed) since it was attached: the host values are stale
+    return None
 
 
 def lens_to_device(lens: torch.Tensor) -> torch.Tensor:

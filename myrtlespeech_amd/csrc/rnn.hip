@@ -25,6 +25,7 @@
 // (hidden unit, direction), K split across lanes.  Correct for every shape; not tuned.
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -59,11 +60,18 @@ bool force_generic() {
   return v == 1;
 }
 
+// Every workgroup of a persistent launch spins on its peers, so the whole grid has to be resident at once.  The
+// decision is taken here, once per device and identically at pack time and at launch time: the occupancy API's answer for
+// the persistent kernels (defined below them) times the CU count must cover the grid, otherwise the layer is packed for
+// and run by the per-step kernels, which need no co-residency.
+int persistent_blocks_per_cu(bool gru);
+
 bool use_fast(int cell, int H, int ndir) {
   if (force_generic()) return false;
   if (!(cell == MS_CELL_LSTM || cell == MS_CELL_HARD_LSTM)) return false;
   if (H % 32 != 0 || H > 1024) return false;
-  return ndir * (H / 8) <= ms::num_cus();
+  const int cus = ms::num_cus();
+  return cus > 0 && ndir * (H / 8) <= cus * std::min(1, persistent_blocks_per_cu(false));
 }
 
 // Operand precision of the persistent recurrence: "f32" = exact float32 MFMA,
@@ -98,7 +106,8 @@ bool use_gru_persistent(int cell, int H, int ndir) {
   static const bool off = getenv("MS_GRU_PERSISTENT") && getenv("MS_GRU_PERSISTENT")[0] == '0';
   if (off || force_generic() || !want_split() || cell != MS_CELL_GRU) return false;
   if (H != 1280 && H != 2560) return false;
-  return ndir * (H / GRU_U) <= ms::num_cus();
+  const int cus = ms::num_cus();
+  return cus > 0 && ndir * (H / GRU_U) <= cus * std::min(1, persistent_blocks_per_cu(true));
 }
 
 // MS_LSTM_RING=<slots> (power of two, 2..128; default 2): exchange slots per (stream, plane) of the two-stream LSTM kernel
@@ -1722,6 +1731,107 @@ __global__ void pack_whh_gru_kernel(const float* __restrict__ w, unsigned short*
 
 // ================================================================================================ launch timing
 
+// ================================================================================================ residency
+namespace {
+// MS_RNN_FAKE_OCCUPANCY=<n> (tests): pretend the occupancy API answered n for every persistent kernel.
+int fake_occupancy() {
+  static const int v = getenv("MS_RNN_FAKE_OCCUPANCY") ? atoi(getenv("MS_RNN_FAKE_OCCUPANCY")) : -1;
+  return v;
+}
+
+struct PersistentKernel { const void* fn; size_t lds; };
+
+int min_blocks_per_cu(const PersistentKernel* ks, int n) {
+  int best = 1 << 30;
+  for (int i = 0; i < n; ++i) {
+    if (ks[i].lds > 64 * 1024 &&
+        hipFuncSetAttribute(ks[i].fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return 0;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ks[i].fn, 256, ks[i].lds) != hipSuccess) return 0;
+    best = std::min(best, nb);
+  }
+  return best;
+}
+
+int persistent_blocks_per_cu(bool gru) {
+  if (fake_occupancy() >= 0) return fake_occupancy();
+  static std::atomic<int> cache[2][64];   // per family and device ordinal; 0 = not queried, else answer + 1
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::atomic<int>& slot = cache[gru ? 1 : 0][dev & 63];
+  int v = slot.load(std::memory_order_relaxed);
+  if (v == 0) {
+    const size_t red = (size_t)RED_FLOATS * sizeof(float), big = ((size_t)1024 * 32 + RED_FLOATS) * sizeof(float);
+    int nb;
+    if (gru) {
+      const PersistentKernel ks[] = {{(const void*)gru_persistent_kernel<20, GRU_U>, red},
+                                     {(const void*)gru_persistent_kernel<10, GRU_U>, red}};
+      nb = min_blocks_per_cu(ks, 2);
+    } else {
+      // the heaviest instantiation of every LSTM family (all are __launch_bounds__(256, 1); registers and LDS are
+      // what the API prices): LDS-resident weights at H = 1024, register-resident split / f32 weights at H = 1024
+      const PersistentKernel ks[] = {
+          {(const void*)lstm_persistent_kernel<1, false, true>, big},
+          {(const void*)lstm_persistent_kernel<2, false, true>, big},
+          {(const void*)lstm_persistent_split_kernel<1, 4, false>, big},
+          {(const void*)lstm_persistent_split_kernel<2, 0, false>, big},
+          {(const void*)lstm_persistent_split2_kernel<8, false>, red},
+          {(const void*)lstm_persistent_split2_kernel<8, true>, red},
+          {(const void*)lstm_persistent_split2_kernel<8, false, false, true>, red},
+          {(const void*)lstm_persistent_f32x2_kernel<16, false>, red},
+          {(const void*)lstm_persistent_f32x2_kernel<16, true>, red}};
+      nb = min_blocks_per_cu(ks, (int)(sizeof(ks) / sizeof(ks[0])));
+    }
+    v = nb + 1;
+    slot.store(v, std::memory_order_relaxed);
+  }
+  return v - 1;
+}
+
+// Two persistent launches must never be resident together: each fills (up to) every CU with workgroups that wait for
+// their own peers, so two half-resident grids on two streams would wait for each other until the spin limit.  Launches
+// of this process are therefore chained across streams: a persistent launch on stream S waits (on the device) for the
+// previous persistent launch if that one went to a different stream.  With a single stream -- the normal case -- this
+// costs nothing: no event is recorded until a second stream shows up (that first hand-over synchronises the earlier
+// stream on the host once; from then on every persistent launch records an event).
+struct PersistentChain {
+  std::mutex mu;
+  hipStream_t last = nullptr;
+  bool any = false, multi = false;
+  hipEvent_t done = nullptr;
+};
+PersistentChain g_chain[64];
+
+struct PersistentTurn {
+  PersistentChain* c = nullptr;
+  hipStream_t stream;
+  int rc = MS_OK;
+  explicit PersistentTurn(hipStream_t s) : stream(s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { rc = MS_ERR_HIP; return; }
+    c = &g_chain[dev & 63];
+    c->mu.lock();
+    if (c->any && c->last != stream) {
+      if (!c->multi) {
+        if (hipStreamSynchronize(c->last) != hipSuccess ||
+            hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) rc = MS_ERR_HIP;
+        c->multi = true;
+      } else if (hipStreamWaitEvent(stream, c->done, 0) != hipSuccess) {
+        rc = MS_ERR_HIP;
+      }
+    }
+  }
+  ~PersistentTurn() {
+    if (!c) return;
+    if (c->multi && c->done) (void)hipEventRecord(c->done, stream);
+    c->last = stream;
+    c->any = true;
+    c->mu.unlock();
+  }
+};
+}  // namespace
+
 namespace {
 struct ProfSpan { hipEvent_t a, b; int kind; };
 bool g_prof_on = false;
@@ -2005,6 +2115,8 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
   ProfScope prof_rec(1, stream);
 
   if (fast) {
+    PersistentTurn turn(stream);   // never resident together with another stream's persistent launch
+    if (turn.rc != MS_OK) { ms::set_error("ms_rnn_layer_forward: cross-stream hand-over of the persistent launch failed"); return turn.rc; }
     // batch groups of <= 64 sequences, one persistent launch each (stream-ordered; the epoch
     // flags are re-zeroed in between, the status word is kept so any time-out is reported)
     const bool f32x2 = use_f32x2(cell, H, ndir);
@@ -2091,6 +2203,8 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
   }
 
   if (use_gru_persistent(cell, H, ndir)) {
+    PersistentTurn turn(stream);
+    if (turn.rc != MS_OK) { ms::set_error("ms_rnn_layer_forward: cross-stream hand-over of the persistent launch failed"); return turn.rc; }
     // one persistent launch per group of 32 sequences (two interleaved streams of 16)
     for (int n0 = 0; n0 < N; n0 += 32) {
       const int rs = lstm_ring_shift();

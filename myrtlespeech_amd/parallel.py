@@ -11,10 +11,13 @@ plus the lengths.  At 1.86 MB per shard this is latency-bound, so it is one dire
 all-gather, not a ring of smaller pieces.  When decoding per shard, only the ragged index
 lists are gathered (host objects) and no device collective runs.
 """
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+from myrtlespeech_amd import _lib
 
 
 def shard_bounds(batch: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -35,35 +38,65 @@ def shard_batch(x: torch.Tensor, lens: torch.Tensor, world_size: int, rank: int,
     return x.narrow(batch_dim, b, e - b), lens[b:e]
 
 
+def _force_collective() -> bool:
+    """MS_FORCE_COLLECTIVE=1: take the collective path at world size 1 too (a one-rank RCCL run on a one-GPU box exercises
+    init, the device all-gathers and the stream hand-over of the real N > 1 path; tests/test_gpu_parity.py)."""
+    return os.environ.get("MS_FORCE_COLLECTIVE") == "1"
+
+
+_HOST_GROUPS = {}
+
+
+def _host_group(group: Optional[dist.ProcessGroup]):
+    """Process group for host objects: with the RCCL backend ``all_gather_object`` would stage the pickled bytes through
+    device tensors and read their sizes back (two host syncs in the middle of a step), so small host metadata travels over
+    a gloo twin of ``group`` created (collectively, once) at the first call."""
+    if dist.get_backend(group) == "gloo":
+        return group
+    key = id(group)
+    if key not in _HOST_GROUPS:
+        ranks = None if group is None else dist.get_process_group_ranks(group)
+        _HOST_GROUPS[key] = dist.new_group(ranks=ranks, backend="gloo")
+    return _HOST_GROUPS[key]
+
+
 def gather_logits(logits: torch.Tensor, lens: torch.Tensor, group: Optional[dist.ProcessGroup] = None
                   ) -> Tuple[torch.Tensor, torch.Tensor]:
     """All-gather ``(logits[T_r, N_r, V], lens[N_r])`` of every rank into the full batch
     ``(logits[T_max, sum N_r, V], lens[sum N_r])`` on every rank, shards in rank order.
-    Frames past a shard's own T_r are zero (they lie beyond every length of that shard)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    Frames past a shard's own T_r are zero (they lie beyond every length of that shard).
+
+    The shard shapes travel as host integers (``all_gather_object``), never as device tensors that would have to be read
+    back in the middle of a step; the payload is ONE ``all_gather_into_tensor`` of equal-sized padded blocks plus one for the
+    lengths (RCCL on the device, gloo in the CPU tests).  The lengths returned carry their host values (``_lib.attach_host``),
+    so the decoder that follows does not read them back either."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _force_collective()):
         return logits, lens
     world = dist.get_world_size(group)
     dev = logits.device
-    meta = torch.tensor([logits.shape[0], logits.shape[1]], dtype=torch.int64, device=dev)
-    metas = [torch.empty_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta, group=group)
-    t_all = [int(m[0]) for m in metas]
-    n_all = [int(m[1]) for m in metas]
+    lens_host = _lib.host_lens(lens)
+    shapes: List[Optional[Tuple[int, int, List[int]]]] = [None] * world
+    dist.all_gather_object(shapes, (int(logits.shape[0]), int(logits.shape[1]), lens_host.tolist()),
+                           group=_host_group(group))
+    t_all = [s[0] for s in shapes]
+    n_all = [s[1] for s in shapes]
     t_max, n_max, v = max(t_all), max(n_all), logits.shape[2]
     # equal-sized payloads so the exchange is ONE all-gather
-    pad = torch.zeros((t_max, n_max, v), dtype=logits.dtype, device=dev)
-    pad[:logits.shape[0], :logits.shape[1]] = logits
-    lens_pad = torch.zeros(n_max, dtype=torch.int64, device=dev)
-    lens_pad[:lens.numel()] = lens.to(device=dev, dtype=torch.int64)
+    if logits.shape[0] == t_max and logits.shape[1] == n_max:
+        pad = logits.contiguous()
+    else:
+        pad = torch.zeros((t_max, n_max, v), dtype=logits.dtype, device=dev)
+        pad[:logits.shape[0], :logits.shape[1]] = logits
     out = torch.empty((world * t_max, n_max, v), dtype=logits.dtype, device=dev)
-    out_lens = torch.empty(world * n_max, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(out, pad, group=group)
-    dist.all_gather_into_tensor(out_lens, lens_pad, group=group)
     out = out.view(world, t_max, n_max, v)
-    out_lens = out_lens.view(world, n_max)
-    full = torch.cat([out[r, :, :n_all[r]] for r in range(world)], dim=1)
-    full_lens = torch.cat([out_lens[r, :n_all[r]] for r in range(world)]).to(lens.dtype)
-    return full, full_lens
+    full = out[0, :, :n_all[0]] if world == 1 else torch.cat([out[r, :, :n_all[r]] for r in range(world)], dim=1)
+    full_host = torch.tensor([l for s in shapes for l in s[2]], dtype=torch.int64)
+    if lens.is_cuda:
+        full_lens = _lib.attach_host(_lib.upload(full_host.to(lens.dtype)), full_host)
+    else:
+        full_lens = full_host.to(lens.dtype)
+    return full.contiguous(), full_lens
 
 
 def gather_transcripts(local: Sequence[List[int]], group: Optional[dist.ProcessGroup] = None) -> List[List[int]]:
@@ -72,7 +105,7 @@ def gather_transcripts(local: Sequence[List[int]], group: Optional[dist.ProcessG
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return [list(s) for s in local]
     parts: List[Optional[List[List[int]]]] = [None] * dist.get_world_size(group)
-    dist.all_gather_object(parts, [list(s) for s in local], group=group)
+    dist.all_gather_object(parts, [list(s) for s in local], group=_host_group(group))
     return [s for part in parts for s in part]
 
 

@@ -1,0 +1,108 @@
+"""Config-size checks shared by the in-process GPU tests and their child processes (``MS_PRECISION`` is read once per
+process, so the fp16 legs run in a child: ``python -c "import cfg_checks; cfg_checks.stream64(...)"``).  Needs a GPU."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from util import Golden  # noqa: E402
+
+
+def stream64(atol: float, check_argmax: bool) -> float:
+    """BASELINE.json configs[4] at its stated batch: the config-2 network on 32-frame (320 ms) chunks, state carried, 64
+    ragged utterances (two 32-row batch groups per recurrent layer call, utterances leaving the batch inside and across
+    the groups) against the reference run chunk by chunk with ``hx`` threaded (tests/golden/cfg5_stream_n64_summary.npz,
+    made by tests/golden/gen_golden.py::gen_streaming_n64).  Returns the max |logit error| on the stored sub-grid."""
+    import bench
+    from myrtlespeech_amd.streaming import ChunkedDeepSpeech2
+    g = Golden("cfg5_stream_n64_summary")
+    model = bench.build_model()
+    for k, v in model.state_dict().items():
+        want = g.cfg["weight_abs_sums"][k]
+        assert abs(float(v.double().abs().sum()) - want) <= 1e-6 * max(1.0, want), k
+    gen = torch.Generator().manual_seed(g.cfg["seed_input"])
+    N, Tn = g.cfg["N"], g.cfg["T"]
+    x = torch.randn(N, 1, 80, Tn, generator=gen)
+    lens = torch.sort(torch.randint(20, Tn + 1, (N,), generator=gen), descending=True).values
+    lens[0] = Tn
+    np.testing.assert_array_equal(lens.numpy(), g["in/lens"])
+    (y, out_lens), (hn, cn) = ChunkedDeepSpeech2(model, g.cfg["chunk_frames"])(x, lens)
+    y, hn, cn = y.cpu().numpy(), hn.cpu().numpy(), cn.cpu().numpy()
+    np.testing.assert_array_equal(out_lens.cpu().numpy(), g["out/lens"])
+    np.testing.assert_allclose(y[::3, ::3, ::2], g["out/y_sub"], rtol=0, atol=atol)
+    np.testing.assert_allclose(hn[:, ::3, ::64], g["out/hn_sub"], rtol=0, atol=atol)
+    np.testing.assert_allclose(cn[:, ::3, ::64], g["out/cn_sub"], rtol=0, atol=atol)
+    if check_argmax:
+        # every frame's arg max (what the greedy decoder collapses) equals the reference's, except where the two best
+        # logits of the frame are closer than the tolerance allows one to tell apart
+        am = y.argmax(-1)
+        diff = am != g["out/argmax"].astype(np.int64)
+        if diff.any():
+            top2 = np.sort(y, axis=-1)[..., -2:]
+            margin = top2[..., 1] - top2[..., 0]
+            assert float(margin[diff].max()) < 1e-5, f"{int(diff.sum())} arg-max mismatches, margins up to {margin[diff].max()}"
+    err = float(np.abs(y[::3, ::3, ::2] - g["out/y_sub"]).max())
+    print(f"cfg5 N=64 chunked streaming: max |logit err| {err:.3e} (mean |logit| {g.cfg['y_abs_mean']:.3e})")
+    return err
+
+
+def rccl_one_rank() -> None:
+    """BASELINE.json configs[2]'s exchange step on the one GPU this box has: a ONE-rank RCCL group with the collective
+    path forced (MS_FORCE_COLLECTIVE=1): init, the device all-gather of the padded logits block, the host-side shape
+    exchange over the gloo twin group, and a persistent recurrent launch right behind the collective."""
+    import torch.distributed as dist
+    assert os.environ.get("MS_FORCE_COLLECTIVE") == "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from myrtlespeech_amd import _lib
+        from myrtlespeech_amd import parallel as P
+        from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+        g = torch.Generator().manual_seed(7)
+        logits = torch.randn(501, 32, 29, generator=g).cuda()
+        lens = torch.sort(torch.randint(250, 502, (32,), generator=g), descending=True).values
+        lens_dev = _lib.lens_to_device(lens)
+        full, full_lens = P.gather_logits(logits, lens_dev)
+        assert full.data_ptr() != logits.data_ptr(), "the collective path was not taken"
+        assert torch.equal(full, logits)
+        assert torch.equal(full_lens.cpu(), lens)
+        assert torch.equal(_lib.host_lens(full_lens), lens)          # host values ride along: no read-back in the decoder
+        # the real pipeline: encoder on this rank's shard -> all-gather -> batched decode == per-shard decode
+        import __graft_entry__  # noqa: F401  (same tiny network as smoke())
+        from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+        from myrtlespeech_amd.model.deep_speech_2 import DeepSpeech2
+        from myrtlespeech_amd.model.fully_connected import FullyConnected
+        from myrtlespeech_amd.model.rnn import RNN, RNNType
+        from myrtlespeech_amd.model.seq_len_wrapper import SeqLenWrapper
+        torch.manual_seed(0)
+
+        def act():
+            return SeqLenWrapper(torch.nn.Hardtanh(0.0, 20.0), torch.nn.Identity())
+        cnn = torch.nn.Sequential(MaskConv2d(1, 8, [11, 5], [2, 2], PaddingMode.SAME), act(),
+                                  MaskConv2d(8, 8, [5, 5], [2, 1], PaddingMode.SAME), act())
+        rnn = RNN(RNNType.LSTM, 8 * 10, 256, num_layers=2, bidirectional=True, forget_gate_bias=1.0)   # persistent kernel
+        fc = FullyConnected(512, 29, 1, 96, torch.nn.Hardtanh(0.0, 20.0))
+        model = DeepSpeech2(cnn, rnn, None, fc).eval()
+        x = torch.randn(6, 1, 40, 90, generator=g)
+        xl = torch.tensor([90, 77, 61, 50, 33, 20])
+        dec = CTCGreedyDecoder(28)
+        a = P.sharded_forward_decode(model, dec, x.clone(), xl, batched_decode=True)
+        b = P.sharded_forward_decode(model, dec, x.clone(), xl, batched_decode=False)
+        (y, ol), _ = model((x.clone(), xl))
+        assert a == b == dec(y, ol)
+        for _ in range(3):   # collective and persistent launches back to back
+            (y2, ol2), _ = model((x.clone(), xl))
+            f2, _ = P.gather_logits(y2, ol2)
+            assert torch.equal(f2, y)
+        dist.barrier()
+        torch.cuda.synchronize()
+        print("rccl one-rank ok: backend", dist.get_backend(), "world", dist.get_world_size())
+    finally:
+        dist.destroy_process_group()

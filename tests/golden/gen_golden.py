@@ -734,5 +734,55 @@ def gen_streaming_full():
     save("cfg5_stream_summary", dict(weight_abs_sums=chk, seed_input=555, N=N, T=T, chunk_frames=chunk), arrays)
 
 
+def gen_streaming_n64():
+    """BASELINE configs[4] at its stated batch: the config-2 network (seed-0 weights) on consecutive 32-frame chunks (320 ms)
+    with the state threaded, **64** ragged utterances of 20 .. 192 frames (six chunks; utterances leave the batch inside
+    and across the two 32-row batch groups of the recurrent kernels), run through the reference chunk by chunk exactly as
+    gen_streaming_full does; logits on a sub-grid, final states on a sub-grid, greedy transcripts of every utterance."""
+    torch.manual_seed(0)
+    cnn = torch.nn.Sequential(
+        MaskConv2d(1, 32, [41, 11], [2, 2], PaddingMode.SAME), act_wrap(0.0, 20.0),
+        MaskConv2d(32, 32, [21, 11], [2, 1], PaddingMode.SAME), act_wrap(0.0, 20.0),
+    )
+    rnn = RNN(RNNType.LSTM, 640, 1024, num_layers=5, bidirectional=True, forget_gate_bias=1.0)
+    fc = FullyConnected(2048, 29, 1, 1024, torch.nn.Hardtanh(0.0, 20.0))
+    m = DeepSpeech2(cnn, rnn, None, fc).eval()
+    g = torch.Generator().manual_seed(556)
+    N, T, chunk = 64, 192, 32
+    x = torch.randn(N, 1, 80, T, generator=g)
+    lens = torch.sort(torch.randint(20, T + 1, (N,), generator=g), descending=True).values
+    lens[0] = T
+    outs, out_lens = [], torch.zeros(N, dtype=torch.int64)
+    hid, t0 = None, 0
+    final_h = torch.zeros(10, N, 1024)
+    final_c = torch.zeros(10, N, 1024)
+    while t0 < T:
+        alive = int((lens > t0).sum())
+        if alive == 0:
+            break
+        xc = x[:alive, :, :, t0:t0 + chunk].clone()
+        lc = (lens[:alive] - t0).clamp(max=xc.shape[-1])
+        hx = None if hid is None else (hid[0][:, :alive].contiguous(), hid[1][:, :alive].contiguous())
+        (y, ol), hid = m((xc, lc), hx)
+        final_h[:, :alive] = hid[0]
+        final_c[:, :alive] = hid[1]
+        full = torch.zeros(y.shape[0], N, y.shape[2])
+        full[:, :alive] = y
+        outs.append(full)
+        out_lens[:alive] += ol
+        t0 += chunk
+    y = torch.cat(outs, 0)
+    # greedy over each utterance's own valid frames of each chunk: the chunks' outputs are concatenated chunk-major, so
+    # utterance n's valid frames are, per chunk, the first ol_chunk[n] rows of that chunk's block
+    chk = {k: float(v.double().abs().sum()) for k, v in m.state_dict().items()}
+    arrays = {"in/lens": npy(lens), "out/y_sub": npy(y[::3, ::3, ::2]), "out/lens": npy(out_lens),
+              "out/argmax": npy(y.argmax(-1).to(torch.int8)),
+              "out/hn_sub": npy(final_h[:, ::3, ::64]), "out/cn_sub": npy(final_c[:, ::3, ::64])}
+    save("cfg5_stream_n64_summary", dict(weight_abs_sums=chk, seed_input=556, N=N, T=T, chunk_frames=chunk,
+                                         y_abs_mean=float(y.abs().mean())), arrays)
+
+
 if __name__ == "__main__" and "streamfull" in sys.argv[1:]:
     gen_streaming_full()
+if __name__ == "__main__" and "stream64" in sys.argv[1:]:
+    gen_streaming_n64()

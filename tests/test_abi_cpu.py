@@ -140,3 +140,23 @@ def test_levenshtein():
         a = rng.integers(0, 4, size=int(rng.integers(0, 9))).tolist()
         b = rng.integers(0, 4, size=int(rng.integers(0, 9))).tolist()
         assert levenshtein(a, b) == ref(a, b)
+
+
+def test_host_length_side_channel_drops_stale_values():
+    """the host copy attached to a lengths tensor must not outlive an in-place edit of that tensor
+    (``lens -= k`` between two modules, the reference's float in-place ``out_lens``, ``cnn.py:191-197``)."""
+    from myrtlespeech_amd import _lib
+    host = torch.tensor([9, 7, 4])
+    dev = _lib.attach_host(host.clone(), host)          # a CPU stand-in for the device tensor: same bookkeeping
+    assert torch.equal(_lib.cached_host(dev), host)
+    host[0] = 100                                       # the caller's own tensor is not aliased
+    assert _lib.cached_host(dev)[0] == 9
+    dev.sub_(1)                                         # in-place edit -> version bump -> stale
+    assert _lib.cached_host(dev) is None
+    assert torch.equal(_lib.host_lens(dev), torch.tensor([8, 6, 3]))
+    dev2 = _lib.attach_host(torch.tensor([5, 5]), torch.tensor([5, 5]))
+    dev2.data = torch.tensor([3, 2])                    # re-pointed storage -> address differs -> stale
+    assert _lib.cached_host(dev2) is None
+    dev3 = _lib.attach_host(torch.tensor([5, 5]), torch.tensor([5, 5]))
+    dev3[1] = 2                                         # masked / indexed update
+    assert _lib.cached_host(dev3) is None

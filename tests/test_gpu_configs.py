@@ -1,0 +1,115 @@
+"""BASELINE.json configs[2..4] under a checker at their STATED sizes (VERDICT r1 "next round" item 1).  Needs a real
+MI355X: -m gpu.
+
+* configs[2] (utterance shards + one RCCL all-gather for batched decode): the exchange step executed over RCCL in a fresh
+  one-rank child (this box has one GPU; the N-rank layout is covered by the gloo tests in test_parallel_cpu.py and by the
+  shard == whole-batch property in test_gpu_properties.py);
+* configs[3] (RNN-T, own specification, **parity unpinned**: the reference has no transducer): batch 16, beam 8,
+  2 x LSTM-1024 predictor, joint 512, T = 501 against answers of the numpy oracle stored by
+  tests/golden/gen_rnnt_cfg4.py, plus determinism and shard properties over all sixteen utterances;
+* configs[4] (chunked streaming): batch 64 on 32-frame chunks with the state carried, against the REFERENCE run chunk by
+  chunk (tests/golden/cfg5_stream_n64_summary.npz), in the default bf16x3 arithmetic at the north-star's 1e-3 and in a
+  child process with ``MS_PRECISION=fp16`` ("fp16 MFMA" is what BASELINE.json names) at the fp16 tolerance stated there.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import cfg_checks
+from util import Golden
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _child(call: str, **env):
+    """Run ``cfg_checks.<call>`` in a fresh interpreter (started as a child; the parent keeps running)."""
+    code = f"import sys; sys.path.insert(0, {HERE!r}); import cfg_checks; cfg_checks.{call}; print('child ok')"
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-4000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+# ----------------------------------------------------------------------------- configs[4]: streaming, batch 64
+def test_cfg5_streaming_batch64_bf16x3_vs_reference():
+    err = cfg_checks.stream64(atol=1e-3, check_argmax=True)
+    assert err < 1e-4   # measured ~3e-7; the gate above is the north-star's 1e-3
+
+
+def test_cfg5_streaming_batch64_fp16_mfma_in_subprocess():
+    """``MS_PRECISION=fp16``: one fp16 pass (10-bit mantissa operands, f32 accumulate) in the recurrence, the projection
+    GEMMs, the large Linears and the channels-last convolution.  Stated tolerance for this OPTIONAL mode: 2e-4 absolute
+    on logits of mean magnitude 1.7e-2 and on the final (h, c) states (|h| <= 1), i.e. ~1 % of the logit scale per 5-layer
+    stack -- looser than the 1e-3 relative-to-unit gate would suggest, which is why fp16 is not the default mode."""
+    out = _child("stream64(atol=2e-4, check_argmax=False)", MS_PRECISION="fp16")
+    assert "max |logit err|" in out
+    print(out.strip().splitlines()[-2])
+
+
+# ----------------------------------------------------------------------------- configs[2]: the RCCL exchange step
+def test_cfg3_rccl_all_gather_one_rank_child():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = _child("rccl_one_rank()", MS_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0",
+                 WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    assert "rccl one-rank ok: backend nccl world 1" in out
+
+
+# ----------------------------------------------------------------------------- configs[3]: RNN-T at its stated size
+def _rnnt_cfg4():
+    g = Golden("rnnt_cfg4")
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import gen_rnnt_cfg4 as G
+    pred, joint = G.parts()
+    for k, v in pred.state_dict().items():
+        want = g.cfg["weight_abs_sums"]["pred/" + k]
+        assert abs(float(v.double().abs().sum()) - want) <= 1e-6 * max(1.0, want), k
+    for k, v in joint.state_dict().items():
+        want = g.cfg["weight_abs_sums"]["joint/" + k]
+        assert abs(float(v.double().abs().sum()) - want) <= 1e-6 * max(1.0, want), k
+    enc, lens = G.inputs()
+    assert abs(float(enc.double().abs().sum()) - g.cfg["enc_abs_sum"]) < 1e-3
+    np.testing.assert_array_equal(lens.numpy(), g["in/lens"])
+    return g, pred, joint, enc, lens
+
+
+def test_cfg4_rnnt_batch16_beam8_predictor1024_vs_oracle_answers():
+    from myrtlespeech_amd.post_process.rnnt_decoder import RNNTBeamDecoder, RNNTGreedyDecoder
+    g, pred, joint, enc, lens = _rnnt_cfg4()
+    c = g.cfg
+    assert (c["N"], c["T"], c["beam_width"], c["P"], c["L"], c["J"]) == (16, 501, 8, 1024, 2, 512)
+    greedy = RNNTGreedyDecoder(pred, joint, max_symbols=c["max_symbols"])
+    beam = RNNTBeamDecoder(pred, joint, beam_width=c["beam_width"], max_symbols=c["max_symbols"])
+    enc_d = enc.cuda()
+    got_g = greedy(enc_d, lens)
+    got_b = beam(enc_d, lens)
+    scores = list(beam.last_scores)
+    for n in c["selected"]:
+        assert got_g[n] == g[f"out/greedy_{n}"].tolist(), f"greedy, utterance {n}"
+        want_s = float(g[f"out/beam_score_{n}"])
+        if got_b[n] != g[f"out/beam_{n}"].tolist():
+            # the one documented way to differ: two hypotheses whose float32 totals are <= 4 ulp apart
+            assert abs(scores[n] - want_s) <= 4 * np.spacing(np.float32(abs(want_s))), f"beam, utterance {n}"
+        np.testing.assert_allclose(scores[n], want_s, rtol=1e-4, atol=1e-4)
+    # determinism: a second decode of the same batch gives the same transcripts and bit-equal scores
+    assert beam(enc_d, lens) == got_b and list(beam.last_scores) == scores
+    assert greedy(enc_d, lens) == got_g
+    # utterances do not interact: two shards of eight reproduce the batch of sixteen
+    for b0 in (0, 8):
+        sl = slice(b0, b0 + 8)
+        e8 = enc_d[:int(lens[sl].max()), sl].contiguous()
+        assert beam(e8, lens[sl]) == got_b[sl]
+        assert list(beam.last_scores) == scores[sl]
+        assert greedy(e8, lens[sl]) == got_g[sl]
+    # every transcript stays inside its bound (at most max_symbols - 1 labels per frame for the beam, max_symbols greedy)
+    for n in range(c["N"]):
+        assert len(got_b[n]) <= int(lens[n]) * (c["max_symbols"] - 1)
+        assert len(got_g[n]) <= int(lens[n]) * c["max_symbols"]
+        assert all(0 <= k < c["V"] for k in got_b[n] + got_g[n])

@@ -87,3 +87,29 @@ def test_two_rank_gather_and_decode_gloo():
     assert sorted(r[0] for r in results) == [0, 1]
     for _, ok_gather, ok_batched, ok_local in results:
         assert ok_gather and ok_batched and ok_local
+
+
+def _single_rank_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MS_FORCE_COLLECTIVE"] = "1"
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        logits = torch.arange(5 * 3 * 4, dtype=torch.float32).view(5, 3, 4)
+        lens = torch.tensor([5, 4, 2])
+        full, full_lens = P.gather_logits(logits, lens)
+        q.put((bool(torch.equal(full, logits)), bool(torch.equal(full_lens, lens)), full.data_ptr() != logits.data_ptr()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forced_collective_path_at_world_size_one_gloo():
+    """MS_FORCE_COLLECTIVE=1 sends a one-rank group through the all-gather (the switch the one-GPU RCCL test uses)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_rank_worker, args=(_free_port(), q))
+    p.start()
+    same, same_lens, went_through_collective = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert same and same_lens and went_through_collective
