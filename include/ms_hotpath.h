@@ -211,8 +211,12 @@ size_t ms_rnn_debug_offset(int cell, int T, int N, int In, int H, int ndir);
  * surface).  While enabled, ms_rnn_layer_forward brackets its input-projection
  * GEMM and its recurrent kernel with HIP events on the caller's stream.
  * ms_prof_read synchronises those events and returns the summed milliseconds and
- * launch counts since the last read: out_ms[0]/out_n[0] = input projection,
- * out_ms[1]/out_n[1] = recurrent kernel(s) of one layer. */
+ * launch counts since the last read, MS_PROF_KINDS entries each:
+ * [0] = input projection of one layer (operand split, where the producer did not
+ * hand planes over, + GEMM), [1] = recurrent kernel(s) of one layer, [2] = the
+ * split-operand projection GEMM kernel alone at In >= 1024, [3] = the same at
+ * In < 1024 (the first layer of a stack). */
+#define MS_PROF_KINDS 4
 int ms_prof_enable(int on);
 int ms_prof_read(float* out_ms_host, int* out_n_host);
 

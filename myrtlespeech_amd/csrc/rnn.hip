@@ -1864,8 +1864,7 @@ extern "C" int ms_prof_enable(int on) {
 
 extern "C" int ms_prof_read(float* out_ms, int* out_n) {
   MS_REQUIRE(out_ms && out_n, "null pointer");
-  out_ms[0] = out_ms[1] = 0.f;
-  out_n[0] = out_n[1] = 0;
+  for (int k = 0; k < MS_PROF_KINDS; ++k) { out_ms[k] = 0.f; out_n[k] = 0; }
   for (auto& s : g_spans) {
     MS_HIP(hipEventSynchronize(s.b));
     float ms = 0.f;
@@ -2103,10 +2102,13 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       const unsigned short* wl = wh + (size_t)ndir * GH * In;
       const int prec = use_f16(cell, H, ndir) ? ms::PREC_F16 : ms::PREC_BF16X3;
       rc = x_in_ws ? MS_OK : ms::split_planes_launch(x, xh, xl, (size_t)steps * N * In, prec, stream);
-      if (rc == MS_OK)
+      if (rc == MS_OK) {
+        ProfScope gemm_only(In >= 1024 ? 2 : 3, stream);   // the split GEMM kernel alone, by contraction length
         rc = ms::gemm_bf16x3_launch(xh, xl, wh, wl, (const float*)(pk + L.bias_x), xproj, steps * N, In, (int)(ndir * GH),
                                     MS_ACT_NONE, 0.f, 0.f, prec, stream);
+      }
     } else {
+      ProfScope gemm_only(In >= 1024 ? 2 : 3, stream);
       rc = ms::linear_launch(x, (const float*)(pk + L.wih), (const float*)(pk + L.bias_x), xproj, steps * N, In,
                              (int)(ndir * GH), MS_ACT_NONE, 0.f, 0.f, stream);
     }

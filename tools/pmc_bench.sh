@@ -1,0 +1,24 @@
+#!/bin/bash
+# Counter passes over bench.py itself (HEAD's chained 5-layer stack, the binary the bench times), on the GPU box:
+#     bash tools/pmc_bench.sh [tag] [precision]
+# Each pass is its own rocprofv3 run (PMC only -- no tracing flags), bounded by `timeout`; the program after `--` is
+# python3 itself.  Writes gpurun_out/pmc_bench_<tag>.json (copy it to profiles/r02_pmc_bench.json) and a text summary.
+TAG=${1:-r02}
+PREC=${2:-bf16x3}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/pmc_bench_$TAG
+cd /tmp && export TMPDIR=/tmp
+[ "$PREC" != "bf16x3" ] && export MS_PRECISION=$PREC
+pass() {
+  local name=$1; shift
+  echo "[pmc_bench] pass $name: $*"
+  timeout -k 10 240 rocprofv3 --pmc "$@" -d $OUT/$name -o $name --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-child --no-frontend --no-ragged > $OUT.$name.log 2>&1 || { echo "[pmc_bench] pass $name failed or timed out"; tail -5 $OUT.$name.log; return 1; }
+}
+mkdir -p $OUT
+pass p1 FETCH_SIZE || exit 1
+pass p2 WRITE_SIZE || exit 1
+pass p3 TCC_HIT_sum TCC_MISS_sum || exit 1
+pass p4 SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY || exit 1
+python3 $ROOT/tools/pmc_bench_summary.py $OUT $PREC > $ROOT/gpurun_out/pmc_bench_$TAG.json || exit 1
+find $OUT -name "*.csv" -size +1M -delete
+cat $ROOT/gpurun_out/pmc_bench_$TAG.json
