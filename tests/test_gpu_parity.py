@@ -932,6 +932,55 @@ def test_conv_mfma_paths_small_shape_sweep(monkeypatch):
     assert len(cases) == 408 + 64 + 32
 
 
+def conv_cl_lanemask_trigger_shapes():
+    """(cin, kt, st, dt, tile) for which the round-1 interim build of maskconv_cl_kernel staged zeros (root cause, from its
+    ISA: the runtime feature-window flag was compared by the VALU into an SGPR lane mask inside the FIRST output row's
+    staging loop, under that loop's shrinking EXEC, and re-used in the SECOND row's loop; tools/micro/convflag/).  The mask
+    held only the lanes that were active in a wave's LAST staging iteration, tid < m = KG * PW mod 256 (0 < m < 64); if those
+    lanes are all left-padding frames at the start of the second row (m <= KG * pad_left) and other lanes are not, the wave
+    took the wrong load path.  tile = output frames per workgroup (128, or 32 for short inputs)."""
+    from myrtlespeech_amd.model.cnn import pad_same
+    out = []
+    for tile in (128, 32):
+        for cin in (16, 32, 48, 64):
+            kg = cin // 8
+            for kt in range(1, 12):
+                for st in (1, 2, 3):
+                    for dt in (1, 2, 3):
+                        pw = (tile - 1) * st + (kt - 1) * dt + 1
+                        m = kg * pw % 256
+                        pad_left = pad_same(300, kt, st, dt)[0]
+                        rows = 2 if tile == 128 else 8
+                        lds = 2 * rows * kg * pw * 16 + 2 * ((kt + 1) // 2) * kg * 32 * 16
+                        if 0 < m < 64 and m <= kg * pad_left < 64 and lds <= 160 * 1024:
+                            out.append((cin, kt, st, dt, tile))
+    return out
+
+
+def test_conv_cl_second_row_staging_when_the_last_iteration_is_partial(monkeypatch):
+    """Regression for the staging fault of the interim runtime-flag build (VERDICT r1 item 3 / ADVICE r1): every (channels,
+    taps, stride, dilation) whose staging extent leaves wave 0 a partial last iteration made only of frames that are SAME
+    padding at the start of the next row -- the exact condition under which that build staged zeros -- on both tile shapes,
+    against the oracle.  Kernel 3 / stride 2 / SAME at 16 channels is the smallest member."""
+    from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+    monkeypatch.setenv("MS_CONV_MFMA_MIN_FLOPS", "0")
+    shapes = conv_cl_lanemask_trigger_shapes()
+    assert (16, 3, 2, 1, 128) in shapes and len(shapes) >= 20
+    rng = np.random.default_rng(5)
+    for cin, kt, st, dt, tile in shapes:
+        tn = 300 if tile == 128 else 40           # Tout > 48 selects the 128-frame tile, Tout <= 48 the 32-frame one
+        if tile == 32 and (tn + st - 1) // st > 48:
+            continue
+        torch.manual_seed(2)
+        m = MaskConv2d(cin, 32, [3, kt], [1, st], PaddingMode.SAME, dilation=[1, dt]).eval()
+        x = (rng.normal(size=(2, cin, 5, tn)) + 2.0).astype(np.float32)     # offset: a zero granule cannot hide
+        lens = np.array([tn, tn - 7])
+        y, nl = m((T(x), T(lens)))
+        want, wl = O.mask_conv2d(x, lens, cpu(m.weight), cpu(m.bias), (1, st), True, dilation=(1, dt))
+        np.testing.assert_allclose(cpu(y), want, rtol=1e-4, atol=1e-3, err_msg=str((cin, kt, st, dt, tile)))
+        np.testing.assert_array_equal(cpu(nl), wl)
+
+
 @pytest.mark.parametrize("H,bidir,N,Tn", [(256, True, 37, 9), (512, False, 5, 12), (1024, True, 32, 6)])
 def test_lstm_stack_plane_chaining_is_bit_identical_to_single_layers(H, bidir, N, Tn):
     """A two-stream LSTM stack hands each layer's output to the next layer as GEMM operand planes inside the workspace

@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Lint over hipcc's gfx950 assembly for the miscompile that caused the round-1 maskconv_cl staging fault.
+
+Signature (tools/micro/convflag/): a per-lane condition mask produced by a VALU compare (`v_cmp*_e64 s[a:b], ...`
+or an SALU combination of `vcc` right after a `v_cmp`) inside loop L1 -- so only the lanes that are active in L1 at that
+moment have meaningful bits -- is READ in a block that belongs to a loop L2 of which L1 is not an ancestor (a sibling loop,
+or code after L1), without having been recomputed there.  hipcc / LLVM did this to a wave-uniform runtime flag that it chose
+to evaluate on the VALU; with divergent loop exits the stale mask lacks the bits of lanes that had already left L1.
+
+    python tools/isa_lanemask_audit.py [file.s ...]      # default: compile every csrc/*.hip to assembly first
+
+Reads that only restore / narrow EXEC (`s_or_b64 exec, exec, M`, `s_andn2_b64 exec, exec, M`) are the normal divergent-loop
+bookkeeping and are not reported.  The scan follows layout order, not the CFG, so a report is a place to LOOK, not a proof;
+no report on a kernel means the signature does not occur in it.  Exit status 1 if anything is reported."""
+import glob
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "myrtlespeech_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+LABEL = re.compile(r"^(\.LBB\d+_\d+|; %bb\.\d+):")
+IN_LOOP = re.compile(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)")
+PARENT = re.compile(r"Parent Loop (BB\d+_\d+) Depth=(\d+)")
+HEADER = re.compile(r"This (?:Inner )?Loop Header: Depth=(\d+)")
+SPAIR = re.compile(r"(s\[\d+:\d+\]|\bvcc\b)")
+MASK_SALU = ("s_and_b64", "s_or_b64", "s_andn2_b64", "s_orn2_b64", "s_xor_b64", "s_mov_b64", "s_not_b64", "s_nand_b64",
+             "s_nor_b64", "s_xnor_b64")
+
+
+def assemble(hip, outdir):
+    out = os.path.join(outdir, os.path.basename(hip).replace(".hip", ".s"))
+    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=" + ("off" if hip.endswith("beam.hip") else "on"),
+             "--cuda-device-only", "-S", hip, "-o", out]
+    subprocess.run([HIPCC] + flags, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return out
+
+
+def audit(path):
+    findings = []
+    kernel = None
+    cur_loop = None                 # innermost loop (header label) of the current block
+    parents = {}                    # loop header -> parent loop header (None for top level)
+    masks = {}                      # register -> (loop at definition, line number, text)
+    pending_label = None
+    pending_parents = []
+    with open(path) as f:
+        lines = f.readlines()
+    for ln, raw in enumerate(lines, 1):
+        line = raw.rstrip("\n")
+        stripped = line.strip()
+        km = re.match(r"^([A-Za-z_][\w$.]*):", line)
+        if km:
+            kernel, cur_loop, parents, masks = km.group(1), None, {}, {}
+            continue
+        m = LABEL.match(stripped)
+        if m:
+            pending_label = m.group(1).lstrip(".L") if m.group(1).startswith(".L") else None
+            pending_parents = []
+            cur_loop = None
+            masks.pop("vcc", None)      # vcc is block-local scratch; a mask that lives across loops sits in an SGPR pair
+            il = IN_LOOP.search(line)
+            if il:
+                cur_loop = il.group(1)
+            pp = PARENT.search(line)
+            if pp:
+                pending_parents.append(pp.group(1))
+            if HEADER.search(line) and pending_label:
+                parents[pending_label] = pending_parents[-1] if pending_parents else (cur_loop if cur_loop != pending_label else None)
+                cur_loop = pending_label
+            continue
+        if stripped.startswith(";"):                      # continuation comments of a label (loop structure)
+            pp = PARENT.search(line)
+            if pp:
+                pending_parents.append(pp.group(1))
+            if HEADER.search(line) and pending_label:
+                parents[pending_label] = pending_parents[-1] if pending_parents else None
+                cur_loop = pending_label
+            continue
+        if not stripped or stripped.startswith("."):
+            continue
+        code = stripped.split(";")[0].strip()
+        parts = code.replace(",", " ").split()
+        if not parts:
+            continue
+        op, args = parts[0], parts[1:]
+        regs = SPAIR.findall(code)
+
+        def ancestor_or_self(a, b):                       # is loop a an ancestor of (or equal to) loop b?
+            while b is not None:
+                if a == b:
+                    return True
+                b = parents.get(b)
+            return a is None
+
+        if op.startswith("v_cmp") or op.startswith("v_cmpx"):
+            dest = args[0] if op.endswith("_e64") and args and SPAIR.fullmatch(args[0]) else "vcc"
+            masks[dest] = (cur_loop, ln, code, False)
+            continue
+        dest = args[0] if args else None
+        srcs = args[1:] if args else []
+        is_store = op.startswith(("global_store", "buffer_store", "ds_write", "ds_store", "scratch_store", "flat_store",
+                                  "s_cbranch", "s_branch", "s_waitcnt", "s_barrier", "s_nop", "s_setprio", "s_sleep"))
+        mask_use = op in MASK_SALU or "saveexec" in op or op.startswith("v_cndmask")
+        # reads of tracked masks AS LANE MASKS, inside a loop the defining loop does not enclose (sibling loops): the
+        # signature.  Code after a loop legitimately consumes the masks of the lanes that have just left it.
+        if mask_use and dest != "exec" and cur_loop is not None:
+            for r in set(SPAIR.findall(" ".join(srcs))):
+                if r in masks:
+                    dloop, dln, dtext, accum = masks[r]
+                    if dloop is not None and not accum and not ancestor_or_self(dloop, cur_loop):
+                        findings.append((kernel, ln, code, r, dloop, dln, dtext, cur_loop))
+        # writes: any definition of an SGPR (single or range) ends the life of the masks it overlaps
+        if dest and not is_store:
+            lo = hi = None
+            m1 = re.fullmatch(r"s(\d+)", dest)
+            m2 = re.fullmatch(r"s\[(\d+):(\d+)\]", dest)
+            if m1:
+                lo = hi = int(m1.group(1))
+            elif m2:
+                lo, hi = int(m2.group(1)), int(m2.group(2))
+            if lo is not None:
+                for r in list(masks):
+                    mm = re.fullmatch(r"s\[(\d+):(\d+)\]", r)
+                    if mm and not (int(mm.group(2)) < lo or int(mm.group(1)) > hi):
+                        del masks[r]
+            elif dest == "vcc":
+                masks.pop("vcc", None)
+            if op in MASK_SALU and (m2 or dest == "vcc"):
+                src_regs = SPAIR.findall(" ".join(srcs))
+                tainted = [r for r in src_regs if r in masks or r == "vcc"]
+                if tainted:
+                    # `s_or_b64 X, vcc, X` = the break mask of a divergent loop: it collects every lane as it leaves,
+                    # so it is complete for all lanes that ever ran the loop and may be read anywhere afterwards
+                    accum = op == "s_or_b64" and dest in src_regs
+                    masks[dest] = (cur_loop, ln, code, accum)
+    return findings
+
+
+def main():
+    files = sys.argv[1:]
+    tmp = None
+    if not files:
+        tmp = tempfile.mkdtemp(prefix="isa_audit_")
+        files = [assemble(h, tmp) for h in sorted(glob.glob(os.path.join(CSRC, "*.hip")))]
+    total = 0
+    for f in files:
+        found = audit(f)
+        total += len(found)
+        print(f"{os.path.basename(f)}: {len(found)} finding(s)")
+        for kernel, ln, code, r, dloop, dln, dtext, uloop in found:
+            print(f"  {(kernel or '?')[:90]}\n    line {ln}: `{code}` reads {r} defined in loop {dloop} at line {dln} (`{dtext}`), "
+                  f"use is in loop {uloop}")
+    return 1 if total else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
