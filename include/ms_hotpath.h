@@ -207,6 +207,10 @@ int ms_rnn_status(const void* workspace, void* stream);
  * that the persistent LSTM kernel fills when MS_LSTM_STAMPS=1 is set in the environment. */
 size_t ms_rnn_debug_offset(int cell, int T, int N, int In, int H, int ndir);
 
+/* Tuning switch for same-process A/B runs of the split-operand GEMM (tools/gemm_probe.py): 0 = the shipped choice,
+ * 2 = the register-staged kernel (the round-1 kernel; bit-identical results).  Not part of the reference surface. */
+int ms_gemm_set_variant(int variant);
+
 /* Optional launch timing for bench.py's roofline line (not part of the reference
  * surface).  While enabled, ms_rnn_layer_forward brackets its input-projection
  * GEMM and its recurrent kernel with HIP events on the caller's stream.

@@ -57,6 +57,7 @@ SIGNATURES = {
     "ms_rnn_layer_chains_planes": (c_int, [c_int, c_int, c_int]),
     "ms_rnn_status": (c_int, [_P, _P]),
     "ms_rnn_debug_offset": (c_size_t, [c_int] * 6),
+    "ms_gemm_set_variant": (c_int, [c_int]),
     "ms_prof_enable": (c_int, [c_int]),
     "ms_prof_read": (c_int, [POINTER(c_float), POINTER(c_int)]),
     "ms_ctc_loss_workspace_bytes": (c_size_t, [c_int] * 4),

@@ -351,6 +351,228 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel2(const unsigned 
   }
 }
 
+// ---- 256 x 256 x 32, 8 waves, operands staged by LDS-DMA (`buffer_load_dwordx4 ... lds`), fragments double-buffered in
+// registers.  What kernel2 leaves on the table (profiles/r02b: MFMA pipe 69 % busy): every half K-block its waves issue
+// 12 fragment reads and then wait for them, both waves of a SIMD at the same moment, and 32 VGPRs per lane are tied up
+// staging the next block's operands.  Here the DMA needs no staging registers, which pays for a second fragment set, so
+// the reads of the NEXT half block are in flight under the MFMAs of the current one; one barrier per K-block at mid-block:
+//
+//   top : ds_read frags(b, half 1) -> set B      || 24 MFMA on set A = frags(b, half 0)
+//         s_waitcnt lgkmcnt(0), vmcnt(0); s_barrier      (every wave's DMA of block b+1 has landed; nobody reads stage b&1 any more)
+//   mid : DMA block b+2 -> stage b&1; ds_read frags(b+1, half 0) -> set A   || 24 MFMA on set B
+//
+// LDS image per stage and plane: 256 rows x 64 B, row-major -- what the DMA writes (wave-uniform base + lane * 16: a
+// 1-KB piece = 16 rows, 4 lanes fetch one row's 64 contiguous bytes) -- with the 16-byte granule kg of row r stored at
+// position kg ^ ((r >> 2) & 3): the source address is permuted, the destination stays linear, and the fragment read
+// (row = lane & 31, kg = 2 half + (lane >> 5)) applies the same involution, which spreads every 16-lane group of a
+// ds_read_b128 over all 64 banks.  Accumulation order per output element is kernel2's, so results are bit-identical.
+constexpr int G4_PLANE = 256 * 64;
+constexpr int G4_STAGE = 4 * G4_PLANE;
+constexpr int G4_LDS = 2 * G4_STAGE;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// one LDS-DMA piece: 64 lanes x 16 B from (rsrc, voff + soff) to LDS [dst, dst + 1 KiB) in lane order.  (A __device__ helper:
+// the generic -> LDS pointer cast does not exist in the host pass that emits the kernel's launch stub.)
+__device__ __forceinline__ void lds_dma_16(__amdgpu_buffer_rsrc_t rsrc, char* dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)dst, 16, voff, soff, 0, 0);
+}
+
+template <bool F16>
+__global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4(const unsigned short* __restrict__ Ah,
+                                                                 const unsigned short* __restrict__ Al,
+                                                                 const unsigned short* __restrict__ Wh,
+                                                                 const unsigned short* __restrict__ Wl,
+                                                                 const float* __restrict__ bias, float* __restrict__ Y,
+                                                                 int M, int K, int N, int act, float lo, float hi) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int nbn = (N + S2_N - 1) / S2_N, nbm = (M + S2_M - 1) / S2_M;
+  const int nwg = nbn * nbm;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  constexpr int GM = 4;
+  const int per_group = GM * nbn;
+  const int first_m = (bid / per_group) * GM;
+  const int gm = min(GM, nbm - first_m);
+  const int bm = first_m + (bid % per_group) % gm;
+  const int bn = (bid % per_group) / gm;
+  const int m0 = bm * S2_M, n0 = bn * S2_N;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  // ---- this wave's DMA pieces: NP pieces of 16 rows, all in one operand plane
+  constexpr int NP = F16 ? 4 : 8;
+  const int g0 = wave * NP;                                  // first piece; pieces are numbered plane-major, 16 per plane
+  const int plane = F16 ? (g0 >> 4) * 2 : (g0 >> 4);         // 0 = A hi, 1 = A lo, 2 = W hi, 3 = W lo
+  const int prow0 = (g0 & 15) * 16;                          // first row (in the tile) of the first piece
+  const unsigned short* src = plane == 0 ? Ah : plane == 1 ? Al : plane == 2 ? Wh : Wl;
+  const int rows = plane < 2 ? M : N, row_base = plane < 2 ? m0 : n0;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(src), 0, (unsigned)((size_t)rows * K * 2), 0x00020000);
+  int voff[NP];                                              // byte offset of this lane's granule at k0 = 0
+  {
+    const int kgs = (lane & 3) ^ ((lane >> 4) & 3);          // granule fetched into position lane & 3 of row lane >> 2
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      voff[p] = min(row_base + prow0 + p * 16 + (lane >> 2), rows - 1) * (K * 2) + kgs * 16;
+  }
+  auto dma_pieces = [&](int kb, int stage, int p0, int p1) {   // pieces [p0, p1) of K-block kb
+    const int soff = __builtin_amdgcn_readfirstlane(kb * (SB_K * 2));
+    char* dst = lds + stage * G4_STAGE + plane * G4_PLANE + prow0 * 64;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      if (p >= p0 && p < p1) lds_dma_16(rsrc, dst + p * 1024, voff[p], soff);
+  };
+  auto dma_block = [&](int kb, int stage) { dma_pieces(kb, stage, 0, NP); };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses: row (lane & 31) of a 32-row group, granule kg = 2 h + half at position kg ^ ((row >> 2) & 3)
+  const int sw = (l31 >> 2) & 3;
+  const int foff0 = l31 * 64 + ((half ^ sw) * 16);           // h = 0: kg = half
+  const int foff1 = l31 * 64 + (((2 + half) ^ sw) * 16);     // h = 1: kg = 2 + half
+  const int a_base = wm * 64 * 64, b_base = 2 * G4_PLANE + wn * 128 * 64;
+
+  u32x4 fa[2][6 + 6];   // [set][ah0 ah1 al0 al1 | bh0..3 bl0..3]: 12 granules per set
+  auto read_frags = [&](int set, int stage, int h) {
+    const char* st = lds + stage * G4_STAGE + (h ? foff1 : foff0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[set][i] = *reinterpret_cast<const u32x4*>(st + a_base + i * 32 * 64);
+      if (!F16) fa[set][2 + i] = *reinterpret_cast<const u32x4*>(st + G4_PLANE + a_base + i * 32 * 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fa[set][4 + j] = *reinterpret_cast<const u32x4*>(st + b_base + j * 32 * 64);
+      if (!F16) fa[set][8 + j] = *reinterpret_cast<const u32x4*>(st + G4_PLANE + b_base + j * 32 * 64);
+    }
+  };
+  // operand roles: the W fragment is the MFMA's A operand and the x fragment its B operand, so a lane's accumulator
+  // registers r = 4 g .. 4 g + 3 are four CONSECUTIVE output columns n of one row m (one 16-byte store instead of four
+  // 4-byte ones); every output element is the same k-ordered sum of the same products as in kernel2 (bit-identical)
+  auto mfma_set = [&](int set) {
+    if (F16) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set][4 + j]),
+                                                             __builtin_bit_cast(f16x8, fa[set][i]), acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][4 + j]),
+                                                              __builtin_bit_cast(bf16x8, fa[set][i]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][4 + j]),
+                                                              __builtin_bit_cast(bf16x8, fa[set][2 + i]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][8 + j]),
+                                                              __builtin_bit_cast(bf16x8, fa[set][i]), acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nk = K / SB_K;
+  dma_block(0, 0);
+  dma_block(min(1, nk - 1), 1);
+  // (waits are the builtin, not inline asm: the compiler's own wait insertion then knows the fragment sets are complete
+  // and does not wait again at their first use, which would also cover the reads issued in between)
+  __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+  __builtin_amdgcn_s_barrier();
+  read_frags(0, 0, 0);
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+  __builtin_amdgcn_sched_barrier(0);
+
+  constexpr int NR = F16 ? 6 : 12;          // fragment reads per half block
+  constexpr int MPR = F16 ? 8 / 6 + 1 : 2;  // MFMAs issued per read in the interleave (F16: 8 MFMAs, 6 reads)
+  for (int b = 0; b < nk; ++b) {
+    const int cur = b & 1;
+    // ---- top: frags(b, half 1) -> set 1 under the MFMAs on set 0
+    read_frags(1, cur, 1);
+    mfma_set(0);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0070);   // lgkmcnt(0): set 1 complete; vmcnt(0): this wave's pieces of block b+1 landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- mid: block b+2 -> the stage just drained; frags(b+1, half 0) -> set 0 under the MFMAs on set 1
+    // (the tail re-loads the last block into a stage nobody reads again and reads fragments nobody uses: no branches)
+    dma_block(min(b + 2, nk - 1), cur);
+    read_frags(0, cur ^ 1, 0);
+    mfma_set(1);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      if (i < NP) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): set 0 complete
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);     // the tail's DMA must have landed before the LDS is released
+
+  // D[n][m]: lane = column m (lane & 31), register r -> row n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  const bool n_vec = (N % 4) == 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 64 + i * 32 + l31;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 128 + j * 32 + 8 * g + 4 * half;
+        f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if (n_vec && n + 3 < N) {
+          if (bias != nullptr) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+            v += bv;
+          }
+          if (act == MS_ACT_CLAMP) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], lo), hi);
+          }
+          *reinterpret_cast<f32x4*>(Y + (size_t)m * N + n) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < N) {
+              float x = v[e] + (bias != nullptr ? bias[n + e] : 0.f);
+              if (act == MS_ACT_CLAMP) x = fminf(fmaxf(x, lo), hi);
+              Y[(size_t)m * N + n + e] = x;
+            }
+        }
+      }
+  }
+}
+
+// tuning switch (tools/gemm_probe.py A/B runs in one process): 0 = default choice (kernel4, LDS-DMA), 2 = kernel2 (register staging)
+static std::atomic<int> g_gemm_variant{0};
+
 // hi/lo planes of an f32 matrix [rows, K] (K % 4 == 0, 16-byte aligned)
 int split_planes_launch(const float* x, unsigned short* hi, unsigned short* lo, size_t elems, int prec, hipStream_t stream) {
   const size_t n4 = elems / 4;
@@ -372,6 +594,8 @@ int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT2_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT2_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     attr_once.done();
   }
   static const bool small_tile = getenv("MS_GEMM_TILE128") && getenv("MS_GEMM_TILE128")[0] == '1';
@@ -383,6 +607,16 @@ int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const
   if (f16 || (!small_tile && !starved && (long)M * N >= 4L * 1024 * 1024)) {
     const int nwg2 = cdiv(M, S2_M) * cdiv(N, S2_N);
     auto kern = f16 ? gemm_nt_bf16x3_kernel2<true> : gemm_nt_bf16x3_kernel2<false>;
+    const int variant = g_gemm_variant.load(std::memory_order_relaxed);
+    // the DMA kernel addresses its planes with 32-bit byte offsets
+    // the LDS-DMA kernel (default) addresses its planes with 32-bit byte offsets; MS_GEMM_REGSTAGE=1 / variant 2 keep kernel2
+    static const bool regstage = getenv("MS_GEMM_REGSTAGE") && getenv("MS_GEMM_REGSTAGE")[0] == '1';
+    if (variant != 2 && !regstage && (size_t)std::max(M, N) * K * 2 < ((size_t)1 << 31)) {
+      auto k4 = f16 ? gemm_nt_bf16x3_kernel4<true> : gemm_nt_bf16x3_kernel4<false>;
+      hipLaunchKernelGGL(k4, dim3(nwg2), dim3(512), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);
+      MS_LAUNCH_CHECK();
+      return MS_OK;
+    }
     hipLaunchKernelGGL(kern, dim3(nwg2), dim3(512), SPLIT2_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);
     MS_LAUNCH_CHECK();
     return MS_OK;
@@ -394,6 +628,11 @@ int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const
 }
 
 }  // namespace ms
+
+extern "C" int ms_gemm_set_variant(int v) {
+  ms::g_gemm_variant.store(v, std::memory_order_relaxed);
+  return MS_OK;
+}
 
 extern "C" size_t ms_linear_split_workspace_bytes(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 0;

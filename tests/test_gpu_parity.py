@@ -571,6 +571,42 @@ def test_linear_split_bf16x3(lib, M, K, N, act):
     assert np.abs(cpu(y) - want).max() <= bound
 
 
+@pytest.mark.parametrize("M,K,N,act", [(2100, 96, 2052, None),        # ragged M edge, N % 4 == 0 but not a tile multiple
+                                       (4100, 32, 1026, (0.0, 20.0)),  # one K-block; N % 4 != 0 -> scalar epilogue tail
+                                       (16032, 640, 8192, None),       # the first projection of config 2
+                                       (2048, 2048, 2048, (-1.0, 1.0))])
+def test_split_gemm_lds_dma_kernel_vs_float64_and_register_staged_kernel(lib, M, K, N, act):
+    """The shipped split-operand GEMM (kernel4: operands staged by LDS-DMA with a swizzled source address, double-buffered
+    fragments, W as the MFMA's A operand) against float64 AND against the round-1 register-staged kernel2
+    (``ms_gemm_set_variant(2)``): every output is the same k-ordered sum of the same products, so the two must agree bit
+    for bit -- a swizzle, a DMA landing order or an epilogue index that is wrong anywhere shows up as a difference."""
+    from myrtlespeech_amd import _lib
+    rng = np.random.default_rng(M + K + N)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.normal(size=(N,)).astype(np.float32)
+    xd, wd, bd = T(x).cuda(), T(w).cuda(), T(b).cuda()
+    ws = torch.empty(lib.ms_linear_split_workspace_bytes(M, K, N), dtype=torch.uint8, device="cuda")
+    a, lo, hi = (0, 0.0, 0.0) if act is None else (1, act[0], act[1])
+    ys = []
+    try:
+        for variant in (0, 2):
+            lib.ms_gemm_set_variant(variant)
+            y = torch.full((M + 1, N), float("nan"), dtype=torch.float32, device="cuda")   # guard row: nothing past M is written
+            _lib.check(lib.ms_linear_split_forward(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), M, K, N, a, lo, hi,
+                                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "linear_split")
+            assert bool(torch.isnan(y[M]).all())
+            ys.append(y[:M])
+    finally:
+        lib.ms_gemm_set_variant(0)
+    assert torch.equal(ys[0], ys[1])
+    want = x.astype(np.float64) @ w.T.astype(np.float64) + b
+    if act is not None:
+        want = np.clip(want, *act)
+    bound = 1e-5 * (np.abs(x).astype(np.float64) @ np.abs(w.T).astype(np.float64)).max() + 1e-6
+    assert np.abs(cpu(ys[0]) - want).max() <= bound
+
+
 @pytest.mark.parametrize("name", ["ctc_grad_small", "ctc_grad_v29"])
 def test_ctc_loss_backward_matches_reference_autograd(name):
     """loss.backward() through the accelerated CTCLoss fills x.grad like the reference module (golden x.grad from the

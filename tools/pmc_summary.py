@@ -11,7 +11,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
+            m = re.search(r"(\w+_kernel\d?)", r["Kernel_Name"])
             name = m.group(1) if m else r["Kernel_Name"][:60]
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, cs in sorted(acc.items()):
