@@ -377,15 +377,17 @@ __device__ __forceinline__ void lds_dma_16(__amdgpu_buffer_rsrc_t rsrc, char* ds
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)dst, 16, voff, soff, 0, 0);
 }
 
-template <bool F16>
-__global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4(const unsigned short* __restrict__ Ah,
-                                                                 const unsigned short* __restrict__ Al,
-                                                                 const unsigned short* __restrict__ Wh,
-                                                                 const unsigned short* __restrict__ Wl,
-                                                                 const float* __restrict__ bias, float* __restrict__ Y,
-                                                                 int M, int K, int N, int act, float lo, float hi) {
+// WN = wave columns: 2 = 256 x 256 tile, 8 waves, two per SIMD (the shipped form); 1 = 256 x 128 tile, 4 waves, one per
+// SIMD: 224 VGPRs and 128 KB of LDS per workgroup, i.e. a workgroup that fits on a CU BESIDE a workgroup of the persistent
+// LSTM kernel (272 VGPRs, 20 KB) -- the co-residency experiment of DESIGN 7.0 (tools/overlap_probe.py)
+template <bool F16, int WN>
+__device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah, const unsigned short* __restrict__ Al,
+                                           const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
+                                           const float* __restrict__ bias, float* __restrict__ Y, int M, int K, int N, int act,
+                                           float lo, float hi) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int nbn = (N + S2_N - 1) / S2_N, nbm = (M + S2_M - 1) / S2_M;
+  constexpr int TN = 128 * WN;
+  const int nbn = (N + TN - 1) / TN, nbm = (M + S2_M - 1) / S2_M;
   const int nwg = nbn * nbm;
   int bid = blockIdx.x;
   {
@@ -398,37 +400,53 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4(const unsigned 
   const int gm = min(GM, nbm - first_m);
   const int bm = first_m + (bid % per_group) % gm;
   const int bn = (bid % per_group) / gm;
-  const int m0 = bm * S2_M, n0 = bn * S2_N;
+  const int m0 = bm * S2_M, n0 = bn * TN;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
   const int l31 = lane & 31, half = lane >> 5;
 
-  // ---- this wave's DMA pieces: NP pieces of 16 rows, all in one operand plane
-  constexpr int NP = F16 ? 4 : 8;
-  const int g0 = wave * NP;                                  // first piece; pieces are numbered plane-major, 16 per plane
-  const int plane = F16 ? (g0 >> 4) * 2 : (g0 >> 4);         // 0 = A hi, 1 = A lo, 2 = W hi, 3 = W lo
-  const int prow0 = (g0 & 15) * 16;                          // first row (in the tile) of the first piece
-  const unsigned short* src = plane == 0 ? Ah : plane == 1 ? Al : plane == 2 ? Wh : Wl;
-  const int rows = plane < 2 ? M : N, row_base = plane < 2 ? m0 : n0;
-  const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(src), 0, (unsigned)((size_t)rows * K * 2), 0x00020000);
+  // ---- this wave's DMA pieces (16 rows each): NPA pieces of x plane PA from tile row RA, NPB pieces of W plane PB from RB.
+  // WN = 2: 8 waves x 8 pieces of ONE plane (F16: 4); WN = 1: 4 waves x (8 of an x plane + 4 of a W plane) (F16: 4 + 2).
+  constexpr int NPA = WN == 2 ? (F16 ? 4 : 8) : (F16 ? 4 : 8);
+  constexpr int NPB = WN == 2 ? 0 : (F16 ? 2 : 4);
+  constexpr int NP = NPA + NPB;
+  int PA, RA, PB = 2, RB = 0;
+  if (WN == 2) {
+    const int g0 = wave * NPA;                               // pieces numbered plane-major, 16 per plane
+    PA = F16 ? (g0 >> 4) * 2 : (g0 >> 4);                    // 0 = x hi, 1 = x lo, 2 = W hi, 3 = W lo
+    RA = (g0 & 15) * 16;
+  } else if (F16) {
+    PA = 0; RA = wave * 64; PB = 2; RB = wave * 32;
+  } else {
+    PA = wave >> 1; RA = (wave & 1) * 128; PB = 2 + (wave >> 1); RB = (wave & 1) * 64;
+  }
+  auto plane_rsrc = [&](int pl) {
+    const unsigned short* src = pl == 0 ? Ah : pl == 1 ? Al : pl == 2 ? Wh : Wl;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(src), 0, (unsigned)((size_t)(pl < 2 ? M : N) * K * 2), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsrc_a = plane_rsrc(PA), rsrc_b = plane_rsrc(PB);
   int voff[NP];                                              // byte offset of this lane's granule at k0 = 0
   {
     const int kgs = (lane & 3) ^ ((lane >> 4) & 3);          // granule fetched into position lane & 3 of row lane >> 2
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
-      voff[p] = min(row_base + prow0 + p * 16 + (lane >> 2), rows - 1) * (K * 2) + kgs * 16;
+    for (int p = 0; p < NP; ++p) {
+      const int pl = p < NPA ? PA : PB;
+      const int rows = pl < 2 ? M : N, row = (pl < 2 ? m0 : n0) + (p < NPA ? RA + p * 16 : RB + (p - NPA) * 16) + (lane >> 2);
+      voff[p] = min(row, rows - 1) * (K * 2) + kgs * 16;
+    }
   }
-  auto dma_pieces = [&](int kb, int stage, int p0, int p1) {   // pieces [p0, p1) of K-block kb
+  auto dma_block = [&](int kb, int stage) {                  // all pieces of K-block kb
     const int soff = __builtin_amdgcn_readfirstlane(kb * (SB_K * 2));
-    char* dst = lds + stage * G4_STAGE + plane * G4_PLANE + prow0 * 64;
+    char* dst_a = lds + stage * G4_STAGE + PA * G4_PLANE + RA * 64;
+    char* dst_b = lds + stage * G4_STAGE + PB * G4_PLANE + RB * 64;
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
-      if (p >= p0 && p < p1) lds_dma_16(rsrc, dst + p * 1024, voff[p], soff);
+    for (int p = 0; p < NP; ++p) {
+      if (p < NPA) lds_dma_16(rsrc_a, dst_a + p * 1024, voff[p], soff);
+      else lds_dma_16(rsrc_b, dst_b + (p - NPA) * 1024, voff[p], soff);
+    }
   };
-  auto dma_block = [&](int kb, int stage) { dma_pieces(kb, stage, 0, NP); };
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -444,7 +462,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4(const unsigned 
   const int foff1 = l31 * 64 + (((2 + half) ^ sw) * 16);     // h = 1: kg = 2 + half
   const int a_base = wm * 64 * 64, b_base = 2 * G4_PLANE + wn * 128 * 64;
 
-  u32x4 fa[2][6 + 6];   // [set][ah0 ah1 al0 al1 | bh0..3 bl0..3]: 12 granules per set
+  u32x4 fa[WN == 1 ? 1 : 2][6 + 6];   // [set][ah0 ah1 al0 al1 | bh0..3 bl0..3]: 12 granules per set
   auto read_frags = [&](int set, int stage, int h) {
     const char* st = lds + stage * G4_STAGE + (h ? foff1 : foff0);
 #pragma unroll
@@ -498,6 +516,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4(const unsigned 
   // and does not wait again at their first use, which would also cover the reads issued in between)
   __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
   __builtin_amdgcn_s_barrier();
+  if (WN == 1) {
+    // the co-residency experiment's form: ONE fragment set (208 registers must suffice), reads exposed, one barrier per block
+    for (int b = 0; b < nk; ++b) {
+      const int cur = b & 1;
+      read_frags(0, cur, 0);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      mfma_set(0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(0, cur, 1);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      mfma_set(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0x0070);
+      __builtin_amdgcn_s_barrier();
+      dma_block(min(b + 2, nk - 1), cur);
+    }
+  } else {
   read_frags(0, 0, 0);
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
   __builtin_amdgcn_sched_barrier(0);
@@ -532,6 +567,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4(const unsigned 
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): set 0 complete
     __builtin_amdgcn_sched_barrier(0);
+  }
   }
   __builtin_amdgcn_s_waitcnt(0x0070);     // the tail's DMA must have landed before the LDS is released
 
@@ -570,7 +606,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4(const unsigned 
   }
 }
 
-// tuning switch (tools/gemm_probe.py A/B runs in one process): 0 = default choice (kernel4, LDS-DMA), 2 = kernel2 (register staging)
+template <bool F16>
+__global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4(const unsigned short* __restrict__ Ah,
+                                                                 const unsigned short* __restrict__ Al,
+                                                                 const unsigned short* __restrict__ Wh,
+                                                                 const unsigned short* __restrict__ Wl,
+                                                                 const float* __restrict__ bias, float* __restrict__ Y,
+                                                                 int M, int K, int N, int act, float lo, float hi) {
+  gemm4_body<F16, 2>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi);
+}
+
+// the 4-wave form, capped at 208 VGPRs (the two-stream LSTM kernel allocates 304 of a SIMD's 512): experiment only
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel4n(
+    const unsigned short* __restrict__ Ah, const unsigned short* __restrict__ Al, const unsigned short* __restrict__ Wh,
+    const unsigned short* __restrict__ Wl, const float* __restrict__ bias, float* __restrict__ Y, int M, int K, int N, int act,
+    float lo, float hi) {
+  gemm4_body<F16, 1>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi);
+}
+
+// tuning switch (tools/gemm_probe.py A/B runs in one process): 0 = default choice (kernel4, LDS-DMA), 2 = kernel2 (register staging), 7 = kernel4 with 256 x 128 tiles / 4 waves
 static std::atomic<int> g_gemm_variant{0};
 
 // hi/lo planes of an f32 matrix [rows, K] (K % 4 == 0, 16-byte aligned)
@@ -596,6 +651,8 @@ int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT2_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     attr_once.done();
   }
   static const bool small_tile = getenv("MS_GEMM_TILE128") && getenv("MS_GEMM_TILE128")[0] == '1';
@@ -612,6 +669,13 @@ int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const
     // the LDS-DMA kernel (default) addresses its planes with 32-bit byte offsets; MS_GEMM_REGSTAGE=1 / variant 2 keep kernel2
     static const bool regstage = getenv("MS_GEMM_REGSTAGE") && getenv("MS_GEMM_REGSTAGE")[0] == '1';
     if (variant != 2 && !regstage && (size_t)std::max(M, N) * K * 2 < ((size_t)1 << 31)) {
+      if (variant == 7) {   // 256 x 128 tiles, 4 waves: co-resident with the persistent LSTM (tools/overlap_probe.py)
+        auto k41 = f16 ? gemm_nt_bf16x3_kernel4n<true> : gemm_nt_bf16x3_kernel4n<false>;
+        hipLaunchKernelGGL(k41, dim3(cdiv(M, S2_M) * cdiv(N, 128)), dim3(256), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N,
+                           act, lo, hi);
+        MS_LAUNCH_CHECK();
+        return MS_OK;
+      }
       auto k4 = f16 ? gemm_nt_bf16x3_kernel4<true> : gemm_nt_bf16x3_kernel4<false>;
       hipLaunchKernelGGL(k4, dim3(nwg2), dim3(512), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);
       MS_LAUNCH_CHECK();
