@@ -157,3 +157,50 @@ def test_word_error_rate():
     w.update(hyp, tgt, torch.tensor([5, 5]))
     # "ab c" vs "ab ca": 1 substitution of 2 words; "a" vs "a b c": 2 deletions of 3 words -> 3/5
     assert w.distances == [1, 2] and w.lengths == [2, 3] and abs(w.value() - 60.0) < 1e-9
+
+
+# ----------------------------------------------------------------------------- the reference's own shipped configs
+REF_CONFIGS = "/root/reference/src/myrtlespeech/configs"
+
+
+def _speech_to_text_block(text: str) -> str:
+    """The body of the ``speech_to_text { ... }`` message of a TaskConfig text file (the train / eval / dataset parts of
+    the TaskConfig are the control plane, out of scope: tests/configs/test_configs.py:37-56 swaps them for fakes too)."""
+    start = text.index("speech_to_text")
+    i = text.index("{", start)
+    depth, j = 0, i
+    in_str = False
+    while True:
+        c = text[j]
+        if c == '"' and text[j - 1] != "\\":
+            in_str = not in_str
+        elif not in_str:
+            depth += c == "{"
+            depth -= c == "}"
+            if depth == 0:
+                return text[i + 1:j]
+        j += 1
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir(REF_CONFIGS), reason="reference checkout not mounted (GPU box)")
+@pytest.mark.parametrize("name", ["deep_speech_1_en.config", "deep_speech_2_en.config"])
+def test_reference_shipped_config_files_parse_and_build(name):
+    """tests/configs/test_configs.py:37-56 on the REAL files: the speech_to_text block of every shipped .config parses
+    with the runtime descriptors and builds onto the accelerated modules (read as data; nothing is copied)."""
+    import os
+    with open(os.path.join(REF_CONFIGS, name)) as f:
+        cfg = P.parse(_speech_to_text_block(f.read()), P.SpeechToText)
+    stt = build_stt(cfg)
+    n_params = sum(p.numel() for p in stt.model.parameters())
+    if name.startswith("deep_speech_1"):
+        assert stt.model.__class__.__name__ == "DeepSpeech1" and 30.9e6 < n_params < 31.1e6
+    else:
+        assert stt.model.__class__.__name__ == "DeepSpeech2" and 106e6 < n_params < 107e6
+        assert stt.model.rnn.rnn.__class__ is torch.nn.GRU and stt.model.rnn.rnn.hidden_size == 2560
+        assert "lookahead.0.weight" in stt.model.state_dict()
+    assert stt.post_process.blank_index == 28 and len(stt.alphabet) == 29
+    # and the restated texts above say the same thing as the files
+    restated = build_stt(P.parse(DS1_EN if name.startswith("deep_speech_1") else DS2_EN, P.SpeechToText))
+    assert [(k, tuple(v.shape)) for k, v in restated.model.state_dict().items()] == \
+           [(k, tuple(v.shape)) for k, v in stt.model.state_dict().items()]
+    assert [s for _, s in restated.pre_process_steps] == [s for _, s in stt.pre_process_steps]
