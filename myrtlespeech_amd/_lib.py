@@ -214,6 +214,18 @@ def split_precision():
     return os.environ.get("MS_PRECISION") != "f32"
 
 
+# Issue-point hook: called by the recurrent stack after every layer's launches have been enqueued (and by DeepSpeech2 after
+# its convolutions).  None except while ``pipeline.TwoBatchesInFlight`` runs, which uses it to alternate the host-side issue
+# of two batches layer by layer.
+issue_point = None
+
+
+def at_issue_point():
+    hook = issue_point
+    if hook is not None:
+        hook()
+
+
 class Workspace:
     """Grow-only device scratch buffer owned by a module."""
 

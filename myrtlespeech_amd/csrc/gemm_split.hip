@@ -517,20 +517,64 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
   __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
   __builtin_amdgcn_s_barrier();
   if (WN == 1) {
-    // the co-residency experiment's form: ONE fragment set (208 registers must suffice), reads exposed, one barrier per block
+    // One wave per SIMD and at most 208 registers (the two-stream LSTM kernel holds 304 of the SIMD's 512): one x fragment
+    // set per half block and a two-deep ring of W fragment pairs, each fetched under the six MFMAs of the pair before it;
+    // the barrier sits in front of the block's last MFMA group (all reads of the stage are complete by then), so the next
+    // block's first fragments are fetched under that group too.
+    u32x4 xa[2][4], wb[2][2];      // [ring][x hi0 hi1 lo0 lo1], [ring][W hi, W lo]
+    auto rd_x = [&](int ring, int stage, int h) {
+      const char* st = lds + stage * G4_STAGE + (h ? foff1 : foff0) + a_base;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        xa[ring][i] = *reinterpret_cast<const u32x4*>(st + i * 32 * 64);
+        if (!F16) xa[ring][2 + i] = *reinterpret_cast<const u32x4*>(st + G4_PLANE + i * 32 * 64);
+      }
+    };
+    auto rd_w = [&](int ring, int stage, int h, int j) {
+      const char* st = lds + stage * G4_STAGE + (h ? foff1 : foff0) + b_base + j * 32 * 64;
+      wb[ring][0] = *reinterpret_cast<const u32x4*>(st);
+      if (!F16) wb[ring][1] = *reinterpret_cast<const u32x4*>(st + G4_PLANE);
+    };
+    auto mm = [&](int xr, int wr, int j) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (F16) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wb[wr][0]), __builtin_bit_cast(f16x8, xa[xr][i]), acc[i][j], 0, 0, 0);
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[wr][0]), __builtin_bit_cast(bf16x8, xa[xr][i]), acc[i][j], 0, 0, 0);
+        }
+      }
+      if (!F16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[wr][0]), __builtin_bit_cast(bf16x8, xa[xr][2 + i]), acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[wr][1]), __builtin_bit_cast(bf16x8, xa[xr][i]), acc[i][j], 0, 0, 0);
+      }
+    };
+    rd_x(0, 0, 0);
+    rd_w(0, 0, 0, 0);
     for (int b = 0; b < nk; ++b) {
       const int cur = b & 1;
-      read_frags(0, cur, 0);
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      mfma_set(0);
-      __builtin_amdgcn_sched_barrier(0);
-      read_frags(0, cur, 1);
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      mfma_set(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0x0070);
-      __builtin_amdgcn_s_barrier();
-      dma_block(min(b + 2, nk - 1), cur);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int step = h * 4 + j;               // 0..7: W pair `step` lives in ring slot step & 1, x set h in ring slot h
+          if (step == 7) {
+            // every read of this stage has been issued and (below) waited for: the stage may be refilled, the next one read
+            __builtin_amdgcn_s_waitcnt(0x0070);     // lgkmcnt(0) + vmcnt(0): block b+1 has landed (this wave's pieces)
+            __builtin_amdgcn_s_barrier();
+            dma_block(min(b + 2, nk - 1), cur);
+            rd_x(0, cur ^ 1, 0);
+            rd_w(0, cur ^ 1, 0, 0);
+          } else {
+            if (j == 3) rd_x(1, cur, 1);            // h = 0, j = 3: the second half's x set
+            rd_w((step + 1) & 1, cur, (step + 1) >> 2, (step + 1) & 3);
+          }
+          mm(h, step & 1, j);
+        }
     }
   } else {
   read_frags(0, 0, 0);

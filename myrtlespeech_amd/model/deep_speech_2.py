@@ -91,7 +91,9 @@ class DeepSpeech2(torch.nn.Module):
         if self.cnn is not None:
             h = self._run_cnn(h)
         h = (self._conv_to_rnn_size(h[0]), h[1])
+        _lib.at_issue_point()
         h, hid = self.rnn(h, hx=hx)
+        _lib.at_issue_point()
         seq, lens = h
 
         fc = self.fully_connected

@@ -95,6 +95,8 @@ def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max
                                                _lib.stream_ptr()),
                    "ms_rnn_layer_forward")
         inp = out
+        if layer + 1 < nl:
+            _lib.at_issue_point()   # two batches in flight: the other batch's next layer is issued here
     if check:
         _lib.check(lib.ms_rnn_status(_lib.ptr(ws), _lib.stream_ptr()), "ms_rnn_layer_forward")
     return inp, hn, cn

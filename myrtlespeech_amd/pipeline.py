@@ -1,0 +1,144 @@
+"""Two batches in flight on one MI355X (new design; the reference runs one batch at a time on one stream).
+
+Why: the persistent LSTM recurrence is a latency chain -- its CUs idle about half the time waiting for the hand-over of
+``h`` -- while the input-projection GEMM of the next layer is MFMA-bound, and within ONE batch the two cannot overlap
+(layer k+1's projection needs both directions of layer k at every frame).  With a SECOND batch in flight, batch B's
+projection runs in the shadow of batch A's recurrence and vice versa:
+
+* two HIP streams, one per batch; the host issues the two batches LAYER BY LAYER in turn (A1 B1 A2 B2 ...), because the
+  library chains persistent launches across streams in host issue order (two recurrences must never be resident together:
+  each fills every CU with workgroups that wait for their own peers, ``csrc/rnn.hip`` PersistentTurn);
+* while the pipeline runs, the projection GEMMs use the 4-wave 256 x 128 form of the LDS-DMA kernel (176 VGPRs, 128 KB of
+  LDS, ``ms_gemm_set_variant(7)``), whose workgroups fit on a CU BESIDE a workgroup of the recurrence (304 VGPRs, 20 KB);
+  the shipped 8-wave form cannot share a CU with it and would only time-slice (``tools/overlap_probe.py``);
+* results are bit-identical to the one-batch path (same kernels' arithmetic; ``tests/test_gpu_pipeline.py``).
+
+Measured (``profiles/r02*_overlap*``): the recurrence slows by ~45 % under its co-tenant (its exchange shares the CU's
+memory queue with the GEMM's operand stream), the GEMM hides completely, net ~12 % more batches per second on the recurrent
+stack; per-batch latency is that of two batches.  A throughput mode, therefore: a caller that needs the lowest latency
+per batch keeps calling the model directly.
+
+The alternation is done with two host threads that pass a baton at the issue points of ``_lib.at_issue_point`` (after the
+convolutions, after every recurrent layer): only one thread runs at a time, so nothing in the library or the modules has to
+be thread-safe beyond that.
+"""
+import copy
+import threading
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from myrtlespeech_amd import _lib
+
+COTENANT_GEMM_VARIANT = 7
+
+
+class _Baton:
+    """Strict alternation between two threads; a thread that has finished leaves the other one running freely."""
+
+    def __init__(self):
+        self.cv = threading.Condition()
+        self.turn = 0
+        self.active = [True, True]
+
+    def wait_turn(self, me: int):
+        with self.cv:
+            while self.turn != me and self.active[1 - me]:
+                self.cv.wait()
+            self.turn = me
+
+    def pass_on(self, me: int):
+        with self.cv:
+            if self.active[1 - me]:
+                self.turn = 1 - me
+                self.cv.notify_all()
+        self.wait_turn(me)
+
+    def leave(self, me: int):
+        with self.cv:
+            self.active[me] = False
+            self.turn = 1 - me
+            self.cv.notify_all()
+
+
+class TwoBatchesInFlight:
+    """``TwoBatchesInFlight(model)(batches)``: run ``model`` over a list of ``(x, lens)`` batches, two at a time.
+
+    ``model`` is any module of this package whose forward enqueues work on the current stream (normally ``DeepSpeech2``); a
+    deep copy serves the second stream (its own workspaces and packed-weight caches; the weights are replicated, 457 MB
+    for the config-2 network).  ``post`` (optional) is called on each batch's output on that batch's stream right after
+    its forward was issued -- e.g. ``decoder.launch`` of ``CTCGreedyDecoder``, whose ``.result()`` the caller collects
+    afterwards -- so that no host read-back interrupts the alternation.  Results come back in the order of ``batches``."""
+
+    def __init__(self, model: torch.nn.Module, post: Optional[Callable] = None, pre: Optional[Callable] = None):
+        _lib.require_gpu()
+        self.models = (model, copy.deepcopy(model))
+        self.streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        self.post = post
+        self.pre = pre      # called with the batch index on the batch's stream before its forward is issued (e.g. to record an event)
+        # a per-call status check of the recurrent stack synchronises its stream in the middle of the alternation: the sticky
+        # time-out word is read once per ``__call__`` instead
+        self._stacks = [m for mod in self.models for m in mod.modules() if hasattr(m, "check_status") and hasattr(m, "_workspace")]
+        for m in self._stacks:
+            m.check_status = False
+
+    def __call__(self, batches: Sequence) -> List:
+        lib = _lib.load()
+        results: List = [None] * len(batches)
+        errors: List = []
+        baton = _Baton()
+        slot_of = {}
+        device = torch.cuda.current_device()
+        caller = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(caller)
+
+        def hook():
+            me = slot_of.get(threading.get_ident())
+            if me is not None:
+                baton.pass_on(me)
+
+        def worker(me: int):
+            slot_of[threading.get_ident()] = me
+            try:
+                torch.cuda.set_device(device)                   # the current device is a per-thread setting
+                baton.wait_turn(me)
+                with torch.cuda.stream(self.streams[me]), torch.no_grad():
+                    self.streams[me].wait_event(ready)          # inputs made on the caller's stream
+                    for k in range(me, len(batches), 2):
+                        if self.pre is not None:
+                            self.pre(k)
+                        out = self.models[me](batches[k])
+                        results[k] = out if self.post is None else self.post(out)
+                        baton.pass_on(me)
+            except BaseException as e:  # noqa: BLE001 -- re-raised on the caller's thread
+                errors.append(e)
+            finally:
+                baton.leave(me)
+
+        prev_hook = _lib.issue_point
+        _lib.issue_point = hook
+        lib.ms_gemm_set_variant(COTENANT_GEMM_VARIANT)
+        try:
+            threads = [threading.Thread(target=worker, args=(m,), daemon=True) for m in (0, 1)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            lib.ms_gemm_set_variant(0)
+            _lib.issue_point = prev_hook
+        for s in self.streams:                                  # later work on the caller's stream sees the results
+            done = torch.cuda.Event()
+            done.record(s)
+            caller.wait_event(done)
+        if errors:
+            raise errors[0]
+        return results
+
+    def check_status(self):
+        """Raise if a persistent recurrent launch of either replica timed out since the last check (synchronises)."""
+        lib = _lib.load()
+        for m in self._stacks:
+            if m._workspace.buf is not None:
+                _lib.check(lib.ms_rnn_status(_lib.ptr(m._workspace.buf), _lib.stream_ptr()), "persistent recurrent layer")

@@ -1,0 +1,86 @@
+"""Two batches in flight (myrtlespeech_amd/pipeline.py): bit-identical to running the batches one after the other.
+Needs a real MI355X: -m gpu."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_ds2(H):
+    from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+    from myrtlespeech_amd.model.deep_speech_2 import DeepSpeech2
+    from myrtlespeech_amd.model.fully_connected import FullyConnected
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    from myrtlespeech_amd.model.seq_len_wrapper import SeqLenWrapper
+    torch.manual_seed(H)
+
+    def act():
+        return SeqLenWrapper(torch.nn.Hardtanh(0.0, 20.0), torch.nn.Identity())
+    cnn = torch.nn.Sequential(MaskConv2d(1, 8, [11, 5], [2, 2], PaddingMode.SAME), act(),
+                              MaskConv2d(8, 8, [5, 5], [2, 1], PaddingMode.SAME), act())
+    rnn = RNN(RNNType.LSTM, 8 * 10, H, num_layers=3, bidirectional=True, forget_gate_bias=1.0)
+    fc = FullyConnected(2 * H, 29, 1, 96, torch.nn.Hardtanh(0.0, 20.0))
+    return DeepSpeech2(cnn, rnn, None, fc).eval()
+
+
+def _batches(n, N, T_, F, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        x = torch.randn(N, 1, F, T_, generator=g).cuda()
+        lens = torch.sort(torch.randint(T_ // 2, T_ + 1, (N,), generator=g), descending=True).values
+        lens[0] = T_
+        out.append((x, lens))
+    return out
+
+
+@pytest.mark.parametrize("H,n_batches", [(256, 5), (128, 2), (64, 3)])   # persistent two-stream, persistent one-stream, step kernels
+def test_two_batches_in_flight_equal_the_sequential_run(H, n_batches):
+    from myrtlespeech_amd.pipeline import TwoBatchesInFlight
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    model = _small_ds2(H)
+    dec = CTCGreedyDecoder(28)
+    batches = _batches(n_batches, 12, 90, 40, H)
+    want = []
+    for x, lens in batches:
+        (y, ol), (hn, cn) = model((x.clone(), lens))
+        want.append((y, ol, hn, cn, dec(y, ol)))
+    pipe = TwoBatchesInFlight(model, post=lambda out: (out, dec.launch(out[0][0], out[0][1])))
+    got = pipe([(x.clone(), lens) for x, lens in batches])
+    pipe.check_status()
+    assert len(got) == n_batches
+    for (((y, ol), (hn, cn)), pending), (wy, wol, whn, wcn, wdec) in zip(got, want):
+        assert torch.equal(y, wy) and torch.equal(ol.cpu(), wol.cpu())
+        assert torch.equal(hn, whn) and torch.equal(cn, wcn)
+        assert pending.result() == wdec
+    # the one-batch path is back to its own kernels afterwards
+    (y, _), _ = model((batches[0][0].clone(), batches[0][1]))
+    assert torch.equal(y, want[0][0])
+
+
+def test_two_batches_in_flight_full_size_network():
+    """The config-2 network (5 x BiLSTM-1024, batch 32 x 1001 frames): the co-tenant projection GEMM (4 waves, 256 x 128
+    tiles) and the cross-stream chain of the persistent launches at the size they were built for."""
+    import bench
+    from myrtlespeech_amd.pipeline import TwoBatchesInFlight
+    model = bench.build_model()
+    batches = _batches(4, 32, 1001, 80, 7)
+    want = [model((x.clone(), lens))[0][0] for x, lens in batches]
+    pipe = TwoBatchesInFlight(model)
+    got = pipe([(x.clone(), lens) for x, lens in batches])
+    pipe.check_status()
+    for ((y, _), _), w in zip(got, want):
+        assert torch.equal(y, w)
+
+
+def test_pipeline_propagates_errors_and_restores_the_hooks():
+    from myrtlespeech_amd import _lib
+    from myrtlespeech_amd.pipeline import TwoBatchesInFlight
+    model = _small_ds2(64)
+    pipe = TwoBatchesInFlight(model)
+    good = _batches(1, 4, 60, 40, 1)[0]
+    bad = (good[0], torch.tensor([10, 20, 30, 40]))          # not sorted in decreasing order
+    with pytest.raises(RuntimeError):
+        pipe([good, bad, good])
+    assert _lib.issue_point is None
+    assert len(pipe([good, good, good])) == 3
