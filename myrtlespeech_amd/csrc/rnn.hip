@@ -780,8 +780,12 @@ __global__ void hx_init_kernel(unsigned* __restrict__ hx, size_t words_per_dir, 
 //    (hi*hi + lo*hi + hi*lo, f32 accumulate): 48 MFMA x 32 cycles per wave and step instead
 //    of 128 x 64;
 //  * the hand-off carries its own validity: every 16-bit element of the exchanged h has its
-//    least significant mantissa bit replaced by a 1-bit epoch tag (the lo part is computed
-//    against the tagged hi, so the split stays exact to 2^-17).  A consumer simply loads
+//    least significant mantissa bit replaced by a 1-bit epoch tag.  The lo part is computed
+//    against the TAGGED hi, so hi's lost bit is recovered by lo; lo's own tag bit is not: the
+//    copy of h that other workgroups multiply is h * (1 + e) with |e| <= ~2^-13 in the worst
+//    case (|lo| <= 1.5 * 2^-7 |h|, and its tagged 8-bit significand is off by up to 1.5 * 2^-7
+//    of that), ~2^-15 typically, against 2^-17 for an untagged split; the own state, the
+//    outputs and h_n / c_n are not affected.  End to end: DESIGN.md 2.  A consumer simply loads
 //    (sc1) and re-loads until every element of its chunk shows the expected tag -- no flag,
 //    no producer-side drain, no second hop (MI355X_MICROARCH.md "R2: the data IS the flag",
 //    with per-element tags so even a torn 16-byte transfer is detected).  The exchange
