@@ -555,18 +555,30 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
     };
     rd_x(0, 0, 0);
     rd_w(0, 0, 0, 0);
+    // (block 1 was issued in the prologue with block 0; from block 2 on a block's DMA pieces are issued a few at a time in
+    // the first steps of the block BEFORE it -- a single wave cannot hide a burst of 12 DMA issues behind six MFMAs)
+    constexpr int DMA_STEPS = 4, PER_STEP = (NP + DMA_STEPS - 1) / DMA_STEPS;
     for (int b = 0; b < nk; ++b) {
       const int cur = b & 1;
+      const int soff_next = __builtin_amdgcn_readfirstlane(min(b + 1, nk - 1) * (SB_K * 2));
+      char* dst_a = lds + (cur ^ 1) * G4_STAGE + PA * G4_PLANE + RA * 64;
+      char* dst_b = lds + (cur ^ 1) * G4_STAGE + PB * G4_PLANE + RB * 64;
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int step = h * 4 + j;               // 0..7: W pair `step` lives in ring slot step & 1, x set h in ring slot h
+          if (b > 0 && step < DMA_STEPS) {          // block b+1 -> the other stage (free since the barrier of block b-1)
+#pragma unroll
+            for (int p = step * PER_STEP; p < (step + 1) * PER_STEP && p < NP; ++p) {
+              if (p < NPA) lds_dma_16(rsrc_a, dst_a + p * 1024, voff[p], soff_next);
+              else lds_dma_16(rsrc_b, dst_b + (p - NPA) * 1024, voff[p], soff_next);
+            }
+          }
           if (step == 7) {
-            // every read of this stage has been issued and (below) waited for: the stage may be refilled, the next one read
-            __builtin_amdgcn_s_waitcnt(0x0070);     // lgkmcnt(0) + vmcnt(0): block b+1 has landed (this wave's pieces)
+            // every read of this stage has been issued and (below) waited for; the next block has landed (this wave's pieces)
+            __builtin_amdgcn_s_waitcnt(0x0070);     // lgkmcnt(0) + vmcnt(0)
             __builtin_amdgcn_s_barrier();
-            dma_block(min(b + 2, nk - 1), cur);
             rd_x(0, cur ^ 1, 0);
             rd_w(0, cur ^ 1, 0, 0);
           } else {

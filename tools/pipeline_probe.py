@@ -33,17 +33,19 @@ def par():
         p.result()
 
 
-for fn in (seq, par):
+MODES = os.environ.get("PROBE_MODES", "seq,par").split(",")
+fns = [(n, f) for n, f in (("seq", seq), ("par", par)) if n in MODES]
+for _, fn in fns:
     fn()
 res = {"seq": [], "par": []}
-for _ in range(5):
-    for name, fn in (("seq", seq), ("par", par)):
+for _ in range(int(os.environ.get("PROBE_ROUNDS", "5"))):
+    for name, fn in fns:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         fn()
         torch.cuda.synchronize()
         res[name].append((time.perf_counter() - t0) / K * 1e3)
 pipe.check_status()
-for name in ("seq", "par"):
+for name, _ in fns:
     t = sorted(res[name])
     print(f"{name}: median {t[len(t) // 2]:.3f} ms per batch (min {t[0]:.3f}, max {t[-1]:.3f}) = {320.0 / t[len(t) // 2] * 1e3:.0f} audio-s/s")
