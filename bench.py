@@ -15,7 +15,7 @@ Prints ONE JSON line on rank 0 (see the task contract): metric = audio-sec/s wit
   nothing about headroom) AND what physically binds: ``hbm_frac_measured`` (PMC FETCH/WRITE bytes of this binary, from
   profiles/, / the live duration / 8 TB/s), ``mfma_frac`` (PMC MFMA instruction count x FLOP per instruction / live
   duration / 2.5 PFLOP/s) and ``bound`` -- for this kernel the cross-CU exchange of ``h`` each step;
-* ``projection_gemm``: the same three figures for the second-largest kernel (``gemm_nt_bf16x3_kernel2`` at K = 2048);
+* ``projection_gemm``: the same three figures for the second-largest kernel (``gemm_nt_bf16x3_kernel4`` at K = 2048);
 * ``ragged_lengths``: the same step on lengths ~U[501, 1001] (sorted), BASELINE.md 3's second case;
 * ``precision_f32``: the whole bench repeated by a child process in ``MS_PRECISION=f32`` (float32 MFMA everywhere -- the
   reference's own arithmetic width), started before this process touches the GPU (N = 1 only);
@@ -393,7 +393,7 @@ def main():
         # ---- second kernel: the input-projection GEMM at K = 2048 (layers 1..4): 3 bf16 MFMA passes in bf16x3 mode
         M, K, N = T_OUT * BATCH_PER_GPU, 2 * HIDDEN, 2 * 4 * HIDDEN
         passes = {"bf16x3": 3, "fp16": 1, "f32": 1}[mode]
-        gname = "gemm_nt_f32_kernel" if mode == "f32" else "gemm_nt_bf16x3_kernel2"
+        gname = "gemm_nt_f32_kernel" if mode == "f32" else "gemm_nt_bf16x3_kernel4"
         gemm = {"kernel": f"{gname} (M {M} x N {N} x K {K}; layers 2-5 of the stack)", "bound": "mfma"}
         g_ms = gemm_k2048_ms
         if g_ms > 0:

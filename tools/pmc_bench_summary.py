@@ -4,7 +4,7 @@
 Per kernel and launch: HBM bytes = 2 x FETCH_SIZE KB + WRITE_SIZE KB (MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE tallies
 128-B requests at 64 B, so it is doubled; WRITE_SIZE is exact; both are reported in KB), MFMA FLOP = SQ_INSTS_MFMA x FLOP
 of the kernel's MFMA shape, L2 hit rate, MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES).
-The split-operand GEMM is reported per contraction length: its five full-grid launches per step are, in dispatch order,
+The split-operand GEMM (gemm_nt_bf16x3_kernel4, the LDS-DMA kernel) is reported per contraction length: its five full-grid launches per step are, in dispatch order,
 layer 1 (K = 640) and layers 2-5 (K = 2048)."""
 import csv
 import glob
@@ -20,6 +20,7 @@ sys.path.insert(0, REPO)
 
 # FLOP per MFMA wave-instruction of each kernel's shape
 MFMA_FLOP = {"lstm_persistent_split2_kernel": 2 * 16 * 16 * 32, "gemm_nt_bf16x3_kernel2": 2 * 32 * 32 * 16,
+             "gemm_nt_bf16x3_kernel4": 2 * 32 * 32 * 16,
              "lstm_persistent_f32x2_kernel": 2 * 16 * 16 * 4, "gemm_nt_f32_kernel": 2 * 32 * 32 * 2,
              "maskconv_cl_kernel": 2 * 32 * 32 * 16}
 
@@ -52,7 +53,7 @@ kernels = {}
 for name, counters in rows.items():
     if not any(k in name for k in ("lstm", "gemm", "maskconv", "gru")):
         continue
-    if name == ("gemm_nt_f32_kernel" if precision == "f32" else "gemm_nt_bf16x3_kernel2"):   # the projection GEMM of this mode
+    if name == ("gemm_nt_f32_kernel" if precision == "f32" else "gemm_nt_bf16x3_kernel4"):   # the projection GEMM of this mode
         grid_max = max(g for v in counters.values() for _, g, _ in v)
         split = {"@K640": defaultdict(list), "@K2048": defaultdict(list), "@other": defaultdict(list)}
         for cname, v in counters.items():
