@@ -34,35 +34,45 @@ COTENANT_GEMM_VARIANT = 7
 
 
 class _Baton:
-    """Strict alternation between two threads; a thread that has finished leaves the other one running freely."""
+    """Round-robin alternation between the worker threads; a thread that has finished is skipped from then on."""
 
-    def __init__(self):
+    def __init__(self, n: int):
         self.cv = threading.Condition()
+        self.n = n
         self.turn = 0
-        self.active = [True, True]
+        self.active = [True] * n
+
+    def _next_active(self, after: int) -> int:
+        for d in range(1, self.n + 1):
+            k = (after + d) % self.n
+            if self.active[k]:
+                return k
+        return after
 
     def wait_turn(self, me: int):
         with self.cv:
-            while self.turn != me and self.active[1 - me]:
+            while self.turn != me:
                 self.cv.wait()
-            self.turn = me
 
     def pass_on(self, me: int):
         with self.cv:
-            if self.active[1 - me]:
-                self.turn = 1 - me
-                self.cv.notify_all()
+            self.turn = self._next_active(me)
+            self.cv.notify_all()
         self.wait_turn(me)
 
     def leave(self, me: int):
         with self.cv:
             self.active[me] = False
-            self.turn = 1 - me
+            if self.turn == me:
+                self.turn = self._next_active(me)
             self.cv.notify_all()
 
 
-class TwoBatchesInFlight:
-    """``TwoBatchesInFlight(model)(batches)``: run ``model`` over a list of ``(x, lens)`` batches, two at a time.
+class BatchesInFlight:
+    """``BatchesInFlight(model, depth=2)(batches)``: run ``model`` over a list of ``(x, lens)`` batches, ``depth`` at a time
+    (``TwoBatchesInFlight`` = depth 2).  With depth 3 there is always a batch whose projection has finished when a
+    recurrence ends, so the recurrences follow each other without a gap (with depth 2 the slot that carries a batch's
+    output layers, the next batch's convolutions and its first projection is longer than the recurrence it hides under).
 
     ``model`` is any module of this package whose forward enqueues work on the current stream (normally ``DeepSpeech2``); a
     deep copy serves the second stream (its own workspaces and packed-weight caches; the weights are replicated, 457 MB
@@ -70,10 +80,13 @@ class TwoBatchesInFlight:
     its forward was issued -- e.g. ``decoder.launch`` of ``CTCGreedyDecoder``, whose ``.result()`` the caller collects
     afterwards -- so that no host read-back interrupts the alternation.  Results come back in the order of ``batches``."""
 
-    def __init__(self, model: torch.nn.Module, post: Optional[Callable] = None, pre: Optional[Callable] = None):
+    def __init__(self, model: torch.nn.Module, post: Optional[Callable] = None, pre: Optional[Callable] = None, depth: int = 2):
         _lib.require_gpu()
-        self.models = (model, copy.deepcopy(model))
-        self.streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        if depth < 2 or depth > 4:
+            raise ValueError(f"depth={depth} must be in [2, 4]")
+        self.depth = depth
+        self.models = tuple([model] + [copy.deepcopy(model) for _ in range(depth - 1)])
+        self.streams = tuple(torch.cuda.Stream() for _ in range(depth))
         self.post = post
         self.pre = pre      # called with the batch index on the batch's stream before its forward is issued (e.g. to record an event)
         # a per-call status check of the recurrent stack synchronises its stream in the middle of the alternation: the sticky
@@ -86,7 +99,7 @@ class TwoBatchesInFlight:
         lib = _lib.load()
         results: List = [None] * len(batches)
         errors: List = []
-        baton = _Baton()
+        baton = _Baton(self.depth)
         slot_of = {}
         device = torch.cuda.current_device()
         caller = torch.cuda.current_stream()
@@ -105,7 +118,7 @@ class TwoBatchesInFlight:
                 baton.wait_turn(me)
                 with torch.cuda.stream(self.streams[me]), torch.no_grad():
                     self.streams[me].wait_event(ready)          # inputs made on the caller's stream
-                    for k in range(me, len(batches), 2):
+                    for k in range(me, len(batches), self.depth):
                         if self.pre is not None:
                             self.pre(k)
                         out = self.models[me](batches[k])
@@ -120,7 +133,7 @@ class TwoBatchesInFlight:
         _lib.issue_point = hook
         lib.ms_gemm_set_variant(COTENANT_GEMM_VARIANT)
         try:
-            threads = [threading.Thread(target=worker, args=(m,), daemon=True) for m in (0, 1)]
+            threads = [threading.Thread(target=worker, args=(m,), daemon=True) for m in range(self.depth)]
             for t in threads:
                 t.start()
             for t in threads:
@@ -142,3 +155,8 @@ class TwoBatchesInFlight:
         for m in self._stacks:
             if m._workspace.buf is not None:
                 _lib.check(lib.ms_rnn_status(_lib.ptr(m._workspace.buf), _lib.stream_ptr()), "persistent recurrent layer")
+
+
+class TwoBatchesInFlight(BatchesInFlight):
+    def __init__(self, model: torch.nn.Module, post: Optional[Callable] = None, pre: Optional[Callable] = None):
+        super().__init__(model, post=post, pre=pre, depth=2)

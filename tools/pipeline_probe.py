@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-from myrtlespeech_amd.pipeline import TwoBatchesInFlight  # noqa: E402
+from myrtlespeech_amd.pipeline import BatchesInFlight  # noqa: E402
 from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder  # noqa: E402
 
 K = int(os.environ.get("PROBE_STEPS", "40"))
@@ -19,7 +19,7 @@ dec = CTCGreedyDecoder(28)
 g = torch.Generator().manual_seed(1234)
 x = torch.randn(32, 1, 80, 1001, generator=g).cuda()
 lens = torch.full((32,), 1001, dtype=torch.int64)
-pipe = TwoBatchesInFlight(model, post=lambda out: dec.launch(out[0][0], out[0][1]))
+pipe = BatchesInFlight(model, post=lambda out: dec.launch(out[0][0], out[0][1]), depth=int(os.environ.get("PROBE_DEPTH", "2")))
 
 
 def seq():
