@@ -106,3 +106,35 @@ def rccl_one_rank() -> None:
         print("rccl one-rank ok: backend", dist.get_backend(), "world", dist.get_world_size())
     finally:
         dist.destroy_process_group()
+
+
+def gemm_variants_equal() -> None:
+    """The split-operand GEMM's three kernels (0 = LDS-DMA 8-wave, 7 = LDS-DMA 4-wave co-tenant form, 2 = register-staged) on the
+    same operands in THIS process's precision mode (run in a child with MS_PRECISION=fp16 for the single-pass instantiations):
+    bit-identical outputs, ragged edges included."""
+    from myrtlespeech_amd import _lib
+    lib = _lib.load()
+    for M, K, N, act in ((2100, 96, 2052, 0), (4100, 32, 1026, 1), (3000, 640, 2048, 0)):
+        g = torch.Generator().manual_seed(M + K + N)
+        x = torch.randn(M, K, generator=g).cuda()
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        ws = torch.empty(lib.ms_linear_split_workspace_bytes(M, K, N), dtype=torch.uint8, device="cuda")
+        ys = []
+        try:
+            for variant in (0, 7, 2):
+                lib.ms_gemm_set_variant(variant)
+                y = torch.full((M + 1, N), float("nan"), device="cuda")
+                _lib.check(lib.ms_linear_split_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), M, K, N, act, 0.0, 1.5,
+                                                       _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "linear_split")
+                assert bool(torch.isnan(y[M]).all())
+                ys.append(y[:M])
+        finally:
+            lib.ms_gemm_set_variant(0)
+        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2]), (M, K, N)
+        want = x.double() @ w.double().T + b.double()
+        if act:
+            want = want.clamp(0.0, 1.5)
+        tol = 2e-3 if os.environ.get("MS_PRECISION") == "fp16" else 1e-4
+        assert float((ys[0].double() - want).abs().max()) < tol * float(want.abs().max() + 1.0)
+    print("gemm variants equal in mode", os.environ.get("MS_PRECISION", "bf16x3"))

@@ -52,6 +52,14 @@ def test_cfg5_streaming_batch64_fp16_mfma_in_subprocess():
     print(out.strip().splitlines()[-2])
 
 
+def test_split_gemm_kernels_agree_in_both_operand_modes():
+    """kernel4 (8 waves), kernel4n (4 waves, the co-tenant form of the two-in-flight pipeline) and kernel2 (register staging):
+    bit-identical in the default bf16x3 mode and, in a child, in the single-pass fp16 mode of configs[4]."""
+    cfg_checks.gemm_variants_equal()
+    out = _child("gemm_variants_equal()", MS_PRECISION="fp16")
+    assert "gemm variants equal in mode fp16" in out
+
+
 # ----------------------------------------------------------------------------- configs[2]: the RCCL exchange step
 def test_cfg3_rccl_all_gather_one_rank_child():
     with socket.socket() as s:

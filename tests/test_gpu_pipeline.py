@@ -58,6 +58,21 @@ def test_two_batches_in_flight_equal_the_sequential_run(H, n_batches):
     assert torch.equal(y, want[0][0])
 
 
+def test_three_batches_in_flight_equal_the_sequential_run():
+    """The depth parameter (measured slower than 2 on config 2; kept for other shapes): same outputs."""
+    from myrtlespeech_amd.pipeline import BatchesInFlight
+    model = _small_ds2(256)
+    batches = _batches(7, 8, 70, 40, 3)
+    want = [model((x.clone(), lens))[0][0] for x, lens in batches]
+    pipe = BatchesInFlight(model, depth=3)
+    got = pipe([(x.clone(), lens) for x, lens in batches])
+    pipe.check_status()
+    for ((y, _), _), w in zip(got, want):
+        assert torch.equal(y, w)
+    with pytest.raises(ValueError):
+        BatchesInFlight(model, depth=1)
+
+
 def test_two_batches_in_flight_full_size_network():
     """The config-2 network (5 x BiLSTM-1024, batch 32 x 1001 frames): the co-tenant projection GEMM (4 waves, 256 x 128
     tiles) and the cross-stream chain of the persistent launches at the size they were built for."""
