@@ -279,7 +279,7 @@ def main():
         ev = []
         ms = (ctypes.c_float * 4)()
         cnt = (ctypes.c_int * 4)()
-        lib.ms_prof_enable(0 if two else 1)
+        lib.ms_prof_enable(0 if (two and os.environ.get('BENCH_PROF_TWO') == '0') else 1)
         lib.ms_prof_read(ms, cnt)       # drop spans recorded so far
         barrier()
         t0 = time.perf_counter()
@@ -313,11 +313,26 @@ def main():
         step(lens_full)
     # leg 1: one batch at a time (kernel durations, rooflines, the encoder / decode split)
     one_elapsed, spans, enc_ms, dec_ms = timed(lens_full, args.steps, False)
-    # leg 2 (headline when --in-flight 2): two batches in flight
+    # leg 2 (headline when --in-flight 2): two batches in flight.  A failure here must not cost the run its headline: the
+    # one-batch figure (already measured) is reported instead, with the reason.
+    pipeline_error = None
+    two_spans = None
     if pipelined:
-        pipe([(x, lens_full)] * max(2, min(args.warmup, 4)))
-        elapsed, _, latency_ms, _ = timed(lens_full, args.steps, True)
-    else:
+        try:
+            pipe([(x, lens_full)] * max(2, min(args.warmup, 4)))
+            elapsed, two_spans, latency_ms, _ = timed(lens_full, args.steps, True)
+        except Exception as e:  # noqa: BLE001
+            pipeline_error = f"{type(e).__name__}: {e}"[:300]
+            pipelined = False
+            lib.ms_gemm_set_variant(0)
+            torch.cuda.synchronize()
+    two_in_flight = None
+    if pipelined:
+        two_in_flight = {"value": round(world * BATCH_PER_GPU * CLIP_SECONDS * args.steps / elapsed, 1),
+                         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "latency_ms_per_batch": round(latency_ms, 3)}
+        if elapsed >= one_elapsed:   # few steps: the pipeline's fill and drain outweigh what it hides; the headline is the faster leg
+            pipelined = False
+    if not pipelined:
         elapsed, latency_ms = one_elapsed, None
 
     ragged = None
@@ -379,6 +394,9 @@ def main():
                 "definition": "frac = SURVEY 8d algorithmic bytes (17 825 792 B x 1002 layer-direction-steps, W_hh counted "
                               "once per step although it stays in registers) / launch_ms / 8 TB/s: the north-star's "
                               "roofline figure, not a physical utilisation"}
+        if pipelined and two_spans is not None:
+            roof["launch_ms_two_in_flight"] = round(two_spans[1], 4)
+            roof["frac_two_in_flight"] = round(launch_bytes / (two_spans[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if two_spans[1] > 0 else None
         rec, why = pmc_record(kname)
         if rec is not None and rec_ms > 0:
             roof["traffic"] = int(rec["hbm_bytes"])
@@ -404,6 +422,10 @@ def main():
                          "first_layer_k640_launch_ms": round(gemm_k640_ms, 4) if gemm_k640_ms > 0 else None})
             if gemm_k640_ms > 0:
                 gemm["first_layer_k640_frac"] = round(passes * 2.0 * M * N * 640 / (gemm_k640_ms * 1e-3) / 1e12 / mfma_peak, 4)
+            if pipelined and two_spans is not None and two_spans[2] > 0:
+                gemm["launch_ms_two_in_flight"] = round(two_spans[2], 4)
+                gemm["two_in_flight_note"] = ("gemm_nt_bf16x3_kernel4n: 256 x 128 tiles, one wave per SIMD, resident beside the "
+                                              "recurrence of the other batch; its duration under that co-tenant")
             grec, gwhy = pmc_record(gname + "@K2048")
             if grec is not None:
                 gemm["traffic"] = int(grec["hbm_bytes"])
@@ -443,6 +465,10 @@ def main():
             "kernel_ms": {"lstm_recurrent_per_layer": round(rec_ms, 3), "lstm_input_projection_per_layer": round(proj_ms, 3)},
             "roofline": roof, "projection_gemm": gemm,
         }
+        if two_in_flight is not None:
+            out["two_batches_in_flight"] = two_in_flight
+        if pipeline_error is not None:
+            out["pipeline_error"] = pipeline_error
         if frontend_ms is not None:
             out["frontend_ms_not_in_value"] = round(frontend_ms, 3)
         if ragged is not None:

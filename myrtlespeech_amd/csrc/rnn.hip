@@ -2118,11 +2118,11 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
     }
   }
   if (rc != MS_OK) return rc;
-  ProfScope prof_rec(1, stream);
 
   if (fast) {
     PersistentTurn turn(stream);   // never resident together with another stream's persistent launch
     if (turn.rc != MS_OK) { ms::set_error("ms_rnn_layer_forward: cross-stream hand-over of the persistent launch failed"); return turn.rc; }
+    ProfScope prof_rec(1, stream); // after the hand-over's stream wait: the span is the launch(es), not the queueing behind another stream
     // batch groups of <= 64 sequences, one persistent launch each (stream-ordered; the epoch
     // flags are re-zeroed in between, the status word is kept so any time-out is reported)
     const bool f32x2 = use_f32x2(cell, H, ndir);
@@ -2211,6 +2211,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
   if (use_gru_persistent(cell, H, ndir)) {
     PersistentTurn turn(stream);
     if (turn.rc != MS_OK) { ms::set_error("ms_rnn_layer_forward: cross-stream hand-over of the persistent launch failed"); return turn.rc; }
+    ProfScope prof_rec(1, stream);
     // one persistent launch per group of 32 sequences (two interleaved streams of 16)
     for (int n0 = 0; n0 < N; n0 += 32) {
       const int rs = lstm_ring_shift();
@@ -2247,6 +2248,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
   }
 
   // generic: one launch per time step
+  ProfScope prof_rec(1, stream);
   float* sh = (float*)(ws + W.state_h);
   float* sc = (float*)(ws + W.state_c);
   const size_t st = (size_t)ndir * N * H;
