@@ -86,11 +86,21 @@ class DeepSpeech2(torch.nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, x: Tuple[torch.Tensor, torch.Tensor], hx: Optional[RNNState] = None
                 ) -> Tuple[Tuple[torch.Tensor, torch.Tensor], RNNState]:
+        return self.back(self.front(x), hx)
+
+    def front(self, x: Tuple[torch.Tensor, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The part of ``forward`` that depends on the input only: convolutions and the (N,C,F,T) -> (T,N,C*F) re-layout
+        (deep_speech_2.py:150-157).  ``forward(x, hx) == back(front(x), hx)``; a pipeline may run ``front`` of a later batch
+        on another stream while an earlier batch is in its recurrent layers (``pipeline.BatchesInFlight``)."""
         _lib.require_gpu()
         h = (x[0].cuda() if not x[0].is_cuda else x[0], x[1])
         if self.cnn is not None:
             h = self._run_cnn(h)
-        h = (self._conv_to_rnn_size(h[0]), h[1])
+        return self._conv_to_rnn_size(h[0]), h[1]
+
+    def back(self, h: Tuple[torch.Tensor, torch.Tensor], hx: Optional[RNNState] = None
+             ) -> Tuple[Tuple[torch.Tensor, torch.Tensor], RNNState]:
+        """Recurrent layers, lookahead and fully-connected layers on the output of ``front`` (deep_speech_2.py:158-172)."""
         _lib.at_issue_point()
         h, hid = self.rnn(h, hx=hx)
         _lib.at_issue_point()
