@@ -1818,8 +1818,12 @@ struct PersistentTurn {
     c->mu.lock();
     if (c->any && c->last != stream) {
       if (!c->multi) {
-        if (hipStreamSynchronize(c->last) != hipSuccess ||
-            hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) rc = MS_ERR_HIP;
+        // (the earlier stream may have been destroyed by its owner since: then everything is waited for once)
+        if (hipStreamSynchronize(c->last) != hipSuccess) {
+          (void)hipGetLastError();
+          if (hipDeviceSynchronize() != hipSuccess) rc = MS_ERR_HIP;
+        }
+        if (hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) rc = MS_ERR_HIP;
         c->multi = true;
       } else if (hipStreamWaitEvent(stream, c->done, 0) != hipSuccess) {
         rc = MS_ERR_HIP;
