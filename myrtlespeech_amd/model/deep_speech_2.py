@@ -101,11 +101,19 @@ class DeepSpeech2(torch.nn.Module):
     def back(self, h: Tuple[torch.Tensor, torch.Tensor], hx: Optional[RNNState] = None
              ) -> Tuple[Tuple[torch.Tensor, torch.Tensor], RNNState]:
         """Recurrent layers, lookahead and fully-connected layers on the output of ``front`` (deep_speech_2.py:158-172)."""
+        return self.output(*self.recurrent(h, hx))
+
+    def recurrent(self, h: Tuple[torch.Tensor, torch.Tensor], hx: Optional[RNNState] = None):
+        """The recurrent stack on the output of ``front``: ``(seq [T, N, D*H], lens, hid)``."""
         _lib.at_issue_point()
         h, hid = self.rnn(h, hx=hx)
         _lib.at_issue_point()
-        seq, lens = h
+        return h[0], h[1], hid
 
+    def output(self, seq: torch.Tensor, lens: torch.Tensor, hid: RNNState
+               ) -> Tuple[Tuple[torch.Tensor, torch.Tensor], RNNState]:
+        """Lookahead and fully-connected layers on the recurrent stack's output (the part of ``forward`` that a pipeline may
+        issue late: nothing of the NEXT batch depends on it)."""
         fc = self.fully_connected
         fused_fc = isinstance(fc, FullyConnected)
         if self.lookahead is not None:

@@ -35,7 +35,17 @@ def linear_stack_plan(module: Union[torch.nn.Linear, torch.nn.Sequential], train
 
 
 _SPLIT_MIN_FLOPS = 2e9  # below this the two plane-split passes cost more than they save
-_split_ws = _lib.Workspace()
+# Operand-plane scratch of the split GEMM, one per HIP stream: work on one stream is ordered, so successive layers may share
+# a buffer, but two streams (pipeline.BatchesInFlight) must not -- one stream's planes would be overwritten under the other's GEMM.
+_split_ws = {}
+
+
+def _stream_workspace() -> "_lib.Workspace":
+    key = torch.cuda.current_stream().cuda_stream
+    ws = _split_ws.get(key)
+    if ws is None:
+        ws = _split_ws[key] = _lib.Workspace()
+    return ws
 
 
 def run_linear_stack(x2d: torch.Tensor, plan) -> torch.Tensor:
@@ -53,7 +63,7 @@ def run_linear_stack(x2d: torch.Tensor, plan) -> torch.Tensor:
         w = _lib.f32c(lin.weight.detach())
         b = None if lin.bias is None else _lib.f32c(lin.bias.detach())
         if _lib.split_precision() and k % 32 == 0 and 2.0 * m * k * n >= _SPLIT_MIN_FLOPS:
-            ws = _split_ws.get(lib.ms_linear_split_workspace_bytes(m, k, n))
+            ws = _stream_workspace().get(lib.ms_linear_split_workspace_bytes(m, k, n))
             _lib.check(lib.ms_linear_split_forward(_lib.ptr(h), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), m, k, n, a, lo, hi,
                                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "ms_linear_split_forward")
         else:

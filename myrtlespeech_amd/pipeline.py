@@ -16,7 +16,8 @@ projection runs in the shadow of batch A's recurrence and vice versa:
 Measured and dropped: more than two batches in flight (depth 3: 14.2, depth 4: 15.1 ms per batch against 13.7 for depth 2), and
 issuing the NEXT batch's convolutions early on a third stream so that they leave the critical slot between a batch's output
 layers and the next one's first projection (14.5 ms): a third resident kernel takes LDS and CU share from the co-tenant GEMM,
-which the recurrences then wait for.
+which the recurrences then wait for; issuing a batch's output layers late (behind the first recurrent layer of the slot's next
+batch, so that the next batch's convolutions and first projection come first: 14.08 against 13.74 .. 13.95 ms).
 
 Measured (``profiles/r02*_overlap*``): the recurrence slows by ~45 % under its co-tenant (its exchange shares the CU's
 memory queue with the GEMM's operand stream), the GEMM hides completely, net ~12 % more batches per second on the recurrent

@@ -99,3 +99,24 @@ def test_pipeline_propagates_errors_and_restores_the_hooks():
         pipe([good, bad, good])
     assert _lib.issue_point is None
     assert len(pipe([good, good, good])) == 3
+
+
+def test_split_gemm_scratch_is_per_stream():
+    """The operand planes of a large Linear are made in a scratch buffer: one per HIP stream, or the two streams of the
+    pipeline would overwrite each other's planes under a running GEMM (found by review in round 2; the alternation happened
+    to keep the two output stacks apart in time)."""
+    from myrtlespeech_amd.model import fully_connected as F
+    lin = torch.nn.Linear(2048, 1024).cuda()
+    x = torch.randn(16032, 2048, device="cuda")
+    want = F.run_linear_stack(x, [(lin, None)])
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(4):
+        for s in (s1, s2):
+            with torch.cuda.stream(s):
+                outs.append(F.run_linear_stack(x, [(lin, None)]))
+    torch.cuda.synchronize()
+    keys = {s1.cuda_stream, s2.cuda_stream}
+    assert keys <= set(F._split_ws) and F._split_ws[s1.cuda_stream].buf.data_ptr() != F._split_ws[s2.cuda_stream].buf.data_ptr()
+    assert all(torch.equal(o, want) for o in outs)
