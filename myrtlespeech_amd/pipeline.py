@@ -153,6 +153,18 @@ class BatchesInFlight:
             caller.wait_event(done)
         if errors:
             raise errors[0]
+
+        def hand_over(obj):
+            """Result tensors were allocated on a worker stream and will be used (and freed) on the caller's: tell the
+            caching allocator, or a freed block could be re-used by the worker stream under the caller's kernels."""
+            if isinstance(obj, torch.Tensor):
+                if obj.is_cuda:
+                    obj.record_stream(caller)
+            elif isinstance(obj, (tuple, list)):
+                for o in obj:
+                    hand_over(o)
+
+        hand_over(results)
         return results
 
     def check_status(self):
