@@ -2,7 +2,7 @@
 """Randomised soak on the GPU box: many small seeded cases of the index-producing paths against the numpy oracle
 (CTC prefix beam search with separators / word weights / a toy LM, RNN-T greedy + beam, CTC greedy), plus ragged
 LSTM / GRU layers and masked convolutions (all three kernels) against the oracle within 1e-4.  Prints one line per family; exits non-zero on the first mismatch.
-    python tests/soak.py [seconds per family, default 40] [first seed, default 0]"""
+    python tests/soak.py [seconds per family, default 40] [first seed, default 0] [substring of the one family to run]"""
 import os
 import sys
 import time
@@ -18,7 +18,12 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 
 
+only = sys.argv[3] if len(sys.argv) > 3 else ""
+
+
 def family(name, one_case):
+    if only and only not in name:
+        return
     t0, n = time.time(), 0
     while time.time() - t0 < budget:
         one_case(seed0 + n)
@@ -229,13 +234,14 @@ def linear_case(seed):
         ws = torch.empty(lib.ms_linear_split_workspace_bytes(M, K, N), dtype=torch.uint8, device="cuda")
         _lib.check(lib.ms_linear_split_forward(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), M, K, N, act, lo, hi,
                                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "split")
-        if M * N >= 4 * 1024 * 1024:   # the LDS-DMA kernel must agree bit for bit with the register-staged one
-            y2 = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
-            lib.ms_gemm_set_variant(2)
-            _lib.check(lib.ms_linear_split_forward(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y2), M, K, N, act, lo, hi,
-                                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "split (kernel2)")
-            lib.ms_gemm_set_variant(0)
-            assert torch.equal(y, y2), ("split kernels differ", seed, M, K, N)
+        if M * N >= 4 * 1024 * 1024:   # the LDS-DMA kernels (8-wave and 4-wave co-tenant form) must agree bit for bit with the register-staged one
+            for variant in (2, 7):
+                y2 = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+                lib.ms_gemm_set_variant(variant)
+                _lib.check(lib.ms_linear_split_forward(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y2), M, K, N, act, lo, hi,
+                                                       _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "split (variant)")
+                lib.ms_gemm_set_variant(0)
+                assert torch.equal(y, y2), ("split kernels differ", variant, seed, M, K, N)
     else:
         _lib.check(lib.ms_linear_forward(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), M, K, N, act, lo, hi,
                                          _lib.stream_ptr()), "linear")
