@@ -75,7 +75,6 @@ def rccl_one_rank() -> None:
         assert torch.equal(full_lens.cpu(), lens)
         assert torch.equal(_lib.host_lens(full_lens), lens)          # host values ride along: no read-back in the decoder
         # the real pipeline: encoder on this rank's shard -> all-gather -> batched decode == per-shard decode
-        import __graft_entry__  # noqa: F401  (same tiny network as smoke())
         from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
         from myrtlespeech_amd.model.deep_speech_2 import DeepSpeech2
         from myrtlespeech_amd.model.fully_connected import FullyConnected

@@ -18,7 +18,6 @@ import sys
 
 import numpy as np
 import pytest
-import torch
 
 import cfg_checks
 from util import Golden

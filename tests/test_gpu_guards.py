@@ -9,11 +9,8 @@ import os
 import subprocess
 import sys
 
-import numpy as np
 import pytest
 import torch
-
-from oracle import ds_oracle as O
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
