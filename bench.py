@@ -424,8 +424,11 @@ def main():
                 gemm["first_layer_k640_frac"] = round(passes * 2.0 * M * N * 640 / (gemm_k640_ms * 1e-3) / 1e12 / mfma_peak, 4)
             if pipelined and two_spans is not None and two_spans[2] > 0:
                 gemm["launch_ms_two_in_flight"] = round(two_spans[2], 4)
-                gemm["two_in_flight_note"] = ("gemm_nt_bf16x3_kernel4n: 256 x 128 tiles, one wave per SIMD, resident beside the "
-                                              "recurrence of the other batch; its duration under that co-tenant")
+                gemm["two_in_flight_note"] = (
+                    "the same float32 GEMM time-slicing with the other batch's recurrence (it cannot share a CU with it)"
+                    if mode == "f32" else
+                    "gemm_nt_bf16x3_kernel4n: 256 x 128 tiles, one wave per SIMD, resident beside the recurrence of the other "
+                    "batch; its duration under that co-tenant")
             grec, gwhy = pmc_record(gname + "@K2048")
             if grec is not None:
                 gemm["traffic"] = int(grec["hbm_bytes"])
