@@ -216,6 +216,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        from myrtlespeech_amd import parallel
+        parallel.init_host_group()      # gloo twin for host metadata: collective over the world, so at set-up time
     else:
         torch.cuda.set_device(0)
 
@@ -462,9 +464,12 @@ def main():
             "encoder_ms": round(enc_ms, 3), "decode_ms": round(dec_ms, 3),
             "encoder_ms_per_rnn_step": round(enc_ms / T_OUT, 4),
             "parity": {"tolerance": "logits within 1e-3 of the reference (fp32), CTC indices bit-exact",
-                       "measured": "full-size config-2 run vs the reference's golden summary: max |logit error| 2.5e-7 in the "
-                                   "default bf16x3 mode, 3.9e-8 with MS_PRECISION=f32, 1.1e-5 with MS_PRECISION=fp16; greedy "
-                                   "transcripts bit-exact (tests/test_gpu_parity.py::test_ds2_cfg2_full_size_vs_reference_summary)"},
+                       "measured": "full-size config-2 run vs the reference's golden summary (tests/cfg_checks.py::cfg2_full): "
+                                   "max |logit error| 2.5e-7 in the default bf16x3 mode "
+                                   "(tests/test_gpu_parity.py::test_ds2_cfg2_full_size_vs_reference_summary), 3.9e-8 with "
+                                   "MS_PRECISION=f32 (tests/test_gpu_configs.py::test_cfg2_full_size_f32_mode_vs_reference_in_"
+                                   "subprocess, the two-in-flight f32 leg by ::test_two_batches_in_flight_full_size_f32_mode_in_"
+                                   "subprocess); greedy transcripts bit-exact in both"},
             "kernel_ms": {"lstm_recurrent_per_layer": round(rec_ms, 3), "lstm_input_projection_per_layer": round(proj_ms, 3)},
             "roofline": roof, "projection_gemm": gemm,
         }
@@ -483,6 +488,7 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
+        parallel.drop_host_groups()
         dist.destroy_process_group()
 
 

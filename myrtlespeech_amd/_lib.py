@@ -169,8 +169,14 @@ def attach_host(dev: torch.Tensor, host: torch.Tensor) -> torch.Tensor:
     device tensor's version counter and storage address (like the weight caches in ``model/rnn.py``): an in-place edit of
     the lengths between two modules (``lens -= k``, a masked update, the reference's float in-place ``out_lens``,
     ``cnn.py:191-197``) bumps ``_version`` and the stale host values are dropped in ``host_lens``."""
-    dev._ms_host = (host.detach().clone(), dev._version, dev.data_ptr())
+    dev._ms_host = (host.detach().clone(), version_of(dev), dev.data_ptr())
     return dev
+
+
+def version_of(t: torch.Tensor) -> int:
+    """Version counter of ``t``; tensors made under ``torch.inference_mode()`` do not track one (reading it raises) and
+    cannot be edited in place outside inference mode, so they are keyed on their address alone."""
+    return -1 if t.is_inference() else t._version
 
 
 def host_lens(lens: torch.Tensor) -> torch.Tensor:
@@ -189,7 +195,7 @@ def cached_host(lens: torch.Tensor):
     if rec is None:
         return None
     h, version, address = rec
-    if h.shape == lens.shape and version == lens._version and address == lens.data_ptr():
+    if h.shape == lens.shape and version == version_of(lens) and address == lens.data_ptr():
         return h
     lens._ms_host = None  # edited in place (or re-pointed) since it was attached: the host values are stale
     return None

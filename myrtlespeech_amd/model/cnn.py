@@ -58,7 +58,7 @@ class _PackedFilters:
 
     def get_cl(self, weight: torch.Tensor) -> torch.Tensor:
         """Split-bf16 channels-last bank for the multi-channel kernel (conv_cl.hip)."""
-        key = (weight.data_ptr(), weight._version, tuple(weight.shape))
+        key = (weight.data_ptr(), _lib.version_of(weight), tuple(weight.shape))
         if key != self.key_cl:
             lib = _lib.load()
             cout, cin, kf, kt = weight.shape
@@ -71,7 +71,7 @@ class _PackedFilters:
 
     def get_fwin(self, weight: torch.Tensor) -> torch.Tensor:
         """Split-bf16 bank of a single-channel filter for the feature-window kernel (conv_cl.hip, ms_maskconv_fwin_*)."""
-        key = (weight.data_ptr(), weight._version, tuple(weight.shape), "fwin")
+        key = (weight.data_ptr(), _lib.version_of(weight), tuple(weight.shape), "fwin")
         if key != self.key_cl:
             lib = _lib.load()
             cout, _, kf, kt = weight.shape
@@ -84,7 +84,7 @@ class _PackedFilters:
 
     def get_gemm1d(self, weight: torch.Tensor) -> torch.Tensor:
         """bf16 hi / lo planes [Cout, Cin*KT padded to 32] for the im2col + split-GEMM conv1d path (conv1d_gemm.hip)."""
-        key = (weight.data_ptr(), weight._version, tuple(weight.shape), "gemm1d")
+        key = (weight.data_ptr(), _lib.version_of(weight), tuple(weight.shape), "gemm1d")
         if key != self.key_cl:
             lib = _lib.load()
             cout, cin, _, kt = weight.shape
@@ -96,7 +96,7 @@ class _PackedFilters:
         return self.buf_cl
 
     def get(self, weight: torch.Tensor, groups: int) -> torch.Tensor:
-        key = (weight.data_ptr(), weight._version, tuple(weight.shape), groups)
+        key = (weight.data_ptr(), _lib.version_of(weight), tuple(weight.shape), groups)
         if key != self.key:
             lib = _lib.load()
             cout, cin_g, kf, kt = weight.shape

@@ -41,7 +41,7 @@ class PackedLayer:
 
     def get(self, cell: int, in_size: int, hidden: int, params: List[Tuple[Optional[torch.Tensor], ...]]):
         """params: per direction (w_ih, w_hh, b_ih | None, b_hh | None)."""
-        key = tuple((p.data_ptr(), p._version) if p is not None else None for d in params for p in d)
+        key = tuple((p.data_ptr(), _lib.version_of(p)) if p is not None else None for d in params for p in d)
         if key != self.key:
             lib = _lib.load()
             ndir = len(params)

@@ -44,20 +44,49 @@ def _force_collective() -> bool:
     return os.environ.get("MS_FORCE_COLLECTIVE") == "1"
 
 
-_HOST_GROUPS = {}
+_HOST_GROUPS = {}      # ranks tuple of a device group -> its gloo twin
+
+
+def _ranks_key(group: Optional[dist.ProcessGroup]) -> Tuple[int, ...]:
+    if group is None or group is dist.group.WORLD:
+        return tuple(range(dist.get_world_size()))
+    return tuple(dist.get_process_group_ranks(group))
+
+
+def init_host_group(group: Optional[dist.ProcessGroup] = None):
+    """Create the gloo twin of ``group`` (default: the world) that carries small host metadata (shard shapes, lengths,
+    transcripts).  ``torch.distributed.new_group`` must be entered by EVERY rank of the default group, members of ``group`` or
+    not, so this is a set-up call for all world ranks, once, right after ``init_process_group`` / ``new_group(...)`` -- not
+    something ``gather_logits`` may do lazily from inside a sub-group.  Returns the twin (``group`` itself when it already is
+    a gloo group)."""
+    if dist.get_backend(group) == "gloo":
+        return group
+    key = _ranks_key(group)
+    if key not in _HOST_GROUPS:
+        _HOST_GROUPS[key] = dist.new_group(ranks=list(key), backend="gloo")
+    return _HOST_GROUPS[key]
+
+
+def drop_host_groups() -> None:
+    """Forget the gloo twins (call before ``destroy_process_group``; a later ``init_process_group`` starts afresh)."""
+    _HOST_GROUPS.clear()
 
 
 def _host_group(group: Optional[dist.ProcessGroup]):
     """Process group for host objects: with the RCCL backend ``all_gather_object`` would stage the pickled bytes through
     device tensors and read their sizes back (two host syncs in the middle of a step), so small host metadata travels over
-    a gloo twin of ``group`` created (collectively, once) at the first call."""
+    a gloo twin of ``group`` (``init_host_group``).  For the WORLD group every rank reaches the first gather together, so
+    the twin may still be created there; for a sub-group it must have been created at set-up time by all world ranks."""
     if dist.get_backend(group) == "gloo":
         return group
-    key = id(group)
-    if key not in _HOST_GROUPS:
-        ranks = None if group is None else dist.get_process_group_ranks(group)
-        _HOST_GROUPS[key] = dist.new_group(ranks=ranks, backend="gloo")
-    return _HOST_GROUPS[key]
+    key = _ranks_key(group)
+    twin = _HOST_GROUPS.get(key)
+    if twin is None:
+        if len(key) != dist.get_world_size():
+            raise RuntimeError("myrtlespeech_amd.parallel: call init_host_group(group) on EVERY world rank right after creating "
+                               "the sub-group (torch.distributed.new_group is collective over the whole world)")
+        twin = init_host_group(group)
+    return twin
 
 
 def gather_logits(logits: torch.Tensor, lens: torch.Tensor, group: Optional[dist.ProcessGroup] = None

@@ -74,6 +74,16 @@ class _Baton:
             self.cv.notify_all()
 
 
+def replica(model: torch.nn.Module) -> torch.nn.Module:
+    """A copy of ``model`` for another stream that SHARES its Parameters and buffers (the same objects: a later
+    ``load_state_dict`` / ``checkpoint.load`` / in-place edit of the caller's model is seen by every replica, whose
+    packed-weight caches are keyed on the parameters' version counters and addresses and repack by themselves) and owns
+    everything else: workspaces, packed-weight caches, convolution scratch.  The reference's contract is that checkpoints
+    load into ``stt.model`` (scripts/export_ds1_onnx.py:49-50) -- there is one set of weights."""
+    memo = {id(t): t for t in list(model.parameters()) + list(model.buffers())}
+    return copy.deepcopy(model, memo)
+
+
 class BatchesInFlight:
     """``BatchesInFlight(model, depth=2)(batches)``: run ``model`` over a list of ``(x, lens)`` batches, ``depth`` at a time
     (``TwoBatchesInFlight`` = depth 2).  With depth 3 there is always a batch whose projection has finished when a
@@ -81,8 +91,8 @@ class BatchesInFlight:
     output layers, the next batch's convolutions and its first projection is longer than the recurrence it hides under).
 
     ``model`` is any module of this package whose forward enqueues work on the current stream (normally ``DeepSpeech2``); a
-    deep copy serves the second stream (its own workspaces and packed-weight caches; the weights are replicated, 457 MB
-    for the config-2 network).  ``post`` (optional) is called on each batch's output on that batch's stream right after
+    ``replica`` serves the second stream (its own workspaces and packed-weight caches, the SAME Parameter objects: weights
+    loaded or edited after the pipe was built reach both streams).  ``post`` (optional) is called on each batch's output on that batch's stream right after
     its forward was issued -- e.g. ``decoder.launch`` of ``CTCGreedyDecoder``, whose ``.result()`` the caller collects
     afterwards -- so that no host read-back interrupts the alternation.  Results come back in the order of ``batches``."""
 
@@ -91,15 +101,12 @@ class BatchesInFlight:
         if depth < 2 or depth > 4:
             raise ValueError(f"depth={depth} must be in [2, 4]")
         self.depth = depth
-        self.models = tuple([model] + [copy.deepcopy(model) for _ in range(depth - 1)])
+        self.models = tuple([model] + [replica(model) for _ in range(depth - 1)])
         self.streams = tuple(torch.cuda.Stream() for _ in range(depth))
         self.post = post
         self.pre = pre      # called with the batch index on the batch's stream before its forward is issued (e.g. to record an event)
-        # a per-call status check of the recurrent stack synchronises its stream in the middle of the alternation: the sticky
-        # time-out word is read once per ``__call__`` instead
         self._stacks = [m for mod in self.models for m in mod.modules() if hasattr(m, "check_status") and hasattr(m, "_workspace")]
-        for m in self._stacks:
-            m.check_status = False
+        self._n_caller_stacks = len(self._stacks) // depth
 
     def __call__(self, batches: Sequence) -> List:
         lib = _lib.load()
@@ -111,6 +118,7 @@ class BatchesInFlight:
         caller = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(caller)
+        inference = torch.is_inference_mode_enabled()
 
         def hook():
             me = slot_of.get(threading.get_ident())
@@ -122,7 +130,8 @@ class BatchesInFlight:
             try:
                 torch.cuda.set_device(device)                   # the current device is a per-thread setting
                 baton.wait_turn(me)
-                with torch.cuda.stream(self.streams[me]), torch.no_grad():
+                # grad / inference mode are per-thread settings: the workers take the caller's inference mode
+                with torch.cuda.stream(self.streams[me]), torch.no_grad(), torch.inference_mode(inference):
                     self.streams[me].wait_event(ready)          # inputs made on the caller's stream
                     for k in range(me, len(batches), self.depth):
                         if self.pre is not None:
@@ -138,6 +147,12 @@ class BatchesInFlight:
         prev_hook = _lib.issue_point
         _lib.issue_point = hook
         lib.ms_gemm_set_variant(COTENANT_GEMM_VARIANT)
+        # a per-call status check of a recurrent stack synchronises its stream in the middle of the alternation: switched
+        # off while the pipe runs (and put back: models[0] is the CALLER's model), the sticky time-out word is read once
+        # at the end of this call instead
+        prev_check = [m.check_status for m in self._stacks]
+        for m in self._stacks:
+            m.check_status = False
         try:
             threads = [threading.Thread(target=worker, args=(m,), daemon=True) for m in range(self.depth)]
             for t in threads:
@@ -145,6 +160,8 @@ class BatchesInFlight:
             for t in threads:
                 t.join()
         finally:
+            for m, c in zip(self._stacks, prev_check):
+                m.check_status = c
             lib.ms_gemm_set_variant(0)
             _lib.issue_point = prev_hook
         for s in self.streams:                                  # later work on the caller's stream sees the results
@@ -165,6 +182,12 @@ class BatchesInFlight:
                     hand_over(o)
 
         hand_over(results)
+        if any(prev_check[:self._n_caller_stacks]):       # self._stacks lists the caller's model first
+            # one host sync per call, after the streams have been joined to the caller's: a persistent launch that gave up
+            # (MS_ERR_TIMEOUT, outputs are garbage) must not pass silently.  A caller that switched the per-call check of
+            # its model off (``model.rnn.check_status = False``: it checks by itself, like bench.py's timed region) is not
+            # synchronised here either.
+            self.check_status()
         return results
 
     def check_status(self):

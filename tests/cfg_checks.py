@@ -12,7 +12,71 @@ for p in (ROOT, HERE):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-from util import Golden  # noqa: E402
+from util import Golden, unragged  # noqa: E402
+
+
+def cfg2_full(atol: float = 1e-3) -> float:
+    """BASELINE.json configs[1] at full size (32 x 1001 frames, 2 x conv2d + 5 x BiLSTM-1024 + FC) in THIS process's precision
+    mode against the reference's own outputs (tests/golden/ds2_cfg2_summary.npz, made by gen_golden.py::gen_cfg2_summary
+    from the imported reference, model/deep_speech_2.py:123-172 in fp32): weights and inputs regenerated from the
+    generator's seeds (weight checksums pinned), logits on the stored sub-grid and (h_n, c_n) within `atol`, output
+    lengths equal, greedy transcripts bit-exact.  Returns the max |logit error| on the sub-grid."""
+    import bench
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    g = Golden("ds2_cfg2_summary")
+    model = bench.build_model()
+    for k, v in model.state_dict().items():
+        want = g.cfg["weight_abs_sums"][k]
+        assert abs(float(v.double().abs().sum()) - want) <= 1e-6 * max(1.0, want), k
+    gen = torch.Generator().manual_seed(g.cfg["seed_input"])
+    N, Tn = g.cfg["N"], g.cfg["T"]
+    x = torch.randn(N, 1, 80, Tn, generator=gen)
+    lens = torch.sort(torch.randint(501, 1002, (N,), generator=gen), descending=True).values
+    lens[0] = Tn
+    assert abs(float(x.double().abs().sum()) - float(g["in/x_abs_sum"])) < 1e-3
+    np.testing.assert_array_equal(lens.numpy(), g["in/lens"])
+    (y, ol), (hn, cn) = model((x, lens))
+    np.testing.assert_array_equal(ol.cpu().numpy(), g["out/lens"])
+    y_sub = y[::25, ::4, :].cpu().numpy()
+    np.testing.assert_allclose(y_sub, g["out/y_sub"], rtol=0, atol=atol)
+    np.testing.assert_allclose(hn[:, ::8, ::64].cpu().numpy(), g["out/hn_sub"], rtol=0, atol=atol)
+    np.testing.assert_allclose(cn[:, ::8, ::64].cpu().numpy(), g["out/cn_sub"], rtol=0, atol=atol)
+    dec = CTCGreedyDecoder(28)(y, ol)
+    assert dec == unragged(g["out/greedy_flat"], g["out/greedy_lens"])
+    err = float(np.abs(y_sub - g["out/y_sub"]).max())
+    print(f"cfg2 full-size [{os.environ.get('MS_PRECISION', 'bf16x3')}] max |logit err| on the sub-grid: {err:.3e} "
+          f"(mean |logit| {float(g['out/y_abs_mean']):.3e})")
+    return err
+
+
+def pipeline_full_equal(n_batches: int = 4) -> None:
+    """``TwoBatchesInFlight`` on full-size config-2 batches in THIS process's precision mode: logits, lengths, final
+    states and greedy transcripts ``torch.equal`` to the same batches run one after the other on one stream."""
+    import bench
+    from myrtlespeech_amd.pipeline import TwoBatchesInFlight
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    model = bench.build_model()
+    dec = CTCGreedyDecoder(28)
+    g = torch.Generator().manual_seed(7)
+    batches = []
+    for _ in range(n_batches):
+        x = torch.randn(32, 1, 80, 1001, generator=g).cuda()
+        lens = torch.sort(torch.randint(501, 1002, (32,), generator=g), descending=True).values
+        lens[0] = 1001
+        batches.append((x, lens))
+    want = []
+    for x, lens in batches:
+        (y, ol), (hn, cn) = model((x.clone(), lens))
+        want.append((y, ol, hn, cn, dec(y, ol)))
+    pipe = TwoBatchesInFlight(model, post=lambda out: (out, dec.launch(out[0][0], out[0][1])))
+    got = pipe([(x.clone(), lens) for x, lens in batches])
+    pipe.check_status()
+    for (((y, ol), (hn, cn)), pending), (wy, wol, whn, wcn, wdec) in zip(got, want):
+        assert torch.equal(y, wy) and torch.equal(ol.cpu(), wol.cpu())
+        assert torch.equal(hn, whn) and torch.equal(cn, wcn)
+        assert pending.result() == wdec
+    print(f"two batches in flight == sequential run, {n_batches} full-size batches, mode "
+          f"{os.environ.get('MS_PRECISION', 'bf16x3')}")
 
 
 def stream64(atol: float, check_argmax: bool) -> float:

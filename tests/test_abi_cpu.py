@@ -160,3 +160,20 @@ def test_host_length_side_channel_drops_stale_values():
     dev3 = _lib.attach_host(torch.tensor([5, 5]), torch.tensor([5, 5]))
     dev3[1] = 2                                         # masked / indexed update
     assert _lib.cached_host(dev3) is None
+
+
+def test_host_length_side_channel_under_inference_mode():
+    """inference tensors track no version counter (reading ``_version`` raises); they cannot be edited in
+    place outside inference mode either, so the side channel keys them on their address."""
+    from myrtlespeech_amd import _lib
+    with torch.inference_mode():
+        host = torch.tensor([9, 7, 4])
+        dev = _lib.attach_host(host.clone(), host)
+        assert dev.is_inference()
+        assert torch.equal(_lib.cached_host(dev), host)
+        assert torch.equal(_lib.host_lens(dev), host)
+    assert torch.equal(_lib.cached_host(dev), host)         # read back outside the mode: still keyed on the address
+    with torch.inference_mode():
+        p = torch.nn.Parameter(torch.zeros(2, 2))
+        assert _lib.version_of(p) == -1
+    assert _lib.version_of(torch.zeros(2)) == 0

@@ -59,6 +59,27 @@ def test_split_gemm_kernels_agree_in_both_operand_modes():
     assert "gemm variants equal in mode fp16" in out
 
 
+# ----------------------------------------------------------------------------- configs[1] in the reference's own arithmetic width
+def test_cfg2_full_size_f32_mode_vs_reference_in_subprocess():
+    """``MS_PRECISION=f32`` (float32 MFMA everywhere: the reference is fp32 end to end, model/rnn.py:177, model/cnn.py:481,
+    model/fully_connected.py:164) at FULL size: the five-layer two-stream f32 recurrence, ``gemm_nt_f32_kernel`` at
+    16032 x 8192 x 2048 and the f32 convolutions at 32 x 1001 frames against the reference's own outputs.  This is the mode
+    ``bench.py``'s ``precision_f32`` leg times."""
+    out = _child("cfg2_full(atol=1e-3)", MS_PRECISION="f32")
+    line = [l for l in out.splitlines() if "max |logit err|" in l][-1]
+    assert "[f32]" in line
+    err = float(line.split("sub-grid:")[1].split()[0])
+    assert err < 1e-6, line   # measured 3.9e-8
+    print(line)
+
+
+def test_two_batches_in_flight_full_size_f32_mode_in_subprocess():
+    """The f32 two-in-flight leg of ``bench.py``: the float32 GEMM time-slices with the other batch's recurrence; outputs
+    bit-identical to the sequential run."""
+    out = _child("pipeline_full_equal(4)", MS_PRECISION="f32")
+    assert "two batches in flight == sequential run, 4 full-size batches, mode f32" in out
+
+
 # ----------------------------------------------------------------------------- configs[2]: the RCCL exchange step
 def test_cfg3_rccl_all_gather_one_rank_child():
     with socket.socket() as s:

@@ -149,3 +149,21 @@ def test_in_place_edit_of_the_lengths_between_two_modules_is_seen():
     l1[l1 > 25] = 25
     y, l2 = c2((h.clone(), l1))
     assert [int(v) for v in l2.cpu()] == [13, 11, 5]
+
+
+def test_ds2_forward_under_inference_mode_equals_no_grad():
+    """a forward under ``torch.inference_mode()`` (lengths and activations are inference tensors without
+    a version counter) must run and give the bits of the ``no_grad`` run, through the pipeline too."""
+    import __graft_entry__  # noqa: F401  (sys.path)
+    from myrtlespeech_amd.pipeline import TwoBatchesInFlight
+    from test_gpu_pipeline import _batches, _small_ds2
+    model = _small_ds2(256)
+    batches = _batches(3, 6, 80, 40, 21)
+    with torch.no_grad():
+        want = [model((x.clone(), lens)) for x, lens in batches]
+    with torch.inference_mode():
+        got = [model((x.clone(), lens)) for x, lens in batches]
+        piped = TwoBatchesInFlight(model)([(x.clone(), lens) for x, lens in batches])
+    for ((y, ol), (hn, cn)), ((wy, wol), (whn, wcn)), ((py, _), _) in zip(got, want, piped):
+        assert torch.equal(y, wy) and torch.equal(ol.cpu(), wol.cpu()) and torch.equal(hn, whn) and torch.equal(cn, wcn)
+        assert torch.equal(py, wy)

@@ -120,3 +120,55 @@ def test_split_gemm_scratch_is_per_stream():
     keys = {s1.cuda_stream, s2.cuda_stream}
     assert keys <= set(F._split_ws) and F._split_ws[s1.cuda_stream].buf.data_ptr() != F._split_ws[s2.cuda_stream].buf.data_ptr()
     assert all(torch.equal(o, want) for o in outs)
+
+
+def test_weights_loaded_after_the_pipe_was_built_reach_both_streams(tmp_path):
+    """The replicas share the caller's Parameters: a checkpoint loaded into ``model`` AFTER the pipe was
+    constructed (the reference loads into ``stt.model``, scripts/export_ds1_onnx.py:49-50), and an in-place edit after
+    that, are seen by every stream -- every batch equals the sequential run on the new weights."""
+    from myrtlespeech_amd import checkpoint
+    from myrtlespeech_amd.pipeline import TwoBatchesInFlight
+    model = _small_ds2(256)
+    batches = _batches(4, 12, 90, 40, 11)
+    pipe = TwoBatchesInFlight(model)
+    before = [o[0][0].clone() for o in pipe([(x.clone(), lens) for x, lens in batches])]
+    assert all(p is q for p, q in zip(pipe.models[0].parameters(), pipe.models[1].parameters()))
+    torch.manual_seed(99)
+    other = _small_ds2(256)
+    with torch.no_grad():
+        for p in other.parameters():
+            p.mul_(1.25)
+    path = tmp_path / "state_dict_1.pt"
+    torch.save({k: v.detach().cpu() for k, v in other.state_dict().items()}, str(path))
+    checkpoint.load(model, path)
+    want = [model((x.clone(), lens))[0][0] for x, lens in batches]
+    assert not torch.equal(want[0], before[0])
+    got = pipe([(x.clone(), lens) for x, lens in batches])
+    for ((y, _), _), w in zip(got, want):
+        assert torch.equal(y, w)
+    with torch.no_grad():                      # in-place edit: version counters move, both packed caches rebuild
+        model.rnn.rnn.weight_hh_l1.mul_(0.5)
+        model.fully_connected.fully_connected[0].bias.add_(0.125)
+    want2 = [model((x.clone(), lens))[0][0] for x, lens in batches]
+    assert not torch.equal(want2[0], want[0])
+    got2 = pipe([(x.clone(), lens) for x, lens in batches])
+    for ((y, _), _), w in zip(got2, want2):
+        assert torch.equal(y, w)
+
+
+def test_pipe_checks_the_status_word_and_restores_the_models_own_setting():
+    """the per-call status check is switched off only WHILE the pipe runs and the sticky time-out word is read
+    at the end of every call (one sync)."""
+    from myrtlespeech_amd.pipeline import TwoBatchesInFlight
+    model = _small_ds2(256)
+    assert model.rnn.check_status is True
+    pipe = TwoBatchesInFlight(model)
+    assert model.rnn.check_status is True and pipe.models[1].rnn.check_status is True
+    calls = []
+    orig = pipe.check_status
+    pipe.check_status = lambda: (calls.append(1), orig())[1]
+    pipe(_batches(3, 8, 70, 40, 5))
+    assert calls == [1] and model.rnn.check_status is True
+    model.rnn.check_status = False             # a caller that checks by itself (bench.py) is not synchronised by the pipe
+    pipe(_batches(2, 8, 70, 40, 6))
+    assert calls == [1] and model.rnn.check_status is False

@@ -53,6 +53,33 @@ def test_pipeline_argument_checks_need_no_gpu():
         BatchesInFlight(torch.nn.Identity())
 
 
+def test_replica_shares_parameters_and_owns_its_caches():
+    """``pipeline.replica``: the second stream's model holds the SAME Parameter objects (a checkpoint loaded into the caller's
+    model afterwards reaches it) and its own workspaces / packed-weight caches."""
+    import torch
+    import bench
+    from myrtlespeech_amd.pipeline import replica
+    from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+    from myrtlespeech_amd.model.deep_speech_2 import DeepSpeech2
+    from myrtlespeech_amd.model.fully_connected import FullyConnected
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    cnn = torch.nn.Sequential(MaskConv2d(1, 4, [5, 3], [2, 2], PaddingMode.SAME))
+    rnn = RNN(RNNType.LSTM, 4 * 10, 32, num_layers=2, bidirectional=True, forget_gate_bias=1.0)
+    model = DeepSpeech2(cnn, rnn, None, FullyConnected(64, 29, 1, 16, torch.nn.Hardtanh(0.0, 20.0))).eval()
+    rep = replica(model)
+    a, b = dict(model.named_parameters()), dict(rep.named_parameters())
+    assert a.keys() == b.keys() and all(a[k] is b[k] for k in a)
+    assert rep is not model and rep.rnn is not model.rnn
+    assert rep.rnn._workspace is not model.rnn._workspace
+    assert all(p is not q for p, q in zip(rep.rnn._packed, model.rnn._packed))
+    # the parameter container's flat weight list points at the shared objects too
+    assert all(p is q for p, q in zip(rep.rnn.rnn._flat_weights, model.rnn.rnn._flat_weights))
+    sd = {k: torch.full_like(v, 0.25) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    assert all(float(p.min()) == 0.25 == float(p.max()) for p in rep.parameters())
+    assert bench.BATCH_PER_GPU == 32
+
+
 def test_bench_refuses_a_stale_counter_profile(tmp_path, monkeypatch):
     import bench
     digests = bench.source_sha16()
