@@ -211,16 +211,20 @@ size_t ms_rnn_debug_offset(int cell, int T, int N, int In, int H, int ndir);
  * 2 = the register-staged kernel (the round-1 kernel; bit-identical results).  Not part of the reference surface. */
 int ms_gemm_set_variant(int variant);
 
-/* Optional launch timing for bench.py's roofline line (not part of the reference
- * surface).  While enabled, ms_rnn_layer_forward brackets its input-projection
- * GEMM and its recurrent kernel with HIP events on the caller's stream.
- * ms_prof_read synchronises those events and returns the summed milliseconds and
- * launch counts since the last read, MS_PROF_KINDS entries each:
- * [0] = input projection of one layer (operand split, where the producer did not
- * hand planes over, + GEMM), [1] = recurrent kernel(s) of one layer, [2] = the
- * split-operand projection GEMM kernel alone at In >= 1024, [3] = the same at
- * In < 1024 (the first layer of a stack). */
-#define MS_PROF_KINDS 4
+/* Optional launch timing for bench.py's roofline line and its per-stage breakdown (not part of the reference
+ * surface).  While enabled, the entry points on a DeepSpeech step bracket their launches with HIP events on the
+ * caller's stream.  ms_prof_read synchronises those events and returns the summed milliseconds and launch counts
+ * since the last read, MS_PROF_KINDS entries each, indexed by MS_PROF_*:
+ * PROJECTION = input projection of one recurrent layer (operand split, where the producer did not hand planes
+ * over, + GEMM), RECURRENCE = recurrent kernel(s) of one layer, GEMM_K_LARGE = the split-operand projection GEMM
+ * kernel alone at In >= 1024, GEMM_K_SMALL = the same at In < 1024 (the first layer of a stack) -- both nested
+ * inside PROJECTION --, CONV = one masked convolution call (mask, layout pass and kernel), LAYOUT = ms_nct_to_tnc,
+ * LINEAR = one ms_linear(_split)_forward call, GREEDY = ms_ctc_greedy_decode, OTHER = clamp / mask / lookahead. */
+enum {
+  MS_PROF_PROJECTION = 0, MS_PROF_RECURRENCE = 1, MS_PROF_GEMM_K_LARGE = 2, MS_PROF_GEMM_K_SMALL = 3, MS_PROF_CONV = 4,
+  MS_PROF_LAYOUT = 5, MS_PROF_LINEAR = 6, MS_PROF_GREEDY = 7, MS_PROF_OTHER = 8
+};
+#define MS_PROF_KINDS 9
 int ms_prof_enable(int on);
 int ms_prof_read(float* out_ms_host, int* out_n_host);
 

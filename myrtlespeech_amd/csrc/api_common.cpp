@@ -1,6 +1,8 @@
 // Error string + device query shared by every entry point.
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -30,7 +32,51 @@ int precision_mode() {
   }
   return v;
 }
+
+namespace {
+struct ProfSpan { hipEvent_t a, b; int kind; };
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;
+std::vector<ProfSpan> g_spans;      // recorded, not yet read
+std::vector<ProfSpan> g_free;       // event pairs ready for re-use
+}  // namespace
+
+ProfScope::ProfScope(int kind_, hipStream_t st) : kind(kind_), stream(st), on(g_prof_on.load(std::memory_order_relaxed)) {
+  if (!on) return;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_free.empty()) { a = g_free.back().a; b = g_free.back().b; g_free.pop_back(); }
+  }
+  if (!a && (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)) { on = false; return; }
+  (void)hipEventRecord(a, stream);
+}
+ProfScope::~ProfScope() {
+  if (!on) return;
+  (void)hipEventRecord(b, stream);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_spans.push_back({a, b, kind});
+}
 }  // namespace ms
+
+extern "C" int ms_prof_enable(int on) {
+  ms::g_prof_on.store(on != 0, std::memory_order_relaxed);
+  return MS_OK;
+}
+
+extern "C" int ms_prof_read(float* out_ms, int* out_n) {
+  MS_REQUIRE(out_ms && out_n, "null pointer");
+  for (int k = 0; k < MS_PROF_KINDS; ++k) { out_ms[k] = 0.f; out_n[k] = 0; }
+  std::lock_guard<std::mutex> lk(ms::g_prof_mu);
+  for (auto& s : ms::g_spans) {
+    MS_HIP(hipEventSynchronize(s.b));
+    float t = 0.f;
+    MS_HIP(hipEventElapsedTime(&t, s.a, s.b));
+    if (s.kind >= 0 && s.kind < MS_PROF_KINDS) { out_ms[s.kind] += t; out_n[s.kind] += 1; }
+    ms::g_free.push_back(s);
+  }
+  ms::g_spans.clear();
+  return MS_OK;
+}
 
 extern "C" int ms_abi_version(void) { return MS_ABI_VERSION; }
 extern "C" const char* ms_last_error(void) {

@@ -57,6 +57,19 @@ struct DeviceOnce {
   void done() { done_mask.fetch_or(bit(), std::memory_order_release); }
 };
 
+// Optional per-family launch timing (ms_prof_enable / ms_prof_read; api_common.cpp): while enabled, an entry point
+// brackets its launches with HIP events on the caller's stream.  Kinds: MS_PROF_* in include/ms_hotpath.h.
+struct ProfScope {
+  hipEvent_t a = nullptr, b = nullptr;
+  int kind;
+  hipStream_t stream;
+  bool on;
+  ProfScope(int kind, hipStream_t st);
+  ~ProfScope();
+  ProfScope(const ProfScope&) = delete;
+  ProfScope& operator=(const ProfScope&) = delete;
+};
+
 // Operand precision of the split kernels, from MS_PRECISION: 0 = "f32" (exact float32 MFMA),
 // 1 = "bf16x3" (default: bf16 hi+lo, three MFMAs), 2 = "fp16" (single fp16 pass; ~2^-11 operands).
 enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_F16 = 2 };

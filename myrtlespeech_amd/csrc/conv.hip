@@ -155,6 +155,7 @@ extern "C" int ms_maskconv_forward(const float* x, const int32_t* lens, const vo
                                    float* y, int N, int Cin, int Fin, int Tin, int Cout, int Fout, int Tout, int KF,
                                    int KT, int SF, int ST, int DF, int DT, int pad_f_l, int pad_t_l, int groups, int act,
                                    float act_lo, float act_hi, void* stream) {
+  ms::ProfScope prof_span(MS_PROF_CONV, (hipStream_t)stream);
   MS_REQUIRE(x && packed_w && y, "null pointer");
   MS_REQUIRE(N > 0 && Cin > 0 && Fin > 0 && Tin > 0 && Cout > 0 && Fout > 0 && Tout > 0, "bad shape");
   MS_REQUIRE(KF > 0 && KT > 0 && SF > 0 && ST > 0 && DF > 0 && DT > 0, "bad kernel/stride/dilation");

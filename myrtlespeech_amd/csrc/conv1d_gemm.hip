@@ -117,6 +117,7 @@ extern "C" int ms_maskconv1d_gemm_forward(const float* x, const int32_t* lens, c
                                           float* y, int N, int Cin, int Tin, int Cout, int Tout, int KT, int ST, int DT,
                                           int pad_l, int act, float act_lo, float act_hi, void* workspace,
                                           size_t workspace_bytes, void* stream_) {
+  ms::ProfScope prof_span(MS_PROF_CONV, (hipStream_t)stream_);
   MS_REQUIRE(x && lens && packed && y && workspace, "null pointer");
   MS_REQUIRE(N > 0 && Cin > 0 && Tin > 0 && Cout > 0 && Tout > 0 && KT > 0 && ST > 0 && DT > 0 && pad_l >= 0, "bad shape");
   MS_REQUIRE(act == MS_ACT_NONE || act == MS_ACT_CLAMP, "bad act");

@@ -354,6 +354,7 @@ extern "C" int ms_maskconv_fwin_forward(const float* x, const int32_t* lens, con
                                         int N, int Fin, int Tin, int Cout, int Fout, int Tout, int KF, int KT, int SF, int ST,
                                         int DT, int pad_f_l, int pad_t_l, int act, float act_lo, float act_hi, void* workspace,
                                         size_t workspace_bytes, void* stream_) {
+  ms::ProfScope prof_span(MS_PROF_CONV, (hipStream_t)stream_);
   MS_REQUIRE(x && packed_w && y && workspace, "null pointer");
   MS_REQUIRE(N > 0 && Fin > 0 && Tin > 0 && Cout > 0 && Fout > 0 && Tout > 0, "bad shape");
   MS_REQUIRE(KF > 0 && KT > 0 && SF > 0 && ST > 0 && DT > 0 && pad_f_l >= 0 && pad_t_l >= 0, "bad kernel");
@@ -411,6 +412,7 @@ extern "C" int ms_maskconv_cl_forward(const float* x, const int32_t* lens, const
                                       int N, int Cin, int Fin, int Tin, int Cout, int Fout, int Tout, int KF, int KT,
                                       int SF, int ST, int DF, int DT, int pad_f_l, int pad_t_l, int act, float act_lo,
                                       float act_hi, void* workspace, size_t workspace_bytes, void* stream_) {
+  ms::ProfScope prof_span(MS_PROF_CONV, (hipStream_t)stream_);
   MS_REQUIRE(x && packed_w && y && workspace, "null pointer");
   MS_REQUIRE(N > 0 && Cin > 0 && Cin % 16 == 0 && Fin > 0 && Tin > 0 && Cout > 0 && Fout > 0 && Tout > 0, "bad shape");
   MS_REQUIRE(KF > 0 && KT > 0 && SF > 0 && ST > 0 && DF > 0 && DT > 0 && pad_f_l >= 0 && pad_t_l >= 0, "bad kernel");

@@ -340,6 +340,7 @@ extern "C" int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, 
 
 extern "C" int ms_ctc_greedy_decode(const float* x, const int32_t* lens, int32_t* out_idx, int32_t* out_len, int T,
                                     int N, int V, int blank, void* stream) {
+  ms::ProfScope prof_span(MS_PROF_GREEDY, (hipStream_t)stream);
   MS_REQUIRE(x && lens && out_idx && out_len, "null pointer");
   MS_REQUIRE(T > 0 && N > 0 && V > 0, "bad shape");
   hipLaunchKernelGGL(ctc_greedy_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, lens, out_idx, out_len, T, N, V,

@@ -44,6 +44,7 @@ __global__ void clamp_kernel(const float* x, float* y, size_t n, float lo, float
 }  // namespace
 
 extern "C" int ms_mask_time_(float* x, const int32_t* lens, int N, int inner, int T, void* stream) {
+  ms::ProfScope prof_span(MS_PROF_OTHER, (hipStream_t)stream);
   MS_REQUIRE(x && lens, "null pointer");
   MS_REQUIRE(N > 0 && inner > 0 && T > 0, "bad shape");
   MS_REQUIRE(N <= 65535, "N exceeds grid limits");
@@ -54,6 +55,7 @@ extern "C" int ms_mask_time_(float* x, const int32_t* lens, int N, int inner, in
 }
 
 extern "C" int ms_nct_to_tnc(const float* x, float* y, int N, int CF, int T, void* stream) {
+  ms::ProfScope prof_span(MS_PROF_LAYOUT, (hipStream_t)stream);
   MS_REQUIRE(x && y, "null pointer");
   MS_REQUIRE(N > 0 && CF > 0 && T > 0, "bad shape");
   MS_REQUIRE(N <= 65535 && ms::cdiv(CF, 32) <= 65535, "N/CF exceed grid limits");
@@ -64,6 +66,7 @@ extern "C" int ms_nct_to_tnc(const float* x, float* y, int N, int CF, int T, voi
 }
 
 extern "C" int ms_clamp(const float* x, float* y, size_t n, float lo, float hi, void* stream) {
+  ms::ProfScope prof_span(MS_PROF_OTHER, (hipStream_t)stream);
   MS_REQUIRE((x && y) || n == 0, "null pointer");
   if (n == 0) return MS_OK;
   size_t blocks = (n + 255) / 256;

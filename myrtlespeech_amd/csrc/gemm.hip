@@ -203,6 +203,7 @@ int linear_splitk_launch(const float* x, const float* w, const float* bias, floa
 
 extern "C" int ms_linear_forward(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
                                  int act, float act_lo, float act_hi, void* stream) {
+  ms::ProfScope prof_span(MS_PROF_LINEAR, (hipStream_t)stream);
   MS_REQUIRE(x && w && y, "null pointer");
   MS_REQUIRE(M > 0 && K > 0 && N > 0, "bad shape");
   MS_REQUIRE(act == MS_ACT_NONE || act == MS_ACT_CLAMP, "bad act");

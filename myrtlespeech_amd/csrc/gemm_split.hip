@@ -762,6 +762,7 @@ extern "C" size_t ms_linear_split_workspace_bytes(int M, int K, int N) {
 extern "C" int ms_linear_split_forward(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
                                        int act, float act_lo, float act_hi, void* workspace, size_t workspace_bytes,
                                        void* stream_) {
+  ms::ProfScope prof_span(MS_PROF_LINEAR, (hipStream_t)stream_);
   MS_REQUIRE(x && w && y && workspace, "null pointer");
   MS_REQUIRE(M > 0 && K > 0 && N > 0, "bad shape");
   MS_REQUIRE(K % 32 == 0, "K must be a multiple of 32 (use ms_linear_forward otherwise)");

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void lookahead_strided_kernel(const float* __r
 extern "C" int ms_lookahead_forward(const float* x, const float* w, float* y, int N, int F, int T, int ctx, long xs_n,
                                     long xs_f, long xs_t, long ys_n, long ys_f, long ys_t, int act, float act_lo,
                                     float act_hi, void* stream) {
+  ms::ProfScope prof_span(MS_PROF_OTHER, (hipStream_t)stream);
   MS_REQUIRE(x && w && y, "null pointer");
   MS_REQUIRE(N > 0 && F > 0 && T > 0 && ctx > 0, "bad shape");
   MS_REQUIRE(act == MS_ACT_NONE || act == MS_ACT_CLAMP, "bad act");

@@ -1840,50 +1840,7 @@ struct PersistentTurn {
 };
 }  // namespace
 
-namespace {
-struct ProfSpan { hipEvent_t a, b; int kind; };
-bool g_prof_on = false;
-std::vector<ProfSpan> g_spans;      // recorded, not yet read
-std::vector<ProfSpan> g_free;       // event pairs ready for re-use
-
-struct ProfScope {
-  ProfSpan s{};
-  hipStream_t stream;
-  bool on;
-  ProfScope(int kind, hipStream_t st) : stream(st), on(g_prof_on) {
-    if (!on) return;
-    if (!g_free.empty()) { s = g_free.back(); g_free.pop_back(); }
-    else if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) { on = false; return; }
-    s.kind = kind;
-    (void)hipEventRecord(s.a, stream);
-  }
-  ~ProfScope() {
-    if (!on) return;
-    (void)hipEventRecord(s.b, stream);
-    g_spans.push_back(s);
-  }
-};
-}  // namespace
-
-extern "C" int ms_prof_enable(int on) {
-  g_prof_on = on != 0;
-  return MS_OK;
-}
-
-extern "C" int ms_prof_read(float* out_ms, int* out_n) {
-  MS_REQUIRE(out_ms && out_n, "null pointer");
-  for (int k = 0; k < MS_PROF_KINDS; ++k) { out_ms[k] = 0.f; out_n[k] = 0; }
-  for (auto& s : g_spans) {
-    MS_HIP(hipEventSynchronize(s.b));
-    float ms = 0.f;
-    MS_HIP(hipEventElapsedTime(&ms, s.a, s.b));
-    out_ms[s.kind] += ms;
-    out_n[s.kind] += 1;
-    g_free.push_back(s);
-  }
-  g_spans.clear();
-  return MS_OK;
-}
+using ms::ProfScope;
 
 // ================================================================================================ C ABI
 
@@ -2102,7 +2059,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
   float* xproj = (float*)(ws + W.xproj);
   int rc;
   {
-    ProfScope prof(0, stream);
+    ProfScope prof(MS_PROF_PROJECTION, stream);
     if (use_split_gemm(cell, H, ndir, In)) {
       unsigned short* xh = (unsigned short*)(ws + W.xsplit);
       unsigned short* xl = xh + (size_t)steps * N * In;
@@ -2111,12 +2068,12 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       const int prec = use_f16(cell, H, ndir) ? ms::PREC_F16 : ms::PREC_BF16X3;
       rc = x_in_ws ? MS_OK : ms::split_planes_launch(x, xh, xl, (size_t)steps * N * In, prec, stream);
       if (rc == MS_OK) {
-        ProfScope gemm_only(In >= 1024 ? 2 : 3, stream);   // the split GEMM kernel alone, by contraction length
+        ProfScope gemm_only(In >= 1024 ? MS_PROF_GEMM_K_LARGE : MS_PROF_GEMM_K_SMALL, stream);   // the split GEMM kernel alone, by contraction length
         rc = ms::gemm_bf16x3_launch(xh, xl, wh, wl, (const float*)(pk + L.bias_x), xproj, steps * N, In, (int)(ndir * GH),
                                     MS_ACT_NONE, 0.f, 0.f, prec, stream);
       }
     } else {
-      ProfScope gemm_only(In >= 1024 ? 2 : 3, stream);
+      ProfScope gemm_only(In >= 1024 ? MS_PROF_GEMM_K_LARGE : MS_PROF_GEMM_K_SMALL, stream);
       rc = ms::linear_launch(x, (const float*)(pk + L.wih), (const float*)(pk + L.bias_x), xproj, steps * N, In,
                              (int)(ndir * GH), MS_ACT_NONE, 0.f, 0.f, stream);
     }
@@ -2126,7 +2083,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
   if (fast) {
     PersistentTurn turn(stream);   // never resident together with another stream's persistent launch
     if (turn.rc != MS_OK) { ms::set_error("ms_rnn_layer_forward: cross-stream hand-over of the persistent launch failed"); return turn.rc; }
-    ProfScope prof_rec(1, stream); // after the hand-over's stream wait: the span is the launch(es), not the queueing behind another stream
+    ProfScope prof_rec(MS_PROF_RECURRENCE, stream); // after the hand-over's stream wait: the span is the launch(es), not the queueing behind another stream
     // batch groups of <= 64 sequences, one persistent launch each (stream-ordered; the epoch
     // flags are re-zeroed in between, the status word is kept so any time-out is reported)
     const bool f32x2 = use_f32x2(cell, H, ndir);
@@ -2215,7 +2172,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
   if (use_gru_persistent(cell, H, ndir)) {
     PersistentTurn turn(stream);
     if (turn.rc != MS_OK) { ms::set_error("ms_rnn_layer_forward: cross-stream hand-over of the persistent launch failed"); return turn.rc; }
-    ProfScope prof_rec(1, stream);
+    ProfScope prof_rec(MS_PROF_RECURRENCE, stream);
     // one persistent launch per group of 32 sequences (two interleaved streams of 16)
     for (int n0 = 0; n0 < N; n0 += 32) {
       const int rs = lstm_ring_shift();
@@ -2252,7 +2209,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
   }
 
   // generic: one launch per time step
-  ProfScope prof_rec(1, stream);
+  ProfScope prof_rec(MS_PROF_RECURRENCE, stream);
   float* sh = (float*)(ws + W.state_h);
   float* sc = (float*)(ws + W.state_c);
   const size_t st = (size_t)ndir * N * H;
