@@ -162,8 +162,8 @@ def f32_child(args):
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
-        keep = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "one_batch_in_flight", "latency_ms_per_batch",
-                "encoder_ms", "decode_ms", "kernel_ms",
+        keep = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "one_batch_in_flight", "two_batches_in_flight",
+                "latency_ms_per_batch", "encoder_ms", "decode_ms", "kernel_ms",
                 "roofline", "projection_gemm", "ragged_lengths")
         return {k: d[k] for k in keep if k in d}
     except Exception as e:  # the headline must not die with the side measurement
@@ -234,9 +234,11 @@ def main():
     lens_full = torch.full((BATCH_PER_GPU,), FRAMES, dtype=torch.int64)
     lens_ragged = torch.sort(torch.randint(501, FRAMES + 1, (BATCH_PER_GPU,), generator=g), descending=True).values
 
-    def step(lens, ev=None):
-        # the masked convolution zeroes its input past each length IN PLACE (cnn.py:442), so the ragged leg gets its own
-        # copy of the batch (made outside the timed region) and the full-length leg's input stays intact
+    def step_launch(lens, ev=None):
+        """Enqueue one whole step (encoder forward, greedy decode, copy of the transcripts to pinned host memory) on the
+        current stream; returns the pending transcripts.  The masked convolution zeroes its input past each length IN PLACE
+        (cnn.py:442), so the ragged leg gets its own copy of the batch (made outside the timed region) and the full-length
+        leg's input stays intact."""
         e0 = e1 = e2 = None
         if ev is not None:
             e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
@@ -247,11 +249,14 @@ def main():
         if args.gather_logits and dist is not None:
             from myrtlespeech_amd.parallel import gather_logits
             logits, out_lens = gather_logits(logits, out_lens)
-        hyp = decoder(logits, out_lens)
+        pending = decoder.launch(logits, out_lens)
         if ev is not None:
             e2.record()
             ev.append((e0, e1, e2))
-        return hyp
+        return pending
+
+    def step(lens, ev=None):
+        return step_launch(lens, ev).result()
 
     def barrier():
         if dist is not None:
@@ -276,11 +281,16 @@ def main():
 
         pipe = TwoBatchesInFlight(model, post=post, pre=pre)
 
-    def timed(lens, steps, two):
-        """`steps` passes bracketed by barrier + synchronize on both sides; MAX over ranks; in-library HIP-event spans."""
+    STAGES = ("projection", "recurrence", "gemm_k_large", "gemm_k_small", "conv", "layout", "linear", "greedy", "other")
+
+    def timed(lens, steps, two, run_ahead=True):
+        """`steps` passes bracketed by barrier + synchronize on both sides; MAX over ranks; in-library HIP-event spans of every
+        kernel family.  One batch at a time (`two` False): the host enqueues step k+1 BEFORE it collects step k's transcripts
+        (`run_ahead`; one stream, so the device still runs one batch after the other and never idles while the host builds
+        the lists) -- every step's transcripts are on the host before the clock stops either way."""
         ev = []
-        ms = (ctypes.c_float * 4)()
-        cnt = (ctypes.c_int * 4)()
+        ms = (ctypes.c_float * len(STAGES))()
+        cnt = (ctypes.c_int * len(STAGES))()
         lib.ms_prof_enable(0 if (two and os.environ.get('BENCH_PROF_TWO') == '0') else 1)
         lib.ms_prof_read(ms, cnt)       # drop spans recorded so far
         barrier()
@@ -290,8 +300,15 @@ def main():
             for pd, _ in pend:
                 pd.result()                      # every step's transcripts are on the host before the clock stops
         else:
+            prev = None
             for _ in range(steps):
-                step(lens, ev)
+                cur = step_launch(lens, ev)
+                if not run_ahead:
+                    cur.result()
+                elif prev is not None:
+                    prev.result()
+                prev = cur
+            prev.result()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         barrier()
@@ -303,35 +320,68 @@ def main():
         t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         if dist is not None:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        spans = [ms[k] / max(cnt[k], 1) for k in range(4)]
-        enc = sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev) if ev else None
-        dec = sum(b.elapsed_time(c) for _, b, c in ev) / len(ev) if ev else None
+        r = {"elapsed": float(t_max.item()), "steps": steps,
+             "per_launch": {k: ms[i] / max(cnt[i], 1) for i, k in enumerate(STAGES)},
+             "per_step": {k: ms[i] / steps for i, k in enumerate(STAGES)},
+             "launches_per_step": {k: cnt[i] / steps for i, k in enumerate(STAGES)}}
+        if ev:
+            r["enc"] = sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev)
+            r["dec"] = sum(b.elapsed_time(c) for _, b, c in ev) / len(ev)
+            r["span"] = sum(a.elapsed_time(c) for a, _, c in ev) / len(ev)          # first kernel of a step -> its copy enqueued
+            # device time between one step's last event and the next step's first: the device waiting for the host
+            r["between"] = (sum(ev[i][2].elapsed_time(ev[i + 1][0]) for i in range(len(ev) - 1)) / (len(ev) - 1)) if len(ev) > 1 else 0.0
         if two:   # per-batch latency: first launch of the batch -> its transcripts' copy enqueued and done
-            enc = sum(starts[k].elapsed_time(end) for k, (_, end) in enumerate(pend)) / len(pend)
-        return float(t_max.item()), spans, enc, dec
+            r["latency"] = sum(starts[k].elapsed_time(end) for k, (_, end) in enumerate(pend)) / len(pend)
+        return r
+
+    def stage_report(r, overlapped):
+        """Per-step device time by kernel family (the nested GEMM-only spans are inside `projection`), what of the step's
+        device span is NOT inside any family's span (`gpu_idle_ms_per_step`: launch gaps between dependent kernels, torch's
+        own small kernels for the transcripts' packing) and the device time between two steps (`between_steps_ms`)."""
+        top = ("conv", "layout", "projection", "recurrence", "linear", "greedy", "other")
+        out = {"stage_ms": {k: round(r["per_step"][k], 4) for k in top},
+               "stage_launches_per_step": {k: round(r["launches_per_step"][k], 2) for k in top},
+               "stage_sum_ms": round(sum(r["per_step"][k] for k in top), 4)}
+        if overlapped:
+            out["note"] = ("two batches in flight: the spans of the two streams overlap in time (a projection GEMM runs beside "
+                           "the other batch's recurrence), so the sum exceeds the wall time per step by design")
+            out["wall_ms_per_step"] = round(r["elapsed"] / r["steps"] * 1e3, 4)
+        else:
+            out["event_span_ms"] = round(r["span"], 4)
+            out["gpu_idle_ms_per_step"] = round(r["span"] - out["stage_sum_ms"], 4)
+            out["between_steps_ms"] = round(r["between"], 4)
+            out["wall_ms_per_step"] = round(r["elapsed"] / r["steps"] * 1e3, 4)
+        return out
 
     x_ragged = x.clone()
     for _ in range(args.warmup):
         step(lens_full)
     # leg 1: one batch at a time (kernel durations, rooflines, the encoder / decode split)
-    one_elapsed, spans, enc_ms, dec_ms = timed(lens_full, args.steps, False)
+    one = timed(lens_full, args.steps, False)
+    one_elapsed, enc_ms, dec_ms = one["elapsed"], one["enc"], one["dec"]
+    # leg 1b (short): the same with the host collecting every step's transcripts before it issues the next step -- the
+    # difference to leg 1 is the device time the host's read-back and list building would otherwise expose
+    sync_each = timed(lens_full, max(5, args.steps // 4), False, run_ahead=False)
     # leg 2 (headline when --in-flight 2): two batches in flight.  A failure here must not cost the run its headline: the
     # one-batch figure (already measured) is reported instead, with the reason.
     pipeline_error = None
-    two_spans = None
+    two = None
     if pipelined:
         try:
             pipe([(x, lens_full)] * max(2, min(args.warmup, 4)))
-            elapsed, two_spans, latency_ms, _ = timed(lens_full, args.steps, True)
+            two = timed(lens_full, args.steps, True)
+            elapsed, latency_ms = two["elapsed"], two["latency"]
         except Exception as e:  # noqa: BLE001
             pipeline_error = f"{type(e).__name__}: {e}"[:300]
             pipelined = False
+            two = None
             lib.ms_gemm_set_variant(0)
             torch.cuda.synchronize()
     two_in_flight = None
     if pipelined:
         two_in_flight = {"value": round(world * BATCH_PER_GPU * CLIP_SECONDS * args.steps / elapsed, 1),
                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "latency_ms_per_batch": round(latency_ms, 3)}
+        two_in_flight.update(stage_report(two, True))
         if elapsed >= one_elapsed:   # few steps: the pipeline's fill and drain outweigh what it hides; the headline is the faster leg
             pipelined = False
     if not pipelined:
@@ -344,7 +394,7 @@ def main():
             step(lens_ragged)
         if pipelined:
             pipe([(x_ragged, lens_ragged)] * 2)
-        r_elapsed, r_spans, r_enc, r_dec = timed(lens_ragged, rsteps, pipelined)
+        r_elapsed = timed(lens_ragged, rsteps, pipelined)["elapsed"]
         audio_s = float(lens_ragged.sum()) * CLIP_SECONDS / (FRAMES - 1) * world   # hop 10 ms
         ragged = {"workload": "same batch, lengths ~U[501, 1001] frames sorted in decreasing order (BASELINE.md 3 (ii)); "
                               "the backward direction of every utterance starts at its own last frame",
@@ -375,7 +425,12 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * BATCH_PER_GPU * CLIP_SECONDS * args.steps / elapsed
         one_ms = one_elapsed / args.steps * 1e3
-        proj_ms, rec_ms, gemm_k2048_ms, gemm_k640_ms = spans
+        pl = one["per_launch"]
+        proj_ms, rec_ms, gemm_k2048_ms, gemm_k640_ms = pl["projection"], pl["recurrence"], pl["gemm_k_large"], pl["gemm_k_small"]
+        two_spans = None
+        if two is not None:
+            tl = two["per_launch"]
+            two_spans = (tl["projection"], tl["recurrence"], tl["gemm_k_large"], tl["gemm_k_small"])
         # ---- dominant kernel: the persistent recurrence (one launch = one layer, both directions, 501 steps)
         launch_bytes = T_OUT * 2 * LSTM_STEP_BYTES
         achieved = launch_bytes / (rec_ms * 1e-3) / 1e9 if rec_ms > 0 else 0.0
@@ -455,12 +510,22 @@ def main():
                                     "bit-identical to the one-batch path") if pipelined else "one batch at a time",
                        "decode": "all-gather logits, batched decode on every rank" if args.gather_logits else
                                  "per-shard decode (no data-path collective)"},
-            "one_batch_in_flight": {"value": round(world * BATCH_PER_GPU * CLIP_SECONDS * args.steps / one_elapsed, 1),
-                                    "ms_per_step": round(one_ms, 3), "latency_ms_per_batch": round(one_ms, 3),
-                                    "encoder_ms": round(enc_ms, 3), "decode_ms": round(dec_ms, 3),
-                                    "note": "same run, same process: K steps one after the other on one stream; the kernel "
-                                            "durations and rooflines below are taken here"},
-            "latency_ms_per_batch": round(latency_ms if pipelined else ms_per_step, 3),
+            "one_batch_in_flight": dict(
+                {"value": round(world * BATCH_PER_GPU * CLIP_SECONDS * args.steps / one_elapsed, 1),
+                 "ms_per_step": round(one_ms, 3),
+                 "latency_ms_per_batch": round(one["span"], 3),
+                 "latency_note": "device time from a batch's first kernel to the copy of its transcripts (HIP events); the host "
+                                 "enqueues batch k+1 before it collects batch k's transcripts, the device runs one batch at a time",
+                 "encoder_ms": round(enc_ms, 3), "decode_ms": round(dec_ms, 3),
+                 "sync_each_step": {"steps": sync_each["steps"],
+                                    "ms_per_step": round(sync_each["elapsed"] / sync_each["steps"] * 1e3, 3),
+                                    "between_steps_ms": round(sync_each["between"], 4),
+                                    "note": "the same leg with every step's transcripts collected before the next step is "
+                                            "issued (round 2's protocol): the difference is the device idling while the host "
+                                            "reads back, builds the lists and issues the next step's first launches"},
+                 "note": "same run, same process: K steps one after the other on one stream; the kernel "
+                         "durations and rooflines below are taken here"}, **stage_report(one, False)),
+            "latency_ms_per_batch": round(latency_ms if pipelined else one["span"], 3),
             "encoder_ms": round(enc_ms, 3), "decode_ms": round(dec_ms, 3),
             "encoder_ms_per_rnn_step": round(enc_ms / T_OUT, 4),
             "parity": {"tolerance": "logits within 1e-3 of the reference (fp32), CTC indices bit-exact",
