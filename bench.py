@@ -152,6 +152,57 @@ def cpu_baseline(model, sample_batch=BATCH_PER_GPU):
                                       f"stock torch CPU operators in the reference's order, {dt:.1f} s wall"}
 
 
+class GpuRuntime:
+    """Everything ``main`` touches outside its own control flow (device, events, library handle, model, decoder, pipeline).
+    The product runtime is this class; tests/test_bench_flow_cpu.py drives the same control flow -- legs, barriers, the
+    MAX all-reduce, the ``--gather-logits`` branch -- on two gloo ranks with a CPU stand-in, so that the first real
+    N > 1 run is not also the first execution of that code."""
+    dist_backend = "nccl"
+    device = "cuda"
+
+    def set_device(self, local_rank):
+        torch.cuda.set_device(local_rank)
+
+    def init_process_group(self, dist, rank, world, local_rank):
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(self.dist_backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def to_device(self, t):
+        return t.cuda()
+
+    def synchronize(self):
+        torch.cuda.synchronize()
+
+    def event(self):
+        return torch.cuda.Event(enable_timing=True)
+
+    def lib(self):
+        from myrtlespeech_amd import _lib
+        return _lib.load()
+
+    def batch_per_rank(self, rank):
+        return BATCH_PER_GPU
+
+    def build_model(self, rank):
+        model = build_model()
+        model.rnn.check_status = False  # no per-layer host sync inside the timed region (checked once afterwards)
+        return model
+
+    def decoder(self):
+        from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+        return CTCGreedyDecoder(BLANK)
+
+    def pipe(self, model, post, pre):
+        from myrtlespeech_amd.pipeline import TwoBatchesInFlight
+        return TwoBatchesInFlight(model, post=post, pre=pre)
+
+    def check_status(self, models):
+        from myrtlespeech_amd import _lib
+        lib = _lib.load()
+        for m in models:
+            _lib.check(lib.ms_rnn_status(_lib.ptr(m.rnn._workspace.buf), _lib.stream_ptr()), "persistent LSTM")
+
+
 def f32_child(args):
     """The fp32-arithmetic figure, timed by the driver's own run: a child process in MS_PRECISION=f32 (the mode is read
     once per process), started BEFORE this process makes its first GPU call, run to completion, its JSON line kept."""
@@ -170,7 +221,8 @@ def f32_child(args):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
-def main():
+def main(argv=None, runtime=None, json_fd=None):
+    rt = runtime or GpuRuntime()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -190,15 +242,16 @@ def main():
     ap.add_argument("--gather-logits", action="store_true",
                     help="batched-decode path: all-gather every shard's logits (RCCL over xGMI) and decode the whole "
                          "global batch on every rank instead of decoding per shard")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.precision is not None:   # read once by the library at its first launch
         os.environ["MS_PRECISION"] = args.precision
 
     # Anything the runtime libraries print (RCCL's banner goes to stdout) is sent to stderr, so that stdout carries
     # the ONE JSON line and nothing else.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+    if json_fd is None:
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -213,26 +266,23 @@ def main():
     if world > 1 or "RANK" in os.environ:  # under torchrun (also with one rank) the collective path is exercised
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        rt.set_device(local_rank)
+        rt.init_process_group(dist, rank, world, local_rank)
         from myrtlespeech_amd import parallel
         parallel.init_host_group()      # gloo twin for host metadata: collective over the world, so at set-up time
     else:
-        torch.cuda.set_device(0)
+        rt.set_device(0)
 
-    from myrtlespeech_amd import _lib
-    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
-    lib = _lib.load()
-    model = build_model()
-    model.rnn.check_status = False  # no per-layer host sync inside the timed region (checked once afterwards)
-    decoder = CTCGreedyDecoder(BLANK)
+    lib = rt.lib()
+    model = rt.build_model(rank)
+    decoder = rt.decoder()
 
     # this rank's shard of the global batch: 32 utterances, resident in HBM before timing starts
     g = torch.Generator().manual_seed(1234 + rank)
-    x = torch.randn(BATCH_PER_GPU, 1, FEATURES, FRAMES, generator=g).cuda()
-    lens_full = torch.full((BATCH_PER_GPU,), FRAMES, dtype=torch.int64)
-    lens_ragged = torch.sort(torch.randint(501, FRAMES + 1, (BATCH_PER_GPU,), generator=g), descending=True).values
+    n_rank = rt.batch_per_rank(rank)
+    x = rt.to_device(torch.randn(n_rank, 1, FEATURES, FRAMES, generator=g))
+    lens_full = torch.full((n_rank,), FRAMES, dtype=torch.int64)
+    lens_ragged = torch.sort(torch.randint(501, FRAMES + 1, (n_rank,), generator=g), descending=True).values
 
     def step_launch(lens, ev=None):
         """Enqueue one whole step (encoder forward, greedy decode, copy of the transcripts to pinned host memory) on the
@@ -241,7 +291,7 @@ def main():
         leg's input stays intact."""
         e0 = e1 = e2 = None
         if ev is not None:
-            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0, e1, e2 = (rt.event() for _ in range(3))
             e0.record()
         (logits, out_lens), _ = model((x if lens is lens_full else x_ragged, lens))
         if ev is not None:
@@ -261,25 +311,24 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        rt.synchronize()
 
     pipelined = args.in_flight == 2 and not (args.gather_logits and dist is not None)
     pipe = None
     if pipelined:
-        from myrtlespeech_amd.pipeline import TwoBatchesInFlight
         starts = {}
 
         def pre(k):
-            starts[k] = torch.cuda.Event(enable_timing=True)
+            starts[k] = rt.event()
             starts[k].record()
 
         def post(out):
             pending = decoder.launch(out[0][0], out[0][1])
-            end = torch.cuda.Event(enable_timing=True)
+            end = rt.event()
             end.record()
             return pending, end
 
-        pipe = TwoBatchesInFlight(model, post=post, pre=pre)
+        pipe = rt.pipe(model, post, pre)
 
     STAGES = ("projection", "recurrence", "gemm_k_large", "gemm_k_small", "conv", "layout", "linear", "greedy", "other")
 
@@ -309,15 +358,13 @@ def main():
                     prev.result()
                 prev = cur
             prev.result()
-        torch.cuda.synchronize()
+        rt.synchronize()
         elapsed = time.perf_counter() - t0
         barrier()
         lib.ms_prof_read(ms, cnt)
         lib.ms_prof_enable(0)
-        for m in ([model] if not two else list(pipe.models)):
-            ws = m.rnn._workspace.buf
-            _lib.check(lib.ms_rnn_status(_lib.ptr(ws), _lib.stream_ptr()), "persistent LSTM")
-        t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        rt.check_status([model] if not two else list(pipe.models))
+        t_max = torch.tensor([elapsed], dtype=torch.float64, device=rt.device)
         if dist is not None:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         r = {"elapsed": float(t_max.item()), "steps": steps,
@@ -376,7 +423,7 @@ def main():
             pipelined = False
             two = None
             lib.ms_gemm_set_variant(0)
-            torch.cuda.synchronize()
+            rt.synchronize()
     two_in_flight = None
     if pipelined:
         two_in_flight = {"value": round(world * BATCH_PER_GPU * CLIP_SECONDS * args.steps / elapsed, 1),
@@ -409,15 +456,15 @@ def main():
         # side measurement, NOT part of `value` (the metric starts at feature tensors resident in HBM): the same batch
         # from 16 kHz waveforms -- MFCC(80, win 400, hop 160) + Standardize of the shipped DS2 config on the device
         from myrtlespeech_amd.data.preprocess import MFCC, Standardize
-        waves = (torch.randn(BATCH_PER_GPU, 160000, generator=g) * 0.1).cuda()
+        waves = rt.to_device(torch.randn(BATCH_PER_GPU, 160000, generator=g) * 0.1)
         wl = torch.full((BATCH_PER_GPU,), 160000)
         mfcc, std = MFCC(n_mfcc=FEATURES, melkwargs={"win_length": 400, "hop_length": 160}), Standardize()
         for i in range(8):
             if i == 3:
-                torch.cuda.synchronize()
+                rt.synchronize()
                 tf0 = time.perf_counter()
             std.batch(*mfcc.batch(waves, wl))
-        torch.cuda.synchronize()
+        rt.synchronize()
         frontend_ms = (time.perf_counter() - tf0) / 5 * 1e3
 
     if rank == 0:
