@@ -11,7 +11,8 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_long,
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libms_hotpath.so")
+# MS_HOTPATH_LIB: another build of the same library (same-box A/B runs of two kernel versions, tools/ab_lib.sh)
+LIB_PATH = os.environ.get("MS_HOTPATH_LIB") or os.path.join(_HERE, "libms_hotpath.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ms_hotpath.h")
 
 MS_OK = 0

@@ -6,6 +6,7 @@ state_dict keys (``fully_connected.{0,2,..}.weight``) and repr match; the module
 are parameter containers -- the forward pass runs each Linear (+ its clamp) as one
 MFMA GEMM with a fused epilogue (``ms_linear_forward``).
 """
+from collections import OrderedDict
 from typing import List, Optional, Tuple, Union
 
 import torch
@@ -37,14 +38,23 @@ def linear_stack_plan(module: Union[torch.nn.Linear, torch.nn.Sequential], train
 _SPLIT_MIN_FLOPS = 2e9  # below this the two plane-split passes cost more than they save
 # Operand-plane scratch of the split GEMM, one per HIP stream: work on one stream is ordered, so successive layers may share
 # a buffer, but two streams (pipeline.BatchesInFlight) must not -- one stream's planes would be overwritten under the other's GEMM.
-_split_ws = {}
+_split_ws = OrderedDict()
+_SPLIT_WS_STREAMS = 4    # scratch buffers kept: the most recently used streams (a pipeline uses two)
 
 
 def _stream_workspace() -> "_lib.Workspace":
+    """Least-recently-used cache keyed on the stream handle: a stream that has been destroyed (its handle may be re-issued
+    later) or is no longer used loses its buffer once ``_SPLIT_WS_STREAMS`` other streams have come by.  Dropping an entry is
+    safe while its stream still runs: the caching allocator hands a block allocated on stream S only to later allocations
+    on S, i.e. behind the kernels that read it."""
     key = torch.cuda.current_stream().cuda_stream
     ws = _split_ws.get(key)
     if ws is None:
         ws = _split_ws[key] = _lib.Workspace()
+        while len(_split_ws) > _SPLIT_WS_STREAMS:
+            _split_ws.popitem(last=False)
+    else:
+        _split_ws.move_to_end(key)
     return ws
 
 

@@ -172,3 +172,21 @@ def test_pipe_checks_the_status_word_and_restores_the_models_own_setting():
     model.rnn.check_status = False             # a caller that checks by itself (bench.py) is not synchronised by the pipe
     pipe(_batches(2, 8, 70, 40, 6))
     assert calls == [1] and model.rnn.check_status is False
+
+
+def test_split_gemm_scratch_is_pruned_when_streams_come_and_go():
+    """VERDICT r2 small close: the per-stream scratch of the split GEMM is a small LRU, not one buffer per stream handle for
+    the life of the process."""
+    from myrtlespeech_amd.model import fully_connected as F
+    lin = torch.nn.Linear(2048, 1024).cuda()
+    x = torch.randn(4096, 2048, device="cuda")
+    want = F.run_linear_stack(x, [(lin, None)])
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(12):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            outs.append(F.run_linear_stack(x, [(lin, None)]))
+    torch.cuda.synchronize()
+    assert len(F._split_ws) <= F._SPLIT_WS_STREAMS
+    assert all(torch.equal(o, want) for o in outs)
