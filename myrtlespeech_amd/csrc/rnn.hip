@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
           acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl1, acc1, 0, 0, 0);
         }
       }
-      if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[1] += now - st_prev; st_prev = now; }
+      if (STAMP) st_sum[1] += spins;   // slot 1: failed tag checks (repeated requests) of this stream-step, not a time
 
       // ---- reduce the 4 K-quarters, cell update on waves 0/1, publish.  `red` is double-buffered
       // by stream, so the only barrier is write -> read (the readers of this buffer two

@@ -25,7 +25,7 @@ w = torch.randn(NN, K, device="cuda") * 0.02
 y = torch.empty(M, NN, device="cuda")
 ws = torch.empty(lib.ms_linear_split_workspace_bytes(M, K, NN), dtype=torch.uint8, device="cuda")
 side = torch.cuda.Stream()
-names = ["wait h (tags)", "mfma issue", "lds write+barrier", "cell+publish"]
+names = ["wait h (tags)", "repeated requests", "mfma+lds write+barrier", "cell+publish"]
 
 
 def stamps():
@@ -35,7 +35,8 @@ def stamps():
     out = {}
     for grp, label in ((0, "cell waves 0-1"), (4, "waves 2-3")):
         per = dbg[:, grp:grp + 4] / 2.0 / T * 10.0      # ns per step (both streams), 100 MHz ticks
-        out[label] = [float(per[:, k].mean()) for k in range(4)] + [float(per.sum(1).mean())]
+        per[:, 1] = dbg[:, grp + 1] / 2.0 / T / 2.0     # slot 1 counts failed tag checks: per wave and stream-step
+        out[label] = [float(per[:, k].mean()) for k in range(4)] + [float((per[:, 0] + per[:, 2] + per[:, 3]).mean())]
     return out
 
 
@@ -57,5 +58,5 @@ for variant, label in ((0, "alone"), (7, "with the 4-wave co-tenant GEMM (varian
     s = stamps()
     print(f"{label}: layer call (projection + recurrence) {wall:.3f} ms")
     for grp, v in s.items():
-        print(f"   {grp:15s} " + "  ".join(f"{n} {t:7.1f} ns" for n, t in zip(names, v[:4])) + f"   sum {v[4]:7.1f} ns per step")
+        print(f"   {grp:15s} " + "  ".join(f"{n} {t:7.2f}" + (" per stream-step" if k == 1 else " ns") for k, (n, t) in enumerate(zip(names, v[:4]))) + f"   sum {v[4]:7.1f} ns per step")
 lib.ms_gemm_set_variant(0)

@@ -30,14 +30,16 @@ dbg = ws[off:off + 256 * 8 * 8].view(torch.int64).reshape(256, 8).cpu().double()
 two_stream = os.environ.get("MS_LSTM_ONE_STREAM") != "1" and os.environ.get("MS_PRECISION") != "f32"
 if two_stream:
     # two-stream kernel: slots 0-3 = cell waves (0, 1), slots 4-7 = waves 2, 3; each slot sums 2 waves
-    names = ["wait h (tags)", "mfma issue", "lds write+barrier", "cell+publish"]
+    names = ["wait h (tags)", "re-requests", "mfma+lds write+barrier", "cell+publish"]
     for grp, label in ((0, "waves 0-1"), (4, "waves 2-3")):
         per = dbg[:, grp:grp + 4] / 2.0 / T * 10.0
+        per[:, 1] = dbg[:, grp + 1] / 2.0 / T / 2.0          # slot 1 counts failed tag checks: per wave and stream-step
         print(label)
         for k, nm in enumerate(names):
             c = per[:, k]
-            print(f"  {nm:18s} mean {c.mean():8.1f} ns  min {c.min():8.1f}  max {c.max():8.1f}")
-        print(f"  sum mean {per.sum(1).mean():.1f} ns per step (both streams)")
+            unit = "per stream-step" if k == 1 else "ns"
+            print(f"  {nm:24s} mean {c.mean():8.2f} {unit}  min {c.min():8.2f}  max {c.max():8.2f}")
+        print(f"  sum mean {(per[:, 0] + per[:, 2] + per[:, 3]).mean():.1f} ns per step (both streams)")
 else:
     per_wave = dbg[:, :4] / 4.0 / T * 10.0  # ns per step (4 waves add up; 100 MHz ticks = 10 ns)
     names = ["wait_flags", "mfma_loop", "reduce+cell", "publish"]
