@@ -380,7 +380,7 @@ __device__ __forceinline__ void lds_dma_16(__amdgpu_buffer_rsrc_t rsrc, char* ds
 // WN = wave columns: 2 = 256 x 256 tile, 8 waves, two per SIMD (the shipped form); 1 = 256 x 128 tile, 4 waves, one per
 // SIMD: 224 VGPRs and 128 KB of LDS per workgroup, i.e. a workgroup that fits on a CU BESIDE a workgroup of the persistent
 // LSTM kernel (272 VGPRs, 20 KB) -- the co-residency experiment of DESIGN 7.0 (tools/overlap_probe.py)
-template <bool F16, int WN>
+template <bool F16, int WN, int PER_STEP_ = 3, bool SPACED = false>
 __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah, const unsigned short* __restrict__ Al,
                                            const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
                                            const float* __restrict__ bias, float* __restrict__ Y, int M, int K, int N, int act,
@@ -535,7 +535,9 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
       wb[ring][0] = *reinterpret_cast<const u32x4*>(st);
       if (!F16) wb[ring][1] = *reinterpret_cast<const u32x4*>(st + G4_PLANE);
     };
-    auto mm = [&](int xr, int wr, int j) {
+    // (issue(k): the k-th DMA piece of this step, placed in front of MFMA group k when the pieces are SPACED)
+    auto mm = [&](int xr, int wr, int j, auto&& issue) {
+      issue(0);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (F16) {
@@ -545,9 +547,11 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
         }
       }
       if (!F16) {
+        issue(1);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[wr][0]), __builtin_bit_cast(bf16x8, xa[xr][2 + i]), acc[i][j], 0, 0, 0);
+        issue(2);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[wr][1]), __builtin_bit_cast(bf16x8, xa[xr][i]), acc[i][j], 0, 0, 0);
@@ -557,7 +561,7 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
     rd_w(0, 0, 0, 0);
     // (block 1 was issued in the prologue with block 0; from block 2 on a block's DMA pieces are issued a few at a time in
     // the first steps of the block BEFORE it -- a single wave cannot hide a burst of 12 DMA issues behind six MFMAs)
-    constexpr int DMA_STEPS = 4, PER_STEP = (NP + DMA_STEPS - 1) / DMA_STEPS;
+    constexpr int PER_STEP = PER_STEP_, DMA_STEPS = (NP + PER_STEP - 1) / PER_STEP;   // shipped: 3 pieces in each of 4 steps
     for (int b = 0; b < nk; ++b) {
       const int cur = b & 1;
       const int soff_next = __builtin_amdgcn_readfirstlane(min(b + 1, nk - 1) * (SB_K * 2));
@@ -568,13 +572,17 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int step = h * 4 + j;               // 0..7: W pair `step` lives in ring slot step & 1, x set h in ring slot h
-          if (b > 0 && step < DMA_STEPS) {          // block b+1 -> the other stage (free since the barrier of block b-1)
+          auto piece = [&](int p) {                  // block b+1 -> the other stage (free since the barrier of block b-1)
+            if (p < NPA) lds_dma_16(rsrc_a, dst_a + p * 1024, voff[p], soff_next);
+            else lds_dma_16(rsrc_b, dst_b + (p - NPA) * 1024, voff[p], soff_next);
+          };
+          if (!SPACED && b > 0 && step < DMA_STEPS) {
 #pragma unroll
-            for (int p = step * PER_STEP; p < (step + 1) * PER_STEP && p < NP; ++p) {
-              if (p < NPA) lds_dma_16(rsrc_a, dst_a + p * 1024, voff[p], soff_next);
-              else lds_dma_16(rsrc_b, dst_b + (p - NPA) * 1024, voff[p], soff_next);
-            }
+            for (int p = step * PER_STEP; p < (step + 1) * PER_STEP && p < NP; ++p) piece(p);
           }
+          auto issue = [&](int k) {                  // SPACED: piece k of this step in front of MFMA group k
+            if (SPACED && b > 0 && step < DMA_STEPS && k < PER_STEP && step * PER_STEP + k < NP) piece(step * PER_STEP + k);
+          };
           if (step == 7) {
             // every read of this stage has been issued and (below) waited for; the next block has landed (this wave's pieces)
             __builtin_amdgcn_s_waitcnt(0x0070);     // lgkmcnt(0) + vmcnt(0)
@@ -585,7 +593,7 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
             if (j == 3) rd_x(1, cur, 1);            // h = 0, j = 3: the second half's x set
             rd_w((step + 1) & 1, cur, (step + 1) >> 2, (step + 1) & 3);
           }
-          mm(h, step & 1, j);
+          mm(h, step & 1, j, issue);
         }
     }
   } else {
@@ -673,12 +681,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4(const unsigned 
 }
 
 // the 4-wave form, capped at 208 VGPRs (the two-stream LSTM kernel allocates 304 of a SIMD's 512): experiment only
-template <bool F16>
+template <bool F16, int PER_STEP = 3, bool SPACED = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel4n(
     const unsigned short* __restrict__ Ah, const unsigned short* __restrict__ Al, const unsigned short* __restrict__ Wh,
     const unsigned short* __restrict__ Wl, const float* __restrict__ bias, float* __restrict__ Y, int M, int K, int N, int act,
     float lo, float hi) {
-  gemm4_body<F16, 1>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi);
+  gemm4_body<F16, 1, PER_STEP, SPACED>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi);
 }
 
 // tuning switch (tools/gemm_probe.py A/B runs in one process): 0 = default choice (kernel4, LDS-DMA), 2 = kernel2 (register staging), 7 = kernel4 with 256 x 128 tiles / 4 waves
@@ -709,6 +717,10 @@ int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     attr_once.done();
   }
   static const bool small_tile = getenv("MS_GEMM_TILE128") && getenv("MS_GEMM_TILE128")[0] == '1';
@@ -725,8 +737,17 @@ int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const
     // the LDS-DMA kernel (default) addresses its planes with 32-bit byte offsets; MS_GEMM_REGSTAGE=1 / variant 2 keep kernel2
     static const bool regstage = getenv("MS_GEMM_REGSTAGE") && getenv("MS_GEMM_REGSTAGE")[0] == '1';
     if (variant != 2 && !regstage && (size_t)std::max(M, N) * K * 2 < ((size_t)1 << 31)) {
-      if (variant == 7) {   // 256 x 128 tiles, 4 waves: co-resident with the persistent LSTM (tools/overlap_probe.py)
+      if (variant >= 7 && variant <= 11) {   // 256 x 128 tiles, 4 waves: co-resident with the persistent LSTM (tools/overlap_probe.py)
+        // how a wave issues the next block's 12 DMA pieces (bf16x3; experiments of tools/cotenant_variants.py): 7 = 3 per step
+        // over four steps, 8 = 2 per step over six, 9 = 6 per step over two, 10 / 11 = as 7 / 8 with a step's pieces spaced
+        // between its three MFMA groups
         auto k41 = f16 ? gemm_nt_bf16x3_kernel4n<true> : gemm_nt_bf16x3_kernel4n<false>;
+        if (!f16) {
+          if (variant == 8) k41 = gemm_nt_bf16x3_kernel4n<false, 2>;
+          if (variant == 9) k41 = gemm_nt_bf16x3_kernel4n<false, 6>;
+          if (variant == 10) k41 = gemm_nt_bf16x3_kernel4n<false, 3, true>;
+          if (variant == 11) k41 = gemm_nt_bf16x3_kernel4n<false, 2, true>;
+        }
         hipLaunchKernelGGL(k41, dim3(cdiv(M, S2_M) * cdiv(N, 128)), dim3(256), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N,
                            act, lo, hi);
         MS_LAUNCH_CHECK();

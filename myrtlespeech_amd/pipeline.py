@@ -9,7 +9,7 @@ projection runs in the shadow of batch A's recurrence and vice versa:
   library chains persistent launches across streams in host issue order (two recurrences must never be resident together:
   each fills every CU with workgroups that wait for their own peers, ``csrc/rnn.hip`` PersistentTurn);
 * while the pipeline runs, the projection GEMMs use the 4-wave 256 x 128 form of the LDS-DMA kernel (176 VGPRs, 128 KB of
-  LDS, ``ms_gemm_set_variant(7)``), whose workgroups fit on a CU BESIDE a workgroup of the recurrence (304 VGPRs, 20 KB);
+  LDS, ``ms_gemm_set_variant(COTENANT_GEMM_VARIANT)``), whose workgroups fit on a CU BESIDE a workgroup of the recurrence (304 VGPRs, 20 KB);
   the shipped 8-wave form cannot share a CU with it and would only time-slice (``tools/overlap_probe.py``);
 * results are bit-identical to the one-batch path (same kernels' arithmetic; ``tests/test_gpu_pipeline.py``).
 
@@ -36,7 +36,12 @@ import torch
 
 from myrtlespeech_amd import _lib
 
-COTENANT_GEMM_VARIANT = 7
+# ms_gemm_set_variant value of the co-tenant projection GEMM: the 4-wave 256 x 128 LDS-DMA kernel with a wave's 12 DMA pieces of
+# the next K-block issued ONE in front of each MFMA group of the block's first four steps (variant 10).  Round 2 issued them
+# three at a time at the head of those steps (variant 7): same-process A/B on the bench network, 40 batches x 4 rounds
+# (tools/cotenant_variants.py, profiles/r03g_*): 14.42 -> 13.52 ms per batch; the GEMM's own time beside the recurrence
+# 2.79 -> 2.46 ms, the recurrence's 2.68 -> 2.58 ms.  Bit-identical outputs (tests/cfg_checks.py::gemm_variants_equal).
+COTENANT_GEMM_VARIANT = 10
 
 
 class _Baton:

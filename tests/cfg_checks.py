@@ -172,7 +172,8 @@ def rccl_one_rank() -> None:
 
 
 def gemm_variants_equal() -> None:
-    """The split-operand GEMM's three kernels (0 = LDS-DMA 8-wave, 7 = LDS-DMA 4-wave co-tenant form, 2 = register-staged) on the
+    """The split-operand GEMM's kernels (0 = LDS-DMA 8-wave, 7 / 8 / 10 / 11 = LDS-DMA 4-wave co-tenant forms that differ in how the
+    DMA pieces are issued -- 10 is the one the pipeline uses --, 2 = register-staged) on the
     same operands in THIS process's precision mode (run in a child with MS_PRECISION=fp16 for the single-pass instantiations):
     bit-identical outputs, ragged edges included."""
     from myrtlespeech_amd import _lib
@@ -185,7 +186,7 @@ def gemm_variants_equal() -> None:
         ws = torch.empty(lib.ms_linear_split_workspace_bytes(M, K, N), dtype=torch.uint8, device="cuda")
         ys = []
         try:
-            for variant in (0, 7, 2):
+            for variant in (0, 7, 8, 10, 11, 2):
                 lib.ms_gemm_set_variant(variant)
                 y = torch.full((M + 1, N), float("nan"), device="cuda")
                 _lib.check(lib.ms_linear_split_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), M, K, N, act, 0.0, 1.5,
@@ -194,7 +195,7 @@ def gemm_variants_equal() -> None:
                 ys.append(y[:M])
         finally:
             lib.ms_gemm_set_variant(0)
-        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2]), (M, K, N)
+        assert all(torch.equal(ys[0], y) for y in ys[1:]), (M, K, N)
         want = x.double() @ w.double().T + b.double()
         if act:
             want = want.clamp(0.0, 1.5)

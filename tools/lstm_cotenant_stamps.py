@@ -40,7 +40,8 @@ def stamps():
     return out
 
 
-for variant, label in ((0, "alone"), (7, "with the 4-wave co-tenant GEMM (variant 7) on a second stream"),
+for variant, label in ((0, "alone"), (7, "with the 4-wave co-tenant GEMM, 3 DMA pieces at the head of a step (variant 7, round 2) on a second stream"),
+                       (10, "with the 4-wave co-tenant GEMM, one DMA piece per MFMA group (variant 10, round 3) on a second stream"),
                        (2, "with the 8-wave register-staged GEMM (cannot be co-resident) on a second stream")):
     lib.ms_gemm_set_variant(variant if variant else 0)
     for it in range(3):
