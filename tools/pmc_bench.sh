@@ -2,8 +2,8 @@
 # Counter passes over bench.py itself (HEAD's chained 5-layer stack, the binary the bench times), on the GPU box:
 #     bash tools/pmc_bench.sh [tag] [precision]
 # Each pass is its own rocprofv3 run (PMC only -- no tracing flags), bounded by `timeout`; the program after `--` is
-# python3 itself.  Writes gpurun_out/pmc_bench_<tag>.json (copy it to profiles/r02_pmc_bench.json) and a text summary.
-TAG=${1:-r02}
+# python3 itself.  Writes gpurun_out/pmc_bench_<tag>.json (copy it to profiles/r03_pmc_bench.json) and a text summary.
+TAG=${1:-r03}
 PREC=${2:-bf16x3}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmc_bench_$TAG
