@@ -13,8 +13,19 @@
 //   predictor step       gather [embedding(label) | h_src] rows -> exact-f32 MFMA GEMM against [W_ih | W_hh] ->
 //                        lstm_cell_kernel (writes the new state, builds the next layer's rows) -> ... -> pred_proj GEMM
 //   beam_frame_end_kernel  B sorted (stable, descending) -> beam_width survivors; their states move to the frame-start region
-// Rows of utterances that have ended (t >= len) or of empty beam slots are skipped inside the kernels, so the launch
+// Rows of utterances that have ended (t >= len) or of empty beam slots are skipped inside the kernels, so the beam's launch
 // sequence does not depend on the data.
+//
+// Greedy decode (round 3) does not pay for blanks any more.  The predictor's output only changes when a label is emitted, so
+// between two emissions of an utterance every frame's joint is evaluated against the SAME predictor output: one iteration =
+//   joint_slots_kernel<CHUNK>  log P(. | frame cur_t[i] + c, pred_i) for GREEDY_CHUNK consecutive frames of every utterance at once
+//   greedy_scan_kernel         per utterance: walk those frames in order, blanks advance the frame, the FIRST label is emitted
+//                              (at most max_symbols per frame, then the frame advances), requests ONE predictor step and stops
+//   predictor step             only for the utterances that emitted
+// i.e. about (labels of the longest transcript + blank runs longer than a chunk) iterations instead of T x max_symbols rounds,
+// with the same arithmetic per (frame, prediction) pair and therefore the same transcripts.  The number of iterations depends
+// on the data: the host enqueues iterations ahead and every few of them fetches a device counter of finished utterances
+// (4 bytes, asynchronously, looked at two checks later so that the queue never drains).
 #include <math.h>
 
 #include "common.h"
@@ -27,6 +38,7 @@ int linear_splitk_launch(const float* x, const float* w, const float* bias, floa
 }
 
 constexpr int KSPLIT = 8;  // K slices of the gate GEMMs (partials added in slice order by lstm_cell_kernel)
+constexpr int GREEDY_CHUNK = 32;  // greedy decode: frames evaluated per utterance and iteration
 
 namespace {
 
@@ -81,7 +93,7 @@ DecLayout dec_layout(int T, int N, int V, int D, int H, int L, int J, int w, int
   W.xrow = take((size_t)R * in_max * 4);
   W.gates = take((size_t)KSPLIT * R * 4 * H * 4);
   W.htop = take((size_t)R * H * 4);
-  W.logp = take((size_t)R * V1 * 4);
+  W.logp = take((size_t)R * (greedy ? GREEDY_CHUNK : 1) * V1 * 4);
   size_t wc = 0, bc = 0;
   for (int l = 0; l < L; ++l) {
     W.wcat_off[l] = wc;
@@ -178,6 +190,10 @@ __global__ void lstm_cell_kernel(const float* __restrict__ gates, const int32_t*
 // A row whose predictor state was requested by the previous round (ext_dst[r] >= 0) finds its projected predictor
 // output as KSPLIT partial sums in pp_tmp[.][r]: they are added here in slice order and the sum is also stored in
 // pp[slot] (the copy that survives the frame), which used to be a kernel of its own.
+// CHUNK (greedy, round 3): `w` consecutive frames of utterance i against ONE predictor output: row r = i * w + c is frame
+// A_cnt[i] + c (A_cnt = the utterance's current frame), its predictor row (slot, request, pp_tmp row) is i; row c == 0 commits
+// the projected predictor output, the others add the same partial sums in the same order without storing them.
+template <bool CHUNK>
 __global__ __launch_bounds__(256) void joint_slots_kernel(const float* __restrict__ enc_p, const int32_t* __restrict__ lens,
                                                           float* __restrict__ pp, const float* __restrict__ pp_tmp,
                                                           const int32_t* __restrict__ ext_dst,
@@ -192,7 +208,9 @@ __global__ __launch_bounds__(256) void joint_slots_kernel(const float* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // four independent loads (one memory round trip), then the test: these words were written by the previous kernel on
   // another XCD, every dependent global load here costs ~2 us
-  const int len_i = lens[i], cnt_i = A_cnt[i], slot = A_slot[r], fresh = ext_dst[r];
+  const int pr = CHUNK ? i : r;                     // row of the predictor-side arrays
+  const int len_i = lens[i], cnt_i = A_cnt[i], slot = A_slot[pr], fresh = ext_dst[pr];
+  if (CHUNK) t = cnt_i + j;
   // Everything that does not depend on those words is requested before they are looked at: this wave's W_out rows
   // (symbols v = wave, wave + 4, ...) and the frame's encoder projection.
   constexpr int KMAX = 8, VMAX = 8;  // register tile: J <= 512, V1 <= 32
@@ -207,33 +225,41 @@ __global__ __launch_bounds__(256) void joint_slots_kernel(const float* __restric
         wreg[kk][vi] = (k < J && v < V1) ? w_out[(size_t)v * J + k] : 0.f;
       }
   }
-  const float* e = enc_p + ((size_t)t * N + i) * J;
   float ereg[4] = {0.f, 0.f, 0.f, 0.f};
   const bool e_tile = J <= 1024;
-  if (e_tile) {
+  if (e_tile && !CHUNK) {
+    const float* e = enc_p + ((size_t)t * N + i) * J;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
       if (tid + 256 * m < J) ereg[m] = e[tid + 256 * m];
   }
-  if (t >= len_i || j >= cnt_i) return;
+  if (t >= len_i || (!CHUNK && j >= cnt_i)) return;
   float* p = pp + (size_t)slot * J;
   const size_t part = (size_t)R * J;
   auto pred_term = [&](int k) {
     if (fresh < 0) return p[k];
-    float pv = pp_tmp[(size_t)r * J + k];
+    float pv = pp_tmp[(size_t)pr * J + k];
 #pragma unroll
-    for (int zz = 1; zz < KSPLIT; ++zz) pv += pp_tmp[zz * part + (size_t)r * J + k];
-    p[k] = pv;
+    for (int zz = 1; zz < KSPLIT; ++zz) pv += pp_tmp[zz * part + (size_t)pr * J + k];
+    if (!CHUNK || j == 0) p[k] = pv;
     return pv;
   };
   if (e_tile) {
+    // (CHUNK: the frame is known only now, so the encoder row is loaded here)
+    if (CHUNK) {
+      const float* ec = enc_p + ((size_t)t * N + i) * J;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (tid + 256 * m < J) ereg[m] = ec[tid + 256 * m];
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int k = tid + 256 * m;
       if (k < J) z[k] = tanhf(ereg[m] + pred_term(k));
     }
   } else {
-    for (int k = tid; k < J; k += 256) z[k] = tanhf(e[k] + pred_term(k));
+    const float* ec = enc_p + ((size_t)t * N + i) * J;
+    for (int k = tid; k < J; k += 256) z[k] = tanhf(ec[k] + pred_term(k));
   }
   __syncthreads();
   if (reg_tile) {
@@ -552,53 +578,73 @@ __global__ void beam_init_kernel(BeamP p) {
 // ---- greedy -----------------------------------------------------------------------------------------------------
 
 __global__ void greedy_init_kernel(int32_t* ext_label, int32_t* ext_src, int32_t* ext_dst, int32_t* slot, int32_t* out_cnt,
-                                   int N, int blank) {
+                                   int32_t* cur_t, int32_t* sym, int32_t* done_cnt, int N, int blank) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *done_cnt = 0;
   if (i >= N) return;
   ext_label[i] = blank;
   ext_src[i] = -1;
   ext_dst[i] = i;
   slot[i] = i;
   out_cnt[i] = 0;
+  cur_t[i] = 0;
+  sym[i] = 0;
 }
 
-__global__ void greedy_frame_start_kernel(const int32_t* __restrict__ lens, int32_t* __restrict__ live, int N, int t) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) live[i] = t < lens[i] ? 1 : 0;
-}
-
-// argmax over the symbols (first maximum); blank ends the frame for this utterance, a label is emitted and requests a
-// predictor step in place (source slot = destination slot = i).
-__global__ __launch_bounds__(64) void greedy_round_kernel(const float* __restrict__ logp, int32_t* __restrict__ live,
-                                                          int32_t* __restrict__ out_idx, int32_t* __restrict__ out_cnt,
-                                                          int32_t* __restrict__ ext_label, int32_t* __restrict__ ext_src,
-                                                          int32_t* __restrict__ ext_dst, int V1, int blank, int out_stride) {
+// One wave per utterance: walk the chunk's frames in order.  A frame's symbol is the argmax of its log-probabilities
+// (first maximum); blank moves on to the next frame; a label is emitted, requests a predictor step in place (source slot =
+// destination slot = i) and ends the walk, because every later joint of the chunk was computed against the old prediction.
+// After max_symbols labels on one frame the frame advances.  An utterance whose frame reaches its length is finished.
+__global__ __launch_bounds__(64) void greedy_scan_kernel(const float* __restrict__ logp, const int32_t* __restrict__ lens,
+                                                         int32_t* __restrict__ cur_t, int32_t* __restrict__ sym,
+                                                         int32_t* __restrict__ done_cnt, int32_t* __restrict__ out_idx,
+                                                         int32_t* __restrict__ out_cnt, int32_t* __restrict__ ext_label,
+                                                         int32_t* __restrict__ ext_src, int32_t* __restrict__ ext_dst, int V1,
+                                                         int blank, int out_stride, int max_symbols) {
   const int i = blockIdx.x, lane = threadIdx.x;
+  const int len_i = lens[i], t0 = cur_t[i];
+  int nsym = sym[i];
   if (lane == 0) ext_dst[i] = -1;
-  if (!live[i]) return;
-  float bv = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int v = lane; v < V1; v += 64) {
-    const float x = logp[(size_t)i * V1 + v];
-    if (x > bv || (x == bv && v < bi) || bi == 0x7fffffff) { bv = x; bi = v; }
-  }
+  if (t0 >= len_i) return;                                   // finished in an earlier iteration
+  int t = t0, emitted = -1;
+  for (int c = 0; c < GREEDY_CHUNK && t < len_i; ++c) {       // row c of the chunk is frame t0 + c == t on every pass
+    const float* row = logp + ((size_t)i * GREEDY_CHUNK + c) * V1;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = lane; v < V1; v += 64) {
+      const float x = row[v];
+      if (x > bv || (x == bv && v < bi) || bi == 0x7fffffff) { bv = x; bi = v; }
+    }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(bv, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
-    if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+    }
+    if (bi == blank) {
+      ++t;
+      nsym = 0;
+      continue;
+    }
+    emitted = bi;
+    if (++nsym >= max_symbols) {                              // the frame's quota is used up: the next joint is frame t + 1's
+      ++t;
+      nsym = 0;
+    }
+    break;
   }
   if (lane == 0) {
-    if (bi == blank) {
-      live[i] = 0;
-    } else {
+    if (emitted >= 0) {
       const int n = out_cnt[i];
-      if (n < out_stride) out_idx[(size_t)i * out_stride + n] = bi;
+      if (n < out_stride) out_idx[(size_t)i * out_stride + n] = emitted;
       out_cnt[i] = n + 1;
-      ext_label[i] = bi;
+      ext_label[i] = emitted;
       ext_src[i] = i;
       ext_dst[i] = i;
     }
+    cur_t[i] = t;
+    sym[i] = nsym;
+    if (t >= len_i) atomicAdd(done_cnt, 1);
   }
 }
 
@@ -680,33 +726,58 @@ extern "C" int ms_rnnt_decode(const float* enc_p, const int32_t* lens, const flo
   float* pp = (float*)(ws + W.pp);
 
   if (greedy) {
-    int32_t* live = (int32_t*)(ws + W.live);
+    int32_t* cur_t = (int32_t*)(ws + W.live);          // current frame of every utterance
+    int32_t* sym = (int32_t*)(ws + W.A_cnt);           // labels emitted on that frame so far
+    int32_t* done_cnt = (int32_t*)(ws + W.B_cnt);      // utterances that have reached their length
     int32_t* out_cnt = (int32_t*)(ws + W.out_cnt);
     const int out_stride = T * max_symbols;
     hipLaunchKernelGGL(greedy_init_kernel, dim3(ms::cdiv(N, 64)), dim3(64), 0, s, (int32_t*)(ws + W.ext_label),
-                       (int32_t*)(ws + W.ext_src), (int32_t*)(ws + W.ext_dst), A_slot, out_cnt, N, V);
+                       (int32_t*)(ws + W.ext_src), (int32_t*)(ws + W.ext_dst), A_slot, out_cnt, cur_t, sym, done_cnt, N, V);
     MS_LAUNCH_CHECK();
     int rc = predictor_step(net, W, ws, s);
     if (rc != MS_OK) return rc;
     const float* pp_tmp = (const float*)(ws + W.pp_tmp);
     const int32_t* ext_dst = (const int32_t*)(ws + W.ext_dst);
-    for (int t = 0; t < T; ++t) {
-      hipLaunchKernelGGL(greedy_frame_start_kernel, dim3(ms::cdiv(N, 64)), dim3(64), 0, s, lens, live, N, t);
-      MS_LAUNCH_CHECK();
-      for (int v = 0; v < max_symbols; ++v) {
-        hipLaunchKernelGGL(joint_slots_kernel, dim3(R), dim3(256), joint_lds, s, enc_p, lens, pp, pp_tmp, ext_dst, A_slot,
-                           live, w_out, b_out, logp, t, N, 1, J, V1, R);
-        MS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(greedy_round_kernel, dim3(N), dim3(64), 0, s, logp, live, out_idx, out_cnt,
-                           (int32_t*)(ws + W.ext_label), (int32_t*)(ws + W.ext_src), (int32_t*)(ws + W.ext_dst), V1, V,
-                           out_stride);
-        MS_LAUNCH_CHECK();
-        rc = predictor_step(net, W, ws, s);
-        if (rc != MS_OK) return rc;
+    // every iteration advances every unfinished utterance by one label or by a whole chunk of blanks, so this bound is
+    // never reached unless the device counter cannot be read
+    const long max_iters = (long)T * max_symbols + ms::cdiv(T, GREEDY_CHUNK) + 1;
+    constexpr int CHECK_EVERY = 2, RING = 4;
+    int32_t* host_done = nullptr;
+    hipEvent_t ev[RING] = {nullptr, nullptr, nullptr, nullptr};
+    bool polled = hipHostMalloc((void**)&host_done, RING * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
+    for (int k = 0; polled && k < RING; ++k) {
+      host_done[k] = 0;
+      polled = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) == hipSuccess;
+    }
+    long checks = 0;
+    rc = MS_OK;
+    for (long it = 0; it < max_iters && rc == MS_OK; ++it) {
+      hipLaunchKernelGGL(joint_slots_kernel<true>, dim3(N * GREEDY_CHUNK), dim3(256), joint_lds, s, enc_p, lens, pp, pp_tmp, ext_dst,
+                         A_slot, cur_t, w_out, b_out, logp, 0, N, GREEDY_CHUNK, J, V1, R);
+      hipLaunchKernelGGL(greedy_scan_kernel, dim3(N), dim3(64), 0, s, logp, lens, cur_t, sym, done_cnt, out_idx, out_cnt,
+                         (int32_t*)(ws + W.ext_label), (int32_t*)(ws + W.ext_src), (int32_t*)(ws + W.ext_dst), V1, V, out_stride,
+                         max_symbols);
+      if (hipGetLastError() != hipSuccess) { ms::set_error("ms_rnnt_decode: launch failed"); rc = MS_ERR_HIP; break; }
+      rc = predictor_step(net, W, ws, s);
+      if (rc != MS_OK || !polled || (it + 1) % CHECK_EVERY != 0) continue;
+      // fetch the counter behind this iteration; look at the one fetched two checks ago (already complete, or nearly):
+      // the queue stays at least CHECK_EVERY iterations deep and at most 2 * CHECK_EVERY iterations run past the end
+      const int slot = (int)(checks % RING);
+      if (hipMemcpyAsync(&host_done[slot], done_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+          hipEventRecord(ev[slot], s) != hipSuccess) { polled = false; continue; }
+      ++checks;
+      if (checks > 2) {
+        const int old = (int)((checks - 3) % RING);
+        if (hipEventSynchronize(ev[old]) == hipSuccess && host_done[old] >= N) break;
       }
     }
-    MS_HIP(hipMemcpyAsync(out_len, out_cnt, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
-    return MS_OK;
+    if (rc == MS_OK && hipMemcpyAsync(out_len, out_cnt, (size_t)N * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = MS_ERR_HIP;
+    if (host_done) {
+      (void)hipStreamSynchronize(s);                    // the pinned words are targets of copies in flight
+      for (int k = 0; k < RING; ++k) if (ev[k]) (void)hipEventDestroy(ev[k]);
+      (void)hipHostFree(host_done);
+    }
+    return rc;
   }
 
   BeamP p;
@@ -743,7 +814,7 @@ extern "C" int ms_rnnt_decode(const float* enc_p, const int32_t* lens, const flo
   for (int t = 0; t < T; ++t) {
     for (int v = 0; v < max_symbols; ++v) {
       const int last = v == max_symbols - 1;
-      hipLaunchKernelGGL(joint_slots_kernel, dim3(R), dim3(256), joint_lds, s, enc_p, lens, pp, pp_tmp, p.ext_dst, A_slot, A_cnt,
+      hipLaunchKernelGGL(joint_slots_kernel<false>, dim3(R), dim3(256), joint_lds, s, enc_p, lens, pp, pp_tmp, p.ext_dst, A_slot, A_cnt,
                          w_out, b_out, logp, t, N, w, J, V1, R);
       MS_LAUNCH_CHECK();
       hipLaunchKernelGGL(beam_round_kernel, dim3(N), dim3(256), cand_lds, s, p, t, 2 + v, v == 0, last);

@@ -1,8 +1,11 @@
 """RNN-T greedy and time-synchronous beam decoding -- OWN specification (see model/rnnt.py and
 oracle/rnnt_oracle.py; the reference has no transducer).  The whole decode of a batch is ONE call into the
 library (``ms_rnnt_decode``): the frame loop, the hypothesis lists, the prefix trie that gives merged blank
-transitions their identity, the predictor-state pool and the top-k pruning all live on the device, nothing is
-read back until the label lists are fetched at the end.
+transitions their identity, the predictor-state pool and the top-k pruning all live on the device; the beam reads
+nothing back until the label lists are fetched at the end.  The greedy decode is event-driven (the predictor only
+steps after a label; 32 frames per utterance are scored against the current prediction at once), so its launch
+count depends on the data: the library fetches a 4-byte counter of finished utterances every second iteration,
+asynchronously and two checks behind the queue.
 """
 import ctypes
 from typing import List, Optional

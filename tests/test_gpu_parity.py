@@ -776,6 +776,32 @@ def test_rnnt_greedy_and_beam_vs_oracle():
     np.testing.assert_allclose(dec.last_scores, want_scores, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("ms,blank_bias,seed", [(1, 0.0, 0), (3, 0.5, 2), (4, 0.75, 3), (2, 1.0, 4), (3, 1.5, 5), (3, 30.0, 6)])
+def test_rnnt_greedy_event_driven_decode_vs_oracle(ms, blank_bias, seed):
+    """The greedy decode evaluates the joint for 32 consecutive frames of every utterance against the current prediction and
+    steps the predictor only after a label (round 3).  Sequences longer than several chunks, blank runs that span chunk
+    boundaries (raised blank logit; +30 = no label at all), labels on consecutive frames, the per-frame quota ``max_symbols``
+    and utterances that end inside a chunk, an empty one included: transcripts equal to the oracle's frame-by-frame loop."""
+    from myrtlespeech_amd.post_process.rnnt_decoder import RNNTGreedyDecoder
+    from oracle import rnnt_oracle as RO
+    V, E, P = 9, 24, 64
+    pred, joint, psd, jsd = _rnnt_parts(V=V, E=E, D=8, P=P, J=32, seed=10 + seed)
+    with torch.no_grad():
+        joint.out.bias[V] += blank_bias
+    jsd = {k: cpu(v) for k, v in joint.state_dict().items()}
+    rng = np.random.default_rng(seed)
+    steps, N = 150, 5
+    enc = (rng.normal(size=(steps, N, E)) * 2.0).astype(np.float32)
+    lens = np.array([150, 97, 64, 33, 0])
+    want = RO.greedy_decode(enc, lens, psd, jsd, P, 2, V, ms)
+    dec = RNNTGreedyDecoder(pred, joint, max_symbols=ms)
+    got = dec(T(enc), T(lens))
+    assert got == want
+    # (dense transcripts at bias 0 .. 0.75: 1 .. 3 labels per frame; 52 labels over 150 frames at 1.0; 0 .. 4 at 1.5; none at 30)
+    assert sum(map(len, want)) > 0 if blank_bias < 30.0 else all(h == [] for h in want)
+    assert dec(T(enc), T(lens)) == got                      # a second call re-uses the workspace
+
+
 @pytest.mark.parametrize("V,w,ms,N,steps,seed", [(4, 8, 3, 4, 24, 0), (11, 1, 2, 2, 12, 1), (6, 5, 4, 3, 10, 2),
                                                  (28, 8, 3, 2, 8, 3), (3, 16, 2, 2, 16, 4)])
 def test_rnnt_device_decode_sweep(V, w, ms, N, steps, seed):
