@@ -228,6 +228,12 @@ enum {
 int ms_prof_enable(int on);
 int ms_prof_read(float* out_ms_host, int* out_n_host);
 
+/* Diagnostic (tools/clock_probe.py; not part of the reference surface): ONE wave that samples the shader clock counter
+ * and the 100 MHz wall clock `samples` times, about `spacing_us` apart, into out_dev[2 * samples] (u64 pairs
+ * {wall ticks, shader cycles}).  Launched on a stream of its own beside other kernels it shows the clock the chip holds
+ * under their load (MI355X_MICROARCH.md, DVFS give-back item 6).  samples * spacing_us is capped at 50 ms. */
+int ms_clock_probe(unsigned long long* out_dev, int samples, int spacing_us, void* stream);
+
 /* ---- loss/ctc_loss.py ---------------------------------------------------- */
 
 size_t ms_ctc_loss_workspace_bytes(int T, int N, int V, int S_max);

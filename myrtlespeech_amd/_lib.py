@@ -61,6 +61,7 @@ SIGNATURES = {
     "ms_gemm_set_variant": (c_int, [c_int]),
     "ms_prof_enable": (c_int, [c_int]),
     "ms_prof_read": (c_int, [POINTER(c_float), POINTER(c_int)]),
+    "ms_clock_probe": (c_int, [_P, c_int, c_int, _P]),
     "ms_ctc_loss_workspace_bytes": (c_size_t, [c_int] * 4),
     "ms_ctc_loss_forward": (c_int, [_P] * 7 + [c_int] * 7 + [_P, c_size_t, _P]),
     "ms_ctc_loss_backward_workspace_bytes": (c_size_t, [c_int] * 4),

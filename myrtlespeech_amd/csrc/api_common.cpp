@@ -78,6 +78,29 @@ extern "C" int ms_prof_read(float* out_ms, int* out_n) {
   return MS_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, int samples, unsigned long long spacing_ticks) {
+  if (threadIdx.x != 0) return;
+  unsigned long long next = wall_clock64();
+  for (int i = 0; i < samples; ++i) {
+    unsigned long long now;
+    while ((now = wall_clock64()) < next) __builtin_amdgcn_s_sleep(8);     // bounded: `next` is at most 50 ms away in total
+    out[2 * i] = now;
+    out[2 * i + 1] = clock64();
+    next = now + spacing_ticks;
+  }
+}
+}  // namespace
+
+extern "C" int ms_clock_probe(unsigned long long* out_dev, int samples, int spacing_us, void* stream) {
+  MS_REQUIRE(out_dev && samples > 0 && spacing_us > 0, "bad arguments");
+  MS_REQUIRE((long)samples * spacing_us <= 50000, "at most 50 ms of sampling");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_dev, samples,
+                     (unsigned long long)spacing_us * 100ull);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}
+
 extern "C" int ms_abi_version(void) { return MS_ABI_VERSION; }
 extern "C" const char* ms_last_error(void) {
   static thread_local std::string copy;
