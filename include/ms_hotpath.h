@@ -245,10 +245,17 @@ size_t ms_ctc_loss_workspace_bytes(int T, int N, int V, int S_max);
  * nll [N] = -log p(target | input) (reduction='none');
  * reduced [1] = 'sum' (reduction=2) or 'mean' (reduction=1: nll/clamp(len,1),
  * batch mean, ctc_loss.py:17-19); zero_infinity replaces inf by 0. */
+#define MS_CTC_LOG_PROBS_IN 2 /* OR-ed into `zero_infinity`: `logits` already hold the values torch.nn.CTCLoss is to take as
+                              * log-probabilities -- CTCLoss(dim != -1), ctc_loss.py:37-45, normalises over another axis
+                              * (ms_log_softmax_axis) -- so no log-softmax over the symbols is applied */
 int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, const int32_t* targets,
                         const int32_t* tgt_offsets, const int32_t* tgt_lens, float* nll, float* reduced, int T,
                         int N, int V, int S_max, int blank, int reduction, int zero_infinity, void* workspace,
                         size_t workspace_bytes, void* stream);
+
+/* LogSoftmax over an axis other than the last one (ctc_loss.py:45 passes the constructor's `dim` through): x, y are
+ * contiguous [outer, axis, inner]; y = x - logsumexp over `axis`. */
+int ms_log_softmax_axis(const float* x, float* y, int outer, int axis, int inner, void* stream);
 
 /* Gradient of ms_ctc_loss_forward's per-utterance losses with respect to the logits (what autograd gives the
  * reference through LogSoftmax + torch.nn.CTCLoss, loss/ctc_loss.py:95-101): alpha rows forward, beta rows backward,

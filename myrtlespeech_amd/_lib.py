@@ -64,6 +64,7 @@ SIGNATURES = {
     "ms_clock_probe": (c_int, [_P, c_int, c_int, _P]),
     "ms_ctc_loss_workspace_bytes": (c_size_t, [c_int] * 4),
     "ms_ctc_loss_forward": (c_int, [_P] * 7 + [c_int] * 7 + [_P, c_size_t, _P]),
+    "ms_log_softmax_axis": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ms_ctc_loss_backward_workspace_bytes": (c_size_t, [c_int] * 4),
     "ms_ctc_loss_backward": (c_int, [_P] * 7 + [c_int] * 6 + [_P, c_size_t, _P]),
     "ms_ctc_greedy_decode": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

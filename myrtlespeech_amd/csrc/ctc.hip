@@ -30,7 +30,8 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_kernel(const float* __r
                                                                 const int32_t* __restrict__ tgt_offsets,
                                                                 const int32_t* __restrict__ tgt_lens,
                                                                 float* __restrict__ nll, float* __restrict__ logz_ws,
-                                                                int T, int N, int V, int S_max, int blank) {
+                                                                int T, int N, int V, int S_max, int blank,
+                                                                int log_probs_in) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x, tid = threadIdx.x;
   int* ext = reinterpret_cast<int*>(smem);   // [S_max]
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_kernel(const float* __r
   const int32_t* tg = targets + tgt_offsets[n];
 
   for (int t = tid; t < Tn; t += CTC_THREADS) {
+    if (log_probs_in) { logz[t] = 0.f; continue; }   // the caller normalised over another axis (CTCLoss(dim != -1))
     const float* row = logits + ((size_t)t * N + n) * V;
     float m = neg_inf();
     for (int v = 0; v < V; ++v) m = fmaxf(m, row[v]);
@@ -328,13 +330,43 @@ extern "C" int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, 
     attr_once.done();
   }
   hipLaunchKernelGGL(ctc_alpha_kernel, dim3(N), dim3(CTC_THREADS), lds, (hipStream_t)stream, logits, in_lens, targets,
-                     tgt_offsets, tgt_lens, nll, (float*)workspace, T, N, V, S_max, blank);
+                     tgt_offsets, tgt_lens, nll, (float*)workspace, T, N, V, S_max, blank,
+                     (zero_infinity & MS_CTC_LOG_PROBS_IN) ? 1 : 0);
   MS_LAUNCH_CHECK();
+  zero_infinity &= 1;
   if (reduction != 0 || zero_infinity) {
     hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nll, tgt_lens, reduced, N,
                        reduction, zero_infinity);
     MS_LAUNCH_CHECK();
   }
+  return MS_OK;
+}
+
+namespace {
+// y[o, a, i] = x[o, a, i] - logsumexp_a x[o, :, i] on a contiguous [outer, axis, inner] view: one thread per (o, i),
+// consecutive threads = consecutive i (coalesced for every a)
+__global__ void log_softmax_axis_kernel(const float* __restrict__ x, float* __restrict__ y, int outer, int axis, int inner) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)outer * inner) return;
+  const int o = (int)(id / inner), i = (int)(id % inner);
+  const float* xp = x + (size_t)o * axis * inner + i;
+  float* yp = y + (size_t)o * axis * inner + i;
+  float m = -INFINITY;
+  for (int a = 0; a < axis; ++a) m = fmaxf(m, xp[(size_t)a * inner]);
+  float sum = 0.f;
+  for (int a = 0; a < axis; ++a) sum += expf(xp[(size_t)a * inner] - m);
+  const float lz = logf(sum) + m;
+  for (int a = 0; a < axis; ++a) yp[(size_t)a * inner] = xp[(size_t)a * inner] - lz;
+}
+}  // namespace
+
+extern "C" int ms_log_softmax_axis(const float* x, float* y, int outer, int axis, int inner, void* stream) {
+  MS_REQUIRE(x && y, "null pointer");
+  MS_REQUIRE(outer > 0 && axis > 0 && inner > 0, "bad shape");
+  const long n = (long)outer * inner;
+  hipLaunchKernelGGL(log_softmax_axis_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, outer,
+                     axis, inner);
+  MS_LAUNCH_CHECK();
   return MS_OK;
 }
 

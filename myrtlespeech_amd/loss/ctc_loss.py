@@ -73,10 +73,22 @@ class CTCLoss(torch.nn.Module):
         if x.dim() != 3:
             raise RuntimeError("inputs must be [max_seq_len, batch, features]")
         dim = self.log_softmax.dim
-        if dim not in (-1, 2):
-            raise NotImplementedError("log-softmax is fused over the symbol axis (dim=-1) only")
+        if not -3 <= dim <= 2:
+            raise IndexError(f"Dimension out of range (expected to be in range of [-3, 2], but got {dim})")
+        dim %= 3
         x = _lib.f32c(x)
         t, n, v = x.shape
+        log_probs_in = 0
+        if dim != 2:
+            # ctc_loss.py:37-45 forwards ANY dim to LogSoftmax: the values normalised over time (0) or over the batch (1) are
+            # what torch.nn.CTCLoss then takes as log-probabilities.  One extra pass; the kernel skips its own normalisation.
+            if torch.is_grad_enabled() and x.requires_grad:
+                raise NotImplementedError("the gradient kernel covers the log-softmax over the symbol axis (dim=-1) only")
+            xn = torch.empty_like(x)
+            outer, axis, inner = (1, t, n * v) if dim == 0 else (t, n, v)
+            _lib.check(lib.ms_log_softmax_axis(_lib.ptr(x), _lib.ptr(xn), outer, axis, inner, _lib.stream_ptr()),
+                       "ms_log_softmax_axis")
+            x, log_probs_in = xn, 2       # MS_CTC_LOG_PROBS_IN
         blank = self.ctc_loss.blank
         if not 0 <= blank < v:
             raise RuntimeError("blank must be in label range")
@@ -103,6 +115,7 @@ class CTCLoss(torch.nn.Module):
             y_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
         red = _REDUCTION[self.ctc_loss.reduction]
         zero_inf = int(bool(self.ctc_loss.zero_infinity))
+        fwd_flags = zero_inf | log_probs_in
         xl_dev, off_dev, yl_dev = _lib.lens_i32(xl), _lib.lens_i32(offsets), _lib.lens_i32(yl)
 
         def run_forward(logits: torch.Tensor) -> torch.Tensor:
@@ -111,7 +124,7 @@ class CTCLoss(torch.nn.Module):
             ws = self._workspace.get(lib.ms_ctc_loss_workspace_bytes(t, n, v, s_max))
             _lib.check(lib.ms_ctc_loss_forward(_lib.ptr(logits), _lib.ptr(xl_dev), _lib.ptr(y_dev), _lib.ptr(off_dev),
                                                _lib.ptr(yl_dev), _lib.ptr(nll), _lib.ptr(reduced), t, n, v, s_max, blank,
-                                               red, zero_inf, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                                               red, fwd_flags, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
                        "ms_ctc_loss_forward")
             return nll if red == 0 else reduced[0]
 

@@ -310,6 +310,23 @@ def gen_ctc_loss():
     save("ctc_loss_v29", dict(blank=28), arrays)
 
 
+def gen_ctc_loss_dim():
+    """CTCLoss(dim != -1): the reference forwards ANY dim to LogSoftmax (loss/ctc_loss.py:37-45), i.e. normalises over time
+    (dim 0) or over the batch (dim 1) and hands those values to torch.nn.CTCLoss as if they were log-probabilities."""
+    torch.manual_seed(43)
+    T, N, V = 23, 4, 7
+    x = torch.randn(T, N, V) * 1.5
+    x_lens = torch.tensor([23, 23, 16, 9], dtype=torch.int32)
+    y_lens = torch.tensor([6, 3, 4, 0], dtype=torch.int32)
+    y = torch.randint(0, 6, (N, 6), dtype=torch.int32)
+    arrays = {"in/x": npy(x), "in/x_lens": npy(x_lens), "in/y": npy(y), "in/y_lens": npy(y_lens)}
+    for dim in (0, 1, -3, -2, 2):
+        for red in ("none", "mean", "sum"):
+            out = CTCLoss(blank=6, reduction=red, dim=dim)((x.clone(), x_lens), (y, y_lens))
+            arrays[f"out/dim{dim}_{red}"] = npy(out)
+    save("ctc_loss_dim", dict(blank=6, dims=[0, 1, -3, -2, 2]), arrays)
+
+
 # ----------------------------------------------------------------------------- decoders
 def gen_greedy():
     torch.manual_seed(51)
@@ -786,3 +803,7 @@ if __name__ == "__main__" and "streamfull" in sys.argv[1:]:
     gen_streaming_full()
 if __name__ == "__main__" and "stream64" in sys.argv[1:]:
     gen_streaming_n64()
+
+
+if __name__ == "__main__" and "ctc_dim" in sys.argv[1:]:
+    gen_ctc_loss_dim()

@@ -148,6 +148,16 @@ def test_ctc_loss_small():
     np.testing.assert_allclose(got, g["out/none_flat"], rtol=1e-4, atol=1e-4)
 
 
+def test_ctc_loss_dim():
+    """CTCLoss(dim != -1) as the reference runs it (fixture made by the reference with dim in {0, 1, -3, -2, 2})."""
+    g = Golden("ctc_loss_dim")
+    for dim in g.cfg["dims"]:
+        for red in ("none", "mean", "sum"):
+            got = O.ctc_loss(g["in/x"], g["in/x_lens"], g["in/y"], g["in/y_lens"], g.cfg["blank"], red, dim=dim)
+            np.testing.assert_allclose(got, g[f"out/dim{dim}_{red}"], rtol=1e-4, atol=1e-4)
+    assert not np.allclose(g["out/dim0_none"], g["out/dim2_none"])
+
+
 def test_ctc_loss_v29():
     g = Golden("ctc_loss_v29")
     for red in ("none", "mean", "sum"):
