@@ -589,6 +589,11 @@ def main(argv=None, runtime=None, json_fd=None):
             "roofline": roof, "projection_gemm": gemm,
         }
         if two_in_flight is not None:
+            two_in_flight["what_binds"] = (
+                "each layer slot = one batch's persistent recurrence beside the other batch's projection GEMM on the same CUs; "
+                "both cross the CU's one vector-memory path and the chip holds ~1.9 GHz under the pair (2.25 GHz under the "
+                "recurrence alone, 1.5 GHz under the GEMM alone: profiles/r03m_clock_probe.txt); board power 1.32 kW of the "
+                "1.4 kW cap against 1.08 kW one batch at a time (profiles/r03o_power_trace.txt, not measured in this run)")
             out["two_batches_in_flight"] = two_in_flight
         if pipeline_error is not None:
             out["pipeline_error"] = pipeline_error
