@@ -83,9 +83,13 @@ def main():
         b = RNNTBeamDecoder(pred, joint, beam_width=8, max_symbols=3)
         ms_enc = timed(lambda: enc_model((x, lens)))
         ms_g = timed(lambda: g(enc, el), warmup=1, iters=2)
+        labels_dense = [len(h) for h in g(enc, el)]
         ms_b = timed(lambda: b(enc, el), warmup=1, iters=2)
+        # (a random-initialised joint makes the GREEDY search emit max_symbols labels on every frame: the worst case of the
+        # event-driven greedy decode; transcripts as sparse as a trained transducer's: tools/rnnt_cfg4_time.py)
         out["cfg4_rnnt"] = {"workload": "DS2 encoder (batch 16 x 10 s) + 2-layer LSTM-1024 predictor + joint 512, 501 frames",
                             "encoder_ms": round(ms_enc, 2), "greedy_decode_ms": round(ms_g, 1),
+                            "greedy_labels_per_utterance": [min(labels_dense), max(labels_dense)],
                             "beam8_decode_ms": round(ms_b, 1),
                             "audio_sec_per_s_beam8": round(160.0 / (ms_enc + ms_b) * 1e3, 1)}
 
