@@ -1,4 +1,4 @@
-cd /root/repo
+cd "$(dirname "$0")/../.."
 echo "== 1-D pattern (the shipped decomposition), one stream, no arithmetic: vector of 64 KB pulled whole by every workgroup"
 timeout -k 5 60 tools/micro/exchange_latency 2 128 32 16 0
 timeout -k 5 60 tools/micro/exchange_latency 2 128 32 16 4

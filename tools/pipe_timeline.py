@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Timeline of one TwoBatchesInFlight call on the bench network: when the host returns, when each batch's transcripts are
+enqueued (HIP events), the steady-state spacing of batch pairs -- and the hipMalloc stall of a first call that is longer than
+its warm-up (why bench.py warms the pipeline with a call of the timed call's length)."""
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from myrtlespeech_amd.pipeline import TwoBatchesInFlight
 from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder

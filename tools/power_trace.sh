@@ -1,4 +1,4 @@
-cd /root/repo
+cd "$(dirname "$0")/.."
 rocm-smi --showpower --showmaxpower 2>&1 | grep -i "power\|cap" | head -8
 (for i in $(seq 60); do rocm-smi --showpower --showclocks 2>/dev/null | grep -i "Average Graphics Package Power\|Current Socket\|sclk" | tr '\n' ' '; echo; sleep 0.25; done) > gpurun_out/r03o_power_trace.txt &
 SM=$!
