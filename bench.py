@@ -487,9 +487,11 @@ def main(argv=None, runtime=None, json_fd=None):
         kname = {"f32": "lstm_persistent_kernel" if os.environ.get("MS_LSTM_F32_ONE_STREAM") == "1"
                  else "lstm_persistent_f32x2_kernel"}.get(mode, "lstm_persistent_split2_kernel")
         mfma_peak = MFMA_F32_PEAK_TF if mode == "f32" else MFMA_BF16_PEAK_TF
-        roof = {"bound": "exchange latency (every step each of the 256 workgroups publishes its 8 units of h and pulls "
-                         "the whole h of its direction from the other CUs through L2: ~2.7 us of the ~3.5 us step with no "
-                         "arithmetic at all, tools/micro/exchange_latency.hip); neither HBM nor MFMA",
+        roof = {"bound": "L2 delivery in series with the step's arithmetic: every step each of the 256 workgroups publishes its 8 "
+                         "units of h and pulls the whole h of its direction (128 KB) out of its XCD's L2 -- 32 MB per step chip-wide "
+                         "at the ~18 TB/s the eight L2s deliver to CUs that all pull at once = 1.8 us of the ~3.5 us step, during "
+                         "which the CU computes nothing (in-kernel stamps: no request is ever repeated, the wait is the load); "
+                         "neither HBM nor MFMA",
                 "kernel": kname + " (one launch = 1 layer x 2 directions x 501 steps)",
                 "launch_ms": round(rec_ms, 4),
                 "launch_ms_source": "HIP events on the launch stream, mean over the timed steps of the one-batch-in-flight leg "
@@ -591,7 +593,7 @@ def main(argv=None, runtime=None, json_fd=None):
         if two_in_flight is not None:
             two_in_flight["what_binds"] = (
                 "each layer slot = one batch's persistent recurrence beside the other batch's projection GEMM on the same CUs; "
-                "both cross the CU's one vector-memory path and the chip holds ~1.9 GHz under the pair (2.25 GHz under the "
+                "both are fed by the same L2 -> CU path (~70 GB/s per CU when every CU pulls) and the chip holds ~1.9 GHz under the pair (2.25 GHz under the "
                 "recurrence alone, 1.5 GHz under the GEMM alone: profiles/r03m_clock_probe.txt); board power 1.32 kW of the "
                 "1.4 kW cap against 1.08 kW one batch at a time (profiles/r03o_power_trace.txt, not measured in this run)")
             out["two_batches_in_flight"] = two_in_flight
