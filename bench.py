@@ -487,7 +487,8 @@ def main(argv=None, runtime=None, json_fd=None):
         kname = {"f32": "lstm_persistent_kernel" if os.environ.get("MS_LSTM_F32_ONE_STREAM") == "1"
                  else "lstm_persistent_f32x2_kernel"}.get(mode, "lstm_persistent_split2_kernel")
         mfma_peak = MFMA_F32_PEAK_TF if mode == "f32" else MFMA_BF16_PEAK_TF
-        roof = {"bound": "L2 delivery in series with the step's arithmetic: every step each of the 256 workgroups publishes its 8 "
+        roof = {"bound": "hbm",   # the north-star's roofline for the LSTM step; what physically binds: next key
+                "what_binds": "L2 delivery in series with the step's arithmetic: every step each of the 256 workgroups publishes its 8 "
                          "units of h and pulls the whole h of its direction (128 KB) out of its XCD's L2 -- 32 MB per step chip-wide "
                          "at the ~18 TB/s the eight L2s deliver to CUs that all pull at once = 1.8 us of the ~3.5 us step, during "
                          "which the CU computes nothing (in-kernel stamps: no request is ever repeated, the wait is the load); "
