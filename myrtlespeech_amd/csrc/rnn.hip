@@ -1303,6 +1303,216 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
 }
 
 
+// ------------------------------------------------------------------------------------------------ persistent LSTM, split-bf16, two streams, wide workgroups
+//
+// Round 3.  What binds lstm_persistent_split2_kernel is the delivery of h out of the XCDs' L2s: every one of the 256
+// workgroups pulls the whole 64 KB of its direction's h per stream-step, for the 8 hidden units it owns (section 4 of
+// DESIGN.md, "Round 3").  This form fuses two unit blocks into one workgroup of 8 waves (16 units, 64 gate rows, two
+// waves per SIMD): a wave contracts one EIGHTH of K (4 k-steps) for all 64 gate rows, so the same 64 KB feed twice the
+// arithmetic and a batch group of 32 rows needs 128 workgroups instead of 256.  The other half of the chip takes a SECOND
+// batch group of 32 rows in the same launch (blockIdx -> group): two batches side by side for the L2 traffic of one.
+// Same packed weights, same exchange layout and tags, same cell; the K split into eighths changes the order of the
+// float32 partial sums, so results agree with the quarter-split kernel to rounding, not bit for bit.
+// H = 1024 only (KS = 4 k-steps per wave), LSTM cell, bf16x3 operands.
+constexpr int WIDE_RED_STRIDE = 72;                        // floats per reduction row: 64 gate columns + 8 (bank spread)
+constexpr int WIDE_RED2 = 8 * 16 * WIDE_RED_STRIDE;        // 8 waves x 16 rows, per stream
+
+template <bool HARD>
+__global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p) {
+  constexpr int H = 1024, KG = H / 8, KS = 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* red = smem;  // [stream][8 waves][16 rows][WIDE_RED_STRIDE]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q = lane >> 4;
+  const int JJ = p.J / 2;                                  // workgroups per direction and group
+  const int grp = blockIdx.x / (p.ndir * JJ);
+  const int rem = blockIdx.x % (p.ndir * JJ);
+  const int d = rem / JJ, jj = rem % JJ;
+  const int n_base = p.n_base + 32 * grp;
+  const int N = min(32, p.N - 32 * grp);                   // rows of this group (the host launches only groups with rows)
+  // cell threads: waves 0-3; unit block b (0 / 1), batch row nl, unit u of the block
+  const int cb = (tid >> 7) & 1, nl = (tid >> 3) & 15, u = tid & 7;
+  const int jb = 2 * jj + cb;                              // 8-unit block of this cell thread
+  const int unit = 8 * jb + u;
+  const bool cellw = wave < 4;
+
+  // this wave's share of W_hh: its K-eighth x 64 gate rows (two blocks x two column tiles), hi and lo planes, 128 VGPRs
+  u32x4 wh[2][2][KS], wl[2][2][KS];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const char* wsrc = reinterpret_cast<const char*>(p.whh) + ((size_t)d * p.J + 2 * jj + b) * 128 * H;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int kg = 4 * (KS * wave + ks) + q;
+      const char* wp = wsrc + (kg * 32 + c16) * 16;
+      wh[b][0][ks] = *reinterpret_cast<const u32x4*>(wp);
+      wh[b][1][ks] = *reinterpret_cast<const u32x4*>(wp + 256);
+      wl[b][0][ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512);
+      wl[b][1][ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512 + 256);
+    }
+  }
+
+  const int rs = p.ring_shift;
+  const int PLANE = (KG * 256) << rs;       // bytes: [slot][kg][16][8 bf16]
+  const int STREAM = 2 * PLANE;
+  char* hx_d = reinterpret_cast<char*>(p.hx) + ((size_t)grp * p.ndir + d) * 2 * STREAM;
+  const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx_d, 0, 2 * STREAM, 0x00020000);
+
+  float c[2] = {0.f, 0.f}, h[2] = {0.f, 0.f};
+  int len_n[2] = {0, 0};
+  if (cellw) {
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      const int n = sg * 16 + nl;
+      const bool valid = n < N;
+      const size_t sidx = ((size_t)d * p.N_total + n_base + n) * H + unit;
+      h[sg] = (valid && p.h0) ? p.h0[sidx] : 0.f;
+      c[sg] = (valid && p.c0) ? p.c0[sidx] : 0.f;
+      len_n[sg] = valid ? (p.lens ? p.lens[n_base + n] : p.steps) : 0;
+      const int off = sg * STREAM + epoch_par0(d, p.steps, rs) * KG * 256 + jb * 256 + nl * 16;  // slot read by the first step
+      publish_split<false>(h[sg], epoch_tag0(d, p.steps, rs), hx_rsrc, off, PLANE + off, lane);
+    }
+  }
+  __syncthreads();
+
+  const int xcols = p.ndir * 4 * H;
+  const int lane_off = q * 256 + c16 * 16;
+  bool alive = true;
+
+  for (int s = 0; s < p.steps; ++s) {
+    const int t = d ? (p.steps - 1 - s) : s;
+    const EpochClock ec = epoch_clock(d, s, p.steps, rs);
+    const int par = ec.par;
+    const unsigned em = ec.em;
+    const unsigned wtag = ec.wtag;
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      float xg[4] = {0.f, 0.f, 0.f, 0.f};
+      const int n = sg * 16 + nl;
+      if (cellw && n < N) {
+        const float* xp = p.xproj + ((size_t)t * p.N_total + n_base + n) * xcols + d * 4 * H + jb * 32 + u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xg[g] = xp[g * 8];
+      }
+
+      // ---- h_{t-1} of this stream: the 4 k-steps of the wave's K-eighth, hi and lo (8 loads of 1 KB)
+      const int base = sg * STREAM + par * KG * 256 + KS * wave * 1024;
+      u32x4 ah[KS], al[KS];
+      const unsigned long long t_wait0 = wall_clock64();
+      unsigned spins = 0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {   // first request: agent scope; the re-requests below: system scope + volatile
+        ah[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, base + ks * 1024, /*aux: sc1*/ 16);
+        al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, PLANE + base + ks * 1024, /*aux: sc1*/ 16);
+      }
+      for (;;) {
+        unsigned bad = 0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bad |= (ah[ks][e] ^ em) | (al[ks][e] ^ em);
+        if (!alive || !__any((bad & 0x00010001u) != 0)) break;
+        if ((++spins & 63u) == 0) {
+          const unsigned dead = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (dead != 0 || wall_clock64() - t_wait0 > SPIN_LIMIT_TICKS) {
+            if (lane == 0) flag_timeout(p.status);
+            alive = false;
+            break;
+          }
+        }
+        for (int z = 0; z < p.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          ah[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, base + ks * 1024, (int)(0x80000000u | 16u));
+          al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, PLANE + base + ks * 1024, (int)(0x80000000u | 16u));
+        }
+      }
+
+      f32x4v acc[2][2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[b][ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]);
+        const bf16x8 xl = __builtin_bit_cast(bf16x8, al[ks]);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const bf16x8 bh0 = __builtin_bit_cast(bf16x8, wh[b][0][ks]);
+          const bf16x8 bh1 = __builtin_bit_cast(bf16x8, wh[b][1][ks]);
+          const bf16x8 bl0 = __builtin_bit_cast(bf16x8, wl[b][0][ks]);
+          const bf16x8 bl1 = __builtin_bit_cast(bf16x8, wl[b][1][ks]);
+          acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh0, acc[b][0], 0, 0, 0);
+          acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh1, acc[b][1], 0, 0, 0);
+          acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh0, acc[b][0], 0, 0, 0);
+          acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh1, acc[b][1], 0, 0, 0);
+          acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl0, acc[b][0], 0, 0, 0);
+          acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl1, acc[b][1], 0, 0, 0);
+        }
+      }
+
+      // ---- reduce the 8 K-eighths, cell update on waves 0-3, publish.  `red` is double-buffered by stream (see
+      // lstm_persistent_split2_kernel): one barrier per stream-step
+      float* redb = red + sg * WIDE_RED2;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) redb[(wave * 16 + 4 * q + i) * WIDE_RED_STRIDE + b * 32 + ct * 16 + c16] = acc[b][ct][i];
+      __syncthreads();
+      if (cellw) {
+        float gsum[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v = xg[g];
+#pragma unroll
+          for (int w2 = 0; w2 < 8; ++w2) v += redb[(w2 * 16 + nl) * WIDE_RED_STRIDE + cb * 32 + g * 8 + u];
+          gsum[g] = v;
+        }
+        float cnew, hnew;
+        if (HARD) {
+          cnew = clamp01(0.2f * gsum[1] + 0.5f) * c[sg] + clamp01(0.2f * gsum[0] + 0.5f) * clamp11(gsum[2]);
+          hnew = clamp01(0.2f * gsum[3] + 0.5f) * clamp11(cnew);
+        } else {
+          cnew = fast_sigmoid(gsum[1]) * c[sg] + fast_sigmoid(gsum[0]) * fast_tanh(gsum[2]);
+          hnew = fast_sigmoid(gsum[3]) * fast_tanh(cnew);
+        }
+        const bool active = t < len_n[sg];
+        c[sg] = active ? cnew : c[sg];
+        h[sg] = active ? hnew : h[sg];
+        const int off = sg * STREAM + ec.wpar * KG * 256 + jb * 256 + nl * 16;
+        publish_split<false>(h[sg], wtag, hx_rsrc, off, PLANE + off, lane);
+        if (n < N) {
+          const size_t oidx = ((size_t)t * p.N_total + n_base + n) * (p.ndir * H) + d * H + unit;
+          const float ov = active ? hnew : 0.f;
+          if (p.out_hi) {   // exactly split_planes_kernel's arithmetic
+            const unsigned hb = bf16_bits(ov);
+            p.out_hi[oidx] = (unsigned short)hb;
+            p.out_lo[oidx] = (unsigned short)bf16_bits(ov - bf16_val(hb));
+          } else {
+            p.out[oidx] = ov;
+          }
+        }
+      }
+    }
+  }
+  if (cellw) {
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      const int n = sg * 16 + nl;
+      if (n < N) {
+        const size_t sidx = ((size_t)d * p.N_total + n_base + n) * H + unit;
+        p.hn[sidx] = h[sg];
+        p.cn[sidx] = c[sg];
+      }
+    }
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------------ persistent LSTM, float32 MFMA, two streams
 //
 // MS_PRECISION=f32 on the two-stream shapes.  The same decomposition as lstm_persistent_split2_kernel -- 8 units per
@@ -1962,6 +2172,46 @@ static int launch_split2(const LstmP& p, hipStream_t stream) {
   return MS_OK;
 }
 
+// wide workgroups (16 units, 8 waves), `groups` batch groups of <= 32 rows side by side in one launch
+static int launch_wide2(const LstmP& p, bool hard, int groups, hipStream_t stream) {
+  const size_t lds = (size_t)2 * WIDE_RED2 * sizeof(float);
+  static ms::DeviceOnce attr_once;
+  if (attr_once.need()) {
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_once.done();
+  }
+  const dim3 grid(groups * p.ndir * (p.J / 2));
+  if (hard) hipLaunchKernelGGL(lstm_persistent_wide2_kernel<true>, grid, dim3(512), lds, stream, p);
+  else hipLaunchKernelGGL(lstm_persistent_wide2_kernel<false>, grid, dim3(512), lds, stream, p);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}
+
+// The wide-workgroup kernel serves H = 1024 bf16x3 layers of 33 .. 64 sequences (two batch groups side by side: 2.1 ms per
+// layer against 3.5 ms for two launches of the 8-unit kernel, profiles/r03w_*).  A single group of <= 32 rows stays on the
+// 8-unit kernel, which is 8 % faster there (256 workgroups share the arithmetic).  MS_LSTM_WIDE=0 switches it off,
+// MS_LSTM_WIDE=1 also sends single groups to it (A/B runs).
+bool use_wide(int cell, int H, int ndir, int N) {
+  static const int mode = getenv("MS_LSTM_WIDE") ? atoi(getenv("MS_LSTM_WIDE")) : -1;    // -1: default
+  if (mode == 0 || (mode != 1 && N <= 32)) return false;
+  if (H != 1024 || N > 64 || !use_split(cell, H, ndir) || ms::precision_mode() != ms::PREC_BF16X3) return false;
+  static std::atomic<int> ok[64];     // per device: 0 = not asked, 1 = fits, 2 = does not
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  int v = ok[dev & 63].load(std::memory_order_relaxed);
+  if (v == 0) {
+    int nb = 0;
+    const size_t lds = (size_t)2 * WIDE_RED2 * sizeof(float);
+    const bool fits = hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)lstm_persistent_wide2_kernel<false>, 512, lds) == hipSuccess &&
+                      nb >= 1 && ms::num_cus() >= 2 * ndir * (H / 16);
+    v = fits ? 1 : 2;
+    ok[dev & 63].store(v, std::memory_order_relaxed);
+  }
+  return v == 1;
+}
+
 template <int G, bool HARD>
 static int launch_f32x2(const LstmP& p, hipStream_t stream) {
   const size_t lds = (size_t)RED_FLOATS * sizeof(float);
@@ -2114,6 +2364,23 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       p.dbg = (unsigned long long*)(ws + W.dbg);
       const bool pipe = (H % 256 == 0);
       static const bool stamps = getenv("MS_LSTM_STAMPS") && getenv("MS_LSTM_STAMPS")[0] == '1';
+      if (n0 == 0 && use_wide(cell, H, ndir, N)) {
+        // all batch groups (one or two of <= 32 rows) in ONE launch of the wide-workgroup kernel
+        const int groups = ms::cdiv(N, 32);
+        const int rs = 1;
+        const size_t words_per_dir = (size_t)32 * H << rs;
+        p.ring_shift = rs;
+        p.N = N;                       // the kernel cuts it into groups of 32 rows
+        for (int g = 0; g < groups; ++g) {
+          hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir)), dim3(256), 0, stream,
+                             (unsigned*)(ws + W.hx) + (size_t)g * ndir * words_per_dir, words_per_dir, (size_t)8 * H, ndir, steps, rs,
+                             zero_base(0), g == 0 ? zero_words(0) : 0);
+          MS_LAUNCH_CHECK();
+        }
+        rc = launch_wide2(p, cell == MS_CELL_HARD_LSTM, groups, stream);
+        if (rc != MS_OK) return rc;
+        break;
+      }
       if (use_split(cell, H, ndir)) {
         const bool hard_ = (cell == MS_CELL_HARD_LSTM);
         if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.total - W.dbg, stream));
