@@ -196,6 +196,10 @@ class GpuRuntime:
         from myrtlespeech_amd.pipeline import TwoBatchesInFlight
         return TwoBatchesInFlight(model, post=post, pre=pre)
 
+    def paired(self, model, post, pre):
+        from myrtlespeech_amd.pipeline import PairedBatches
+        return PairedBatches(model, post=post, pre=pre)
+
     def check_status(self, models):
         from myrtlespeech_amd import _lib
         lib = _lib.load()
@@ -314,7 +318,7 @@ def main(argv=None, runtime=None, json_fd=None):
         rt.synchronize()
 
     pipelined = args.in_flight == 2 and not (args.gather_logits and dist is not None)
-    pipe = None
+    pipe = paired = None
     if pipelined:
         starts = {}
 
@@ -329,6 +333,7 @@ def main(argv=None, runtime=None, json_fd=None):
             return pending, end
 
         pipe = rt.pipe(model, post, pre)
+        paired = rt.paired(model, post, pre)
 
     STAGES = ("projection", "recurrence", "gemm_k_large", "gemm_k_small", "conv", "layout", "linear", "greedy", "other")
 
@@ -345,7 +350,8 @@ def main(argv=None, runtime=None, json_fd=None):
         barrier()
         t0 = time.perf_counter()
         if two:
-            pend = pipe([(x if lens is lens_full else x_ragged, lens)] * steps)
+            runner = two if callable(two) else pipe          # `two` = the throughput mode's runner (True: the threaded pipeline)
+            pend = runner([(x if lens is lens_full else x_ragged, lens)] * steps)
             for pd, _ in pend:
                 pd.result()                      # every step's transcripts are on the host before the clock stops
         else:
@@ -363,7 +369,7 @@ def main(argv=None, runtime=None, json_fd=None):
         barrier()
         lib.ms_prof_read(ms, cnt)
         lib.ms_prof_enable(0)
-        rt.check_status([model] if not two else list(pipe.models))
+        rt.check_status(list(pipe.models) if (two is True or two is pipe) else [model])
         t_max = torch.tensor([elapsed], dtype=torch.float64, device=rt.device)
         if dist is not None:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -432,8 +438,28 @@ def main(argv=None, runtime=None, json_fd=None):
         two_in_flight = {"value": round(world * BATCH_PER_GPU * CLIP_SECONDS * args.steps / elapsed, 1),
                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "latency_ms_per_batch": round(latency_ms, 3)}
         two_in_flight.update(stage_report(two, True))
-        if elapsed >= one_elapsed:   # few steps: the pipeline's fill and drain outweigh what it hides; the headline is the faster leg
-            pipelined = False
+    # leg 3 (the other throughput mode, round 3): two batches per forward (pipeline.PairedBatches -> one stream, the two
+    # batches' recurrences side by side in one launch of the wide-workgroup kernel)
+    pair = per_forward = None
+    headline = pipe if pipelined else None          # the runner whose figure is `value`
+    if paired is not None:
+        try:
+            paired([(x, lens_full)] * max(2, args.warmup, min(args.steps, 24)))
+            pair = timed(lens_full, args.steps, paired)
+            per_forward = {"value": round(world * BATCH_PER_GPU * CLIP_SECONDS * args.steps / pair["elapsed"], 1),
+                           "ms_per_step": round(pair["elapsed"] / args.steps * 1e3, 3),
+                           "latency_ms_per_batch": round(pair["latency"], 3)}
+            rep = stage_report(pair, True)
+            rep["note"] = ("two batches per forward on ONE stream: every kernel of a step runs once on 64 utterances, the "
+                           "recurrence as one launch of the wide-workgroup kernel for both batches; stage_ms is per batch of 32")
+            per_forward.update(rep)
+            if headline is None or pair["elapsed"] < elapsed:
+                headline, elapsed, latency_ms, pipelined = paired, pair["elapsed"], pair["latency"], True
+        except Exception as e:  # noqa: BLE001
+            per_forward = {"error": f"{type(e).__name__}: {e}"[:300]}
+            rt.synchronize()
+    if pipelined and elapsed >= one_elapsed:   # few steps: fill and drain outweigh what a pipeline hides; the headline is the faster leg
+        pipelined, headline = False, None
     if not pipelined:
         elapsed, latency_ms = one_elapsed, None
 
@@ -443,8 +469,8 @@ def main(argv=None, runtime=None, json_fd=None):
         for _ in range(2):
             step(lens_ragged)
         if pipelined:
-            pipe([(x_ragged, lens_ragged)] * 2)
-        r_elapsed = timed(lens_ragged, rsteps, pipelined)["elapsed"]
+            headline([(x_ragged, lens_ragged)] * 2)
+        r_elapsed = timed(lens_ragged, rsteps, headline if pipelined else False)["elapsed"]
         audio_s = float(lens_ragged.sum()) * CLIP_SECONDS / (FRAMES - 1) * world   # hop 10 ms
         ragged = {"workload": "same batch, lengths ~U[501, 1001] frames sorted in decreasing order (BASELINE.md 3 (ii)); "
                               "the backward direction of every utterance starts at its own last frame",
@@ -504,9 +530,25 @@ def main(argv=None, runtime=None, json_fd=None):
                 "definition": "frac = SURVEY 8d algorithmic bytes (17 825 792 B x 1002 layer-direction-steps, W_hh counted "
                               "once per step although it stays in registers) / launch_ms / 8 TB/s: the north-star's "
                               "roofline figure, not a physical utilisation"}
-        if pipelined and two_spans is not None:
+        if two_spans is not None:
             roof["launch_ms_two_in_flight"] = round(two_spans[1], 4)
             roof["frac_two_in_flight"] = round(launch_bytes / (two_spans[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if two_spans[1] > 0 else None
+        if pair is not None and pair["per_launch"]["recurrence"] > 0:
+            # one launch of lstm_persistent_wide2_kernel = 1 layer x 2 directions x 501 steps of TWO batches of 32
+            pr = pair["per_launch"]["recurrence"]
+            roof["two_batches_per_forward"] = {
+                "kernel": "lstm_persistent_wide2_kernel (16 hidden units per workgroup, two 32-row batch groups side by side)",
+                "launch_ms": round(pr, 4), "algorithmic_bytes_per_launch": 2 * launch_bytes,
+                "achieved": round(2 * launch_bytes / (pr * 1e-3) / 1e9, 1), "frac": round(2 * launch_bytes / (pr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            wrec, wwhy = pmc_record("lstm_persistent_wide2_kernel")
+            if wrec is not None:
+                roof["two_batches_per_forward"].update({
+                    "traffic": int(wrec["hbm_bytes"]),
+                    "hbm_frac_measured": round(wrec["hbm_bytes"] / (pr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "mfma_frac": round(wrec["mfma_flop"] / (pr * 1e-3) / 1e12 / mfma_peak, 4),
+                    "mfma_busy_frac_pmc": wrec.get("mfma_busy_frac"), "l2_hit_rate_pmc": wrec.get("l2_hit_rate")})
+            else:
+                roof["two_batches_per_forward"]["pmc_note"] = wwhy
         rec, why = pmc_record(kname)
         if rec is not None and rec_ms > 0:
             roof["traffic"] = int(rec["hbm_bytes"])
@@ -532,7 +574,7 @@ def main(argv=None, runtime=None, json_fd=None):
                          "first_layer_k640_launch_ms": round(gemm_k640_ms, 4) if gemm_k640_ms > 0 else None})
             if gemm_k640_ms > 0:
                 gemm["first_layer_k640_frac"] = round(passes * 2.0 * M * N * 640 / (gemm_k640_ms * 1e-3) / 1e12 / mfma_peak, 4)
-            if pipelined and two_spans is not None and two_spans[2] > 0:
+            if two_spans is not None and two_spans[2] > 0:
                 gemm["launch_ms_two_in_flight"] = round(two_spans[2], 4)
                 gemm["two_in_flight_note"] = (
                     "the same float32 GEMM time-slicing with the other batch's recurrence (it cannot share a CU with it)"
@@ -557,8 +599,14 @@ def main(argv=None, runtime=None, json_fd=None):
                                    "frames (10 s), batch 32 per GPU, CTC greedy decode (blank 28)",
                        "global_batch": world * BATCH_PER_GPU, "frames": FRAMES, "parallelism": f"utterance-shard x{world}",
                        "in_flight": 2 if pipelined else 1,
-                       "pipeline": ("two batches in flight per GPU on two HIP streams (myrtlespeech_amd.pipeline): the next "
-                                    "batch's projection GEMMs run beside this batch's persistent recurrence on the same CUs; "
+                       "pipeline": ("two batches per forward (myrtlespeech_amd.pipeline.PairedBatches): consecutive batches of 32 go "
+                                    "through the network two at a time on one stream; the two batches' recurrences run side by side "
+                                    "in one launch of the wide-workgroup kernel, every other kernel once on 64 utterances; every "
+                                    "step's full work incl. decode completes inside the timed region; per batch identical to the "
+                                    "forward of the merged batch, equal to the one-batch path within float32 rounding (1.2e-7 on "
+                                    "the logits), transcripts equal") if (pipelined and headline is paired) else
+                                   ("two batches in flight per GPU on two HIP streams (myrtlespeech_amd.pipeline.TwoBatchesInFlight): "
+                                    "the next batch's projection GEMMs run beside this batch's persistent recurrence on the same CUs; "
                                     "every step's full work incl. decode completes inside the timed region; outputs "
                                     "bit-identical to the one-batch path") if pipelined else "one batch at a time",
                        "decode": "all-gather logits, batched decode on every rank" if args.gather_logits else
@@ -598,6 +646,8 @@ def main(argv=None, runtime=None, json_fd=None):
                 "recurrence alone, 1.5 GHz under the GEMM alone: profiles/r03m_clock_probe.txt); board power 1.32 kW of the "
                 "1.4 kW cap against 1.08 kW one batch at a time (profiles/r03o_power_trace.txt, not measured in this run)")
             out["two_batches_in_flight"] = two_in_flight
+        if per_forward is not None:
+            out["two_batches_per_forward"] = per_forward
         if pipeline_error is not None:
             out["pipeline_error"] = pipeline_error
         if frontend_ms is not None:

@@ -206,3 +206,82 @@ class BatchesInFlight:
 class TwoBatchesInFlight(BatchesInFlight):
     def __init__(self, model: torch.nn.Module, post: Optional[Callable] = None, pre: Optional[Callable] = None):
         super().__init__(model, post=post, pre=pre, depth=2)
+
+
+class PairedBatches:
+    """``PairedBatches(model)(batches)``: the other throughput mode (round 3) -- consecutive batches go through ``model`` two at
+    a time as ONE batch.  For the config-2 network (5 x BiLSTM-1024, batches of 32) the library then runs the two batches'
+    recurrences side by side in one launch of the wide-workgroup kernel (``csrc/rnn.hip``, ``lstm_persistent_wide2_kernel``:
+    16 hidden units per workgroup, so the 64 KB of ``h`` a workgroup pulls out of L2 every step feed twice the arithmetic and
+    a batch needs half the chip): 2.1 ms per layer for two batches against 1.75 ms for one, and every other kernel of the
+    step (convolutions, projection GEMMs, output layers, greedy decode) runs once on 64 utterances.  No threads, one stream.
+
+    What a caller gets per batch is what ``model`` returns for the merged batch, cut back to the batch's utterances in
+    their own order: ``((logits[T', N_b, V], lens_b), hid_b)``.  Utterances do not interact in any module, so
+    this equals the one-batch result up to the float32 rounding of the recurrence's partial sums (the wide kernel splits K
+    into eighths, the 8-unit kernel into quarters: ~1e-7 on the config-2 logits; greedy transcripts equal,
+    ``tests/test_gpu_pipeline.py``); it is bit-identical to calling ``model`` on the merged batch.
+
+    Pairs are merged in decreasing length order (``enforce_sorted``, rnn.py:174) and need the same frame count and at most
+    64 utterances together; a batch that cannot be paired (odd one out, different frame counts) runs alone.  Like the
+    reference's ``MaskConv*`` the convolutions zero the input past each length: the callers' tensors receive that masking
+    back (a copy, only when some length is shorter than the frame count).  ``post`` / ``pre`` as in ``BatchesInFlight``."""
+
+    def __init__(self, model: torch.nn.Module, post: Optional[Callable] = None, pre: Optional[Callable] = None, max_rows: int = 64):
+        _lib.require_gpu()
+        self.model, self.post, self.pre, self.max_rows = model, post, pre, max_rows
+
+    def _finish(self, out):
+        return out if self.post is None else self.post(out)
+
+    def __call__(self, batches: Sequence) -> List:
+        results: List = [None] * len(batches)
+        k = 0
+        with torch.no_grad():
+            while k < len(batches):
+                (xa, la) = batches[k]
+                pair = None
+                if k + 1 < len(batches):
+                    (xb, lb) = batches[k + 1]
+                    if xa.shape[1:] == xb.shape[1:] and xa.shape[0] + xb.shape[0] <= self.max_rows and xa.dtype == xb.dtype:
+                        pair = (xb, lb)
+                if pair is None:
+                    if self.pre is not None:
+                        self.pre(k)
+                    results[k] = self._finish(self.model((xa, la)))
+                    k += 1
+                    continue
+                xb, lb = pair
+                ha, hb = _lib.host_lens(la), _lib.host_lens(lb)
+                na = int(ha.numel())
+                both = torch.cat([ha, hb])
+                order = torch.sort(both, descending=True, stable=True).indices          # merged position -> source row
+                where = torch.empty_like(order)
+                where[order] = torch.arange(order.numel())                               # source row -> merged position
+                dev = xa.device if xa.is_cuda else torch.device("cuda")
+                order_d = order.to(dev)
+                x = torch.cat([xa.to(dev), xb.to(dev)]).index_select(0, order_d)
+                lens = both[order].to(la.dtype)
+                if self.pre is not None:
+                    self.pre(k)
+                    self.pre(k + 1)
+                (y, out_lens), hid = self.model((x, lens))
+                if bool((both < xa.shape[-1]).any()):                                    # the reference masks its input in place
+                    back = x.index_select(0, where.to(dev))
+                    if xa.is_cuda:
+                        xa.copy_(back[:na])
+                    if xb.is_cuda:
+                        xb.copy_(back[na:])
+                out_host = _lib.host_lens(out_lens)
+                for b, (lo, hi) in enumerate(((0, na), (na, both.numel()))):
+                    pos = where[lo:hi]
+                    pos_d = pos.to(dev)
+                    lens_b = out_host[pos].to(out_lens.dtype)
+                    lens_b = _lib.attach_host(_lib.upload(lens_b), lens_b) if out_lens.is_cuda else lens_b
+                    if isinstance(hid, tuple):
+                        hid_b = tuple(h.index_select(1, pos_d) for h in hid)
+                    else:
+                        hid_b = None if hid is None else hid.index_select(1, pos_d)
+                    results[k + b] = self._finish(((y.index_select(1, pos_d), lens_b), hid_b))
+                k += 2
+        return results

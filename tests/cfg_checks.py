@@ -49,6 +49,44 @@ def cfg2_full(atol: float = 1e-3) -> float:
     return err
 
 
+def paired_full(atol: float = 1e-3) -> float:
+    """``PairedBatches`` at full size: the golden config-2 batch AND a second seeded batch in one forward of 64 (the two
+    32-row groups side by side in the wide-workgroup recurrence).  The golden batch's logits / states / transcripts against
+    the reference's summary exactly as in ``cfg2_full``; the other batch against the one-batch path."""
+    import bench
+    from myrtlespeech_amd.pipeline import PairedBatches
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    g = Golden("ds2_cfg2_summary")
+    model = bench.build_model()
+    gen = torch.Generator().manual_seed(g.cfg["seed_input"])
+    N, Tn = g.cfg["N"], g.cfg["T"]
+    x = torch.randn(N, 1, 80, Tn, generator=gen)
+    lens = torch.sort(torch.randint(501, 1002, (N,), generator=gen), descending=True).values
+    lens[0] = Tn
+    np.testing.assert_array_equal(lens.numpy(), g["in/lens"])
+    gen2 = torch.Generator().manual_seed(99)
+    x2 = torch.randn(N, 1, 80, Tn, generator=gen2)
+    lens2 = torch.sort(torch.randint(501, 1002, (N,), generator=gen2), descending=True).values
+    dec = CTCGreedyDecoder(28)
+    (y2w, ol2w), _ = model((x2.clone().cuda(), lens2))
+    want2 = dec(y2w, ol2w)
+    got = PairedBatches(model)([(x2.cuda(), lens2), (x.cuda(), lens)])
+    (y2, ol2), _ = got[0]
+    ((y, ol), (hn, cn)) = got[1]
+    np.testing.assert_array_equal(ol.cpu().numpy(), g["out/lens"])
+    y_sub = y[::25, ::4, :].cpu().numpy()
+    np.testing.assert_allclose(y_sub, g["out/y_sub"], rtol=0, atol=atol)
+    np.testing.assert_allclose(hn[:, ::8, ::64].cpu().numpy(), g["out/hn_sub"], rtol=0, atol=atol)
+    np.testing.assert_allclose(cn[:, ::8, ::64].cpu().numpy(), g["out/cn_sub"], rtol=0, atol=atol)
+    assert dec(y, ol) == unragged(g["out/greedy_flat"], g["out/greedy_lens"])
+    assert dec(y2, ol2) == want2
+    torch.testing.assert_close(y2, y2w, rtol=0, atol=1e-5)
+    err = float(np.abs(y_sub - g["out/y_sub"]).max())
+    print(f"cfg2 full-size through PairedBatches (wide-workgroup recurrence): max |logit err| on the sub-grid {err:.3e}; "
+          f"other batch vs the one-batch path max |diff| {float((y2 - y2w).abs().max()):.3e}")
+    return err
+
+
 def pipeline_full_equal(n_batches: int = 4) -> None:
     """``TwoBatchesInFlight`` on full-size config-2 batches in THIS process's precision mode: logits, lengths, final
     states and greedy transcripts ``torch.equal`` to the same batches run one after the other on one stream."""

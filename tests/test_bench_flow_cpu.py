@@ -148,6 +148,19 @@ class _CpuRuntime:
     def pipe(self, model, post, pre):
         return _Pipe(model, post, pre, self.log)
 
+    def paired(self, model, post, pre):
+        log = self.log
+
+        class _Paired:
+            def __call__(self, batches):
+                log.append(("paired", len(batches)))
+                out = []
+                for k, b in enumerate(batches):
+                    pre(k)
+                    out.append(post(model(b)))
+                return out
+        return _Paired()
+
     def check_status(self, models):
         self.log.append(("check_status", len(models)))
 
@@ -192,11 +205,13 @@ def test_bench_control_flow_two_ranks_per_shard_decode(tmp_path):
     assert out["config"]["global_batch"] == 64 and out["config"]["parallelism"] == "utterance-shard x2"
     assert "cpu_baseline" not in out and "precision_f32" not in out          # N = 1 only
     assert out["two_batches_in_flight"]["ms_per_step"] > 0 and out["one_batch_in_flight"]["ms_per_step"] > 0
+    assert out["two_batches_per_forward"]["ms_per_step"] > 0
     assert set(out["one_batch_in_flight"]["stage_ms"]) == {"conv", "layout", "projection", "recurrence", "linear", "greedy", "other"}
     assert out["ragged_lengths"]["steps"] >= 6
     for rank, log in enumerate(logs):
         kinds = [e[0] for e in log]
         assert kinds.count("pipe") >= 2                    # warm-up + timed leg of the pipeline (+ ragged)
+        assert kinds.count("paired") >= 2                  # the same for the two-batches-per-forward mode
         assert ["check_status", 2] in log and ["check_status", 1] in log
         shapes = {tuple(e[1]) for e in log if e[0] == "decode"}
         assert shapes == {(T_RANK[rank], N_RANK[rank], V)}  # per-shard decode: no collective on the data path
@@ -206,9 +221,9 @@ def test_bench_control_flow_two_ranks_gather_logits_unequal_shards(tmp_path):
     out, logs = _run(tmp_path, ["--gather-logits"])
     assert out["n_gpus"] == 2 and out["config"]["in_flight"] == 1
     assert out["config"]["decode"].startswith("all-gather logits")
-    assert "two_batches_in_flight" not in out
+    assert "two_batches_in_flight" not in out and "two_batches_per_forward" not in out
     for log in logs:
-        assert not any(e[0] == "pipe" for e in log)
+        assert not any(e[0] in ("pipe", "paired") for e in log)
         dec = [e for e in log if e[0] == "decode"]
         assert dec and all(tuple(e[1]) == (max(T_RANK), sum(N_RANK), V) for e in dec)
         # lengths of the whole batch, shards in rank order

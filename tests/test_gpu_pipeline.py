@@ -190,3 +190,53 @@ def test_split_gemm_scratch_is_pruned_when_streams_come_and_go():
     torch.cuda.synchronize()
     assert len(F._split_ws) <= F._SPLIT_WS_STREAMS
     assert all(torch.equal(o, want) for o in outs)
+
+
+def test_paired_batches_equal_the_merged_forward_and_match_the_one_batch_path():
+    """``PairedBatches`` (round 3): two batches per forward.  Bit-identical to ``model`` on the merged, length-sorted batch (it
+    is that call); equal to the one-batch path within float32 rounding, greedy transcripts equal; ragged lengths (the merge
+    permutes utterances), an odd batch count, a batch with another frame count (runs alone), the in-place masking of the
+    callers' inputs."""
+    from myrtlespeech_amd.pipeline import PairedBatches
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    model = _small_ds2(256)
+    dec = CTCGreedyDecoder(28)
+    batches = _batches(5, 12, 90, 40, 31)
+    other = _batches(1, 6, 70, 40, 32)[0]                   # 70 frames: cannot be paired with a 90-frame batch
+    batches.insert(2, other)
+    want = []
+    for x, lens in batches:
+        xc = x.clone()
+        (y, ol), (hn, cn) = model((xc, lens))
+        want.append((y, ol, hn, cn, dec(y, ol), xc))
+    ins = [(x.clone(), lens) for x, lens in batches]
+    pipe = PairedBatches(model, post=lambda out: (out, dec.launch(out[0][0], out[0][1])))
+    got = pipe(ins)
+    assert len(got) == len(batches)
+    for k, ((((y, ol), (hn, cn)), pending), (wy, wol, whn, wcn, wdec, wx)) in enumerate(zip(got, want)):
+        assert y.shape == wy.shape and torch.equal(ol.cpu(), wol.cpu()), k
+        torch.testing.assert_close(y, wy, rtol=0, atol=2e-5)
+        torch.testing.assert_close(hn, whn, rtol=0, atol=2e-5)
+        torch.testing.assert_close(cn, wcn, rtol=0, atol=2e-5)
+        assert pending.result() == wdec, k
+        assert torch.equal(ins[k][0], wx), f"batch {k}: the caller's input was not masked like the reference masks it"
+    # batches 2 (other frame count) ran alone, 0+1 and 3+4 were paired, 5 is the odd one out: those equal the one-batch bits
+    for k in (2, 5):
+        assert torch.equal(got[k][0][0][0], want[k][0])
+    # a pair IS the merged forward
+    (xa, la), (xb, lb) = batches[0], batches[1]
+    both = torch.cat([la, lb])
+    order = torch.sort(both, descending=True, stable=True).indices
+    (ym, olm), _ = model((torch.cat([xa, xb]).index_select(0, order.cuda()).clone(), both[order]))
+    where = torch.empty_like(order)
+    where[order] = torch.arange(order.numel())
+    assert torch.equal(got[0][0][0][0], ym.index_select(1, where[:12].cuda()))
+    assert torch.equal(got[1][0][0][0], ym.index_select(1, where[12:].cuda()))
+
+
+def test_paired_batches_full_size_network_uses_the_wide_kernel_and_matches_the_reference():
+    """configs[1] twice per forward: every batch against the reference's own outputs (golden summary) within the
+    north-star's 1e-3, transcripts bit-exact -- through ``lstm_persistent_wide2_kernel`` (two 32-row groups per launch)."""
+    import cfg_checks
+    err = cfg_checks.paired_full(atol=1e-3)
+    assert err < 1e-5

@@ -19,6 +19,18 @@ pass p1 FETCH_SIZE || exit 1
 pass p2 WRITE_SIZE || exit 1
 pass p3 TCC_HIT_sum TCC_MISS_sum || exit 1
 pass p4 SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY || exit 1
+# the two-batches-per-forward mode (pipeline.PairedBatches): the wide-workgroup recurrence and the 64-utterance GEMMs
+passw() {
+  local name=$1; shift
+  echo "[pmc_bench] pass $name: $*"
+  PROBE_STEPS=2 timeout -k 10 240 rocprofv3 --pmc "$@" -d $OUT/$name -o $name --output-format csv -- python3 $ROOT/tools/n64_probe.py > $OUT.$name.log 2>&1 || { echo "[pmc_bench] pass $name failed or timed out"; tail -5 $OUT.$name.log; return 1; }
+}
+if [ "$PREC" == "bf16x3" ]; then
+  passw w1 FETCH_SIZE || exit 1
+  passw w2 WRITE_SIZE || exit 1
+  passw w3 TCC_HIT_sum TCC_MISS_sum || exit 1
+  passw w4 SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY || exit 1
+fi
 python3 $ROOT/tools/pmc_bench_summary.py $OUT $PREC > $ROOT/gpurun_out/pmc_bench_$TAG.json || exit 1
 find $OUT -name "*.csv" -size +1M -delete
 cat $ROOT/gpurun_out/pmc_bench_$TAG.json
