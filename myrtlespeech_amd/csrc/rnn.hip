@@ -502,6 +502,7 @@ struct LstmP {
   unsigned long long* dbg;  // [ndir*J][8] stamp sums (diagnostic build only)
   int steps, N, n_base, N_total, H, ndir, J, NPAD;
   int poll_sleep;  // s_sleep(1) repetitions between polls of the exchange buffer
+  int xcd_map;     // wide kernel: (group, direction) -> XCD pair (two groups, two directions, J / 2 = 64)
   int ring_shift;  // two-stream kernel: log2 of the number of exchange slots per (stream, plane) (1 = two slots)
   // two-stream kernel: when set, the layer output goes out as the NEXT layer's GEMM operand planes [T*N][ndir*H] (bf16
   // hi / lo, or one fp16 plane) instead of float32 `out` -- same bytes, and the separate plane-split pass disappears
@@ -1326,9 +1327,17 @@ __global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p) 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
   const int JJ = p.J / 2;                                  // workgroups per direction and group
-  const int grp = blockIdx.x / (p.ndir * JJ);
+  int grp = blockIdx.x / (p.ndir * JJ);
   const int rem = blockIdx.x % (p.ndir * JJ);
-  const int d = rem / JJ, jj = rem % JJ;
+  int d = rem / JJ, jj = rem % JJ;
+  if (p.xcd_map) {
+    // experiment (MS_LSTM_WIDE_XCD=1; slower, see the launch site): two groups x two directions, each (group, direction) on
+    // its own pair of XCDs (workgroups are dealt round-robin over the 8 XCDs -- observed, only speed depends on it)
+    const int xcd = blockIdx.x & 7;
+    grp = xcd >> 2;
+    d = (xcd >> 1) & 1;
+    jj = (blockIdx.x >> 3) * 2 + (xcd & 1);
+  }
   const int n_base = p.n_base + 32 * grp;
   const int N = min(32, p.N - 32 * grp);                   // rows of this group (the host launches only groups with rows)
   // cell threads: waves 0-3; unit block b (0 / 1), batch row nl, unit u of the block
@@ -2371,6 +2380,12 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
         const size_t words_per_dir = (size_t)32 * H << rs;
         p.ring_shift = rs;
         p.N = N;                       // the kernel cuts it into groups of 32 rows
+        {
+          // measured SLOWER (2.2 against 1.9 .. 2.06 ms per layer, profiles/r03y_*): with one h vector per XCD all 32 CUs of
+          // the XCD ask the same L2 channels for the same lines at the same time; four vectors per XCD spread the requests
+          static const bool on = getenv("MS_LSTM_WIDE_XCD") && getenv("MS_LSTM_WIDE_XCD")[0] == '1';
+          p.xcd_map = (on && groups == 2 && ndir == 2 && p.J == 128) ? 1 : 0;
+        }
         for (int g = 0; g < groups; ++g) {
           hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir)), dim3(256), 0, stream,
                              (unsigned*)(ws + W.hx) + (size_t)g * ndir * words_per_dir, words_per_dir, (size_t)8 * H, ndir, steps, rs,
