@@ -1318,11 +1318,13 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
 constexpr int WIDE_RED_STRIDE = 72;                        // floats per reduction row: 64 gate columns + 8 (bank spread)
 constexpr int WIDE_RED2 = 8 * 16 * WIDE_RED_STRIDE;        // 8 waves x 16 rows, per stream
 
-template <bool HARD>
-__global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p) {
-  constexpr int H = 1024, KG = H / 8, KS = 4;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* red = smem;  // [stream][8 waves][16 rows][WIDE_RED_STRIDE]
+// One wave's part: KS k-steps starting at k-step k0 of the workgroup's 32; CELL: the wave also applies the cell (waves 0-3).
+// Uneven shares (waves 0-3 take KSC k-steps each, waves 4-7 the other 8 - KSC): the cell waves spend ~0.5 us of every
+// stream-step on the cell and the publish before they request their own operands, waves 4-7 go straight from the barrier
+// to the next request and share the SIMDs' matrix pipes with them.
+template <int KS, bool CELL, bool HARD>
+__device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int k0) {
+  constexpr int H = 1024, KG = H / 8;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
@@ -1344,7 +1346,6 @@ __global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p) 
   const int cb = (tid >> 7) & 1, nl = (tid >> 3) & 15, u = tid & 7;
   const int jb = 2 * jj + cb;                              // 8-unit block of this cell thread
   const int unit = 8 * jb + u;
-  const bool cellw = wave < 4;
 
   // this wave's share of W_hh: its K-eighth x 64 gate rows (two blocks x two column tiles), hi and lo planes, 128 VGPRs
   u32x4 wh[2][2][KS], wl[2][2][KS];
@@ -1353,7 +1354,7 @@ __global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p) 
     const char* wsrc = reinterpret_cast<const char*>(p.whh) + ((size_t)d * p.J + 2 * jj + b) * 128 * H;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const int kg = 4 * (KS * wave + ks) + q;
+      const int kg = 4 * (k0 + ks) + q;
       const char* wp = wsrc + (kg * 32 + c16) * 16;
       wh[b][0][ks] = *reinterpret_cast<const u32x4*>(wp);
       wh[b][1][ks] = *reinterpret_cast<const u32x4*>(wp + 256);
@@ -1370,7 +1371,7 @@ __global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p) 
 
   float c[2] = {0.f, 0.f}, h[2] = {0.f, 0.f};
   int len_n[2] = {0, 0};
-  if (cellw) {
+  if (CELL) {
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg) {
       const int n = sg * 16 + nl;
@@ -1399,14 +1400,14 @@ __global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p) 
     for (int sg = 0; sg < 2; ++sg) {
       float xg[4] = {0.f, 0.f, 0.f, 0.f};
       const int n = sg * 16 + nl;
-      if (cellw && n < N) {
+      if (CELL && n < N) {
         const float* xp = p.xproj + ((size_t)t * p.N_total + n_base + n) * xcols + d * 4 * H + jb * 32 + u;
 #pragma unroll
         for (int g = 0; g < 4; ++g) xg[g] = xp[g * 8];
       }
 
       // ---- h_{t-1} of this stream: the 4 k-steps of the wave's K-eighth, hi and lo (8 loads of 1 KB)
-      const int base = sg * STREAM + par * KG * 256 + KS * wave * 1024;
+      const int base = sg * STREAM + par * KG * 256 + k0 * 1024;
       u32x4 ah[KS], al[KS];
       const unsigned long long t_wait0 = wall_clock64();
       unsigned spins = 0;
@@ -1472,7 +1473,7 @@ __global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p) 
 #pragma unroll
           for (int i = 0; i < 4; ++i) redb[(wave * 16 + 4 * q + i) * WIDE_RED_STRIDE + b * 32 + ct * 16 + c16] = acc[b][ct][i];
       __syncthreads();
-      if (cellw) {
+      if (CELL) {
         float gsum[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1508,7 +1509,7 @@ __global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p) 
       }
     }
   }
-  if (cellw) {
+  if (CELL) {
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg) {
       const int n = sg * 16 + nl;
@@ -1519,6 +1520,15 @@ __global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p) 
       }
     }
   }
+}
+
+template <bool HARD, int KSC>
+__global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p) {
+  static_assert(KSC >= 1 && KSC <= 7, "both wave sets need at least one k-step");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave < 4) wide2_wave<KSC, true, HARD>(p, smem, wave * KSC);
+  else wide2_wave<8 - KSC, false, HARD>(p, smem, 4 * KSC + (wave - 4) * (8 - KSC));
 }
 
 
@@ -2186,13 +2196,23 @@ static int launch_wide2(const LstmP& p, bool hard, int groups, hipStream_t strea
   const size_t lds = (size_t)2 * WIDE_RED2 * sizeof(float);
   static ms::DeviceOnce attr_once;
   if (attr_once.need()) {
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_once.done();
   }
   const dim3 grid(groups * p.ndir * (p.J / 2));
-  if (hard) hipLaunchKernelGGL(lstm_persistent_wide2_kernel<true>, grid, dim3(512), lds, stream, p);
-  else hipLaunchKernelGGL(lstm_persistent_wide2_kernel<false>, grid, dim3(512), lds, stream, p);
+  // k-steps per cell wave: 3 (waves 4-7: 5) measured 1.96 ms per layer of two batches against 2.11 for equal eighths and
+  // 3.1 for 2 / 6, which spills (profiles/r03z_*); MS_LSTM_WIDE_KSC=4 keeps the equal split for A/B runs
+  static const int ksc = getenv("MS_LSTM_WIDE_KSC") ? atoi(getenv("MS_LSTM_WIDE_KSC")) : 3;
+  if (hard) {
+    if (ksc == 4) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 4>), grid, dim3(512), lds, stream, p);
+    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 3>), grid, dim3(512), lds, stream, p);
+  } else {
+    if (ksc == 4) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 4>), grid, dim3(512), lds, stream, p);
+    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3>), grid, dim3(512), lds, stream, p);
+  }
   MS_LAUNCH_CHECK();
   return MS_OK;
 }
@@ -2212,8 +2232,8 @@ bool use_wide(int cell, int H, int ndir, int N) {
   if (v == 0) {
     int nb = 0;
     const size_t lds = (size_t)2 * WIDE_RED2 * sizeof(float);
-    const bool fits = hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)lstm_persistent_wide2_kernel<false>, 512, lds) == hipSuccess &&
+    const bool fits = hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)lstm_persistent_wide2_kernel<false, 3>, 512, lds) == hipSuccess &&
                       nb >= 1 && ms::num_cus() >= 2 * ndir * (H / 16);
     v = fits ? 1 : 2;
     ok[dev & 63].store(v, std::memory_order_relaxed);

@@ -179,6 +179,46 @@ def test_hard_lstm_persistent_vs_oracle():
     np.testing.assert_allclose(cpu(cn), wcn, **TOL)
 
 
+@pytest.mark.parametrize("hard,bidir,N", [(False, True, 40), (False, False, 64), (True, True, 37), (False, True, 33)])
+def test_wide_workgroup_lstm_two_groups_vs_oracle(hard, bidir, N):
+    """``lstm_persistent_wide2_kernel`` (round 3; H = 1024, 33 .. 64 sequences = two batch groups side by side in one launch):
+    ragged lengths that end inside both groups, a second group that is not full, both cells, one and two directions, an
+    initial state -- against the numpy oracle, and utterance by utterance against the 8-unit kernel (the same rows as two
+    calls of <= 32 sequences) within float32 rounding."""
+    from myrtlespeech_amd.model.hard_lstm import HardLSTM
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    H, In, steps = 1024, 32, 9
+    torch.manual_seed(N)
+    if hard:
+        m = HardLSTM(In, H, num_layers=1, bidirectional=bidir, forget_gate_bias=1.0).eval()
+    else:
+        m = RNN(RNNType.LSTM, In, H, num_layers=1, bidirectional=bidir, forget_gate_bias=1.0).eval()
+    rng = np.random.default_rng(N)
+    x = rng.normal(size=(steps, N, In)).astype(np.float32)
+    lens = np.sort(rng.integers(1, steps + 1, size=N))[::-1].copy()
+    lens[0] = steps
+    D = 2 if bidir else 1
+    h0 = (rng.normal(size=(D, N, H)) * 0.3).astype(np.float32)
+    c0 = (rng.normal(size=(D, N, H)) * 0.3).astype(np.float32)
+    hx = None if hard else (T(h0).cuda(), T(c0).cuda())
+    (out, _), (hn, cn) = m((T(x), T(lens)), hx=hx) if not hard else m((T(x), T(lens)))
+    sd = {k[len("rnn."):]: cpu(v) for k, v in m.state_dict().items()}
+    if hard:
+        want, (whn, wcn) = O.hard_lstm_forward(x, sd, H, 1, bidir)
+    else:
+        want, (whn, wcn) = O.rnn_forward(O.LSTM, x, lens, sd, H, 1, bidir, hx=(h0, c0))
+    np.testing.assert_allclose(cpu(out), want, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(cpu(hn), whn, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(cpu(cn), wcn, rtol=1e-4, atol=2e-5)
+    if not hard:
+        # the same utterances through the 8-unit kernel (two calls of <= 32 sequences)
+        for lo, hi in ((0, 32), (32, N)):
+            hx_part = (T(h0[:, lo:hi]).cuda().contiguous(), T(c0[:, lo:hi]).cuda().contiguous())
+            (o2, _), (hn2, cn2) = m((T(x[:int(lens[lo]), lo:hi]).contiguous(), T(lens[lo:hi])), hx=hx_part)
+            torch.testing.assert_close(out[:int(lens[lo]), lo:hi], o2, rtol=0, atol=2e-6)
+            torch.testing.assert_close(cn[:, lo:hi], cn2, rtol=0, atol=2e-6)
+
+
 # ----------------------------------------------------------------------------- conv
 @pytest.mark.parametrize("name", golden_names("conv2d_"))
 def test_conv2d_golden(name):
