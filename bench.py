@@ -217,7 +217,7 @@ def f32_child(args):
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
-        keep = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "one_batch_in_flight", "two_batches_in_flight",
+        keep = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "one_batch_in_flight", "two_batches_in_flight", "two_batches_per_forward",
                 "latency_ms_per_batch", "encoder_ms", "decode_ms", "kernel_ms",
                 "roofline", "projection_gemm", "ragged_lengths")
         return {k: d[k] for k in keep if k in d}
