@@ -581,6 +581,11 @@ def main(argv=None, runtime=None, json_fd=None):
                     if mode == "f32" else
                     "gemm_nt_bf16x3_kernel4n: 256 x 128 tiles, one wave per SIMD, resident beside the recurrence of the other "
                     "batch; its duration under that co-tenant")
+            if pair is not None and pair["per_launch"]["gemm_k_large"] > 0:
+                pg = pair["per_launch"]["gemm_k_large"]          # one launch over the 64 utterances of a pair: M = 32 064
+                gemm["two_batches_per_forward"] = {"launch_ms": round(pg, 4), "M": 2 * M,
+                                                   "achieved": round(2 * flop / (pg * 1e-3) / 1e12, 1),
+                                                   "frac": round(2 * flop / (pg * 1e-3) / 1e12 / mfma_peak, 4)}
             grec, gwhy = pmc_record(gname + "@K2048")
             if grec is not None:
                 gemm["traffic"] = int(grec["hbm_bytes"])
