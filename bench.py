@@ -510,20 +510,23 @@ def main(argv=None, runtime=None, json_fd=None):
         # ---- dominant kernel: the persistent recurrence (one launch = one layer, both directions, 501 steps)
         launch_bytes = T_OUT * 2 * LSTM_STEP_BYTES
         achieved = launch_bytes / (rec_ms * 1e-3) / 1e9 if rec_ms > 0 else 0.0
+        wide = mode == "bf16x3" and os.environ.get("MS_LSTM_WIDE") != "0"
         kname = {"f32": "lstm_persistent_kernel" if os.environ.get("MS_LSTM_F32_ONE_STREAM") == "1"
-                 else "lstm_persistent_f32x2_kernel"}.get(mode, "lstm_persistent_split2_kernel")
+                 else "lstm_persistent_f32x2_kernel"}.get(mode, "lstm_persistent_wide2_kernel" if wide else "lstm_persistent_split2_kernel")
+        pmc_key = kname + ("@1group" if wide else "")
         mfma_peak = MFMA_F32_PEAK_TF if mode == "f32" else MFMA_BF16_PEAK_TF
         roof = {"bound": "hbm",   # the north-star's roofline for the LSTM step; what physically binds: next key
-                "what_binds": "L2 delivery in series with the step's arithmetic: every step each of the 256 workgroups publishes its 8 "
-                         "units of h and pulls the whole h of its direction (128 KB) out of its XCD's L2 -- 32 MB per step chip-wide "
-                         "at the ~18 TB/s the eight L2s deliver to CUs that all pull at once = 1.8 us of the ~3.5 us step, during "
-                         "which the CU computes nothing (in-kernel stamps: no request is ever repeated, the wait is the load); "
-                         "neither HBM nor MFMA",
-                "kernel": kname + " (one launch = 1 layer x 2 directions x 501 steps)",
+                "what_binds": "L2 delivery in series with the step's arithmetic: every step each workgroup publishes its hidden "
+                              "units of h and pulls the whole h of its direction (64 KB per stream-step of 16 rows) out of its XCD's "
+                              "L2, during which it computes nothing (in-kernel stamps of the 8-unit kernel: no request is ever "
+                              "repeated, the wait is the load); 16 units per workgroup halve those bytes per unit of arithmetic and "
+                              "leave half of the CUs to a second batch (two_batches_per_forward) or to the other batch's projection "
+                              "GEMM (two_batches_in_flight); neither HBM nor MFMA",
+                "kernel": kname + (" (one launch = 1 layer x 2 directions x 501 steps of one batch: 128 workgroups of 16 hidden units on "
+                                   "half of the CUs)" if wide else " (one launch = 1 layer x 2 directions x 501 steps)"),
                 "launch_ms": round(rec_ms, 4),
                 "launch_ms_source": "HIP events on the launch stream, mean over the timed steps of the one-batch-in-flight leg "
-                                    "(the kernel alone on the device; under the two-in-flight pipeline it shares every CU "
-                                    "with the other batch's projection GEMM and stretches by ~45 %, by design)",
+                                    "(the kernel alone on the device)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_frac": round(achieved / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_launch": launch_bytes,
@@ -540,7 +543,7 @@ def main(argv=None, runtime=None, json_fd=None):
                 "kernel": "lstm_persistent_wide2_kernel (16 hidden units per workgroup, two 32-row batch groups side by side)",
                 "launch_ms": round(pr, 4), "algorithmic_bytes_per_launch": 2 * launch_bytes,
                 "achieved": round(2 * launch_bytes / (pr * 1e-3) / 1e9, 1), "frac": round(2 * launch_bytes / (pr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            wrec, wwhy = pmc_record("lstm_persistent_wide2_kernel")
+            wrec, wwhy = pmc_record("lstm_persistent_wide2_kernel@2groups")
             if wrec is not None:
                 roof["two_batches_per_forward"].update({
                     "traffic": int(wrec["hbm_bytes"]),
@@ -549,7 +552,7 @@ def main(argv=None, runtime=None, json_fd=None):
                     "mfma_busy_frac_pmc": wrec.get("mfma_busy_frac"), "l2_hit_rate_pmc": wrec.get("l2_hit_rate")})
             else:
                 roof["two_batches_per_forward"]["pmc_note"] = wwhy
-        rec, why = pmc_record(kname)
+        rec, why = pmc_record(pmc_key)
         if rec is not None and rec_ms > 0:
             roof["traffic"] = int(rec["hbm_bytes"])
             roof["hbm_frac_measured"] = round(rec["hbm_bytes"] / (rec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

@@ -200,6 +200,11 @@ int ms_rnn_layer_forward_ex(int cell, const void* packed, const float* x, const 
  * sticky across layer calls -- one check after a whole stack of layers is enough --
  * and lives in the first 256 bytes of the workspace, which must therefore be ZERO
  * when a freshly allocated workspace is used for the first time. */
+/* 1 when a recurrent layer of this kind and batch size runs as the wide-workgroup persistent LSTM kernel, which occupies
+ * at most half of the CUs per batch group of 32 rows (H = 1024, split-bf16 operands, up to 64 sequences): the two-in-flight
+ * pipeline then runs the OTHER batch's projection as the regular GEMM on the free CUs instead of the co-tenant form. */
+int ms_rnn_layer_is_wide(int cell, int H, int ndir, int N);
+
 int ms_rnn_status(const void* workspace, void* stream);
 
 /* Diagnostic: byte offset inside the RNN workspace of the per-workgroup stamp sums

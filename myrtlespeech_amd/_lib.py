@@ -56,6 +56,7 @@ SIGNATURES = {
     "ms_rnn_layer_forward": (c_int, [c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P] + [c_int] * 5 + [_P, c_size_t, _P]),
     "ms_rnn_layer_forward_ex": (c_int, [c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P] + [c_int] * 6 + [_P, c_size_t, _P]),
     "ms_rnn_layer_chains_planes": (c_int, [c_int, c_int, c_int]),
+    "ms_rnn_layer_is_wide": (c_int, [c_int] * 4),
     "ms_rnn_status": (c_int, [_P, _P]),
     "ms_rnn_debug_offset": (c_size_t, [c_int] * 6),
     "ms_gemm_set_variant": (c_int, [c_int]),

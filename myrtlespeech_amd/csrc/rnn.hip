@@ -2217,13 +2217,15 @@ static int launch_wide2(const LstmP& p, bool hard, int groups, hipStream_t strea
   return MS_OK;
 }
 
-// The wide-workgroup kernel serves H = 1024 bf16x3 layers of 33 .. 64 sequences (two batch groups side by side: 2.1 ms per
-// layer against 3.5 ms for two launches of the 8-unit kernel, profiles/r03w_*).  A single group of <= 32 rows stays on the
-// 8-unit kernel, which is 8 % faster there (256 workgroups share the arithmetic).  MS_LSTM_WIDE=0 switches it off,
-// MS_LSTM_WIDE=1 also sends single groups to it (A/B runs).
+// The wide-workgroup kernel serves H = 1024 bf16x3 layers of up to 64 sequences: one batch group of <= 32 rows on 128
+// workgroups (1.70 ms per layer against 1.74 for the 8-unit kernel on 256, and HALF of the CUs stay free -- for the other
+// batch's projection GEMM when two batches are in flight, pipeline.py), two groups side by side on 256 (1.96 ms against
+// 3.5 ms for two launches; profiles/r03w_*, r03ad_*).  Every utterance goes through the same arithmetic whichever group it
+// is in, so one batch at a time, two batches in flight and two batches per forward give the same bits.  MS_LSTM_WIDE=0
+// switches it off (the 8-unit kernel everywhere; A/B runs).
 bool use_wide(int cell, int H, int ndir, int N) {
-  static const int mode = getenv("MS_LSTM_WIDE") ? atoi(getenv("MS_LSTM_WIDE")) : -1;    // -1: default
-  if (mode == 0 || (mode != 1 && N <= 32)) return false;
+  static const int mode = getenv("MS_LSTM_WIDE") ? atoi(getenv("MS_LSTM_WIDE")) : -1;    // -1: default (on)
+  if (mode == 0) return false;
   if (H != 1024 || N > 64 || !use_split(cell, H, ndir) || ms::precision_mode() != ms::PREC_BF16X3) return false;
   static std::atomic<int> ok[64];     // per device: 0 = not asked, 1 = fits, 2 = does not
   int dev = 0;
@@ -2285,6 +2287,11 @@ extern "C" int ms_rnn_layer_chains_planes(int cell, int H, int ndir) {
   if (use_gru_persistent(cell, H, ndir)) return use_split_gemm(cell, H, ndir, ndir * H) ? 1 : 0;
   return use_split(cell, H, ndir) && two_stream_shape(H) && use_split_gemm(cell, H, ndir, ndir * H) &&
          !(getenv("MS_LSTM_ONE_STREAM") && getenv("MS_LSTM_ONE_STREAM")[0] == '1') ? 1 : 0;
+}
+
+extern "C" int ms_rnn_layer_is_wide(int cell, int H, int ndir, int N) {
+  if (cell < 0 || cell > MS_CELL_HARD_LSTM || H <= 0 || ndir < 1 || ndir > 2 || N <= 0) return 0;
+  return use_fast(cell, H, ndir) && use_wide(cell, H, ndir, N) ? 1 : 0;
 }
 
 extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x, const int32_t* lens, int max_len,

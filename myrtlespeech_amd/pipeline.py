@@ -151,7 +151,7 @@ class BatchesInFlight:
 
         prev_hook = _lib.issue_point
         _lib.issue_point = hook
-        lib.ms_gemm_set_variant(COTENANT_GEMM_VARIANT)
+        lib.ms_gemm_set_variant(self._gemm_variant(lib, batches))
         # a per-call status check of a recurrent stack synchronises its stream in the middle of the alternation: switched
         # off while the pipe runs (and put back: models[0] is the CALLER's model), the sticky time-out word is read once
         # at the end of this call instead
@@ -194,6 +194,29 @@ class BatchesInFlight:
             # synchronised here either.
             self.check_status()
         return results
+
+    def _gemm_variant(self, lib, batches) -> int:
+        """Which projection GEMM runs beside the other batch's recurrence.  Recurrent stacks that take the wide-workgroup
+        kernel (H = 1024 LSTM, split-bf16 operands: ``ms_rnn_layer_is_wide``) occupy HALF of the CUs per batch, so the regular
+        8-wave GEMM simply runs on the other half and spreads over all of them when the recurrence ends (round 3, measured
+        11.65 ms per batch against 12.86 with the co-tenant form and 13.4 with the 8-unit recurrence + co-tenant,
+        ``profiles/r03ad_*``); every other persistent recurrence fills all CUs with 304 registers per SIMD and gets the
+        4-wave co-tenant form that fits beside it."""
+        if not batches:
+            return 0
+        from myrtlespeech_amd.model.hard_lstm import HardLSTM
+        from myrtlespeech_amd.model.rnn import _CELL, RNN
+        n = int(batches[0][1].numel())
+        wide = []
+        for m in self._stacks[:self._n_caller_stacks]:
+            if isinstance(m, RNN):
+                cell, hidden = _CELL[m.rnn_type], m.rnn.hidden_size
+            elif isinstance(m, HardLSTM):
+                cell, hidden = _lib.CELL_HARD_LSTM, m.hidden_size
+            else:
+                return COTENANT_GEMM_VARIANT
+            wide.append(bool(lib.ms_rnn_layer_is_wide(int(cell), int(hidden), 2 if m.bidirectional else 1, n)))
+        return 0 if wide and all(wide) else COTENANT_GEMM_VARIANT
 
     def check_status(self):
         """Raise if a persistent recurrent launch of either replica timed out since the last check (synchronises)."""

@@ -71,6 +71,17 @@ for name, counters in rows.items():
                 kernels[name + sfx] = summarise(cs)
                 kernels[name + sfx]["mfma_flop"] = kernels[name + sfx]["counters"].get("SQ_INSTS_MFMA", 0) * MFMA_FLOP[name]
         continue
+    if name == "lstm_persistent_wide2_kernel":
+        # one launch serves one batch group (128 workgroups of 512 threads: the one-batch leg) or two side by side (256)
+        by_groups = {"@1group": defaultdict(list), "@2groups": defaultdict(list)}
+        for cname, v in counters.items():
+            for x in v:
+                by_groups["@2groups" if x[1] >= 256 * 512 else "@1group"][cname].append(x)
+        for sfx, cs in by_groups.items():
+            if cs:
+                kernels[name + sfx] = summarise(cs)
+                kernels[name + sfx]["mfma_flop"] = kernels[name + sfx]["counters"].get("SQ_INSTS_MFMA", 0) * MFMA_FLOP[name]
+        continue
     kernels[name] = summarise(counters)
     if name in MFMA_FLOP:
         kernels[name]["mfma_flop"] = kernels[name]["counters"].get("SQ_INSTS_MFMA", 0) * MFMA_FLOP[name]
