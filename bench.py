@@ -610,11 +610,10 @@ def main(argv=None, runtime=None, json_fd=None):
                        "pipeline": ("two batches per forward (myrtlespeech_amd.pipeline.PairedBatches): consecutive batches of 32 go "
                                     "through the network two at a time on one stream; the two batches' recurrences run side by side "
                                     "in one launch of the wide-workgroup kernel, every other kernel once on 64 utterances; every "
-                                    "step's full work incl. decode completes inside the timed region; per batch identical to the "
-                                    "forward of the merged batch, equal to the one-batch path within float32 rounding (1.2e-7 on "
-                                    "the logits), transcripts equal") if (pipelined and headline is paired) else
+                                    "step's full work incl. decode completes inside the timed region; outputs bit-identical to "
+                                    "the one-batch path") if (pipelined and headline is paired) else
                                    ("two batches in flight per GPU on two HIP streams (myrtlespeech_amd.pipeline.TwoBatchesInFlight): "
-                                    "the next batch's projection GEMMs run beside this batch's persistent recurrence on the same CUs; "
+                                    "this batch's wide-workgroup recurrence takes half of the CUs, the next batch's projection GEMMs the rest; "
                                     "every step's full work incl. decode completes inside the timed region; outputs "
                                     "bit-identical to the one-batch path") if pipelined else "one batch at a time",
                        "decode": "all-gather logits, batched decode on every rank" if args.gather_logits else
@@ -649,10 +648,10 @@ def main(argv=None, runtime=None, json_fd=None):
         }
         if two_in_flight is not None:
             two_in_flight["what_binds"] = (
-                "each layer slot = one batch's persistent recurrence beside the other batch's projection GEMM on the same CUs; "
-                "both are fed by the same L2 -> CU path (~70 GB/s per CU when every CU pulls) and the chip holds ~1.9 GHz under the pair (2.25 GHz under the "
-                "recurrence alone, 1.5 GHz under the GEMM alone: profiles/r03m_clock_probe.txt); board power 1.32 kW of the "
-                "1.4 kW cap against 1.08 kW one batch at a time (profiles/r03o_power_trace.txt, not measured in this run)")
+                "each layer slot = one batch's wide-workgroup recurrence on half of the CUs beside the other batch's projection "
+                "GEMM on the rest (all of them once the recurrence ends); the slot is the recurrence's ~2.1 ms (1.7 ms alone: "
+                "the GEMM shares its L2s and the chip holds a lower clock under it, profiles/r03m_clock_probe.txt), five slots "
+                "per batch plus the convolutions and output layers")
             out["two_batches_in_flight"] = two_in_flight
         if per_forward is not None:
             out["two_batches_per_forward"] = per_forward

@@ -8,9 +8,12 @@ projection runs in the shadow of batch A's recurrence and vice versa:
 * two HIP streams, one per batch; the host issues the two batches LAYER BY LAYER in turn (A1 B1 A2 B2 ...), because the
   library chains persistent launches across streams in host issue order (two recurrences must never be resident together:
   each fills every CU with workgroups that wait for their own peers, ``csrc/rnn.hip`` PersistentTurn);
-* while the pipeline runs, the projection GEMMs use the 4-wave 256 x 128 form of the LDS-DMA kernel (176 VGPRs, 128 KB of
-  LDS, ``ms_gemm_set_variant(COTENANT_GEMM_VARIANT)``), whose workgroups fit on a CU BESIDE a workgroup of the recurrence (304 VGPRs, 20 KB);
-  the shipped 8-wave form cannot share a CU with it and would only time-slice (``tools/overlap_probe.py``);
+* what runs beside a recurrence depends on its kernel (``_gemm_variant``): the wide-workgroup LSTM kernel (H = 1024, round 3)
+  occupies half of the CUs per batch, so the other batch's projection is the regular 8-wave GEMM on the free half (11.5 ms per
+  batch on the config-2 network); the 8-unit persistent kernels fill every CU with 304 registers per SIMD and get the 4-wave
+  256 x 128 form of the LDS-DMA GEMM (176 VGPRs, 128 KB of LDS, ``ms_gemm_set_variant(COTENANT_GEMM_VARIANT)``), whose
+  workgroups fit on a CU BESIDE a workgroup of the recurrence; the 8-wave form cannot share a CU with those and would only
+  time-slice (``tools/overlap_probe.py``);
 * results are bit-identical to the one-batch path (same kernels' arithmetic; ``tests/test_gpu_pipeline.py``).
 
 Measured and dropped: more than two batches in flight (depth 3: 14.2, depth 4: 15.1 ms per batch against 13.7 for depth 2), and
@@ -236,14 +239,13 @@ class PairedBatches:
     a time as ONE batch.  For the config-2 network (5 x BiLSTM-1024, batches of 32) the library then runs the two batches'
     recurrences side by side in one launch of the wide-workgroup kernel (``csrc/rnn.hip``, ``lstm_persistent_wide2_kernel``:
     16 hidden units per workgroup, so the 64 KB of ``h`` a workgroup pulls out of L2 every step feed twice the arithmetic and
-    a batch needs half the chip): 2.1 ms per layer for two batches against 1.75 ms for one, and every other kernel of the
+    a batch needs half the chip): 1.96 ms per layer for two batches against 1.70 ms for one, and every other kernel of the
     step (convolutions, projection GEMMs, output layers, greedy decode) runs once on 64 utterances.  No threads, one stream.
 
     What a caller gets per batch is what ``model`` returns for the merged batch, cut back to the batch's utterances in
-    their own order: ``((logits[T', N_b, V], lens_b), hid_b)``.  Utterances do not interact in any module, so
-    this equals the one-batch result up to the float32 rounding of the recurrence's partial sums (the wide kernel splits K
-    into eighths, the 8-unit kernel into quarters: ~1e-7 on the config-2 logits; greedy transcripts equal,
-    ``tests/test_gpu_pipeline.py``); it is bit-identical to calling ``model`` on the merged batch.
+    their own order: ``((logits[T', N_b, V], lens_b), hid_b)``.  Utterances do not interact in any module and no
+    kernel's arithmetic for an utterance depends on what it is batched with, so this is bit-identical to the one-batch
+    result (``tests/test_gpu_pipeline.py``, full size included).
 
     Pairs are merged in decreasing length order (``enforce_sorted``, rnn.py:174) and need the same frame count and at most
     64 utterances together; a batch that cannot be paired (odd one out, different frame counts) runs alone.  Like the
