@@ -155,7 +155,7 @@ WsLayout ws_layout(int cell, int T, int N, int H, int ndir, int In) {
   // two slots per (stream, plane) by default; the two-stream kernel may use a ring of 2^lstm_ring_shift() slots
   // (the float32 two-stream kernel: ndir * 2 streams * 2 slots * 16 rows * H floats = the same ndir * 256 * H bytes)
   L.hx = o;
-  L.hx_bytes = ms::align_up(((size_t)ndir * 2 * H * std::min(npad, 128) * sizeof(float)) << (lstm_ring_shift() - 1), 256);
+  L.hx_bytes = ms::align_up(((size_t)ndir * 2 * H * std::min(npad, 64) * sizeof(float)) << (lstm_ring_shift() - 1), 256);
   o += L.hx_bytes;
   L.state_h = o; o += ms::align_up((size_t)2 * ndir * N * H * sizeof(float), 256);
   L.state_c = o; o += ms::align_up((size_t)ndir * N * H * sizeof(float), 256);
@@ -842,30 +842,6 @@ __device__ __forceinline__ void publish_split(float hval, unsigned tag, __amdgpu
   }
 }
 
-// The same publish without a branch: every lane issues both stores, the seven lanes of eight that hold no granule with an
-// offset past the end of the resource (the hardware drops them).  The number of stores in flight behind an earlier load
-// is then known to the compiler, which lets a wave wait for that load alone (`s_waitcnt vmcnt(n)`, n > 0) instead of for
-// the acknowledgement of these write-through stores as well.
-constexpr int BUFFER_OOB = 0x7FFFFFF0;
-__device__ __forceinline__ void publish_split_static(float hval, unsigned tag, __amdgpu_buffer_rsrc_t rsrc, int off_hi, int off_lo,
-                                                     int lane) {
-  const unsigned hi = (bf16_bits(hval) & 0xFFFEu) | tag;
-  const unsigned lo = (bf16_bits(hval - bf16_val(hi)) & 0xFFFEu) | tag;
-  const unsigned v = hi | (lo << 16);
-  unsigned g[8];
-  g[0] = v;
-  g[1] = row_shl<1>(v); g[2] = row_shl<2>(v); g[3] = row_shl<3>(v); g[4] = row_shl<4>(v);
-  g[5] = row_shl<5>(v); g[6] = row_shl<6>(v); g[7] = row_shl<7>(v);
-  u32x4 oh, ol;
-  oh[0] = (g[0] & 0xFFFFu) | (g[1] << 16); oh[1] = (g[2] & 0xFFFFu) | (g[3] << 16);
-  oh[2] = (g[4] & 0xFFFFu) | (g[5] << 16); oh[3] = (g[6] & 0xFFFFu) | (g[7] << 16);
-  ol[0] = (g[0] >> 16) | (g[1] & 0xFFFF0000u); ol[1] = (g[2] >> 16) | (g[3] & 0xFFFF0000u);
-  ol[2] = (g[4] >> 16) | (g[5] & 0xFFFF0000u); ol[3] = (g[6] >> 16) | (g[7] & 0xFFFF0000u);
-  const bool mine = (lane & 7) == 0;
-  __builtin_amdgcn_raw_buffer_store_b128(oh, rsrc, mine ? off_hi : BUFFER_OOB, 0, /*aux: sc1*/ 16);
-  __builtin_amdgcn_raw_buffer_store_b128(ol, rsrc, mine ? off_lo : BUFFER_OOB, 0, /*aux: sc1*/ 16);
-}
-
 // NCH > 0: the wave's K-quarter is NCH chunks of 4 k-steps (K = 64 each), all held in registers;
 // NCH == 0: any H % 64 == 0, one k-step at a time.
 template <int NB, int NCH, bool HARD, bool STAMP = false>
@@ -1346,7 +1322,7 @@ constexpr int WIDE_RED2 = 8 * 16 * WIDE_RED_STRIDE;        // 8 waves x 16 rows,
 // Uneven shares (waves 0-3 take KSC k-steps each, waves 4-7 the other 8 - KSC): the cell waves spend ~0.5 us of every
 // stream-step on the cell and the publish before they request their own operands, waves 4-7 go straight from the barrier
 // to the next request and share the SIMDs' matrix pipes with them.
-template <int KS, bool CELL, bool HARD, bool STAMP = false, bool AHEAD = false, int NS = 2, int DIAG = 0>
+template <int KS, bool CELL, bool HARD, bool STAMP = false, bool KPIPE = false>
 __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int k0) {
   constexpr int H = 1024, KG = H / 8;
 
@@ -1356,7 +1332,7 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
   int grp = blockIdx.x / (p.ndir * JJ);
   const int rem = blockIdx.x % (p.ndir * JJ);
   int d = rem / JJ, jj = rem % JJ;
-  if (p.xcd_map == 1) {
+  if (p.xcd_map) {
     // experiment (MS_LSTM_WIDE_XCD=1; slower, see the launch site): two groups x two directions, each (group, direction) on
     // its own pair of XCDs (workgroups are dealt round-robin over the 8 XCDs -- observed, only speed depends on it)
     const int xcd = blockIdx.x & 7;
@@ -1364,8 +1340,8 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
     d = (xcd >> 1) & 1;
     jj = (blockIdx.x >> 3) * 2 + (xcd & 1);
   }
-  const int n_base = p.n_base + 16 * NS * grp;
-  const int N = min(16 * NS, p.N - 16 * NS * grp);         // rows of this group (the host launches only groups with rows)
+  const int n_base = p.n_base + 32 * grp;
+  const int N = min(32, p.N - 32 * grp);                   // rows of this group (the host launches only groups with rows)
   // cell threads: waves 0-3; unit block b (0 / 1), batch row nl, unit u of the block
   const int cb = (tid >> 7) & 1, nl = (tid >> 3) & 15, u = tid & 7;
   const int jb = 2 * jj + cb;                              // 8-unit block of this cell thread
@@ -1390,22 +1366,14 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
   const int rs = p.ring_shift;
   const int PLANE = (KG * 256) << rs;       // bytes: [slot][kg][16][8 bf16]
   const int STREAM = 2 * PLANE;
-  char* hx_d = reinterpret_cast<char*>(p.hx) + ((size_t)grp * p.ndir + d) * NS * STREAM;
-  const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx_d, 0, NS * STREAM, 0x00020000);
+  char* hx_d = reinterpret_cast<char*>(p.hx) + ((size_t)grp * p.ndir + d) * 2 * STREAM;
+  const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx_d, 0, 2 * STREAM, 0x00020000);
 
-  // (AHEAD: the layer's output through buffer resources, so that a row past the batch is an out-of-range offset, not a branch)
-  const size_t out_elems = (size_t)p.steps * p.N_total * p.ndir * H;
-  const __amdgpu_buffer_rsrc_t out_rsrc_a = p.out_hi ? __builtin_amdgcn_make_buffer_rsrc(p.out_hi, 0, (int)(out_elems * 2), 0x00020000)
-                                                     : __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(out_elems * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t out_rsrc_b = __builtin_amdgcn_make_buffer_rsrc(p.out_hi ? p.out_lo : (unsigned short*)p.out, 0,
-                                                                              (int)(out_elems * 2), 0x00020000);
-  float c[NS], h[NS];
-  int len_n[NS];
-#pragma unroll
-  for (int sg = 0; sg < NS; ++sg) { c[sg] = 0.f; h[sg] = 0.f; len_n[sg] = 0; }
+  float c[2] = {0.f, 0.f}, h[2] = {0.f, 0.f};
+  int len_n[2] = {0, 0};
   if (CELL) {
 #pragma unroll
-    for (int sg = 0; sg < NS; ++sg) {
+    for (int sg = 0; sg < 2; ++sg) {
       const int n = sg * 16 + nl;
       const bool valid = n < N;
       const size_t sidx = ((size_t)d * p.N_total + n_base + n) * H + unit;
@@ -1426,37 +1394,6 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
   unsigned long long st_sum[5] = {0, 0, 0, 0, 0}, st_prev = 0;
   if (STAMP) st_prev = wall_clock64();
 
-  // AHEAD: the request for a stream-step's h goes out right after the MFMAs of the stream-step before it (the registers
-  // are free from there on), i.e. BEFORE the barrier and the cell of that step instead of after them: the stamps of the
-  // plain order (profiles/r03ag_wide_stamps.txt) show no wave ever finding a stale tag and ~0.8 us per stream-step spent
-  // waiting for the answer to a request that could have been made ~0.6 us earlier.  A tag found stale is asked for again.
-  u32x4 ah[KS], al[KS];
-  auto request = [&](int sg, int par) {
-    const int base = sg * STREAM + par * KG * 256 + k0 * 1024;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      ah[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, base + ks * 1024, /*aux: sc1*/ 16);
-      if (DIAG == 1) al[ks] = ah[ks];   // TIMING EXPERIMENT ONLY (MS_LSTM_WIDE_HALF=1): wrong results
-      else al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, PLANE + base + ks * 1024, /*aux: sc1*/ 16);
-    }
-  };
-  // (the cell waves' x-projection gates travel with the request: asked for after it, they would be the youngest load in
-  // the queue when the tags are checked, and the check would wait for them)
-  float xg_n[4] = {0.f, 0.f, 0.f, 0.f};
-  auto request_x = [&](int s2, int sg2) {
-    const int n = sg2 * 16 + nl;
-    if (CELL && n < N && s2 < p.steps) {
-      const int t2 = d ? (p.steps - 1 - s2) : s2;
-      const float* xp = p.xproj + ((size_t)t2 * p.N_total + n_base + n) * (p.ndir * 4 * H) + d * 4 * H + jb * 32 + u;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) xg_n[g] = xp[g * 8];
-    }
-  };
-  if (AHEAD) {
-    request_x(0, 0);
-    request(0, epoch_clock(d, 0, p.steps, rs).par);
-  }
-
   for (int s = 0; s < p.steps; ++s) {
     const int t = d ? (p.steps - 1 - s) : s;
     const EpochClock ec = epoch_clock(d, s, p.steps, rs);
@@ -1464,65 +1401,31 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
     const unsigned em = ec.em;
     const unsigned wtag = ec.wtag;
 #pragma unroll
-    for (int sg = 0; sg < NS; ++sg) {
+    for (int sg = 0; sg < 2; ++sg) {
       float xg[4] = {0.f, 0.f, 0.f, 0.f};
       const int n = sg * 16 + nl;
-      if (AHEAD) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) xg[g] = xg_n[g];
-      } else if (CELL && n < N) {
+      if (CELL && n < N) {
         const float* xp = p.xproj + ((size_t)t * p.N_total + n_base + n) * xcols + d * 4 * H + jb * 32 + u;
 #pragma unroll
         for (int g = 0; g < 4; ++g) xg[g] = xp[g * 8];
       }
 
-      // ---- h_{t-1} of this stream: the 4 k-steps of the wave's K-eighth, hi and lo (8 loads of 1 KB)
+      // ---- h_{t-1} of this stream: the k-steps of the wave's K share, hi and lo planes (2 KS loads of 1 KB)
       const int base = sg * STREAM + par * KG * 256 + k0 * 1024;
+      u32x4 ah[KS], al[KS];
       const unsigned long long t_wait0 = wall_clock64();
       unsigned spins = 0;
-      if (!AHEAD) request(sg, par);       // first request: agent scope; the re-requests below: system scope + volatile
-      auto stale = [&]() {
-        unsigned bad = 0;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bad |= (ah[ks][e] ^ em) | (al[ks][e] ^ em);
-        return __any((bad & 0x00010001u) != 0);
-      };
-      // (AHEAD: the first check stands outside the loop, where the compiler knows how many stores were issued after the
-      // request and waits for the request alone)
-      bool first_ok = false;
-      if (AHEAD) first_ok = !alive || !stale();
-      if (!first_ok)
-      for (;;) {
-        if (!AHEAD || spins != 0) {
-          if (!alive || !stale()) break;
-        }
-        if ((++spins & 63u) == 0) {
-          const unsigned dead = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (dead != 0 || wall_clock64() - t_wait0 > SPIN_LIMIT_TICKS) {
-            if (lane == 0) flag_timeout(p.status);
-            alive = false;
-            break;
-          }
-        }
-        for (int z = 0; z < p.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          ah[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, base + ks * 1024, (int)(0x80000000u | 16u));
-          al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, PLANE + base + ks * 1024, (int)(0x80000000u | 16u));
-        }
+      for (int ks = 0; ks < KS; ++ks) {   // first request: agent scope; the re-requests below: system scope + volatile
+        ah[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, base + ks * 1024, /*aux: sc1*/ 16);
+        al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, PLANE + base + ks * 1024, /*aux: sc1*/ 16);
       }
-
-      if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[0] += now - st_prev; st_prev = now; st_sum[1] += spins; }
-
       f32x4v acc[2][2];
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) acc[b][ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < (DIAG == 2 ? 1 : KS); ++ks) {   // DIAG 2 (timing experiment, wrong results): one k-step of MFMAs
+      auto mfma_step = [&](int ks) {
         const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]);
         const bf16x8 xl = __builtin_bit_cast(bf16x8, al[ks]);
 #pragma unroll
@@ -1538,17 +1441,70 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
           acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl0, acc[b][0], 0, 0, 0);
           acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl1, acc[b][1], 0, 0, 0);
         }
+      };
+      if (KPIPE) {
+        // k-step by k-step: the answers to a wave's requests arrive in order over ~0.45 us (64 KB through the CU's one
+        // memory path); a k-step's tags are checked and its 12 MFMAs issued as soon as ITS two granules are there, under
+        // the arrival of the rest, instead of after the last one.  Same products, same order of accumulation.
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          auto stale = [&]() {
+            unsigned bad = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bad |= (ah[ks][e] ^ em) | (al[ks][e] ^ em);
+            return __any((bad & 0x00010001u) != 0);
+          };
+          // (the first check stands outside the loop: there the compiler knows how many younger requests are in flight
+          // and waits for this k-step's two alone, `s_waitcnt vmcnt(2 (KS - 1 - ks))`)
+          if (alive && stale()) {
+            do {
+              if ((++spins & 63u) == 0) {
+                const unsigned dead = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dead != 0 || wall_clock64() - t_wait0 > SPIN_LIMIT_TICKS) {
+                  if (lane == 0) flag_timeout(p.status);
+                  alive = false;
+                  break;
+                }
+              }
+              for (int z = 0; z < p.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+              ah[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, base + ks * 1024, (int)(0x80000000u | 16u));
+              al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, PLANE + base + ks * 1024, (int)(0x80000000u | 16u));
+            } while (stale());
+          }
+          mfma_step(ks);
+        }
+        if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[0] += now - st_prev; st_prev = now; st_sum[1] += spins; }
+      } else {
+      for (;;) {
+        unsigned bad = 0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bad |= (ah[ks][e] ^ em) | (al[ks][e] ^ em);
+        if (!alive || !__any((bad & 0x00010001u) != 0)) break;
+        if ((++spins & 63u) == 0) {
+          const unsigned dead = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (dead != 0 || wall_clock64() - t_wait0 > SPIN_LIMIT_TICKS) {
+            if (lane == 0) flag_timeout(p.status);
+            alive = false;
+            break;
+          }
+        }
+        for (int z = 0; z < p.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          ah[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, base + ks * 1024, (int)(0x80000000u | 16u));
+          al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, PLANE + base + ks * 1024, (int)(0x80000000u | 16u));
+        }
       }
-
-      // (past the last step the request reads a slot nobody waits for)
-      if (AHEAD) {
-        request_x(sg + 1 < NS ? s : s + 1, (sg + 1) % NS);
-        request((sg + 1) % NS, sg + 1 < NS ? par : epoch_clock(d, s + 1, p.steps, rs).par);
+      if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[0] += now - st_prev; st_prev = now; st_sum[1] += spins; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) mfma_step(ks);
       }
 
       // ---- reduce the 8 K-eighths, cell update on waves 0-3, publish.  `red` is double-buffered by stream (see
       // lstm_persistent_split2_kernel): one barrier per stream-step
-      float* redb = red + (sg & 1) * WIDE_RED2;
+      float* redb = red + sg * WIDE_RED2;
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -1567,16 +1523,13 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
         for (int g = 0; g < 4; ++g) {
           float v = xg[g];
 #pragma unroll
-          for (int w2 = 0; w2 < (DIAG == 3 ? 1 : 8); ++w2) v += redb[(w2 * 16 + nl) * WIDE_RED_STRIDE + cb * 32 + g * 8 + u];   // DIAG 3: timing experiment
+          for (int w2 = 0; w2 < 8; ++w2) v += redb[(w2 * 16 + nl) * WIDE_RED_STRIDE + cb * 32 + g * 8 + u];
           gsum[g] = v;
         }
         float cnew, hnew;
         if (HARD) {
           cnew = clamp01(0.2f * gsum[1] + 0.5f) * c[sg] + clamp01(0.2f * gsum[0] + 0.5f) * clamp11(gsum[2]);
           hnew = clamp01(0.2f * gsum[3] + 0.5f) * clamp11(cnew);
-        } else if (DIAG == 3) {   // timing experiment, wrong results: no activations
-          cnew = gsum[1] * c[sg] + gsum[0] * gsum[2];
-          hnew = gsum[3] * cnew;
         } else {
           cnew = fast_sigmoid(gsum[1]) * c[sg] + fast_sigmoid(gsum[0]) * fast_tanh(gsum[2]);
           hnew = fast_sigmoid(gsum[3]) * fast_tanh(cnew);
@@ -1585,20 +1538,6 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
         c[sg] = active ? cnew : c[sg];
         h[sg] = active ? hnew : h[sg];
         const int off = sg * STREAM + ec.wpar * KG * 256 + jb * 256 + nl * 16;
-        if (AHEAD) {
-          // four stores, whatever the lane and the row: see publish_split_static.  (The output of a step is at most
-          // steps * N * ndir * H * 4 bytes from its base: the host keeps the early-request form to < 2 GB.)
-          publish_split_static(h[sg], wtag, hx_rsrc, off, PLANE + off, lane);
-          const unsigned oidx = (unsigned)(((size_t)t * p.N_total + n_base + n) * (p.ndir * H) + d * H + unit);
-          const float ov = active ? hnew : 0.f;
-          {   // the planes exactly as split_planes_kernel makes them, or the float32 output: three stores, no branch
-            const unsigned hb = bf16_bits(ov);
-            const int o2 = (n < N && p.out_hi) ? (int)(oidx * 2u) : BUFFER_OOB;
-            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)hb, out_rsrc_a, o2, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)bf16_bits(ov - bf16_val(hb)), out_rsrc_b, o2, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov), out_rsrc_a, (n < N && !p.out_hi) ? (int)(oidx * 4u) : BUFFER_OOB, 0, 0);
-          }
-        } else {
         publish_split<false>(h[sg], wtag, hx_rsrc, off, PLANE + off, lane);
         if (n < N) {
           const size_t oidx = ((size_t)t * p.N_total + n_base + n) * (p.ndir * H) + d * H + unit;
@@ -1611,7 +1550,6 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
             p.out[oidx] = ov;
           }
         }
-        }
         if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[4] += now - st_prev; st_prev = now; }
       }
     }
@@ -1621,7 +1559,7 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
   }
   if (CELL) {
 #pragma unroll
-    for (int sg = 0; sg < NS; ++sg) {
+    for (int sg = 0; sg < 2; ++sg) {
       const int n = sg * 16 + nl;
       if (n < N) {
         const size_t sidx = ((size_t)d * p.N_total + n_base + n) * H + unit;
@@ -1632,16 +1570,13 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
   }
 }
 
-template <bool HARD, int KSC, bool STAMP = false, bool AHEAD = false, int NS = 2, int DIAG = 0>
+template <bool HARD, int KSC, bool STAMP = false, bool KPIPE = false>
 __global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p) {
   static_assert(KSC >= 1 && KSC <= 7, "both wave sets need at least one k-step");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // the early request is for the cell waves only: they are the critical path (waves 4-7 idle ~0.55 us at the barrier), and
-  // waves 4-7, which would ask ~0.15 us after the publish, find stale tags and pay a second round trip (r03ah_*)
-  // (four streams: a stream's h was published three stream-steps before it is asked for, every wave asks early)
-  if (wave < 4) wide2_wave<KSC, true, HARD, STAMP, AHEAD, NS, DIAG>(p, smem, wave * KSC);
-  else wide2_wave<8 - KSC, false, HARD, STAMP, AHEAD && NS == 4, NS, DIAG>(p, smem, 4 * KSC + (wave - 4) * (8 - KSC));
+  if (wave < 4) wide2_wave<KSC, true, HARD, STAMP, KPIPE>(p, smem, wave * KSC);
+  else wide2_wave<8 - KSC, false, HARD, STAMP, KPIPE>(p, smem, 4 * KSC + (wave - 4) * (8 - KSC));
 }
 
 
@@ -2305,7 +2240,7 @@ static int launch_split2(const LstmP& p, hipStream_t stream) {
 }
 
 // wide workgroups (16 units, 8 waves), `groups` batch groups of <= 32 rows side by side in one launch
-static int launch_wide2(const LstmP& p, bool hard, int groups, int ns, hipStream_t stream) {
+static int launch_wide2(const LstmP& p, bool hard, int groups, hipStream_t stream) {
   const size_t lds = (size_t)2 * WIDE_RED2 * sizeof(float);
   static ms::DeviceOnce attr_once;
   if (attr_once.need()) {
@@ -2315,47 +2250,22 @@ static int launch_wide2(const LstmP& p, bool hard, int groups, int ns, hipStream
     MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, true, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, false, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, false, false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, false, false, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_once.done();
   }
   const dim3 grid(groups * p.ndir * (p.J / 2));
   static const bool stamps = getenv("MS_LSTM_STAMPS") && getenv("MS_LSTM_STAMPS")[0] == '1';
-  static const bool ahead = getenv("MS_LSTM_WIDE_AHEAD") && getenv("MS_LSTM_WIDE_AHEAD")[0] == '1';
-  static const bool half = getenv("MS_LSTM_WIDE_HALF") && getenv("MS_LSTM_WIDE_HALF")[0] == '1';
-  if (half && ns == 2) {   // TIMING EXPERIMENT ONLY: the hi plane of h alone is pulled (wrong results)
-    hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, false, false, 2, 1>), grid, dim3(512), lds, stream, p);
-    MS_LAUNCH_CHECK();
-    return MS_OK;
-  }
-  static const int diag = getenv("MS_LSTM_WIDE_DIAG") ? atoi(getenv("MS_LSTM_WIDE_DIAG")) : 0;
-  if ((diag == 2 || diag == 3) && ns == 2) {   // TIMING EXPERIMENTS ONLY (wrong results): 2 = one k-step of MFMAs, 3 = a cell without reduce and activations
-    if (diag == 2) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, false, false, 2, 2>), grid, dim3(512), lds, stream, p);
-    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, false, false, 2, 3>), grid, dim3(512), lds, stream, p);
-    MS_LAUNCH_CHECK();
-    return MS_OK;
-  }
-  if (ns == 4) {   // experiment: four 16-row streams per workgroup, every wave asks for the next stream-step's h early
-    static const bool plain4 = getenv("MS_LSTM_WIDE_AHEAD") && getenv("MS_LSTM_WIDE_AHEAD")[0] == '0';
-    if (stamps) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, true, true, 4>), grid, dim3(512), lds, stream, p);
-    else if (plain4) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, false, false, 4>), grid, dim3(512), lds, stream, p);
-    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, false, true, 4>), grid, dim3(512), lds, stream, p);
-    MS_LAUNCH_CHECK();
-    return MS_OK;
-  }
+  static const bool kpipe = getenv("MS_LSTM_WIDE_KPIPE") && getenv("MS_LSTM_WIDE_KPIPE")[0] == '1';
   if (stamps && !hard) {   // diagnostic build (tools/wide_stamps.py): the shipped arithmetic with wall-clock stamps around its phases
-    if (ahead) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, true, true>), grid, dim3(512), lds, stream, p);
+    if (kpipe) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, true, true>), grid, dim3(512), lds, stream, p);
     else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, true>), grid, dim3(512), lds, stream, p);
     MS_LAUNCH_CHECK();
     return MS_OK;
   }
-  if (ahead && !hard) {
-    hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, false, true>), grid, dim3(512), lds, stream, p);
+  if (kpipe) {
+    if (hard) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 3, false, true>), grid, dim3(512), lds, stream, p);
+    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, false, true>), grid, dim3(512), lds, stream, p);
     MS_LAUNCH_CHECK();
     return MS_OK;
   }
@@ -2382,8 +2292,7 @@ static int launch_wide2(const LstmP& p, bool hard, int groups, int ns, hipStream
 bool use_wide(int cell, int H, int ndir, int N) {
   static const int mode = getenv("MS_LSTM_WIDE") ? atoi(getenv("MS_LSTM_WIDE")) : -1;    // -1: default (on)
   if (mode == 0) return false;
-  static const bool ns4 = getenv("MS_LSTM_WIDE_NS") && atoi(getenv("MS_LSTM_WIDE_NS")) == 4;
-  if (H != 1024 || N > (ns4 ? 128 : 64) || !use_split(cell, H, ndir) || ms::precision_mode() != ms::PREC_BF16X3) return false;
+  if (H != 1024 || N > 64 || !use_split(cell, H, ndir) || ms::precision_mode() != ms::PREC_BF16X3) return false;
   static std::atomic<int> ok[64];     // per device: 0 = not asked, 1 = fits, 2 = does not
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
@@ -2559,11 +2468,9 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       static const bool stamps = getenv("MS_LSTM_STAMPS") && getenv("MS_LSTM_STAMPS")[0] == '1';
       if (n0 == 0 && use_wide(cell, H, ndir, N)) {
         // all batch groups (one or two of <= 32 rows) in ONE launch of the wide-workgroup kernel
-        static const int ns_env = getenv("MS_LSTM_WIDE_NS") ? atoi(getenv("MS_LSTM_WIDE_NS")) : 2;
-        const int ns = (ns_env == 4 && N > 32 && cell == MS_CELL_LSTM) ? 4 : 2;       // 16-row streams per workgroup
-        const int groups = ms::cdiv(N, 16 * ns);
+        const int groups = ms::cdiv(N, 32);
         const int rs = 1;
-        const size_t words_per_dir = (size_t)16 * ns * H << rs;
+        const size_t words_per_dir = (size_t)32 * H << rs;
         p.ring_shift = rs;
         p.N = N;                       // the kernel cuts it into groups of 32 rows
         {
@@ -2571,7 +2478,6 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
           // the XCD ask the same L2 channels for the same lines at the same time; four vectors per XCD spread the requests
           static const bool on = getenv("MS_LSTM_WIDE_XCD") && getenv("MS_LSTM_WIDE_XCD")[0] == '1';
           p.xcd_map = (on && groups == 2 && ndir == 2 && p.J == 128) ? 1 : 0;
-
         }
         for (int g = 0; g < groups; ++g) {
           hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir)), dim3(256), 0, stream,
@@ -2580,7 +2486,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
           MS_LAUNCH_CHECK();
         }
         if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.xsplit - W.dbg, stream));
-        rc = launch_wide2(p, cell == MS_CELL_HARD_LSTM, groups, ns, stream);
+        rc = launch_wide2(p, cell == MS_CELL_HARD_LSTM, groups, stream);
         if (rc != MS_OK) return rc;
         break;
       }

@@ -36,6 +36,13 @@ __device__ __forceinline__ void st(__amdgpu_buffer_rsrc_t r, int off, unsigned t
   u32x4 v = {tag, tag, tag, tag};
   __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, SAUX);
 }
+// store aux 99: the granule as two 64-bit atomic exchanges at agent scope (executed at the memory side, no return value)
+__device__ __forceinline__ void st_atomic(char* base, int off, unsigned tag) {
+  const unsigned long long v = ((unsigned long long)tag << 32) | tag;
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(base + off);
+  (void)__hip_atomic_exchange(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  (void)__hip_atomic_exchange(q + 1, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <int LAUX, int SAUX>
 __global__ __launch_bounds__(512, 2) void exchange_wide(P p) {
@@ -46,8 +53,13 @@ __global__ __launch_bounds__(512, 2) void exchange_wide(P p) {
   __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(p.hbuf + ((size_t)grp * 2 + d) * dir_bytes, 0, (int)dir_bytes, 0x00020000);
   auto slot_off = [&](int s, int par) { return (s * 2 + par) * 2 * PLANE; };
   // publish: 64 lanes of wave 0, plane = lane >> 5, block = (lane >> 4) & 1, row granule = lane & 15
+  char* hbase = p.hbuf + ((size_t)grp * 2 + d) * dir_bytes;
   auto publish = [&](int s, int par, unsigned tag) {
-    if (tid < 64) st<SAUX>(rh, slot_off(s, par) + (tid >> 5) * PLANE + (2 * jj + ((tid >> 4) & 1)) * 256 + (tid & 15) * 16, tag);
+    const int off = slot_off(s, par) + (tid >> 5) * PLANE + (2 * jj + ((tid >> 4) & 1)) * 256 + (tid & 15) * 16;
+    if (tid < 64) {
+      if (SAUX == 99) st_atomic(hbase, off, tag);
+      else st<SAUX>(rh, off, tag);
+    }
   };
   for (int s = 0; s < NS; ++s) publish(s, 0, 1u);
   __syncthreads();
@@ -101,6 +113,7 @@ static void launch(int saux, int wgs, const P& p) {
   if (saux == 16) hipLaunchKernelGGL((exchange_wide<LAUX, 16>), dim3(wgs), dim3(512), 0, 0, p);
   else if (saux == 17) hipLaunchKernelGGL((exchange_wide<LAUX, 17>), dim3(wgs), dim3(512), 0, 0, p);
   else if (saux == 1) hipLaunchKernelGGL((exchange_wide<LAUX, 1>), dim3(wgs), dim3(512), 0, 0, p);
+  else if (saux == 99) hipLaunchKernelGGL((exchange_wide<LAUX, 99>), dim3(wgs), dim3(512), 0, 0, p);
   else hipLaunchKernelGGL((exchange_wide<LAUX, 18>), dim3(wgs), dim3(512), 0, 0, p);
 }
 
