@@ -1322,7 +1322,7 @@ constexpr int WIDE_RED2 = 8 * 16 * WIDE_RED_STRIDE;        // 8 waves x 16 rows,
 // Uneven shares (waves 0-3 take KSC k-steps each, waves 4-7 the other 8 - KSC): the cell waves spend ~0.5 us of every
 // stream-step on the cell and the publish before they request their own operands, waves 4-7 go straight from the barrier
 // to the next request and share the SIMDs' matrix pipes with them.
-template <int KS, bool CELL, bool HARD, bool STAMP = false, bool KPIPE = false>
+template <int KS, bool CELL, bool HARD, bool STAMP = false>
 __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int k0) {
   constexpr int H = 1024, KG = H / 8;
 
@@ -1442,39 +1442,6 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
           acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl1, acc[b][1], 0, 0, 0);
         }
       };
-      if (KPIPE) {
-        // k-step by k-step: the answers to a wave's requests arrive in order over ~0.45 us (64 KB through the CU's one
-        // memory path); a k-step's tags are checked and its 12 MFMAs issued as soon as ITS two granules are there, under
-        // the arrival of the rest, instead of after the last one.  Same products, same order of accumulation.
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          auto stale = [&]() {
-            unsigned bad = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bad |= (ah[ks][e] ^ em) | (al[ks][e] ^ em);
-            return __any((bad & 0x00010001u) != 0);
-          };
-          // (the first check stands outside the loop: there the compiler knows how many younger requests are in flight
-          // and waits for this k-step's two alone, `s_waitcnt vmcnt(2 (KS - 1 - ks))`)
-          if (alive && stale()) {
-            do {
-              if ((++spins & 63u) == 0) {
-                const unsigned dead = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (dead != 0 || wall_clock64() - t_wait0 > SPIN_LIMIT_TICKS) {
-                  if (lane == 0) flag_timeout(p.status);
-                  alive = false;
-                  break;
-                }
-              }
-              for (int z = 0; z < p.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
-              ah[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, base + ks * 1024, (int)(0x80000000u | 16u));
-              al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, PLANE + base + ks * 1024, (int)(0x80000000u | 16u));
-            } while (stale());
-          }
-          mfma_step(ks);
-        }
-        if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[0] += now - st_prev; st_prev = now; st_sum[1] += spins; }
-      } else {
       for (;;) {
         unsigned bad = 0;
 #pragma unroll
@@ -1500,7 +1467,6 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
       if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[0] += now - st_prev; st_prev = now; st_sum[1] += spins; }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) mfma_step(ks);
-      }
 
       // ---- reduce the 8 K-eighths, cell update on waves 0-3, publish.  `red` is double-buffered by stream (see
       // lstm_persistent_split2_kernel): one barrier per stream-step
@@ -1570,13 +1536,13 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
   }
 }
 
-template <bool HARD, int KSC, bool STAMP = false, bool KPIPE = false>
+template <bool HARD, int KSC, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p) {
   static_assert(KSC >= 1 && KSC <= 7, "both wave sets need at least one k-step");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wave < 4) wide2_wave<KSC, true, HARD, STAMP, KPIPE>(p, smem, wave * KSC);
-  else wide2_wave<8 - KSC, false, HARD, STAMP, KPIPE>(p, smem, 4 * KSC + (wave - 4) * (8 - KSC));
+  if (wave < 4) wide2_wave<KSC, true, HARD, STAMP>(p, smem, wave * KSC);
+  else wide2_wave<8 - KSC, false, HARD, STAMP>(p, smem, 4 * KSC + (wave - 4) * (8 - KSC));
 }
 
 
@@ -2249,23 +2215,12 @@ static int launch_wide2(const LstmP& p, bool hard, int groups, hipStream_t strea
     MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_once.done();
   }
   const dim3 grid(groups * p.ndir * (p.J / 2));
   static const bool stamps = getenv("MS_LSTM_STAMPS") && getenv("MS_LSTM_STAMPS")[0] == '1';
-  static const bool kpipe = getenv("MS_LSTM_WIDE_KPIPE") && getenv("MS_LSTM_WIDE_KPIPE")[0] == '1';
   if (stamps && !hard) {   // diagnostic build (tools/wide_stamps.py): the shipped arithmetic with wall-clock stamps around its phases
-    if (kpipe) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, true, true>), grid, dim3(512), lds, stream, p);
-    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, true>), grid, dim3(512), lds, stream, p);
-    MS_LAUNCH_CHECK();
-    return MS_OK;
-  }
-  if (kpipe) {
-    if (hard) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 3, false, true>), grid, dim3(512), lds, stream, p);
-    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, false, true>), grid, dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, true>), grid, dim3(512), lds, stream, p);
     MS_LAUNCH_CHECK();
     return MS_OK;
   }
