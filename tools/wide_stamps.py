@@ -43,8 +43,8 @@ def run(N, gemm):
         torch.cuda.current_stream().synchronize()
         wall = 1e3 * (time.perf_counter() - t0)
         torch.cuda.synchronize()
-    ns = 4 if (os.environ.get("MS_LSTM_WIDE_NS") == "4" and N > 32) else 2      # 16-row streams per workgroup
-    nwg = 128 * ((N + 16 * ns - 1) // (16 * ns))
+    ns = 2                                  # 16-row streams per workgroup
+    nwg = 128 * ((N + 31) // 32)
     off = lib.ms_rnn_debug_offset(0, T, N, In, H, 2)
     dbg = m._workspace.buf[off:off + nwg * 16 * 8].view(torch.int64).reshape(nwg, 16).cpu().double()
     print(f"N = {N}{' beside the regular GEMM' if gemm else ''}: layer call (projection + recurrence) {wall:.3f} ms, {nwg} workgroups x {ns} streams")
