@@ -66,12 +66,19 @@ __global__ __launch_bounds__(512, 2) void exchange_wide(P p) {
   const unsigned long long t0 = wall_clock64();
   bool ok = true;
   unsigned long long spins = 0;
-  u32x4 v[8];
+  u32x4 v[8], vn[8];
   auto request = [&](int s, int par) {
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       v[l] = ld<LAUX>(rh, slot_off(s, par) + wave * 4096 + l * 1024 + lane * 16);
       v[4 + l] = ld<LAUX>(rh, slot_off(s, par) + PLANE + wave * 4096 + l * 1024 + lane * 16);
+    }
+  };
+  auto request_next = [&](int s, int par) {   // early == 2: a second register set, asked for a whole stream-step ahead
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      vn[l] = ld<LAUX>(rh, slot_off(s, par) + wave * 4096 + l * 1024 + lane * 16);
+      vn[4 + l] = ld<LAUX>(rh, slot_off(s, par) + PLANE + wave * 4096 + l * 1024 + lane * 16);
     }
   };
   if (p.early) request(0, 0);
@@ -91,8 +98,12 @@ __global__ __launch_bounds__(512, 2) void exchange_wide(P p) {
         __builtin_amdgcn_s_sleep(1);
         request(s, par);
       }
+      if (p.early == 2) {   // the tags of this stream-step passed: ask for the next one now, into the other register set
+        const int sn = (s + 1) % NS, tn = s + 1 < NS ? t : t + 1;
+        request_next(sn, tn & 1);
+      }
       for (int z = 0; z < p.mfma_sleeps; ++z) __builtin_amdgcn_s_sleep(8);
-      if (p.early) {   // the next stream-step's request goes out before the barrier and the cell of this one
+      if (p.early == 1) {   // the next stream-step's request goes out before the barrier and the cell of this one
         const int sn = (s + 1) % NS, tn = s + 1 < NS ? t : t + 1;
         request(sn, tn & 1);
       }
@@ -100,6 +111,10 @@ __global__ __launch_bounds__(512, 2) void exchange_wide(P p) {
       if (wave < 4) {
         for (int z = 0; z < p.cell_sleeps; ++z) __builtin_amdgcn_s_sleep(8);
         publish(s, par ^ 1, tag + 1);
+      }
+      if (p.early == 2) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) v[l] = vn[l];
       }
     }
   }
@@ -142,6 +157,6 @@ int main(int argc, char** argv) {
   const double us = t * 10.0 / p.steps / 1000.0;
   printf("wide exchange: %d streams, %d workgroups, mfma=%d cell=%d sleeps, load aux %d, store aux %d, request %s: %.3f us per stream-step, "
          "%.2f repeated requests per wave and stream-step%s\n", p.NS, wgs, p.mfma_sleeps, p.cell_sleeps, laux, saux,
-         p.early ? "before the barrier" : "after the cell", us / p.NS, (double)sp / ((double)wgs * 8 * p.steps * p.NS), f ? "  (TIMEOUTS!)" : "");
+         p.early == 2 ? "a stream-step ahead (second register set)" : p.early ? "before the barrier" : "after the cell", us / p.NS, (double)sp / ((double)wgs * 8 * p.steps * p.NS), f ? "  (TIMEOUTS!)" : "");
   return 0;
 }
