@@ -9,7 +9,7 @@
 // (after the cell of the step before it, as shipped, or before its barrier), the number of workgroups (one or two batch
 // groups).  Reports us per stream-step and the repeated requests per wave and stream-step.
 //   hipcc -O3 --offload-arch=gfx950 tools/micro/exchange_wide.hip -o tools/micro/exchange_wide
-//   exchange_wide <NS> <mfma_sleeps> <cell_sleeps> <load_aux> <store_aux> <early 0|1> <groups 1|2>   (one s_sleep(8) ~ 0.21 us; aux: 1 sc0, 16 sc1, 17 both, 2 nt)
+//   exchange_wide <NS> <mfma_sleeps> <cell_sleeps> <load_aux> <store_aux> <early 0|1|2> <groups 1|2> <ring slots>   (one s_sleep(8) ~ 0.21 us; aux: 1 sc0, 16 sc1, 17 both, 2 nt)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -21,7 +21,7 @@ struct P {
   unsigned long long* out;
   unsigned* fail;
   unsigned long long* spins;
-  int NS, steps, mfma_sleeps, cell_sleeps, early;
+  int NS, steps, mfma_sleeps, cell_sleeps, early, ring;   // ring: slots per stream (a power of two >= 2)
 };
 
 constexpr int PLANE = 32 * 1024;
@@ -49,9 +49,10 @@ __global__ __launch_bounds__(512, 2) void exchange_wide(P p) {
   const int NS = p.NS;
   const int grp = blockIdx.x / 128, d = (blockIdx.x % 128) / 64, jj = blockIdx.x % 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const size_t dir_bytes = (size_t)NS * 2 * 2 * PLANE;
+  const int RING = p.ring;
+  const size_t dir_bytes = (size_t)NS * RING * 2 * PLANE;
   __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(p.hbuf + ((size_t)grp * 2 + d) * dir_bytes, 0, (int)dir_bytes, 0x00020000);
-  auto slot_off = [&](int s, int par) { return (s * 2 + par) * 2 * PLANE; };
+  auto slot_off = [&](int s, int par) { return (s * RING + par) * 2 * PLANE; };   // par: slot index, step & (RING - 1)
   // publish: 64 lanes of wave 0, plane = lane >> 5, block = (lane >> 4) & 1, row granule = lane & 15
   char* hbase = p.hbuf + ((size_t)grp * 2 + d) * dir_bytes;
   auto publish = [&](int s, int par, unsigned tag) {
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void exchange_wide(P p) {
   if (p.early) request(0, 0);
   for (int t = 0; t < p.steps && ok; ++t) {
     const unsigned tag = (unsigned)(t + 1);
-    const int par = t & 1;
+    const int par = t & (RING - 1);
     for (int s = 0; s < NS && ok; ++s) {
       const unsigned long long tw = wall_clock64();
       if (!p.early) request(s, par);
@@ -100,17 +101,17 @@ __global__ __launch_bounds__(512, 2) void exchange_wide(P p) {
       }
       if (p.early == 2) {   // the tags of this stream-step passed: ask for the next one now, into the other register set
         const int sn = (s + 1) % NS, tn = s + 1 < NS ? t : t + 1;
-        request_next(sn, tn & 1);
+        request_next(sn, tn & (RING - 1));
       }
       for (int z = 0; z < p.mfma_sleeps; ++z) __builtin_amdgcn_s_sleep(8);
       if (p.early == 1) {   // the next stream-step's request goes out before the barrier and the cell of this one
         const int sn = (s + 1) % NS, tn = s + 1 < NS ? t : t + 1;
-        request(sn, tn & 1);
+        request(sn, tn & (RING - 1));
       }
       __syncthreads();
       if (wave < 4) {
         for (int z = 0; z < p.cell_sleeps; ++z) __builtin_amdgcn_s_sleep(8);
-        publish(s, par ^ 1, tag + 1);
+        publish(s, (t + 1) & (RING - 1), tag + 1);
       }
       if (p.early == 2) {
 #pragma unroll
@@ -140,9 +141,11 @@ int main(int argc, char** argv) {
   const int laux = argc > 4 ? atoi(argv[4]) : 16, saux = argc > 5 ? atoi(argv[5]) : 16;
   p.early = argc > 6 ? atoi(argv[6]) : 0;
   const int groups = argc > 7 ? atoi(argv[7]) : 1;
+  p.ring = argc > 8 ? atoi(argv[8]) : 2;
+  if (p.ring < 2 || (p.ring & (p.ring - 1)) || p.ring > 256) { printf("ring: a power of two in 2..256\n"); return 1; }
   p.steps = 1000;
   if (p.NS < 1 || p.NS > 8 || groups < 1 || groups > 2) { printf("NS in 1..8, groups in 1..2\n"); return 1; }
-  const size_t hbytes = (size_t)groups * 2 * p.NS * 2 * 2 * PLANE;
+  const size_t hbytes = (size_t)groups * 2 * p.NS * p.ring * 2 * PLANE;
   (void)hipMalloc(&p.hbuf, hbytes); (void)hipMalloc(&p.out, 8); (void)hipMalloc(&p.fail, 4); (void)hipMalloc(&p.spins, 8);
   (void)hipMemset(p.hbuf, 0, hbytes); (void)hipMemset(p.out, 0, 8); (void)hipMemset(p.fail, 0, 4); (void)hipMemset(p.spins, 0, 8);
   const int wgs = groups * 128;
@@ -155,8 +158,8 @@ int main(int argc, char** argv) {
   (void)hipMemcpy(&t, p.out, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&f, p.fail, 4, hipMemcpyDeviceToHost);
   (void)hipMemcpy(&sp, p.spins, 8, hipMemcpyDeviceToHost);
   const double us = t * 10.0 / p.steps / 1000.0;
-  printf("wide exchange: %d streams, %d workgroups, mfma=%d cell=%d sleeps, load aux %d, store aux %d, request %s: %.3f us per stream-step, "
-         "%.2f repeated requests per wave and stream-step%s\n", p.NS, wgs, p.mfma_sleeps, p.cell_sleeps, laux, saux,
+  printf("wide exchange: ring %d, %d streams, %d workgroups, mfma=%d cell=%d sleeps, load aux %d, store aux %d, request %s: %.3f us per stream-step, "
+         "%.2f repeated requests per wave and stream-step%s\n", p.ring, p.NS, wgs, p.mfma_sleeps, p.cell_sleeps, laux, saux,
          p.early == 2 ? "a stream-step ahead (second register set)" : p.early ? "before the barrier" : "after the cell", us / p.NS, (double)sp / ((double)wgs * 8 * p.steps * p.NS), f ? "  (TIMEOUTS!)" : "");
   return 0;
 }
