@@ -21,7 +21,8 @@ struct P {
   unsigned long long* out;
   unsigned* fail;
   unsigned long long* spins;
-  int NS, steps, mfma_sleeps, cell_sleeps, early, ring;   // ring: slots per stream (a power of two >= 2)
+  int NS, steps, mfma_sleeps, cell_sleeps, early, ring, push;   // ring: slots per stream (a power of two >= 2); push: what follows the publish
+  char* dummy;
 };
 
 constexpr int PLANE = 32 * 1024;
@@ -112,6 +113,12 @@ __global__ __launch_bounds__(512, 2) void exchange_wide(P p) {
       if (wave < 4) {
         for (int z = 0; z < p.cell_sleeps; ++z) __builtin_amdgcn_s_sleep(8);
         publish(s, (t + 1) & (RING - 1), tag + 1);
+        if (p.push == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // buffer_wbl2 sc1 + s_waitcnt vmcnt(0)
+        if (p.push == 2) {                                                              // two plain stores elsewhere (the kernel's output stores)
+          float* o = reinterpret_cast<float*>(p.dummy) + ((size_t)blockIdx.x * 512 + tid) * 2;
+          o[0] = (float)t; o[1] = (float)s;
+        }
+        if (p.push == 3) __builtin_amdgcn_s_waitcnt(0x0f70);                            // s_waitcnt vmcnt(0) alone
       }
       if (p.early == 2) {
 #pragma unroll
@@ -142,6 +149,8 @@ int main(int argc, char** argv) {
   p.early = argc > 6 ? atoi(argv[6]) : 0;
   const int groups = argc > 7 ? atoi(argv[7]) : 1;
   p.ring = argc > 8 ? atoi(argv[8]) : 2;
+  p.push = argc > 9 ? atoi(argv[9]) : 0;
+  (void)hipMalloc(&p.dummy, (size_t)256 * 512 * 8);
   if (p.ring < 2 || (p.ring & (p.ring - 1)) || p.ring > 256) { printf("ring: a power of two in 2..256\n"); return 1; }
   p.steps = 1000;
   if (p.NS < 1 || p.NS > 8 || groups < 1 || groups > 2) { printf("NS in 1..8, groups in 1..2\n"); return 1; }
@@ -161,5 +170,6 @@ int main(int argc, char** argv) {
   printf("wide exchange: ring %d, %d streams, %d workgroups, mfma=%d cell=%d sleeps, load aux %d, store aux %d, request %s: %.3f us per stream-step, "
          "%.2f repeated requests per wave and stream-step%s\n", p.ring, p.NS, wgs, p.mfma_sleeps, p.cell_sleeps, laux, saux,
          p.early == 2 ? "a stream-step ahead (second register set)" : p.early ? "before the barrier" : "after the cell", us / p.NS, (double)sp / ((double)wgs * 8 * p.steps * p.NS), f ? "  (TIMEOUTS!)" : "");
+  if (p.push) printf("   (after the publish: %s)\n", p.push == 1 ? "release fence at agent scope" : p.push == 2 ? "two plain stores elsewhere" : "s_waitcnt vmcnt(0)");
   return 0;
 }
