@@ -240,3 +240,36 @@ def gemm_variants_equal() -> None:
         tol = 2e-3 if os.environ.get("MS_PRECISION") == "fp16" else 1e-4
         assert float((ys[0].double() - want).abs().max()) < tol * float(want.abs().max() + 1.0)
     print("gemm variants equal in mode", os.environ.get("MS_PRECISION", "bf16x3"))
+
+
+def wide_layer(path: str, n: int = 32, steps: int = 37) -> None:
+    """One BiLSTM-1024 layer (the wide-workgroup kernel's shape) on seeded inputs with ragged lengths; outputs and final states are
+    saved to ``path``.  Run once in the test process and once in a child with ``MS_LSTM_STAMPS=1`` (the kernel's diagnostic
+    instantiation, which tools/wide_stamps.py reads): the two files must hold the same bits.  With the stamps on, the phase sums of
+    every workgroup must have been written and add up to the same span for both wave classes."""
+    from myrtlespeech_amd import _lib
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    lib = _lib.load()
+    torch.manual_seed(11)
+    m = RNN(RNNType.LSTM, 96, 1024, num_layers=1, bidirectional=True, forget_gate_bias=1.0).eval()
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(steps, n, 96, generator=g).cuda()
+    lens = torch.sort(torch.randint(steps // 2, steps + 1, (n,), generator=g), descending=True).values
+    lens[0] = steps
+    with torch.no_grad():
+        (y, _), (hn, cn) = m((x, lens))
+    torch.cuda.synchronize()
+    np.savez(path, y=y.cpu().numpy(), hn=hn.cpu().numpy(), cn=cn.cpu().numpy())
+    if os.environ.get("MS_LSTM_STAMPS") == "1":
+        assert lib.ms_rnn_layer_is_wide(0, 1024, 2, n) == 1
+        nwg = 128 * ((n + 31) // 32)
+        off = lib.ms_rnn_debug_offset(0, steps, n, 96, 1024, 2)
+        dbg = m._workspace.buf[off:off + nwg * 16 * 8].view(torch.int64).reshape(nwg, 16).cpu().double()
+        span = {}
+        for base in (0, 8):
+            tot = dbg[:, base] + dbg[:, base + 2] + dbg[:, base + 3] + dbg[:, base + 4]      # slot 1 is a count
+            assert float(tot.min()) > 0.0, "a workgroup wrote no stamps"
+            span[base] = tot
+        # both wave classes of a workgroup stamp the same loop: their sums agree to the skew of the last barrier
+        assert float(((span[0] - span[8]).abs() / span[0]).max()) < 0.02
+        print("stamps ok: %.0f ns per stream-step" % (float(span[0].mean()) / 4.0 / (2 * steps) * 10.0))

@@ -59,6 +59,19 @@ def test_split_gemm_kernels_agree_in_both_operand_modes():
     assert "gemm variants equal in mode fp16" in out
 
 
+def test_wide_lstm_stamp_build_is_the_shipped_arithmetic(tmp_path):
+    """``MS_LSTM_STAMPS=1`` selects the diagnostic instantiation of ``lstm_persistent_wide2_kernel`` (wall-clock stamps around the
+    phases of a stream-step, read by tools/wide_stamps.py): same bits as the shipped instantiation, and every workgroup's stamps
+    are there."""
+    a, b = str(tmp_path / "shipped.npz"), str(tmp_path / "stamped.npz")
+    cfg_checks.wide_layer(a)
+    out = _child(f"wide_layer({b!r})", MS_LSTM_STAMPS="1")
+    assert "stamps ok" in out
+    with np.load(a) as fa, np.load(b) as fb:
+        for k in ("y", "hn", "cn"):
+            assert np.array_equal(fa[k], fb[k]), k
+
+
 # ----------------------------------------------------------------------------- configs[1] in the reference's own arithmetic width
 def test_cfg2_full_size_f32_mode_vs_reference_in_subprocess():
     """``MS_PRECISION=f32`` (float32 MFMA everywhere: the reference is fp32 end to end, model/rnn.py:177, model/cnn.py:481,
