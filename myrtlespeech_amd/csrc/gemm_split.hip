@@ -689,259 +689,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel4n(
   gemm4_body<F16, 1, PER_STEP, SPACED>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi);
 }
 
-// ---- kernel4's 8-wave body as a PERSISTENT tile loop (round 3).  kernel4 pays ~12 us per tile outside its K
-// loop: the 256-KB epilogue store, the wait for its acknowledgement before the workgroup's LDS and registers are released,
-// the dispatch of the next workgroup and the latency of its first two operand blocks.  Here a workgroup keeps its CU and
-// draws tiles from eight per-XCD queues (`queue[x]`, zeroed by the host before the launch; a workgroup on XCD x = blockIdx % 8
-// serves queue x, whose tiles share operand panels in that XCD's L2 exactly as kernel4's blockIdx -> tile map arranges, and
-// steals from the next queues once its own is empty -- so a launch that finds half of the CUs taken by another kernel still
-// balances).  The K loop runs straight through the tile boundary: the DMA of the next tile's first two operand blocks goes
-// out under the last two blocks of the current tile, the epilogue's 32 stores per wave are issued between the last MFMA of
-// one tile and the first of the next and drain under it (the first barrier of the new tile waits `vmcnt(32)`: the operand
-// block it needs is older than the stores).  Same products in the same order: bit-identical to kernel4.  K >= 64.
-constexpr int G5_QUEUES = 8;
-
-template <bool F16>
-__global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel5(const unsigned short* __restrict__ Ah,
-                                                                 const unsigned short* __restrict__ Al,
-                                                                 const unsigned short* __restrict__ Wh,
-                                                                 const unsigned short* __restrict__ Wl,
-                                                                 const float* __restrict__ bias, float* __restrict__ Y,
-                                                                 int M, int K, int N, int act, float lo, float hi,
-                                                                 unsigned* __restrict__ queue) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  __shared__ int next_tile_s;
-  const int nbn = (N + S2_N - 1) / S2_N, nbm = (M + S2_M - 1) / S2_M;
-  const int nwg = nbn * nbm;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l31 = lane & 31, half = lane >> 5;
-  const int q8 = nwg / 8, r8 = nwg % 8;
-
-  // the next tile of queue x0, x0 + 1, ... (ticket order inside a queue = kernel4's order inside an XCD), or -1
-  auto draw = [&]() -> int {
-    const int x0 = blockIdx.x & 7;
-    for (int a = 0; a < G5_QUEUES; ++a) {
-      const int x = (x0 + a) & 7;
-      const int cnt = q8 + (x < r8 ? 1 : 0);
-      const int k = (int)atomicAdd(&queue[x], 1u);
-      if (k < cnt) return (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + k;
-    }
-    return -1;
-  };
-  constexpr int GM = 4;
-  auto tile_origin = [&](int bid, int& m0, int& n0) {
-    const int per_group = GM * nbn;
-    const int first_m = (bid / per_group) * GM;
-    const int gm = min(GM, nbm - first_m);
-    m0 = (first_m + (bid % per_group) % gm) * S2_M;
-    n0 = ((bid % per_group) / gm) * S2_N;
-  };
-
-  if (tid == 0) next_tile_s = draw();
-  __syncthreads();
-  int tile = __builtin_amdgcn_readfirstlane(next_tile_s);
-  if (tile < 0) return;
-  __syncthreads();                                           // everybody has read the word before it is written again
-
-  // ---- this wave's DMA pieces: 8 pieces (F16: 4) of ONE plane, 16 rows each (see gemm4_body)
-  constexpr int NP = F16 ? 4 : 8;
-  const int g0 = wave * NP;
-  const int PA = F16 ? (g0 >> 4) * 2 : (g0 >> 4);            // 0 = x hi, 1 = x lo, 2 = W hi, 3 = W lo
-  const int RA = (g0 & 15) * 16;
-  const unsigned short* src = PA == 0 ? Ah : PA == 1 ? Al : PA == 2 ? Wh : Wl;
-  const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(src), 0, (unsigned)((size_t)(PA < 2 ? M : N) * K * 2), 0x00020000);
-  const int kgs = (lane & 3) ^ ((lane >> 4) & 3);            // granule fetched into position lane & 3 of row lane >> 2
-  int voff[NP];                                              // byte offset of this lane's granule at k0 = 0, tile being fetched
-  auto set_voff = [&](int m0, int n0) {
-    const int rows = PA < 2 ? M : N;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) voff[p] = min((PA < 2 ? m0 : n0) + RA + p * 16 + (lane >> 2), rows - 1) * (K * 2) + kgs * 16;
-  };
-  auto dma_block = [&](int kb, int stage) {
-    const int soff = __builtin_amdgcn_readfirstlane(kb * (SB_K * 2));
-    char* dst = lds + stage * G4_STAGE + PA * G4_PLANE + RA * 64;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) lds_dma_16(rsrc, dst + p * 1024, voff[p], soff);
-  };
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int sw = (l31 >> 2) & 3;
-  const int foff0 = l31 * 64 + ((half ^ sw) * 16);
-  const int foff1 = l31 * 64 + (((2 + half) ^ sw) * 16);
-  const int a_base = wm * 64 * 64, b_base = 2 * G4_PLANE + wn * 128 * 64;
-
-  u32x4 fa[2][6 + 6];
-  auto read_frags = [&](int set, int stage, int h) {
-    const char* st = lds + stage * G4_STAGE + (h ? foff1 : foff0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      fa[set][i] = *reinterpret_cast<const u32x4*>(st + a_base + i * 32 * 64);
-      if (!F16) fa[set][2 + i] = *reinterpret_cast<const u32x4*>(st + G4_PLANE + a_base + i * 32 * 64);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      fa[set][4 + j] = *reinterpret_cast<const u32x4*>(st + b_base + j * 32 * 64);
-      if (!F16) fa[set][8 + j] = *reinterpret_cast<const u32x4*>(st + G4_PLANE + b_base + j * 32 * 64);
-    }
-  };
-  auto mfma_set = [&](int set) {
-    if (F16) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set][4 + j]),
-                                                             __builtin_bit_cast(f16x8, fa[set][i]), acc[i][j], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][4 + j]),
-                                                              __builtin_bit_cast(bf16x8, fa[set][i]), acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][4 + j]),
-                                                              __builtin_bit_cast(bf16x8, fa[set][2 + i]), acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][8 + j]),
-                                                              __builtin_bit_cast(bf16x8, fa[set][i]), acc[i][j], 0, 0, 0);
-    }
-  };
-
-  const int nk = K / SB_K;
-  int m0, n0;
-  tile_origin(tile, m0, n0);
-  set_voff(m0, n0);
-  dma_block(0, 0);
-  dma_block(1, 1);
-  __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
-  __builtin_amdgcn_s_barrier();
-  read_frags(0, 0, 0);
-  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
-  __builtin_amdgcn_sched_barrier(0);
-
-  constexpr int NR = F16 ? 6 : 12;
-  constexpr int MPR = F16 ? 8 / 6 + 1 : 2;
-  const bool n_vec = (N % 4) == 0;
-  const int draw_b = nk >= 3 ? 1 : 0;
-  int g = 0;                            // blocks done by this workgroup: block g lives in stage g & 1
-  int st_cnt = 0;                       // store instructions of this wave's last epilogue, if that number is certain (else 0)
-  for (;;) {
-    int next = -1, nm0 = 0, nn0 = 0;
-    for (int b = 0; b < nk; ++b, ++g) {
-      const int cur = g & 1;
-      // ---- top: frags(b, half 1) -> set 1 under the MFMAs on set 0
-      read_frags(1, cur, 1);
-      mfma_set(0);
-#pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // the ticket for the tile after this one; its answer is needed at block nk - 2.  Not in block 0 where it can be helped:
-      // the atomic's answer arrives behind the acknowledgements of this wave's epilogue stores
-      if (b == draw_b && tid == 0) next_tile_s = draw();
-      // lgkmcnt(0): set 1 complete; vmcnt: this wave's pieces of block b + 1 have landed.  In block 0 of a later tile those
-      // pieces went out BEFORE the st_cnt epilogue stores of the tile before, which need not have been acknowledged yet
-      if (b == 0 && st_cnt == 32) __builtin_amdgcn_s_waitcnt(0x8070);        // vmcnt(32) lgkmcnt(0)
-      else if (b == 0 && st_cnt == 16) __builtin_amdgcn_s_waitcnt(0x4070);   // vmcnt(16) lgkmcnt(0)
-      else __builtin_amdgcn_s_waitcnt(0x0070);                               // vmcnt(0) lgkmcnt(0)
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- mid: block b+2 -> the stage just drained; frags(b+1, half 0) -> set 0 under the MFMAs on set 1
-      if (b + 2 < nk) {
-        dma_block(b + 2, cur);
-      } else {
-        if (b + 2 == nk) {                  // from here on the DMA works for the next tile
-          next = __builtin_amdgcn_readfirstlane(next_tile_s);
-          if (next >= 0) {
-            tile_origin(next, nm0, nn0);
-            set_voff(nm0, nn0);
-          }
-        }
-        // (no next tile: the last block again, into a stage nobody reads any more -- no branch around the DMA)
-        dma_block(next >= 0 ? b + 2 - nk : nk - 1, cur);
-      }
-      read_frags(0, cur ^ 1, 0);
-      mfma_set(1);
-#pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        if (i < NP) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): set 0 complete
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // ---- epilogue of the tile: D[n][m]: lane = column m (lane & 31), register r -> row n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + wm * 64 + i * 32 + l31;
-      if (m >= M) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int n = n0 + wn * 128 + j * 32 + 8 * gq + 4 * half;
-          f32x4 v = {acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
-          if (n_vec && n + 3 < N) {
-            if (bias != nullptr) {
-              const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
-              v += bv;
-            }
-            if (act == MS_ACT_CLAMP) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], lo), hi);
-            }
-            *reinterpret_cast<f32x4*>(Y + (size_t)m * N + n) = v;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n + e < N) {
-                float x = v[e] + (bias != nullptr ? bias[n + e] : 0.f);
-                if (act == MS_ACT_CLAMP) x = fminf(fmaxf(x, lo), hi);
-                Y[(size_t)m * N + n + e] = x;
-              }
-          }
-        }
-    }
-    if (next < 0) break;
-    {
-      // every column of this wave inside N: 16 vector stores per 32-row group that has a row inside M, and no others
-      const bool full_n = n_vec && n0 + wn * 128 + 128 <= N;
-      const int groups = (m0 + wm * 64 < M ? 1 : 0) + (m0 + wm * 64 + 32 < M ? 1 : 0);
-      st_cnt = full_n ? 16 * groups : 0;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    m0 = nm0; n0 = nn0;
-  }
-  __builtin_amdgcn_s_waitcnt(0x0070);     // the tail's DMA must have landed before the LDS is released
-}
-
 // tuning switch (tools/gemm_probe.py A/B runs in one process): 0 = default choice (kernel4, LDS-DMA), 2 = kernel2 (register staging), 7 = kernel4 with 256 x 128 tiles / 4 waves
 static std::atomic<int> g_gemm_variant{0};
 
@@ -968,8 +715,6 @@ int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT2_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel5<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel5<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
@@ -1005,18 +750,6 @@ int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const
         }
         hipLaunchKernelGGL(k41, dim3(cdiv(M, S2_M) * cdiv(N, 128)), dim3(256), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N,
                            act, lo, hi);
-        MS_LAUNCH_CHECK();
-        return MS_OK;
-      }
-      if (variant == 14 && K >= 64) {   // experiment: the persistent tile loop, queues from a static ring
-        static unsigned* ring = nullptr;
-        static std::atomic<unsigned> ticket{0};
-        if (!ring) MS_HIP(hipMalloc((void**)&ring, 64 * 32));
-        unsigned* queue = ring + (ticket.fetch_add(1) % 64) * 8;
-        MS_HIP(hipMemsetAsync(queue, 0, 32, stream));
-        auto k5 = f16 ? gemm_nt_bf16x3_kernel5<true> : gemm_nt_bf16x3_kernel5<false>;
-        hipLaunchKernelGGL(k5, dim3(std::min(nwg2, num_cus())), dim3(512), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi,
-                           queue);
         MS_LAUNCH_CHECK();
         return MS_OK;
       }
