@@ -188,8 +188,14 @@ int ms_rnn_layer_forward(int cell, const void* packed, const float* x, const int
  *   MS_RNN_X_PLANES_IN_WS    the input is taken from those planes (left there by the previous layer's call with the
  *                            same T, N, max_len and workspace); `x` may be NULL.
  * Same arithmetic as splitting the float32 output afterwards, one pass over the activations less per layer. */
-enum { MS_RNN_X_PLANES_IN_WS = 1, MS_RNN_OUT_PLANES_TO_WS = 2 };
+enum { MS_RNN_X_PLANES_IN_WS = 1, MS_RNN_OUT_PLANES_TO_WS = 2, MS_RNN_PACKED_ROWS = 4 };
 int ms_rnn_layer_chains_planes(int cell, int H, int ndir);
+/* MS_RNN_PACKED_ROWS (a permission, for batches whose lengths differ): torch's packed sequences (rnn.py:174-181) hold only
+ * the frames t < lens[n]; with this flag the layer does the same where it can -- the input projection runs over sum(lens)
+ * rows instead of max_len * N and the chained planes hold only those rows, frame after frame -- and ignores it where it
+ * cannot.  Outputs are the same bits either way.  Whether a layer can depends on (cell, max_len, N, H, ndir), not on In:
+ * ms_rnn_layer_packs_rows() says; every layer of a chained stack must be given the same flag. */
+int ms_rnn_layer_packs_rows(int cell, int T, int N, int In, int H, int ndir);
 int ms_rnn_layer_forward_ex(int cell, const void* packed, const float* x, const int32_t* lens, int max_len,
                             const float* h0, const float* c0, float* out, float* hn, float* cn, int T, int N, int In,
                             int H, int ndir, int flags, void* workspace, size_t workspace_bytes, void* stream);

@@ -59,6 +59,7 @@ SIGNATURES = {
     "ms_rnn_layer_is_wide": (c_int, [c_int] * 4),
     "ms_rnn_status": (c_int, [_P, _P]),
     "ms_rnn_debug_offset": (c_size_t, [c_int] * 6),
+    "ms_rnn_layer_packs_rows": (c_int, [c_int] * 6),
     "ms_gemm_set_variant": (c_int, [c_int]),
     "ms_prof_enable": (c_int, [c_int]),
     "ms_prof_read": (c_int, [POINTER(c_float), POINTER(c_int)]),

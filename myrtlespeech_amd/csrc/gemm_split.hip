@@ -384,9 +384,16 @@ template <bool F16, int WN, int PER_STEP_ = 3, bool SPACED = false>
 __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah, const unsigned short* __restrict__ Al,
                                            const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
                                            const float* __restrict__ bias, float* __restrict__ Y, int M, int K, int N, int act,
-                                           float lo, float hi) {
+                                           float lo, float hi, const int* __restrict__ m_eff = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int TN = 128 * WN;
+  // m_eff (optional): the number of rows that exist is a word in device memory (<= the M the grid was sized for): the
+  // recurrent layers' packed projection, whose row count is the sum of the batch's lengths (rnn.hip).  Workgroups past
+  // the tiles of that many rows leave at once.
+  if (m_eff != nullptr) {
+    M = __builtin_amdgcn_readfirstlane(*m_eff);
+    if ((int)blockIdx.x >= ((N + TN - 1) / TN) * ((M + S2_M - 1) / S2_M)) return;
+  }
   const int nbn = (N + TN - 1) / TN, nbm = (M + S2_M - 1) / S2_M;
   const int nwg = nbn * nbm;
   int bid = blockIdx.x;
@@ -676,8 +683,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4(const unsigned 
                                                                  const unsigned short* __restrict__ Wh,
                                                                  const unsigned short* __restrict__ Wl,
                                                                  const float* __restrict__ bias, float* __restrict__ Y,
-                                                                 int M, int K, int N, int act, float lo, float hi) {
-  gemm4_body<F16, 2>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi);
+                                                                 int M, int K, int N, int act, float lo, float hi,
+                                                                 const int* __restrict__ m_eff) {
+  gemm4_body<F16, 2>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff);
 }
 
 // the 4-wave form, capped at 208 VGPRs (the two-stream LSTM kernel allocates 304 of a SIMD's 512): experiment only
@@ -685,8 +693,8 @@ template <bool F16, int PER_STEP = 3, bool SPACED = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel4n(
     const unsigned short* __restrict__ Ah, const unsigned short* __restrict__ Al, const unsigned short* __restrict__ Wh,
     const unsigned short* __restrict__ Wl, const float* __restrict__ bias, float* __restrict__ Y, int M, int K, int N, int act,
-    float lo, float hi) {
-  gemm4_body<F16, 1, PER_STEP, SPACED>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi);
+    float lo, float hi, const int* __restrict__ m_eff) {
+  gemm4_body<F16, 1, PER_STEP, SPACED>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff);
 }
 
 // tuning switch (tools/gemm_probe.py A/B runs in one process): 0 = default choice (kernel4, LDS-DMA), 2 = kernel2 (register staging), 7 = kernel4 with 256 x 128 tiles / 4 waves
@@ -705,9 +713,30 @@ int split_planes_launch(const float* x, unsigned short* hi, unsigned short* lo, 
 }
 
 // requires K % 32 == 0 and 16-byte aligned planes
+// whether a GEMM of this size runs on the LDS-DMA kernels, which take the row count from device memory (gemm_bf16x3_launch_rows)
+bool gemm_rows_from_device_ok(int M, int K, int N) {
+  static const bool small_tile = getenv("MS_GEMM_TILE128") && getenv("MS_GEMM_TILE128")[0] == '1';
+  static const bool regstage = getenv("MS_GEMM_REGSTAGE") && getenv("MS_GEMM_REGSTAGE")[0] == '1';
+  const long tiles256 = (long)cdiv(M, S2_M) * cdiv(N, S2_N);
+  const bool starved = tiles256 * 4 < (long)num_cus() * 3 && (long)cdiv(M, SB_M) * cdiv(N, SB_N) > tiles256;
+  return !small_tile && !regstage && !starved && (long)M * N >= 4L * 1024 * 1024 && K % 32 == 0 &&
+         (size_t)std::max(M, N) * K * 2 < ((size_t)1 << 31) && g_gemm_variant.load(std::memory_order_relaxed) != 2;
+}
+
+int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
+                            const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
+                            float hi, int prec, hipStream_t stream, const int* m_eff);
+
 int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
                        const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
                        float hi, int prec, hipStream_t stream) {
+  return gemm_bf16x3_launch_rows(ah, al, wh, wl, bias, y, M, K, N, act, lo, hi, prec, stream, nullptr);
+}
+
+// m_eff: optional device word holding the number of rows that exist (<= M); only where gemm_rows_from_device_ok(M, K, N)
+int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
+                            const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
+                            float hi, int prec, hipStream_t stream, const int* m_eff) {
   static ms::DeviceOnce attr_once;
   if (attr_once.need()) {
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS));
@@ -749,18 +778,26 @@ int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const
           if (variant == 11) k41 = gemm_nt_bf16x3_kernel4n<false, 2, true>;
         }
         hipLaunchKernelGGL(k41, dim3(cdiv(M, S2_M) * cdiv(N, 128)), dim3(256), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N,
-                           act, lo, hi);
+                           act, lo, hi, m_eff);
         MS_LAUNCH_CHECK();
         return MS_OK;
       }
       auto k4 = f16 ? gemm_nt_bf16x3_kernel4<true> : gemm_nt_bf16x3_kernel4<false>;
-      hipLaunchKernelGGL(k4, dim3(nwg2), dim3(512), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);
+      hipLaunchKernelGGL(k4, dim3(nwg2), dim3(512), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi, m_eff);
       MS_LAUNCH_CHECK();
       return MS_OK;
+    }
+    if (m_eff != nullptr) {
+      set_error("gemm_bf16x3_launch_rows: this shape does not run on the kernels that take the row count from the device");
+      return MS_ERR_UNSUPPORTED;
     }
     hipLaunchKernelGGL(kern, dim3(nwg2), dim3(512), SPLIT2_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);
     MS_LAUNCH_CHECK();
     return MS_OK;
+  }
+  if (m_eff != nullptr) {
+    set_error("gemm_bf16x3_launch_rows: this shape does not run on the kernels that take the row count from the device");
+    return MS_ERR_UNSUPPORTED;
   }
   const int nwg = cdiv(M, SB_M) * cdiv(N, SB_N);
   hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, dim3(nwg), dim3(256), SPLIT_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);

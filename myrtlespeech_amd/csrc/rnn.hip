@@ -32,6 +32,10 @@
 
 namespace ms {
 int split_planes_launch(const float* x, unsigned short* hi, unsigned short* lo, size_t elems, int prec, hipStream_t stream);
+bool gemm_rows_from_device_ok(int M, int K, int N);
+int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
+                            const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
+                            float hi, int prec, hipStream_t stream, const int* m_eff);
 int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
                        const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
                        float hi, int prec, hipStream_t stream);
@@ -141,7 +145,7 @@ PackLayout pack_layout(int cell, int In, int H, int ndir) {
 }
 
 struct WsLayout {
-  size_t status, flags, xproj, hx, hx_bytes, state_h, state_c, dbg, xsplit, total;
+  size_t status, flags, xproj, hx, hx_bytes, state_h, state_c, dbg, row_off, xsplit, total;
 };
 WsLayout ws_layout(int cell, int T, int N, int H, int ndir, int In) {
   const size_t GH = (size_t)gates_of(cell) * H;
@@ -160,6 +164,7 @@ WsLayout ws_layout(int cell, int T, int N, int H, int ndir, int In) {
   L.state_h = o; o += ms::align_up((size_t)2 * ndir * N * H * sizeof(float), 256);
   L.state_c = o; o += ms::align_up((size_t)ndir * N * H * sizeof(float), 256);
   L.dbg = o; o += ms::align_up((size_t)ndir * std::max(H / 8, 1) * 16 * sizeof(unsigned long long), 256);
+  L.row_off = o; o += ms::align_up((size_t)(T + 1) * sizeof(int), 256);   // packed rows: first row of every frame, and the total
   L.xsplit = o; o += ms::align_up((size_t)T * N * In * 4, 256);  // bf16 hi + lo planes of the layer input
   L.total = o;
   return L;
@@ -508,6 +513,9 @@ struct LstmP {
   // hi / lo, or one fp16 plane) instead of float32 `out` -- same bytes, and the separate plane-split pass disappears
   unsigned short* out_hi;
   unsigned short* out_lo;
+  // wide kernel, packed rows: row_off[t] = first row of frame t in `xproj` and in the planes, which then hold only the
+  // rows (t, n) with t < lens[n] (lens sorted in decreasing order), frame after frame; null = every frame has N_total rows
+  const int32_t* row_off;
 };
 
 __device__ __forceinline__ f32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
@@ -752,6 +760,45 @@ __device__ __forceinline__ unsigned epoch_tag0(int d, int steps, int rs = 1) {
   return d ? (unsigned)(((steps - 1) >> rs) & 1) : 0u;
 }
 
+__device__ __forceinline__ unsigned bf16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ float bf16_val(unsigned bits) { return __uint_as_float(bits << 16); }
+
+// ---- packed rows (round 3): a batch of ragged lengths, sorted in decreasing order, has sum(lens) rows that exist out of
+// steps * N.  torch's packed sequences (rnn.py:174-181) drop the others; so does the wide-workgroup path when the caller
+// allows it (MS_RNN_PACKED_ROWS): the operand planes and the projection hold frame 0's rows, then frame 1's, ...
+// row_off[t] = rows of the frames before t = sum over n of min(lens[n], t); row_off[steps] = the number of rows.
+__global__ __launch_bounds__(256) void row_offsets_kernel(const int32_t* __restrict__ lens, int N, int steps,
+                                                          int32_t* __restrict__ row_off) {
+  for (int t = threadIdx.x; t <= steps; t += blockDim.x) {
+    int acc = 0;
+    for (int n = 0; n < N; ++n) acc += min(max(lens[n], 0), t);
+    row_off[t] = acc;
+  }
+}
+
+// x f32 [steps][N][In] -> bf16 hi / lo planes of the rows that exist, packed (split_planes_kernel's arithmetic)
+__global__ __launch_bounds__(256) void split_planes_packed_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi,
+                                                                  unsigned short* __restrict__ lo,
+                                                                  const int32_t* __restrict__ lens,
+                                                                  const int32_t* __restrict__ row_off, int N, int In) {
+  const int t = blockIdx.x / N, n = blockIdx.x % N;
+  if (t >= lens[n]) return;
+  const float4* src = reinterpret_cast<const float4*>(x + (size_t)blockIdx.x * In);
+  const size_t dst = ((size_t)row_off[t] + n) * In;
+  for (int k = threadIdx.x; k < In / 4; k += blockDim.x) {
+    const float4 v = src[k];
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = bf16_bits(f[e]);
+      l[e] = bf16_bits(f[e] - bf16_val(h[e]));
+    }
+    *reinterpret_cast<uint2*>(hi + dst + 4 * k) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    *reinterpret_cast<uint2*>(lo + dst + 4 * k) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+  }
+}
+
 // Exchange-buffer initialisation: every 16-bit word of slot p of direction d gets the tag that is NOT the first one
 // expected there (all-ones or all-zeros words), so a poll that runs ahead of the producers never validates.
 // Layout of a direction: ... [parity][slab_bytes] ..., i.e. parity = (byte offset / slab_bytes) & 1.
@@ -796,8 +843,6 @@ __global__ void hx_init_kernel(unsigned* __restrict__ hx, size_t words_per_dir, 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned bf16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
-__device__ __forceinline__ float bf16_val(unsigned bits) { return __uint_as_float(bits << 16); }
 
 // sc1 + the intrinsic's "volatile" marker (aux bit 31): a re-load inside a polling loop
 // must never be merged with the previous one.
@@ -1322,8 +1367,8 @@ constexpr int WIDE_RED2 = 8 * 16 * WIDE_RED_STRIDE;        // 8 waves x 16 rows,
 // Uneven shares (waves 0-3 take KSC k-steps each, waves 4-7 the other 8 - KSC): the cell waves spend ~0.5 us of every
 // stream-step on the cell and the publish before they request their own operands, waves 4-7 go straight from the barrier
 // to the next request and share the SIMDs' matrix pipes with them.
-template <int KS, bool CELL, bool HARD, bool STAMP = false>
-__device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int k0) {
+template <int KS, bool CELL, bool HARD, bool STAMP = false, bool PACKED = false>
+__device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int k0, const int32_t* __restrict__ row_off) {
   constexpr int H = 1024, KG = H / 8;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1394,8 +1439,14 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
   unsigned long long st_sum[5] = {0, 0, 0, 0, 0}, st_prev = 0;
   if (STAMP) st_prev = wall_clock64();
 
+  // PACKED: first row of the step's frame in xproj / the planes; the next step's is fetched a step ahead
+  // (a kernel argument of its own, const and restrict: the compiler may then fetch it with scalar loads, outside the vector
+  // memory queue whose order the tag checks count on)
+  int roff_next = (PACKED && CELL) ? row_off[d ? p.steps - 1 : 0] : 0;
   for (int s = 0; s < p.steps; ++s) {
     const int t = d ? (p.steps - 1 - s) : s;
+    const int roff = roff_next;
+    if (PACKED && CELL) roff_next = row_off[s + 1 < p.steps ? (d ? t - 1 : t + 1) : t];
     const EpochClock ec = epoch_clock(d, s, p.steps, rs);
     const int par = ec.par;
     const unsigned em = ec.em;
@@ -1405,7 +1456,10 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
       float xg[4] = {0.f, 0.f, 0.f, 0.f};
       const int n = sg * 16 + nl;
       if (CELL && n < N) {
-        const float* xp = p.xproj + ((size_t)t * p.N_total + n_base + n) * xcols + d * 4 * H + jb * 32 + u;
+        // (PACKED: a row past its sequence's end does not exist; its thread reads the frame's first row instead -- every
+        // frame < steps has one -- and discards the result as it always did)
+        const size_t row = PACKED ? (size_t)(roff + (t < len_n[sg] ? n_base + n : 0)) : (size_t)t * p.N_total + n_base + n;
+        const float* xp = p.xproj + row * xcols + d * 4 * H + jb * 32 + u;
 #pragma unroll
         for (int g = 0; g < 4; ++g) xg[g] = xp[g * 8];
       }
@@ -1509,9 +1563,13 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
           const size_t oidx = ((size_t)t * p.N_total + n_base + n) * (p.ndir * H) + d * H + unit;
           const float ov = active ? hnew : 0.f;
           if (p.out_hi) {   // exactly split_planes_kernel's arithmetic
+            // (PACKED: a row that does not exist is written to the planes' last row slot, steps * N - 1, which no packed
+            // row of a batch with such a row reaches and nobody reads: a select on the address instead of a branch)
+            const size_t prow = active ? (size_t)(roff + n_base + n) : (size_t)p.steps * p.N_total - 1;
+            const size_t pidx = PACKED ? (prow * (p.ndir * H) + d * H + unit) : oidx;
             const unsigned hb = bf16_bits(ov);
-            p.out_hi[oidx] = (unsigned short)hb;
-            p.out_lo[oidx] = (unsigned short)bf16_bits(ov - bf16_val(hb));
+            p.out_hi[pidx] = (unsigned short)hb;
+            p.out_lo[pidx] = (unsigned short)bf16_bits(ov - bf16_val(hb));
           } else {
             p.out[oidx] = ov;
           }
@@ -1536,13 +1594,13 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
   }
 }
 
-template <bool HARD, int KSC, bool STAMP = false>
-__global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p) {
+template <bool HARD, int KSC, bool STAMP = false, bool PACKED = false>
+__global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p, const int32_t* __restrict__ row_off) {
   static_assert(KSC >= 1 && KSC <= 7, "both wave sets need at least one k-step");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wave < 4) wide2_wave<KSC, true, HARD, STAMP>(p, smem, wave * KSC);
-  else wide2_wave<8 - KSC, false, HARD, STAMP>(p, smem, 4 * KSC + (wave - 4) * (8 - KSC));
+  if (wave < 4) wide2_wave<KSC, true, HARD, STAMP, PACKED>(p, smem, wave * KSC, row_off);
+  else wide2_wave<8 - KSC, false, HARD, STAMP, false>(p, smem, 4 * KSC + (wave - 4) * (8 - KSC), row_off);
 }
 
 
@@ -2215,12 +2273,20 @@ static int launch_wide2(const LstmP& p, bool hard, int groups, hipStream_t strea
     MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_once.done();
   }
   const dim3 grid(groups * p.ndir * (p.J / 2));
   static const bool stamps = getenv("MS_LSTM_STAMPS") && getenv("MS_LSTM_STAMPS")[0] == '1';
+  if (p.row_off != nullptr) {   // packed rows (ragged batch): xproj and the planes hold only the rows that exist
+    if (hard) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 3, false, true>), grid, dim3(512), lds, stream, p, p.row_off);
+    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, false, true>), grid, dim3(512), lds, stream, p, p.row_off);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+  }
   if (stamps && !hard) {   // diagnostic build (tools/wide_stamps.py): the shipped arithmetic with wall-clock stamps around its phases
-    hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, true>), grid, dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, true>), grid, dim3(512), lds, stream, p, p.row_off);
     MS_LAUNCH_CHECK();
     return MS_OK;
   }
@@ -2228,11 +2294,11 @@ static int launch_wide2(const LstmP& p, bool hard, int groups, hipStream_t strea
   // 3.1 for 2 / 6, which spills (profiles/r03z_*); MS_LSTM_WIDE_KSC=4 keeps the equal split for A/B runs
   static const int ksc = getenv("MS_LSTM_WIDE_KSC") ? atoi(getenv("MS_LSTM_WIDE_KSC")) : 3;
   if (hard) {
-    if (ksc == 4) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 4>), grid, dim3(512), lds, stream, p);
-    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 3>), grid, dim3(512), lds, stream, p);
+    if (ksc == 4) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 4>), grid, dim3(512), lds, stream, p, p.row_off);
+    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 3>), grid, dim3(512), lds, stream, p, p.row_off);
   } else {
-    if (ksc == 4) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 4>), grid, dim3(512), lds, stream, p);
-    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3>), grid, dim3(512), lds, stream, p);
+    if (ksc == 4) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 4>), grid, dim3(512), lds, stream, p, p.row_off);
+    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3>), grid, dim3(512), lds, stream, p, p.row_off);
   }
   MS_LAUNCH_CHECK();
   return MS_OK;
@@ -2322,6 +2388,21 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
                                  workspace_bytes, stream_);
 }
 
+// Packed rows need the wide-workgroup recurrence (the only kernel that reads them) and the LDS-DMA GEMM (the only one that
+// takes its row count from device memory); the answer must not depend on In, since a stack's layers chain their planes.
+static bool layer_packs_rows(int cell, int steps, int N, int In, int H, int ndir) {
+  static const bool off = getenv("MS_RNN_PACKED") && getenv("MS_RNN_PACKED")[0] == '0';
+  if (off || !(cell == MS_CELL_LSTM || cell == MS_CELL_HARD_LSTM)) return false;
+  const int GH4 = 4 * H;
+  return use_fast(cell, H, ndir) && use_wide(cell, H, ndir, N) && use_split_gemm(cell, H, ndir, In) && !use_f16(cell, H, ndir) &&
+         ms::gemm_rows_from_device_ok(steps * N, 32, ndir * GH4) && (size_t)steps * N * std::max(In, ndir * H) * 2 < ((size_t)1 << 31);
+}
+
+extern "C" int ms_rnn_layer_packs_rows(int cell, int T, int N, int In, int H, int ndir) {
+  if (cell < 0 || cell > MS_CELL_HARD_LSTM || T <= 0 || N <= 0 || In <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return 0;
+  return layer_packs_rows(cell, T, N, In, H, ndir) ? 1 : 0;
+}
+
 extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float* x, const int32_t* lens, int max_len,
                                        const float* h0, const float* c0, float* out, float* hn, float* cn, int T, int N,
                                        int In, int H, int ndir, int flags, void* workspace, size_t workspace_bytes,
@@ -2350,6 +2431,15 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
   char* ws = (char*)workspace;
   const int steps = max_len;
   const bool fast = use_fast(cell, H, ndir);
+  // packed rows: only the rows (t, n) with t < lens[n] go through the projection and the planes (see row_offsets_kernel)
+  const bool packed_rows = (flags & MS_RNN_PACKED_ROWS) != 0 && lens != nullptr && layer_packs_rows(cell, steps, N, In, H, ndir);
+  MS_REQUIRE(packed_rows || !(flags & MS_RNN_PACKED_ROWS) || lens == nullptr || !(x_in_ws || out_to_ws),
+             "MS_RNN_PACKED_ROWS on a chained layer that cannot pack its rows (ask ms_rnn_layer_packs_rows for every layer of the stack)");
+  int32_t* row_off = (int32_t*)(ws + W.row_off);
+  if (packed_rows) {
+    hipLaunchKernelGGL(row_offsets_kernel, dim3(1), dim3(256), 0, stream, lens, N, steps, row_off);
+    MS_LAUNCH_CHECK();
+  }
 
   // status + epoch flags are re-zeroed on every call (cdna_hip_programming.md G16): by hx_init_kernel on the paths that
   // launch it anyway, by a memset otherwise
@@ -2373,11 +2463,18 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       const unsigned short* wh = (const unsigned short*)(pk + L.wih);
       const unsigned short* wl = wh + (size_t)ndir * GH * In;
       const int prec = use_f16(cell, H, ndir) ? ms::PREC_F16 : ms::PREC_BF16X3;
-      rc = x_in_ws ? MS_OK : ms::split_planes_launch(x, xh, xl, (size_t)steps * N * In, prec, stream);
+      if (x_in_ws) {
+        rc = MS_OK;
+      } else if (packed_rows) {
+        hipLaunchKernelGGL(split_planes_packed_kernel, dim3(steps * N), dim3(256), 0, stream, x, xh, xl, lens, row_off, N, In);
+        rc = hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_HIP;
+      } else {
+        rc = ms::split_planes_launch(x, xh, xl, (size_t)steps * N * In, prec, stream);
+      }
       if (rc == MS_OK) {
         ProfScope gemm_only(In >= 1024 ? MS_PROF_GEMM_K_LARGE : MS_PROF_GEMM_K_SMALL, stream);   // the split GEMM kernel alone, by contraction length
-        rc = ms::gemm_bf16x3_launch(xh, xl, wh, wl, (const float*)(pk + L.bias_x), xproj, steps * N, In, (int)(ndir * GH),
-                                    MS_ACT_NONE, 0.f, 0.f, prec, stream);
+        rc = ms::gemm_bf16x3_launch_rows(xh, xl, wh, wl, (const float*)(pk + L.bias_x), xproj, steps * N, In, (int)(ndir * GH),
+                                         MS_ACT_NONE, 0.f, 0.f, prec, stream, packed_rows ? row_off + steps : nullptr);
       }
     } else {
       ProfScope gemm_only(In >= 1024 ? MS_PROF_GEMM_K_LARGE : MS_PROF_GEMM_K_SMALL, stream);
@@ -2404,6 +2501,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       p.lens = lens;
       p.h0 = h0; p.c0 = c0; p.out = out; p.hn = hn; p.cn = cn;
       p.out_hi = p.out_lo = nullptr;
+      p.row_off = packed_rows ? row_off : nullptr;
       if (out_to_ws) {   // next layer: [steps*N][ndir*H] hi plane, then the lo plane
         p.out_hi = (unsigned short*)(ws + W.xsplit);
         p.out_lo = p.out_hi + (size_t)steps * N * ndir * H;

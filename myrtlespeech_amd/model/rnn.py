@@ -63,8 +63,10 @@ class PackedLayer:
 
 def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max_len: int,
                layer_params: List[List[Tuple[Optional[torch.Tensor], ...]]], packed: List[PackedLayer], hidden: int,
-               h0: Optional[torch.Tensor], c0: Optional[torch.Tensor], workspace: _lib.Workspace, check: bool = True):
-    """x [T,N,In] float32 cuda contiguous -> (out [T,N,D*H], hn, cn|None)."""
+               h0: Optional[torch.Tensor], c0: Optional[torch.Tensor], workspace: _lib.Workspace, check: bool = True,
+               ragged: bool = False):
+    """x [T,N,In] float32 cuda contiguous -> (out [T,N,D*H], hn, cn|None).  ``ragged``: the lengths differ -- layers that can
+    then work on the rows that exist only, like torch's packed sequences (``MS_RNN_PACKED_ROWS``; same outputs)."""
     lib = _lib.load()
     t, n, _ = x.shape
     ndir = len(layer_params[0])
@@ -79,10 +81,13 @@ def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max
     ws = workspace.get(max(lib.ms_rnn_workspace_bytes(cell, t, n, k, hidden, ndir) for k in in_sizes))
     # intermediate outputs of a two-stream LSTM stack travel as the next layer's GEMM operand planes inside the workspace
     chain = nl > 1 and bool(lib.ms_rnn_layer_chains_planes(cell, hidden, ndir)) and (ndir * hidden) % 32 == 0
+    # (all layers or none: a chained stack hands its planes from layer to layer in one row layout)
+    pack_rows = ragged and lens_dev is not None and all(lib.ms_rnn_layer_packs_rows(cell, max_len, n, k, hidden, ndir)
+                                                        for k in in_sizes)
     for layer in range(nl):
         in_size = in_sizes[layer]
         pk = packed[layer].get(cell, in_size, hidden, layer_params[layer])
-        flags = (1 if (chain and layer > 0) else 0) | (2 if (chain and layer < nl - 1) else 0)
+        flags = (1 if (chain and layer > 0) else 0) | (2 if (chain and layer < nl - 1) else 0) | (4 if pack_rows else 0)
         out = None if flags & 2 else torch.empty((t, n, ndir * hidden), dtype=torch.float32, device="cuda")
         sl = slice(layer * ndir, (layer + 1) * ndir)
         h0l = None if h0 is None else h0[sl].contiguous()
@@ -173,7 +178,8 @@ class RNN(torch.nn.Module):
             else:
                 h0 = _lib.f32c(hx)
         out, hn, cn = run_layers(_CELL[self.rnn_type], data, _lib.lens_i32(lens_cpu), max_len, self._layer_params(),
-                                 self._packed, self.rnn.hidden_size, h0, c0, self._workspace, self.check_status)
+                                 self._packed, self.rnn.hidden_size, h0, c0, self._workspace, self.check_status,
+                                 ragged=bool(int(lens_cpu[-1]) < max_len))
         if self.batch_first:
             out = out.transpose(0, 1)
         hid = (hn, cn) if self.rnn_type == RNNType.LSTM else hn

@@ -273,3 +273,36 @@ def wide_layer(path: str, n: int = 32, steps: int = 37) -> None:
         # both wave classes of a workgroup stamp the same loop: their sums agree to the skew of the last barrier
         assert float(((span[0] - span[8]).abs() / span[0]).max()) < 0.02
         print("stamps ok: %.0f ns per stream-step" % (float(span[0].mean()) / 4.0 / (2 * steps) * 10.0))
+
+
+def ragged_stack(path: str, n: int = 40, steps: int = 48, layers: int = 2) -> float:
+    """A chained stack of BiLSTM-1024 layers (the wide-workgroup kernel's shape, two batch groups) on a batch of RAGGED lengths:
+    by default the layers work on the rows that exist only (``MS_RNN_PACKED_ROWS``: projection over sum(lens) rows, packed planes
+    between the layers), with ``MS_RNN_PACKED=0`` in the environment on all ``steps * n`` rows.  Saves outputs and final states
+    to ``path`` (the two modes must give the same bits) and returns the largest error against the numpy oracle."""
+    from oracle import ds_oracle as O
+    from myrtlespeech_amd import _lib
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    lib = _lib.load()
+    torch.manual_seed(21)
+    m = RNN(RNNType.LSTM, 96, 1024, num_layers=layers, bidirectional=True, forget_gate_bias=1.0).eval()
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(steps, n, 96, generator=g)
+    lens = torch.sort(torch.randint(1, steps + 1, (n,), generator=g), descending=True).values
+    lens[0] = steps
+    expect_packed = os.environ.get("MS_RNN_PACKED") != "0"
+    assert bool(lib.ms_rnn_layer_packs_rows(0, steps, n, 96, 1024, 2)) == expect_packed
+    with torch.no_grad():
+        (y, _), (hn, cn) = m((x.cuda(), lens))
+    torch.cuda.synchronize()
+    np.savez(path, y=y.cpu().numpy(), hn=hn.cpu().numpy(), cn=cn.cpu().numpy())
+    sd = {k[len("rnn."):]: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    want, (wh, wc) = O.rnn_forward(O.LSTM, x.numpy(), lens.numpy(), sd, 1024, layers, True, None)
+    err = max(float(np.abs(y.cpu().numpy() - want).max()), float(np.abs(hn.cpu().numpy() - wh).max()),
+              float(np.abs(cn.cpu().numpy() - wc).max()))
+    # rows past a sequence's end are exactly zero (rnn.py:181 pad_packed_sequence)
+    yy = y.cpu().numpy()
+    for i, L in enumerate(lens.tolist()):
+        assert not yy[L:, i].any()
+    print("ragged stack: packed rows" if expect_packed else "ragged stack: all rows", "max err vs oracle %.3e" % err)
+    return err

@@ -72,6 +72,19 @@ def test_wide_lstm_stamp_build_is_the_shipped_arithmetic(tmp_path):
             assert np.array_equal(fa[k], fb[k]), k
 
 
+def test_ragged_batch_packed_rows_equal_all_rows(tmp_path):
+    """A ragged batch (40 sequences of 1 .. 48 frames: enough rows for the 256 x 256 GEMM tiles) through a chained 2-layer BiLSTM-1024 stack: the default path works on the sum(lens) rows that exist (as
+    torch's packed sequences do, rnn.py:174-181), ``MS_RNN_PACKED=0`` on all max_len * N rows.  Same bits, both within 1e-4 of the
+    oracle, rows past a sequence's end exactly zero."""
+    a, b = str(tmp_path / "packed.npz"), str(tmp_path / "dense.npz")
+    assert cfg_checks.ragged_stack(a) < 1e-4
+    out = _child(f"ragged_stack({b!r})", MS_RNN_PACKED="0")
+    assert "ragged stack: all rows" in out
+    with np.load(a) as fa, np.load(b) as fb:
+        for k in ("y", "hn", "cn"):
+            assert np.array_equal(fa[k], fb[k]), k
+
+
 # ----------------------------------------------------------------------------- configs[1] in the reference's own arithmetic width
 def test_cfg2_full_size_f32_mode_vs_reference_in_subprocess():
     """``MS_PRECISION=f32`` (float32 MFMA everywhere: the reference is fp32 end to end, model/rnn.py:177, model/cnn.py:481,

@@ -19,6 +19,9 @@ m = RNN(RNNType.LSTM, In, H, num_layers=1, bidirectional=True, forget_gate_bias=
 m.check_status = False
 x = torch.randn(T, N, In, device="cuda")
 lens = torch.full((N,), T, dtype=torch.int64)
+if os.environ.get("PROBE_RAGGED") == "1":   # lengths ~U[T / 2, T], sorted (the bench's ragged workload)
+    lens = torch.sort(torch.randint(T // 2, T + 1, (N,), generator=torch.Generator().manual_seed(5)), descending=True).values
+    lens[0] = T
 for _ in range(5):
     m((x, lens))
 torch.cuda.synchronize()
@@ -32,5 +35,6 @@ torch.cuda.synchronize()
 lib.ms_prof_read(ms, cnt)
 lib.ms_prof_enable(0)
 _lib.check(lib.ms_rnn_status(_lib.ptr(m._workspace.buf), _lib.stream_ptr()), "status")
+print(f"rows {int(lens.sum())} of {T * N}; ", end="")
 print(f"{os.path.basename(_lib.LIB_PATH)}: recurrence {ms[1] / max(cnt[1], 1):.4f} ms  projection {ms[0] / max(cnt[0], 1):.4f} ms  "
       f"({cnt[1]} launches)")
