@@ -306,3 +306,18 @@ def ragged_stack(path: str, n: int = 40, steps: int = 48, layers: int = 2) -> fl
         assert not yy[L:, i].any()
     print("ragged stack: packed rows" if expect_packed else "ragged stack: all rows", "max err vs oracle %.3e" % err)
     return err
+
+
+def ds2_ragged_logits(path: str) -> None:
+    """The config-2 network on one full-size batch of ragged lengths (~U[501, 1001] frames); logits, output lengths and final
+    states saved to ``path``: the packed-rows path (default) and ``MS_RNN_PACKED=0`` must write the same bits."""
+    import bench
+    model = bench.build_model()
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(32, 1, 80, 1001, generator=g)
+    lens = torch.sort(torch.randint(501, 1002, (32,), generator=g), descending=True).values
+    with torch.no_grad():
+        (y, ol), (hn, cn) = model((x.cuda(), lens))
+    torch.cuda.synchronize()
+    np.savez(path, y=y.cpu().numpy(), ol=ol.cpu().numpy(), hn=hn.cpu().numpy(), cn=cn.cpu().numpy())
+    print("ds2 ragged logits saved:", "all rows" if os.environ.get("MS_RNN_PACKED") == "0" else "packed rows")

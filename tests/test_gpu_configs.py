@@ -85,6 +85,18 @@ def test_ragged_batch_packed_rows_equal_all_rows(tmp_path):
             assert np.array_equal(fa[k], fb[k]), k
 
 
+def test_ragged_config2_batch_packed_rows_equal_all_rows_at_full_size(tmp_path):
+    """The same equality on the whole config-2 network at its stated size (32 x up to 1001 frames, five chained BiLSTM-1024 layers,
+    16 032 possible rows of which ~12 000 exist): logits, output lengths and final states bit for bit."""
+    a, b = str(tmp_path / "packed.npz"), str(tmp_path / "dense.npz")
+    cfg_checks.ds2_ragged_logits(a)
+    out = _child(f"ds2_ragged_logits({b!r})", MS_RNN_PACKED="0")
+    assert "all rows" in out
+    with np.load(a) as fa, np.load(b) as fb:
+        for k in ("y", "ol", "hn", "cn"):
+            assert np.array_equal(fa[k], fb[k]), k
+
+
 # ----------------------------------------------------------------------------- configs[1] in the reference's own arithmetic width
 def test_cfg2_full_size_f32_mode_vs_reference_in_subprocess():
     """``MS_PRECISION=f32`` (float32 MFMA everywhere: the reference is fp32 end to end, model/rnn.py:177, model/cnn.py:481,
