@@ -697,175 +697,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel4n(
   gemm4_body<F16, 1, PER_STEP, SPACED>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff);
 }
 
-// ---- kernel6 (round 3, experiment): TWO workgroups per CU, so that one computes while the other waits for the acknowledgement of
-// its epilogue stores, is replaced and fills its pipeline.  256 x 128 tiles, 4 waves (each 64 rows x 128 columns, the
-// accumulators of kernel4's waves), K-stages of 16 (= one MFMA k-step) in a ring of three LDS slots of 24 KB: 72 KB per
-// workgroup.  A slot is [x hi 256 rows x 32 B][x lo][W hi 128 rows x 32 B][W lo]; a DMA piece is 32 rows (two lanes fetch one
-// row's 32 contiguous bytes), six pieces per wave and stage; a fragment read (row = lane & 31, granule = lane >> 5) covers
-// 1 KB contiguously: no swizzle.  Per stage: DMA of stage s + 2 into the slot stage s - 1 left, 4 x 6 MFMAs with the W
-// fragments one step ahead, `s_waitcnt vmcnt(6)` (this wave's pieces of stage s + 1 have landed; those of s + 2 stay in
-// flight) and the barrier in front of the last MFMA group, under which the next stage's first fragments are read.
-// Same products in the same order per output element as kernel4: bit-identical.  K % 16 == 0, K >= 32.
-constexpr int G6_XP = 256 * 32, G6_WP = 128 * 32;          // bytes of one x / W plane of a slot
-constexpr int G6_SLOT = 2 * G6_XP + 2 * G6_WP;              // 24 KB
-constexpr int G6_LDS = 3 * G6_SLOT;
-
-template <bool F16>
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel6(const unsigned short* __restrict__ Ah,
-                                                                 const unsigned short* __restrict__ Al,
-                                                                 const unsigned short* __restrict__ Wh,
-                                                                 const unsigned short* __restrict__ Wl,
-                                                                 const float* __restrict__ bias, float* __restrict__ Y,
-                                                                 int M, int K, int N, int act, float lo, float hi) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  constexpr int TN = 128;
-  const int nbn = (N + TN - 1) / TN, nbm = (M + S2_M - 1) / S2_M;
-  const int nwg = nbn * nbm;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-  }
-  constexpr int GM = 4;
-  const int per_group = GM * nbn;
-  const int first_m = (bid / per_group) * GM;
-  const int gm = min(GM, nbm - first_m);
-  const int m0 = (first_m + (bid % per_group) % gm) * S2_M, n0 = ((bid % per_group) / gm) * TN;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
-
-  // ---- this wave's DMA pieces of a stage, in the order [x hi 0..7][x lo 0..7][W hi 0..3][W lo 0..3] (F16: [x 0..7][W 0..3])
-  constexpr int NPIECE = F16 ? 12 : 24, NP = NPIECE / 4;
-  __amdgpu_buffer_rsrc_t rs[NP];
-  int voff[NP], dstoff[NP];
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const int g = wave * NP + p;
-    int plane, prow;                                       // plane: 0 x hi, 1 x lo, 2 W hi, 3 W lo; prow: first row of the piece
-    if (F16) { plane = g < 8 ? 0 : 2; prow = (g < 8 ? g : g - 8) * 32; }
-    else { plane = g < 8 ? 0 : g < 16 ? 1 : g < 20 ? 2 : 3; prow = (g < 8 ? g : g < 16 ? g - 8 : g < 20 ? g - 16 : g - 20) * 32; }
-    const unsigned short* src = plane == 0 ? Ah : plane == 1 ? Al : plane == 2 ? Wh : Wl;
-    const int rows = plane < 2 ? M : N;
-    rs[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(src), 0, (unsigned)((size_t)rows * K * 2), 0x00020000);
-    voff[p] = min((plane < 2 ? m0 : n0) + prow + (lane >> 1), rows - 1) * (K * 2) + (lane & 1) * 16;
-    dstoff[p] = (plane == 0 ? 0 : plane == 1 ? G6_XP : plane == 2 ? 2 * G6_XP : 2 * G6_XP + G6_WP) + prow * 32;
-  }
-  auto dma_stage = [&](int st, int slot) {
-    const int soff = __builtin_amdgcn_readfirstlane(st * 32);   // 16 k = 32 bytes along the row
-#pragma unroll
-    for (int p = 0; p < NP; ++p) lds_dma_16(rs[p], lds + slot * G6_SLOT + dstoff[p], voff[p], soff);
-  };
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int foff = l31 * 32 + half * 16;
-  const int xa = (wave * 64) * 32 + foff;                   // x fragment of row group i: + i * 32 rows
-  const int wa = 2 * G6_XP + foff;                          // W fragment of column group j: + j * 32 rows
-  u32x4 xf[2][4];                                           // [set][hi 0, hi 1, lo 0, lo 1]
-  u32x4 wf[2][2];                                           // [ring][hi, lo]
-  auto rd_x = [&](int set, int slot) {
-    const char* b = lds + slot * G6_SLOT + xa;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      xf[set][i] = *reinterpret_cast<const u32x4*>(b + i * 32 * 32);
-      if (!F16) xf[set][2 + i] = *reinterpret_cast<const u32x4*>(b + G6_XP + i * 32 * 32);
-    }
-  };
-  auto rd_w = [&](int ring, int slot, int j) {
-    const char* b = lds + slot * G6_SLOT + wa + j * 32 * 32;
-    wf[ring][0] = *reinterpret_cast<const u32x4*>(b);
-    if (!F16) wf[ring][1] = *reinterpret_cast<const u32x4*>(b + G6_WP);
-  };
-  auto mm = [&](int xs, int wr, int j) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (F16) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[wr][0]), __builtin_bit_cast(f16x8, xf[xs][i]), acc[i][j], 0, 0, 0);
-      } else {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[wr][0]), __builtin_bit_cast(bf16x8, xf[xs][i]), acc[i][j], 0, 0, 0);
-      }
-    }
-    if (!F16) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[wr][0]), __builtin_bit_cast(bf16x8, xf[xs][2 + i]), acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[wr][1]), __builtin_bit_cast(bf16x8, xf[xs][i]), acc[i][j], 0, 0, 0);
-    }
-  };
-
-  const int ns = K / 16;
-  dma_stage(0, 0);
-  dma_stage(1, 1);
-  __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
-  __builtin_amdgcn_s_barrier();
-  rd_x(0, 0);
-  rd_w(0, 0, 0);
-  for (int s = 0; s < ns; ++s) {
-    const int slot = s % 3, xs = s & 1;
-    // stage s + 2 -> the slot stage s - 1 left (its readers passed the barrier of stage s - 1); past the end: the last stage
-    // again, into a slot nobody reads any more, so that the count of pieces in flight stays what the wait below assumes
-    dma_stage(min(s + 2, ns - 1), (s + 2) % 3);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j < 3) {
-        rd_w((j + 1) & 1, slot, j + 1);
-      } else {
-        // this wave's pieces of stage s + 1 have landed (the NP pieces of stage s + 2 may still be in flight); after the
-        // barrier everybody's have, and everybody has issued its last read of this slot
-        __builtin_amdgcn_s_waitcnt(F16 ? 0x0f73 : 0x0f76);
-        __builtin_amdgcn_s_barrier();
-        rd_x(xs ^ 1, (s + 1) % 3);
-        rd_w(0, (s + 1) % 3, 0);
-      }
-      mm(xs, j & 1, j);
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(0x0070);     // the tail's DMA must have landed before the LDS is released
-
-  const bool n_vec = (N % 4) == 0;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wave * 64 + i * 32 + l31;
-    if (m >= M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + j * 32 + 8 * g + 4 * half;
-        f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-        if (n_vec && n + 3 < N) {
-          if (bias != nullptr) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
-            v += bv;
-          }
-          if (act == MS_ACT_CLAMP) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], lo), hi);
-          }
-          *reinterpret_cast<f32x4*>(Y + (size_t)m * N + n) = v;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < N) {
-              float x = v[e] + (bias != nullptr ? bias[n + e] : 0.f);
-              if (act == MS_ACT_CLAMP) x = fminf(fmaxf(x, lo), hi);
-              Y[(size_t)m * N + n + e] = x;
-            }
-        }
-      }
-  }
-}
-
 // tuning switch (tools/gemm_probe.py A/B runs in one process): 0 = default choice (kernel4, LDS-DMA), 2 = kernel2 (register staging), 7 = kernel4 with 256 x 128 tiles / 4 waves
 static std::atomic<int> g_gemm_variant{0};
 
@@ -913,8 +744,6 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT2_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel6<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel6<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G6_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
@@ -950,12 +779,6 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
         }
         hipLaunchKernelGGL(k41, dim3(cdiv(M, S2_M) * cdiv(N, 128)), dim3(256), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N,
                            act, lo, hi, m_eff);
-        MS_LAUNCH_CHECK();
-        return MS_OK;
-      }
-      if (variant == 15 && K >= 32 && m_eff == nullptr) {   // experiment: two 4-wave workgroups per CU (kernel6)
-        auto k6 = f16 ? gemm_nt_bf16x3_kernel6<true> : gemm_nt_bf16x3_kernel6<false>;
-        hipLaunchKernelGGL(k6, dim3(cdiv(M, S2_M) * cdiv(N, 128)), dim3(256), G6_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);
         MS_LAUNCH_CHECK();
         return MS_OK;
       }
