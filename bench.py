@@ -526,12 +526,15 @@ def main(argv=None, runtime=None, json_fd=None):
         pmc_key = kname + ("@1group" if wide else "")
         mfma_peak = MFMA_F32_PEAK_TF if mode == "f32" else MFMA_BF16_PEAK_TF
         roof = {"bound": "hbm",   # the north-star's roofline for the LSTM step; what physically binds: next key
-                "what_binds": "L2 delivery in series with the step's arithmetic: every step each workgroup publishes its hidden "
-                              "units of h and pulls the whole h of its direction (64 KB per stream-step of 16 rows) out of its XCD's "
-                              "L2, during which it computes nothing (in-kernel stamps of the 8-unit kernel: no request is ever "
-                              "repeated, the wait is the load); 16 units per workgroup halve those bytes per unit of arithmetic and "
-                              "leave half of the CUs to a second batch (two_batches_per_forward) or to the other batch's projection "
-                              "GEMM (two_batches_in_flight); neither HBM nor MFMA",
+                "what_binds": "the cross-workgroup exchange of h in series with the step's arithmetic: every stream-step (16 rows) "
+                              "each workgroup publishes its 16 hidden units and pulls the whole h of its direction (64 KB) -- "
+                              "0.95 us at the ~67 GB/s a CU ingests when every CU of its XCD pulls the same rows, plus ~0.75 us of "
+                              "MFMA tail, barrier, cell and publish that cannot overlap it (a publish is answered fresh only ~1 us "
+                              "later; asking earlier, more row streams, a prefetch a stream-step ahead were all measured: "
+                              "profiles/r03ag..r03ao, tools/micro/exchange_wide.hip reproduces the 1.7 us with sleeps for the "
+                              "arithmetic).  16 units per workgroup leave half of the CUs to a second batch "
+                              "(two_batches_per_forward) or to the other batch's projection GEMM (two_batches_in_flight); "
+                              "neither HBM nor MFMA",
                 "kernel": kname + (" (one launch = 1 layer x 2 directions x 501 steps of one batch: 128 workgroups of 16 hidden units on "
                                    "half of the CUs)" if wide else " (one launch = 1 layer x 2 directions x 501 steps)"),
                 "launch_ms": round(rec_ms, 4),
