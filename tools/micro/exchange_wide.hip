@@ -9,7 +9,7 @@
 // (after the cell of the step before it, as shipped, or before its barrier), the number of workgroups (one or two batch
 // groups).  Reports us per stream-step and the repeated requests per wave and stream-step.
 //   hipcc -O3 --offload-arch=gfx950 tools/micro/exchange_wide.hip -o tools/micro/exchange_wide
-//   exchange_wide <NS> <mfma_sleeps> <cell_sleeps> <load_aux> <store_aux> <early 0|1|2> <groups 1|2> <ring slots>   (one s_sleep(8) ~ 0.21 us; aux: 1 sc0, 16 sc1, 17 both, 2 nt)
+//   exchange_wide <NS> <mfma_sleeps> <cell_sleeps> <load_aux> <store_aux> <early 0|1|2> <groups 1|2> <ring slots> <push> <mem>   (one s_sleep(8) ~ 0.21 us; aux: 1 sc0, 16 sc1, 17 both, 2 nt)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -155,7 +155,12 @@ int main(int argc, char** argv) {
   p.steps = 1000;
   if (p.NS < 1 || p.NS > 8 || groups < 1 || groups > 2) { printf("NS in 1..8, groups in 1..2\n"); return 1; }
   const size_t hbytes = (size_t)groups * 2 * p.NS * p.ring * 2 * PLANE;
-  (void)hipMalloc(&p.hbuf, hbytes); (void)hipMalloc(&p.out, 8); (void)hipMalloc(&p.fail, 4); (void)hipMalloc(&p.spins, 8);
+  // <mem>: 0 = hipMalloc (coarse-grained, what the library's callers hand over), 1 = fine-grained device memory, 2 = uncached
+  const int mem = argc > 10 ? atoi(argv[10]) : 0;
+  if (mem == 1) { if (hipExtMallocWithFlags((void**)&p.hbuf, hbytes, hipDeviceMallocFinegrained) != hipSuccess) { printf("fine-grained allocation failed\n"); return 1; } }
+  else if (mem == 2) { if (hipExtMallocWithFlags((void**)&p.hbuf, hbytes, hipDeviceMallocUncached) != hipSuccess) { printf("uncached allocation failed\n"); return 1; } }
+  else (void)hipMalloc(&p.hbuf, hbytes);
+  (void)hipMalloc(&p.out, 8); (void)hipMalloc(&p.fail, 4); (void)hipMalloc(&p.spins, 8);
   (void)hipMemset(p.hbuf, 0, hbytes); (void)hipMemset(p.out, 0, 8); (void)hipMemset(p.fail, 0, 4); (void)hipMemset(p.spins, 0, 8);
   const int wgs = groups * 128;
   if (laux == 16) launch<16>(saux, wgs, p);
@@ -170,6 +175,7 @@ int main(int argc, char** argv) {
   printf("wide exchange: ring %d, %d streams, %d workgroups, mfma=%d cell=%d sleeps, load aux %d, store aux %d, request %s: %.3f us per stream-step, "
          "%.2f repeated requests per wave and stream-step%s\n", p.ring, p.NS, wgs, p.mfma_sleeps, p.cell_sleeps, laux, saux,
          p.early == 2 ? "a stream-step ahead (second register set)" : p.early ? "before the barrier" : "after the cell", us / p.NS, (double)sp / ((double)wgs * 8 * p.steps * p.NS), f ? "  (TIMEOUTS!)" : "");
+  if (mem) printf("   (exchange buffer in %s device memory)\n", mem == 1 ? "fine-grained" : "uncached");
   if (p.push) printf("   (after the publish: %s)\n", p.push == 1 ? "release fence at agent scope" : p.push == 2 ? "two plain stores elsewhere" : "s_waitcnt vmcnt(0)");
   return 0;
 }
