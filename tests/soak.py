@@ -121,6 +121,37 @@ def rnn_case(seed):
     np.testing.assert_allclose(h.cpu().numpy(), whid[0] if isinstance(whid, tuple) else whid, rtol=1e-4, atol=1e-4)
 
 
+_packed_rnn = {}
+
+
+def packed_rows_case(seed):
+    """A ragged batch big enough for the packed-rows path (MS_RNN_PACKED_ROWS: >= 1536 rows, up to 64 sequences of very different
+    lengths, one or two chained BiLSTM-1024 layers, sometimes a short batch group or one sequence much longer than the rest)."""
+    from myrtlespeech_amd import _lib
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    rng = np.random.default_rng(seed)
+    layers = 1 + seed % 2
+    if layers not in _packed_rnn:
+        torch.manual_seed(900 + layers)
+        m = RNN(RNNType.LSTM, 32, 1024, num_layers=layers, bidirectional=True, forget_gate_bias=1.0).eval()
+        _packed_rnn[layers] = (m, {k[len("rnn."):]: v.detach().cpu().numpy() for k, v in m.state_dict().items()})
+    m, sd = _packed_rnn[layers]
+    N = int(rng.integers(33, 65))
+    T_ = int(rng.integers(-(-1536 // N), 64))
+    lo = int(rng.integers(1, T_ + 1))
+    lens = np.sort(rng.integers(lo, T_ + 1, size=N))[::-1].copy()
+    lens[0] = T_
+    if seed % 5 == 0:
+        lens[1:] = np.minimum(lens[1:], max(1, T_ // 4))      # one long sequence, the rest short
+    assert _lib.load().ms_rnn_layer_packs_rows(0, T_, N, 32, 1024, 2) == 1
+    x = rng.normal(size=(T_, N, 32)).astype(np.float32)
+    (out, _), (hn, cn) = m((torch.from_numpy(x), torch.from_numpy(lens)))
+    want, (wh, wc) = O.rnn_forward(O.LSTM, x, lens, sd, 1024, layers, True, None)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(hn.cpu().numpy(), wh, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(cn.cpu().numpy(), wc, rtol=1e-4, atol=1e-4)
+
+
 def ctc_case(seed):
     from myrtlespeech_amd.loss.ctc_loss import CTCLoss
     rng = np.random.default_rng(seed)
@@ -397,6 +428,7 @@ family("rnn-t greedy+beam vs oracle", rnnt_case)
 if _ties:
     print(f"  rnn-t beam: {len(_ties)} case(s) decided by a <= 4 ulp score difference (summation order): seeds {_ties[:8]}", flush=True)
 family("lstm/gru/rnn vs oracle", rnn_case)
+family("ragged LSTM-1024, packed rows", packed_rows_case)
 family("mask-conv2d vs oracle", conv_case)
 family("mask-conv1d vs oracle", conv1d_case)
 family("linear kernels vs float64", linear_case)
