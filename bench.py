@@ -529,7 +529,7 @@ def main(argv=None, runtime=None, json_fd=None):
                 "what_binds": "the cross-workgroup exchange of h in series with the step's arithmetic: every stream-step (16 rows) "
                               "each workgroup publishes its 16 hidden units and pulls the whole h of its direction (64 KB) -- "
                               "0.95 us at the ~67 GB/s a CU ingests when every CU of its XCD pulls the same rows, plus ~0.75 us of "
-                              "MFMA tail, barrier, cell and publish that cannot overlap it (a publish is answered fresh only ~1 us "
+                              "MFMA tail, barrier, cell and publish that cannot overlap it (a publish is answered fresh only ~0.8 us "
                               "later; asking earlier, more row streams, a prefetch a stream-step ahead were all measured: "
                               "profiles/r03ag..r03ao, tools/micro/exchange_wide.hip reproduces the 1.7 us with sleeps for the "
                               "arithmetic).  16 units per workgroup leave half of the CUs to a second batch "
