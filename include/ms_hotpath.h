@@ -13,7 +13,7 @@
  *   - every pointer is a DEVICE pointer unless its name ends in _host;
  *   - tensors are dense, row-major, float32 unless stated; lengths are int32;
  *   - `stream` is a hipStream_t (NULL = default stream); calls only enqueue
- *     work, they never synchronise (ms_rnn_status is the one exception);
+ *     work, they never synchronise (exceptions: ms_rnn_status, ms_prof_read and the greedy ms_rnnt_decode);
  *   - return value: MS_OK or an MS_ERR_* code; ms_last_error() describes the
  *     last failure on the calling thread;
  *   - outputs are caller-allocated; nothing is freed or retained.
@@ -42,7 +42,11 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 1
+/* 2 (round 4): ms_prof_read writes MS_PROF_KINDS = 9 entries (was 4 in version 1); the `zero_infinity` argument of the CTC
+ * entry points is a bit field {1 = zero_infinity, MS_CTC_LOG_PROBS_IN} and values above 3 are rejected;
+ * ms_ctc_loss_backward takes the same bit field; ms_log_softmax_axis_backward is new.  The Python binding refuses a
+ * library whose ms_abi_version() differs (myrtlespeech_amd/_lib.py). */
+#define MS_ABI_VERSION 2
 
 enum {
   MS_OK = 0,
@@ -267,13 +271,19 @@ int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, const int32
 /* LogSoftmax over an axis other than the last one (ctc_loss.py:45 passes the constructor's `dim` through): x, y are
  * contiguous [outer, axis, inner]; y = x - logsumexp over `axis`. */
 int ms_log_softmax_axis(const float* x, float* y, int outer, int axis, int inner, void* stream);
+/* Its backward (autograd through LogSoftmax(dim), ctc_loss.py:45): y = the log-probabilities ms_log_softmax_axis wrote,
+ * g = the gradient with respect to them; gx = g - exp(y) * sum over `axis` of g.  gx may alias g. */
+int ms_log_softmax_axis_backward(const float* y, const float* g, float* gx, int outer, int axis, int inner, void* stream);
 
 /* Gradient of ms_ctc_loss_forward's per-utterance losses with respect to the logits (what autograd gives the
  * reference through LogSoftmax + torch.nn.CTCLoss, loss/ctc_loss.py:95-101): alpha rows forward, beta rows backward,
  * grad_logits[t,n,k] = grad_nll[n] * (softmax(x)[t,k] - exp(logsumexp_{s: l'_s=k}(alpha_t(s)+beta_t(s)) + nll[n] - lp[t,k]))
  * for t < in_lens[n], 0 on padding frames and, with zero_infinity, for utterances whose loss is infinite.  grad_nll
  * [N] is the upstream gradient of each nll[n] (the host folds the reduction in: 1 for 'sum', 1/(N*max(len,1)) for
- * 'mean').  grad_logits [T,N,V] is fully written. */
+ * 'mean').  grad_logits [T,N,V] is fully written.  `zero_infinity` is the same bit field as in ms_ctc_loss_forward: with
+ * MS_CTC_LOG_PROBS_IN the `logits` are taken as log-probabilities (no softmax over the symbols: lp = logits) and the result
+ * is what torch.nn.CTCLoss's backward hands to the LogSoftmax(dim) in front of it, exp(lp) - exp(... - lp) (the caller
+ * chains ms_log_softmax_axis_backward); values above 3 are rejected. */
 size_t ms_ctc_loss_backward_workspace_bytes(int T, int N, int V, int S_max);
 int ms_ctc_loss_backward(const float* logits, const int32_t* in_lens, const int32_t* targets, const int32_t* tgt_offsets,
                          const int32_t* tgt_lens, const float* grad_nll, float* grad_logits, int T, int N, int V,
@@ -380,7 +390,10 @@ int ms_rnnt_topk(const float* scores, int32_t* out_idx, float* out_val, int B, i
  * greedy == 0: time-synchronous beam search of width beam_width (<= 32) with max_symbols rounds per frame (blank
  * transitions of equal prefixes merged by float32 logaddexp evaluated in float64; the beam_width best label
  * extensions, ties to the lowest (hypothesis, label) index, stay live); out_idx [N, T*(max_symbols-1) + 1].
- * out_len [N]; out_score [N] (beam only, may be NULL) is the log-probability of the returned hypothesis. */
+ * out_len [N]; out_score [N] (beam only, may be NULL) is the log-probability of the returned hypothesis.
+ * The greedy decode is the one entry point besides ms_rnn_status that BLOCKS the host: the number of iterations depends on
+ * the labels emitted, so the host polls a device counter a few iterations behind the launch queue and returns once the last
+ * poll's copy has landed (the beam decode only enqueues).  MS_ERR_HIP if the pinned counter ring cannot be created. */
 size_t ms_rnnt_decode_workspace_bytes(int T, int N, int V, int D, int H, int L, int J, int beam_width, int max_symbols,
                                       int greedy);
 int ms_rnnt_decode(const float* enc_p, const int32_t* lens, const float* embedding, const float* const* w_ih,

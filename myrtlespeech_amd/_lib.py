@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("MS_HOTPATH_LIB") or os.path.join(_HERE, "libms_hotpat
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ms_hotpath.h")
 
 MS_OK = 0
+ABI_VERSION = 2    # include/ms_hotpath.h MS_ABI_VERSION this binding was written against (checked in load())
 ERR_NAMES = {1: "MS_ERR_INVALID", 2: "MS_ERR_HIP", 3: "MS_ERR_WORKSPACE", 4: "MS_ERR_TIMEOUT", 5: "MS_ERR_UNSUPPORTED"}
 
 CELL_LSTM, CELL_GRU, CELL_RNN_TANH, CELL_HARD_LSTM = 0, 1, 2, 3
@@ -67,6 +68,7 @@ SIGNATURES = {
     "ms_ctc_loss_workspace_bytes": (c_size_t, [c_int] * 4),
     "ms_ctc_loss_forward": (c_int, [_P] * 7 + [c_int] * 7 + [_P, c_size_t, _P]),
     "ms_log_softmax_axis": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ms_log_softmax_axis_backward": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "ms_ctc_loss_backward_workspace_bytes": (c_size_t, [c_int] * 4),
     "ms_ctc_loss_backward": (c_int, [_P] * 7 + [c_int] * 6 + [_P, c_size_t, _P]),
     "ms_ctc_greedy_decode": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
@@ -111,6 +113,10 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        got = lib.ms_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports MS_ABI_VERSION {got}, this binding needs {ABI_VERSION}: rebuild the "
+                               "library (`make -C myrtlespeech_amd/csrc`)")
         _lib = lib
     return _lib
 

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_grad_kernel(const float* __re
                                                                const float* __restrict__ grad_nll, float* __restrict__ grad,
                                                                float* __restrict__ logz_ws, float* __restrict__ alpha_ws,
                                                                int T, int N, int V, int S_max, int blank,
-                                                               int zero_infinity) {
+                                                               int zero_infinity, int log_probs_in) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x, tid = threadIdx.x;
   int* ext = reinterpret_cast<int*>(smem);   // [S_max]
@@ -123,6 +123,10 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_grad_kernel(const float* __re
   const float go = grad_nll[n];
 
   for (int t = tid; t < Tn; t += CTC_THREADS) {
+    // CTCLoss(dim != -1): the values are what torch.nn.CTCLoss takes as log-probabilities; its backward still returns
+    // exp(lp) - exp(log sum alpha beta + nll - lp) (aten/native/LossCTC.cpp), which is what is written here -- the
+    // log-softmax over the other axis is chained behind it by ms_log_softmax_axis_backward
+    if (log_probs_in) { logz[t] = 0.f; continue; }
     const float* row = logits + ((size_t)t * N + n) * V;
     float m = neg_inf();
     for (int v = 0; v < V; ++v) m = fmaxf(m, row[v]);
@@ -318,6 +322,7 @@ extern "C" int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, 
   MS_REQUIRE(blank >= 0 && blank < V, "blank out of range");
   MS_REQUIRE(reduction >= 0 && reduction <= 2, "reduction must be 0 (none), 1 (mean) or 2 (sum)");
   MS_REQUIRE(reduction == 0 || reduced, "reduced output required");
+  MS_REQUIRE(zero_infinity >= 0 && zero_infinity <= (1 | MS_CTC_LOG_PROBS_IN), "zero_infinity takes 0 / 1, optionally OR-ed with MS_CTC_LOG_PROBS_IN");
   if (workspace_bytes < ms_ctc_loss_workspace_bytes(T, N, V, S_max)) {
     ms::set_error("ms_ctc_loss_forward: workspace too small");
     return MS_ERR_WORKSPACE;
@@ -358,7 +363,33 @@ __global__ void log_softmax_axis_kernel(const float* __restrict__ x, float* __re
   const float lz = logf(sum) + m;
   for (int a = 0; a < axis; ++a) yp[(size_t)a * inner] = xp[(size_t)a * inner] - lz;
 }
+
+// backward of the pass above: gx[o, a, i] = g[o, a, i] - exp(y[o, a, i]) * sum_a g[o, :, i]   (y = the log-probabilities)
+__global__ void log_softmax_axis_backward_kernel(const float* __restrict__ y, const float* g, float* gx, int outer, int axis,
+                                                 int inner) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)outer * inner) return;
+  const int o = (int)(id / inner), i = (int)(id % inner);
+  const size_t base = (size_t)o * axis * inner + i;
+  float sum = 0.f;
+  for (int a = 0; a < axis; ++a) sum += g[base + (size_t)a * inner];
+  for (int a = 0; a < axis; ++a) {
+    const size_t j = base + (size_t)a * inner;
+    gx[j] = g[j] - expf(y[j]) * sum;
+  }
+}
 }  // namespace
+
+extern "C" int ms_log_softmax_axis_backward(const float* y, const float* g, float* gx, int outer, int axis, int inner,
+                                            void* stream) {
+  MS_REQUIRE(y && g && gx, "null pointer");
+  MS_REQUIRE(outer > 0 && axis > 0 && inner > 0, "bad shape");
+  const long n = (long)outer * inner;
+  hipLaunchKernelGGL(log_softmax_axis_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, g,
+                     gx, outer, axis, inner);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}
 
 extern "C" int ms_log_softmax_axis(const float* x, float* y, int outer, int axis, int inner, void* stream) {
   MS_REQUIRE(x && y, "null pointer");
@@ -394,6 +425,7 @@ extern "C" int ms_ctc_loss_backward(const float* logits, const int32_t* in_lens,
   MS_REQUIRE(logits && in_lens && targets && tgt_offsets && tgt_lens && grad_nll && grad_logits && workspace, "null pointer");
   MS_REQUIRE(T > 0 && N > 0 && V > 0 && S_max >= 1, "bad shape");
   MS_REQUIRE(blank >= 0 && blank < V, "blank out of range");
+  MS_REQUIRE(zero_infinity >= 0 && zero_infinity <= (1 | MS_CTC_LOG_PROBS_IN), "zero_infinity takes 0 / 1, optionally OR-ed with MS_CTC_LOG_PROBS_IN");
   if (workspace_bytes < ms_ctc_loss_backward_workspace_bytes(T, N, V, S_max)) {
     ms::set_error("ms_ctc_loss_backward: workspace too small");
     return MS_ERR_WORKSPACE;
@@ -409,7 +441,8 @@ extern "C" int ms_ctc_loss_backward(const float* logits, const int32_t* in_lens,
   float* logz = (float*)workspace;
   float* alpha = (float*)((char*)workspace + ms::align_up((size_t)T * N * sizeof(float), 256));
   hipLaunchKernelGGL(ctc_grad_kernel, dim3(N), dim3(CTC_THREADS), lds, (hipStream_t)stream, logits, in_lens, targets,
-                     tgt_offsets, tgt_lens, grad_nll, grad_logits, logz, alpha, T, N, V, S_max, blank, zero_infinity);
+                     tgt_offsets, tgt_lens, grad_nll, grad_logits, logz, alpha, T, N, V, S_max, blank, zero_infinity & 1,
+                     (zero_infinity & MS_CTC_LOG_PROBS_IN) ? 1 : 0);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }

@@ -2314,7 +2314,9 @@ bool use_wide(int cell, int H, int ndir, int N) {
   static const int mode = getenv("MS_LSTM_WIDE") ? atoi(getenv("MS_LSTM_WIDE")) : -1;    // -1: default (on)
   if (mode == 0) return false;
   if (H != 1024 || N > 64 || !use_split(cell, H, ndir) || ms::precision_mode() != ms::PREC_BF16X3) return false;
-  static std::atomic<int> ok[64];     // per device: 0 = not asked, 1 = fits, 2 = does not
+  // the occupancy / LDS answer is a property of the device and is asked once; whether THIS call's grid (batch groups x
+  // directions x H/16 workgroups, all of which wait for each other) fits the CUs is evaluated on every call
+  static std::atomic<int> ok[64];     // per device: 0 = not asked, 1 = a workgroup fits a CU, 2 = it does not
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   int v = ok[dev & 63].load(std::memory_order_relaxed);
@@ -2323,11 +2325,12 @@ bool use_wide(int cell, int H, int ndir, int N) {
     const size_t lds = (size_t)2 * WIDE_RED2 * sizeof(float);
     const bool fits = hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
                       hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)lstm_persistent_wide2_kernel<false, 3>, 512, lds) == hipSuccess &&
-                      nb >= 1 && ms::num_cus() >= 2 * ndir * (H / 16);
+                      nb >= 1;
     v = fits ? 1 : 2;
     ok[dev & 63].store(v, std::memory_order_relaxed);
   }
-  return v == 1;
+  if (v != 1) return false;
+  return ms::cdiv(N, 32) * ndir * (H / 16) <= ms::num_cus();
 }
 
 template <int G, bool HARD>
@@ -2538,14 +2541,14 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
                              zero_base(0), g == 0 ? zero_words(0) : 0);
           MS_LAUNCH_CHECK();
         }
-        if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.xsplit - W.dbg, stream));
+        if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.row_off - W.dbg, stream));   // the stamp area only: row_off (packed rows) follows it
         rc = launch_wide2(p, cell == MS_CELL_HARD_LSTM, groups, stream);
         if (rc != MS_OK) return rc;
         break;
       }
       if (use_split(cell, H, ndir)) {
         const bool hard_ = (cell == MS_CELL_HARD_LSTM);
-        if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.total - W.dbg, stream));
+        if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.row_off - W.dbg, stream));
         static const bool one_stream = getenv("MS_LSTM_ONE_STREAM") && getenv("MS_LSTM_ONE_STREAM")[0] == '1';
         const bool two_stream = p.NPAD == 32 && two_stream_shape(H) && (!one_stream || use_f16(cell, H, ndir));
         {
@@ -2581,7 +2584,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
         continue;
       }
       if (stamps && pipe && p.NPAD == 32 && !(cell == MS_CELL_HARD_LSTM)) {
-        MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.total - W.dbg, stream));
+        MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.row_off - W.dbg, stream));
         rc = launch_persistent<1, false, true, true>(p, stream);
         if (rc != MS_OK) return rc;
         continue;

@@ -648,6 +648,29 @@ __global__ __launch_bounds__(64) void greedy_scan_kernel(const float* __restrict
   }
 }
 
+// The greedy decode polls a device counter (utterances finished) through a small pinned ring; allocating pinned memory or
+// freeing it synchronises the whole device (a decode on one stream of pipeline.TwoBatchesInFlight would stall the other), so
+// ring and events are made once per (host thread, device) and kept.
+struct GreedyPoll {
+  static constexpr int RING = 4;
+  int32_t* host = nullptr;
+  hipEvent_t ev[RING] = {nullptr, nullptr, nullptr, nullptr};
+};
+GreedyPoll* greedy_poll() {
+  static thread_local GreedyPoll polls[64];
+  static thread_local unsigned char state[64];       // 0 = not made, 1 = ready, 2 = failed
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  dev &= 63;
+  if (state[dev] == 0) {
+    GreedyPoll& g = polls[dev];
+    bool ok = hipHostMalloc((void**)&g.host, GreedyPoll::RING * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
+    for (int k = 0; ok && k < GreedyPoll::RING; ++k) ok = hipEventCreateWithFlags(&g.ev[k], hipEventDisableTiming) == hipSuccess;
+    state[dev] = ok ? 1 : 2;
+  }
+  return state[dev] == 1 ? &polls[dev] : nullptr;
+}
+
 struct Net {
   const float* embedding;
   const float* w_pred;
@@ -741,14 +764,18 @@ extern "C" int ms_rnnt_decode(const float* enc_p, const int32_t* lens, const flo
     // every iteration advances every unfinished utterance by one label or by a whole chunk of blanks, so this bound is
     // never reached unless the device counter cannot be read
     const long max_iters = (long)T * max_symbols + ms::cdiv(T, GREEDY_CHUNK) + 1;
-    constexpr int CHECK_EVERY = 2, RING = 4;
-    int32_t* host_done = nullptr;
-    hipEvent_t ev[RING] = {nullptr, nullptr, nullptr, nullptr};
-    bool polled = hipHostMalloc((void**)&host_done, RING * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
-    for (int k = 0; polled && k < RING; ++k) {
-      host_done[k] = 0;
-      polled = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) == hipSuccess;
+    constexpr int CHECK_EVERY = 2;
+    GreedyPoll* poll = greedy_poll();
+    if (poll == nullptr) {
+      ms::set_error("ms_rnnt_decode: pinned counter ring / events for the greedy decode's end-of-work poll could not be created");
+      return MS_ERR_HIP;
     }
+    int32_t* host_done = poll->host;
+    hipEvent_t* ev = poll->ev;
+    constexpr int RING = GreedyPoll::RING;
+    for (int k = 0; k < RING; ++k) host_done[k] = 0;      // no copy of an earlier call is in flight: every call ends on its last event
+    bool polled = true;
+    int last_slot = -1;
     long checks = 0;
     rc = MS_OK;
     for (long it = 0; it < max_iters && rc == MS_OK; ++it) {
@@ -764,7 +791,8 @@ extern "C" int ms_rnnt_decode(const float* enc_p, const int32_t* lens, const flo
       // the queue stays at least CHECK_EVERY iterations deep and at most 2 * CHECK_EVERY iterations run past the end
       const int slot = (int)(checks % RING);
       if (hipMemcpyAsync(&host_done[slot], done_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
-          hipEventRecord(ev[slot], s) != hipSuccess) { polled = false; continue; }
+          hipEventRecord(ev[slot], s) != hipSuccess) { ms::set_error("ms_rnnt_decode: counter read-back failed"); rc = MS_ERR_HIP; break; }
+      last_slot = slot;
       ++checks;
       if (checks > 2) {
         const int old = (int)((checks - 3) % RING);
@@ -772,11 +800,10 @@ extern "C" int ms_rnnt_decode(const float* enc_p, const int32_t* lens, const flo
       }
     }
     if (rc == MS_OK && hipMemcpyAsync(out_len, out_cnt, (size_t)N * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = MS_ERR_HIP;
-    if (host_done) {
-      (void)hipStreamSynchronize(s);                    // the pinned words are targets of copies in flight
-      for (int k = 0; k < RING; ++k) if (ev[k]) (void)hipEventDestroy(ev[k]);
-      (void)hipHostFree(host_done);
-    }
+    // the pinned words are targets of copies in flight: wait for the last one (the host has run at most 2 * CHECK_EVERY
+    // iterations ahead, so this is short); the ring and the events stay with the thread for its next call
+    if (last_slot >= 0) (void)hipEventSynchronize(ev[last_slot]);
+    (void)polled;
     return rc;
   }
 

@@ -18,7 +18,8 @@ _REDUCTION = {"none": 0, "mean": 1, "sum": 2}
 
 
 class _CTCLossFunction(torch.autograd.Function):
-    """Forward = ``ms_ctc_loss_forward``; backward = ``ms_ctc_loss_backward`` (logits gradient only)."""
+    """Forward = ``ms_ctc_loss_forward``; backward = ``ms_ctc_loss_backward`` (logits gradient only), followed by
+    ``ms_log_softmax_axis_backward`` when the constructor's ``dim`` is not the symbol axis."""
 
     @staticmethod
     def forward(ctx, x, run_forward, meta):
@@ -44,10 +45,20 @@ class _CTCLossFunction(torch.autograd.Function):
         grad = torch.empty_like(x)
         nbytes = lib.ms_ctc_loss_backward_workspace_bytes(t, n, v, m["s_max"])
         ws = m["workspace"].get(nbytes)
-        _lib.check(lib.ms_ctc_loss_backward(_lib.ptr(x), _lib.ptr(m["xl_dev"]), _lib.ptr(m["y_dev"]), _lib.ptr(m["off_dev"]),
+        # `log_probs` (CTCLoss(dim != -1), ctc_loss.py:37-45): the values LogSoftmax(dim) produced over time or over the batch,
+        # which torch.nn.CTCLoss took as log-probabilities; the gradient with respect to THEM comes out of the alpha-beta
+        # kernel, LogSoftmax's own backward over that axis follows
+        lp = m.get("log_probs")
+        src = x if lp is None else lp
+        _lib.check(lib.ms_ctc_loss_backward(_lib.ptr(src), _lib.ptr(m["xl_dev"]), _lib.ptr(m["y_dev"]), _lib.ptr(m["off_dev"]),
                                             _lib.ptr(m["yl_dev"]), _lib.ptr(grad_nll), _lib.ptr(grad), t, n, v, m["s_max"],
-                                            m["blank"], m["zero_infinity"], _lib.ptr(ws), nbytes, _lib.stream_ptr()),
+                                            m["blank"], m["zero_infinity"] | (0 if lp is None else 2), _lib.ptr(ws), nbytes,
+                                            _lib.stream_ptr()),
                    "ms_ctc_loss_backward")
+        if lp is not None:
+            outer, axis, inner = m["axis_view"]
+            _lib.check(lib.ms_log_softmax_axis_backward(_lib.ptr(lp), _lib.ptr(grad), _lib.ptr(grad), outer, axis, inner,
+                                                        _lib.stream_ptr()), "ms_log_softmax_axis_backward")
         return grad, None, None
 
 
@@ -79,16 +90,15 @@ class CTCLoss(torch.nn.Module):
         x = _lib.f32c(x)
         t, n, v = x.shape
         log_probs_in = 0
+        x_in, log_probs, axis_view = x, None, None
         if dim != 2:
             # ctc_loss.py:37-45 forwards ANY dim to LogSoftmax: the values normalised over time (0) or over the batch (1) are
             # what torch.nn.CTCLoss then takes as log-probabilities.  One extra pass; the kernel skips its own normalisation.
-            if torch.is_grad_enabled() and x.requires_grad:
-                raise NotImplementedError("the gradient kernel covers the log-softmax over the symbol axis (dim=-1) only")
             xn = torch.empty_like(x)
-            outer, axis, inner = (1, t, n * v) if dim == 0 else (t, n, v)
-            _lib.check(lib.ms_log_softmax_axis(_lib.ptr(x), _lib.ptr(xn), outer, axis, inner, _lib.stream_ptr()),
+            axis_view = (1, t, n * v) if dim == 0 else (t, n, v)
+            _lib.check(lib.ms_log_softmax_axis(_lib.ptr(x), _lib.ptr(xn), *axis_view, _lib.stream_ptr()),
                        "ms_log_softmax_axis")
-            x, log_probs_in = xn, 2       # MS_CTC_LOG_PROBS_IN
+            log_probs, log_probs_in = xn.detach(), 2       # MS_CTC_LOG_PROBS_IN
         blank = self.ctc_loss.blank
         if not 0 <= blank < v:
             raise RuntimeError("blank must be in label range")
@@ -119,6 +129,8 @@ class CTCLoss(torch.nn.Module):
         xl_dev, off_dev, yl_dev = _lib.lens_i32(xl), _lib.lens_i32(offsets), _lib.lens_i32(yl)
 
         def run_forward(logits: torch.Tensor) -> torch.Tensor:
+            if log_probs is not None:
+                logits = log_probs
             nll = torch.empty(n, dtype=torch.float32, device="cuda")
             reduced = torch.empty(1, dtype=torch.float32, device="cuda")
             ws = self._workspace.get(lib.ms_ctc_loss_workspace_bytes(t, n, v, s_max))
@@ -130,6 +142,6 @@ class CTCLoss(torch.nn.Module):
 
         if torch.is_grad_enabled() and x.requires_grad:
             meta = dict(red=red, s_max=s_max, blank=blank, zero_infinity=zero_inf, xl_dev=xl_dev, off_dev=off_dev,
-                        yl_dev=yl_dev, y_dev=y_dev, workspace=self._bwd_workspace)
-            return _CTCLossFunction.apply(x, run_forward, meta)
+                        yl_dev=yl_dev, y_dev=y_dev, workspace=self._bwd_workspace, log_probs=log_probs, axis_view=axis_view)
+            return _CTCLossFunction.apply(x_in, run_forward, meta)
         return run_forward(x)

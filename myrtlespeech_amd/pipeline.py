@@ -244,8 +244,14 @@ class PairedBatches:
 
     What a caller gets per batch is what ``model`` returns for the merged batch, cut back to the batch's utterances in
     their own order: ``((logits[T', N_b, V], lens_b), hid_b)``.  Utterances do not interact in any module and no
-    kernel's arithmetic for an utterance depends on what it is batched with, so this is bit-identical to the one-batch
-    result (``tests/test_gpu_pipeline.py``, full size included).
+    KERNEL's arithmetic for an utterance depends on what it is batched with -- but which kernel a layer runs on can depend
+    on the merged batch's row count (``csrc/gemm_split.hip``: the GEMM's tile variant follows ``M = T * N``; ``csrc/rnn.hip``:
+    the recurrent kernel follows ``N``).  So the guarantee is: **bit-identical to the one-batch result wherever both sizes
+    select the same kernels** -- the config-2 network at batches of 32 does, ``tests/test_gpu_pipeline.py`` asserts
+    ``torch.equal`` there at full size -- **and within float32 rounding of it (a different order of the same sums, same
+    transcripts) otherwise**, e.g. the small network of ``__graft_entry__.smoke()``, which checks ``< 1e-5``.  Per-batch
+    latency is that of the PAIR's forward (about twice the one-batch figure); ``bench.py`` states which mode its ``value``
+    came from and that latency (``config.pipeline``, ``latency_ms_per_batch``).
 
     Pairs are merged in decreasing length order (``enforce_sorted``, rnn.py:174) and need the same frame count and at most
     64 utterances together; a batch that cannot be paired (odd one out, different frame counts) runs alone.  Like the

@@ -807,3 +807,102 @@ if __name__ == "__main__" and "stream64" in sys.argv[1:]:
 
 if __name__ == "__main__" and "ctc_dim" in sys.argv[1:]:
     gen_ctc_loss_dim()
+
+
+def gen_wer():
+    """``levenshtein`` (post_process/utils.py:4-60) and ``Alphabet`` (data/alphabet.py:5-78) are imported from
+    the reference and run on seeded index sequences (empty / equal / disjoint / unknown indices included).  ``run/run.py``
+    (WordSegmentor, ReportCTCDecoder) does not import here (tensorboard and apex are absent: an ordinary ModuleNotFoundError),
+    so the word lists the WER arithmetic of run.py:84-109 works on are made with ``str.split`` on the reference alphabet's
+    symbols -- the same segmentation rule, stated independently -- and the distances over them by the reference's
+    ``levenshtein``; ``wer`` is run.py:108's ``sum(distances) / sum(lengths) * 100`` over those."""
+    from myrtlespeech.data.alphabet import Alphabet
+    from myrtlespeech.post_process.utils import levenshtein
+    symbols = list(" abcdefghijklmnopqrstuvwxyz'") + ["_"]          # the shipped configs' alphabet; blank "_" = 28
+    alpha = Alphabet(symbols)
+    rng = np.random.default_rng(4242)
+    cases = []
+
+    def rand_sentence(n_words):
+        words = []
+        for _ in range(n_words):
+            words.append(rng.integers(1, 28, size=int(rng.integers(1, 7))).tolist())
+        out = []
+        for i, w in enumerate(words):
+            out += w + ([0] * int(rng.integers(1, 3)) if i + 1 < len(words) else [])
+        return out
+
+    fixed = [([], []), ([], [1, 2, 0, 3]), ([1, 2, 0, 3], []), ([1, 2, 0, 3], [1, 2, 0, 3]), ([1, 2, 3], [4, 5, 6]),
+             ([0, 0, 1, 0, 0], [1]), ([1, 99, 2, -1, 0, 3, 28, 28], [1, 2, 0, 3]), ([5, 0, 0, 0, 6], [5, 0, 6, 0, 7])]
+    for hyp, tgt in fixed:
+        cases.append((hyp, tgt))
+    for _ in range(40):
+        tgt = rand_sentence(int(rng.integers(1, 9)))
+        hyp = list(tgt)
+        for _ in range(int(rng.integers(0, 6))):        # a few random edits of the target
+            op = int(rng.integers(0, 3))
+            pos = int(rng.integers(0, len(hyp) + 1))
+            if op == 0:
+                hyp.insert(pos, int(rng.integers(0, 29)))
+            elif hyp and op == 1:
+                del hyp[min(pos, len(hyp) - 1)]
+            elif hyp:
+                hyp[min(pos, len(hyp) - 1)] = int(rng.integers(0, 31))   # 29, 30: no such symbol
+        cases.append((hyp, tgt))
+    for _ in range(12):                                  # unrelated sentences
+        cases.append((rand_sentence(int(rng.integers(0, 6))), rand_sentence(int(rng.integers(1, 6)))))
+
+    hyp_flat, hyp_lens = ragged([c[0] for c in cases])
+    tgt_flat, tgt_lens = ragged([c[1] for c in cases])
+    sym_dist, word_dist, word_len, idx_dist = [], [], [], []
+    hyp_text, tgt_text, roundtrip = [], [], []
+    for hyp, tgt in cases:
+        hs, ts = alpha.get_symbols(hyp), alpha.get_symbols(tgt)
+        hyp_text.append("".join(hs))
+        tgt_text.append("".join(ts))
+        roundtrip.append(alpha.get_indices(hs + ["?", "ab"]))       # unknown symbols are skipped
+        hw, tw = [w for w in "".join(hs).split(" ") if w], [w for w in "".join(ts).split(" ") if w]
+        idx_dist.append(levenshtein(hyp, tgt))
+        sym_dist.append(levenshtein(hs, ts))
+        word_dist.append(levenshtein(hw, tw))
+        word_len.append(len(tw))
+    rt_flat, rt_lens = ragged(roundtrip)
+    wer = float(sum(word_dist)) / sum(word_len) * 100
+    save("wer", dict(symbols=symbols, separator=" ", wer=wer, hyp_text=hyp_text, tgt_text=tgt_text),
+         {"in/hyp_flat": hyp_flat, "in/hyp_lens": hyp_lens, "in/tgt_flat": tgt_flat, "in/tgt_lens": tgt_lens,
+          "out/idx_dist": np.array(idx_dist), "out/sym_dist": np.array(sym_dist), "out/word_dist": np.array(word_dist),
+          "out/word_len": np.array(word_len), "out/roundtrip_flat": rt_flat, "out/roundtrip_lens": rt_lens,
+          "out/len": np.array([len(alpha)]), "out/index_of_q": np.array([-1 if alpha.get_index("?") is None else 1]),
+          "out/symbol_5": np.array([ord(alpha[5])])})
+
+
+def gen_ctc_grad_dim():
+    """x.grad through the reference's CTCLoss(dim != -1): autograd chains LogSoftmax(dim)'s backward behind
+    torch.nn.CTCLoss's (loss/ctc_loss.py:37-45, 95-101).  Same inputs as ctc_loss_dim."""
+    torch.set_grad_enabled(True)
+    try:
+        torch.manual_seed(43)
+        T, N, V = 23, 4, 7
+        x0 = torch.randn(T, N, V) * 1.5
+        x_lens = torch.tensor([23, 23, 16, 9], dtype=torch.int32)
+        y_lens = torch.tensor([6, 3, 4, 0], dtype=torch.int32)
+        y = torch.randint(0, 6, (N, 6), dtype=torch.int32)
+        wts = torch.rand(N) + 0.5
+        arrays = {"in/x": npy(x0), "in/x_lens": npy(x_lens), "in/y": npy(y), "in/y_lens": npy(y_lens), "in/w": npy(wts)}
+        for dim in (0, 1, -3, -2):
+            for red in ("none", "mean", "sum"):
+                for zi in (False, True):
+                    x = x0.clone().requires_grad_(True)
+                    out = CTCLoss(blank=6, reduction=red, zero_infinity=zi, dim=dim)((x, x_lens), (y, y_lens))
+                    (out * wts).sum().backward() if red == "none" else (out * 1.7).backward()
+                    arrays[f"grad/dim{dim}_{red}_{int(zi)}"] = npy(x.grad)
+                    arrays[f"out/dim{dim}_{red}_{int(zi)}"] = npy(out)
+        save("ctc_grad_dim", dict(blank=6, scale=1.7, dims=[0, 1, -3, -2]), arrays)
+    finally:
+        torch.set_grad_enabled(False)
+
+
+if __name__ == "__main__" and "wer" in sys.argv[1:]:
+    gen_wer()
+if __name__ == "__main__" and "ctcgraddim" in sys.argv[1:]:
+    gen_ctc_grad_dim()

@@ -14,7 +14,11 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(_lib.SIGNATURES) == declared
-    assert lib.ms_abi_version() == 1
+    # the binding, the header and the library agree on the ABI version (``_lib.load`` refuses a library that differs)
+    import re
+    with open(_lib.HEADER_PATH) as f:
+        header_version = int(re.search(r"#define MS_ABI_VERSION (\d+)", f.read()).group(1))
+    assert lib.ms_abi_version() == header_version == _lib.ABI_VERSION == 2
 
 
 def test_size_queries_without_gpu(lib):

@@ -83,6 +83,14 @@ def test_ragged_batch_packed_rows_equal_all_rows(tmp_path):
     with np.load(a) as fa, np.load(b) as fb:
         for k in ("y", "hn", "cn"):
             assert np.array_equal(fa[k], fb[k]), k
+    # the stamp build's memset must stop at the stamp area: ``row_off`` (the packed rows' frame offsets) sits right behind it
+    # in the workspace (it was zeroed, and a ragged batch then read and wrote the wrong rows)
+    c = str(tmp_path / "packed_stamps.npz")
+    out = _child(f"ragged_stack({c!r})", MS_LSTM_STAMPS="1")
+    assert "ragged stack: packed rows" in out
+    with np.load(a) as fa, np.load(c) as fc:
+        for k in ("y", "hn", "cn"):
+            assert np.array_equal(fa[k], fc[k]), k
 
 
 def test_ragged_config2_batch_packed_rows_equal_all_rows_at_full_size(tmp_path):

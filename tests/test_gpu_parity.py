@@ -434,9 +434,33 @@ def test_ctc_loss_dim_golden():
         np.testing.assert_allclose(cpu(got), O.ctc_loss(x, xl, y, yl, 28, "none", dim=dim), rtol=2e-4, atol=1e-2)
     with pytest.raises(IndexError):
         CTCLoss(blank=28, dim=3)((T(x), T(xl)), (T(y), T(yl)))
-    xg = T(x).cuda().requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        CTCLoss(blank=28, dim=0)((xg, T(xl)), (T(y), T(yl)))
+
+
+def test_ctc_loss_dim_backward_matches_reference_autograd():
+    """VERDICT r3 missing 5: ``loss.backward()`` through ``CTCLoss(dim != -1)`` -- the alpha-beta kernel on the values normalised
+    over time / over the batch, LogSoftmax(dim)'s backward behind it -- against x.grad from the reference (ctc_loss.py:37-45,
+    95-101), every reduction, with and without zero_infinity; and at a larger shape against the float64 oracle."""
+    from myrtlespeech_amd.loss.ctc_loss import CTCLoss
+    g = Golden("ctc_grad_dim")
+    w = T(g["in/w"]).cuda()
+    for key in [k for k in g.a if k.startswith("grad/")]:
+        dim, red, zi = key[len("grad/dim"):].split("_")
+        x = T(g["in/x"]).cuda().requires_grad_(True)
+        out = CTCLoss(blank=g.cfg["blank"], reduction=red, zero_infinity=bool(int(zi)), dim=int(dim))(
+            (x, T(g["in/x_lens"])), (T(g["in/y"]), T(g["in/y_lens"])))
+        np.testing.assert_allclose(cpu(out), g["out/" + key[len("grad/"):]], rtol=1e-4, atol=1e-4)
+        ((out * w).sum() if red == "none" else out * g.cfg["scale"]).backward()
+        np.testing.assert_allclose(cpu(x.grad), g[key], rtol=1e-4, atol=2e-5)
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(120, 6, 29)).astype(np.float32)
+    xl = np.sort(rng.integers(60, 121, size=6))[::-1].astype(np.int32)
+    yl = rng.integers(1, 21, size=6).astype(np.int32)
+    y = rng.integers(0, 28, size=(6, 20)).astype(np.int32)
+    for dim in (0, 1):
+        xg = T(x).cuda().requires_grad_(True)
+        CTCLoss(blank=28, reduction="sum", dim=dim)((xg, T(xl)), (T(y), T(yl))).backward()
+        want = O.ctc_grad(x, xl, y, yl, np.ones(6, np.float32), 28, dim=dim)
+        np.testing.assert_allclose(cpu(xg.grad), want, rtol=2e-3, atol=2e-4)
 
 
 def test_ctc_loss_full_size_vs_oracle():
@@ -748,9 +772,17 @@ def test_builder_built_ds2_matches_reference_golden():
     loss = stt.loss((y, lens), (tgt, tl))
     want = O.ctc_loss(g["out/y"], g["out/lens"], tgt.numpy(), tl.numpy(), 10, "sum")
     np.testing.assert_allclose(cpu(loss), want, rtol=1e-4, atol=1e-3)
+    # WER of the decoded batch: run/run.py:84-109's arithmetic with the ORACLE's levenshtein (pinned to the reference's by
+    # tests/golden/wer.npz, test_oracle_golden.py::test_wer_fixture_pins_levenshtein_alphabet_and_wer) over words cut by
+    # str.split from the reference fixture's transcripts
     wer = WordErrorRate(stt.alphabet, WordSegmentor(" "))
     wer.update(hyp, tgt, tl)
-    assert wer.value() >= 0.0 and len(wer.transcripts) == 3
+    symbols = " abcdefghi_"
+    want_hyp = [[w for w in "".join(symbols[i] for i in h).split(" ") if w] for h in unragged(g["out/greedy_flat"], g["out/greedy_lens"])]
+    want_tgt = [[w for w in "".join(symbols[int(i)] for i in t[:int(n)]).split(" ") if w] for t, n in zip(tgt, tl)]
+    dists = [O.levenshtein(a, b) for a, b in zip(want_hyp, want_tgt)]
+    assert wer.transcripts == list(zip(want_hyp, want_tgt)) and wer.distances == dists
+    assert wer.value() == float(sum(dists)) / sum(len(t) for t in want_tgt) * 100
 
 
 # ----------------------------------------------------------------------------- chunked streaming (a16)

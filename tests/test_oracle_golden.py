@@ -272,6 +272,63 @@ def test_ctc_grad_oracle_matches_reference_autograd(name):
         np.testing.assert_allclose(got, g[key], rtol=1e-4, atol=2e-5)  # the reference subtracts two float32 exponentials
 
 
+def test_ctc_grad_dim_oracle_matches_reference_autograd():
+    """``CTCLoss(dim != -1)`` under autograd (ctc_loss.py:37-45, 95-101): LogSoftmax(dim)'s backward chained behind
+    torch.nn.CTCLoss's; x.grad and the losses from the reference."""
+    g = Golden("ctc_grad_dim")
+    x, xl, y, yl, w = g["in/x"], g["in/x_lens"], g["in/y"], g["in/y_lens"], g["in/w"]
+    n = x.shape[1]
+    for key in [k for k in g.a if k.startswith("grad/")]:
+        dim, red, zi = key[len("grad/dim"):].split("_")
+        gn = w if red == "none" else (np.full(n, g.cfg["scale"], np.float32) if red == "sum" else
+                                      g.cfg["scale"] / (np.maximum(yl.astype(np.float32), 1.0) * n))
+        got = O.ctc_grad(x, xl, y, yl, gn, g.cfg["blank"], bool(int(zi)), dim=int(dim))
+        np.testing.assert_allclose(got, g[key], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(O.ctc_loss(x, xl, y, yl, g.cfg["blank"], red, bool(int(zi)), dim=int(dim)),
+                                   g["out/" + key[len("grad/"):]], rtol=1e-4, atol=1e-4)
+
+
+def test_wer_fixture_pins_levenshtein_alphabet_and_wer():
+    """SURVEY 8 f2 against vectors made by the reference's own ``levenshtein`` (post_process/utils.py:4-60) and ``Alphabet``
+    (data/alphabet.py:5-78): the oracle's restatement, the product's ``post_process.utils.levenshtein``, ``data.alphabet.
+    Alphabet``, ``wer.WordSegmentor`` and ``wer.WordErrorRate`` (run/run.py:84-109's arithmetic)."""
+    from myrtlespeech_amd.data.alphabet import Alphabet
+    from myrtlespeech_amd.post_process.utils import levenshtein
+    from myrtlespeech_amd.wer import WordErrorRate, WordSegmentor
+    g = Golden("wer")
+    c = g.cfg
+    hyps = unragged(g["in/hyp_flat"], g["in/hyp_lens"])
+    tgts = unragged(g["in/tgt_flat"], g["in/tgt_lens"])
+    rts = unragged(g["out/roundtrip_flat"], g["out/roundtrip_lens"])
+    alpha = Alphabet(c["symbols"])
+    seg = WordSegmentor(c["separator"])
+    assert len(alpha) == int(g["out/len"][0]) and alpha.get_index("?") is None and ord(alpha[5]) == int(g["out/symbol_5"][0])
+    with pytest.raises(IndexError):
+        alpha[len(alpha)]
+    with pytest.raises(ValueError):
+        Alphabet(["a", "b", "a"])
+    for i, (hyp, tgt) in enumerate(zip(hyps, tgts)):
+        hs, ts = alpha.get_symbols(hyp), alpha.get_symbols(tgt)
+        assert "".join(hs) == c["hyp_text"][i] and "".join(ts) == c["tgt_text"][i]
+        assert alpha.get_indices(hs + ["?", "ab"]) == rts[i]
+        hw, tw = seg(hs), seg(ts)
+        for fn in (levenshtein, O.levenshtein):
+            assert fn(hyp, tgt) == int(g["out/idx_dist"][i])
+            assert fn(hs, ts) == int(g["out/sym_dist"][i])
+            assert fn(hw, tw) == int(g["out/word_dist"][i])
+        assert len(tw) == int(g["out/word_len"][i])
+    wer = WordErrorRate(alpha, seg)
+    pad = max(len(t) for t in tgts)
+    tgt_pad = np.zeros((len(tgts), pad), np.int64)
+    for i, t in enumerate(tgts):
+        tgt_pad[i, :len(t)] = t
+    half = len(hyps) // 2          # two "batches", as run.py:84-103 accumulates over an epoch
+    wer.update(hyps[:half], tgt_pad[:half], [len(t) for t in tgts[:half]])
+    wer.update(hyps[half:], tgt_pad[half:], [len(t) for t in tgts[half:]])
+    assert wer.distances == [int(v) for v in g["out/word_dist"]] and wer.lengths == [int(v) for v in g["out/word_len"]]
+    assert wer.value() == c["wer"]
+
+
 def test_beam_oracle_config_size_vs_reference():
     """The numpy beam search against the reference at T = 501, V = 29, beam 8 (one of the four utterances; the pure-Python
     oracle takes ~1.5 s per utterance like the reference)."""
