@@ -61,15 +61,17 @@ def precision_mode():
 
 
 def precision_label():
-    """Arithmetic of the two dominant kernels (LSTM recurrence + input projection): by default every
-    f32 operand is split into bf16 hi+lo and multiplied as hi*hi + lo*hi + hi*lo with f32 accumulation
-    (MS_PRECISION=f32 selects float32 MFMA instead); conv / FC / CTC are exact f32."""
+    """Arithmetic of the step, kept under 120 characters (the driver's record cuts strings there).  Default mode: every f32
+    operand of the large contractions -- LSTM recurrence, input-projection GEMMs, conv1 (feature-window form), conv2
+    (channels-last) and the hidden FC layer -- is split into bf16 hi + lo and multiplied as hi*hi + lo*hi + hi*lo with f32
+    accumulation (model/cnn.py, model/fully_connected.py route by size); the output layer (29 columns), CTC and the
+    decoders are exact f32.  MS_PRECISION=f32 selects float32 MFMA everywhere."""
     mode = precision_mode()
     if mode == "f32":
-        return "f32 (float32 MFMA; the recurrent state crosses workgroups with its mantissa LSB as epoch tag)"
+        return "f32 (float32 MFMA everywhere; recurrent h crosses workgroups with its mantissa LSB as epoch tag)"
     if mode == "fp16":
-        return "fp16 (single-pass fp16 operands, f32 accumulate; optional fast mode, outside the 1e-3 parity gate)"
-    return "bf16x3 (f32 split into bf16 hi+lo, f32 accumulate)"
+        return "fp16 (one fp16 MFMA pass, f32 accumulate: LSTM, projections, conv2, FC1; optional mode outside the 1e-3 gate)"
+    return "bf16x3 (f32 split in bf16 hi+lo, 3 MFMA passes, f32 acc: LSTM, projections, conv1/2, FC1; FC2/CTC/decode f32)"
 
 
 KERNEL_SOURCES = {"lstm": ("rnn.hip", "common.h"), "gemm_nt_bf16x3": ("gemm_split.hip", "common.h"),
@@ -211,7 +213,7 @@ def f32_child(args):
     """The fp32-arithmetic figure, timed by the driver's own run: a child process in MS_PRECISION=f32 (the mode is read
     once per process), started BEFORE this process makes its first GPU call, run to completion, its JSON line kept."""
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(10, args.steps // 2)), "--warmup",
-           str(args.warmup), "--precision", "f32", "--no-cpu-baseline", "--no-f32-child", "--no-frontend"]
+           str(args.warmup), "--precision", "f32", "--no-cpu-baseline", "--no-f32-child", "--no-frontend", "--no-legs"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -225,6 +227,24 @@ def f32_child(args):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
+def fp16_stream_child():
+    """BASELINE configs[4] names "fp16 MFMA": the streaming leg once more in a child with MS_PRECISION=fp16 (the mode is read
+    once per process), started before this process makes its first GPU call."""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), "stream", "--line", "--no-cpu"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["MS_PRECISION"] = "fp16"
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        return d.get("cfg5_streaming", {"error": "no cfg5_streaming record"})
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+def compact(rec, keys):
+    return {k: rec[k] for k in keys if isinstance(rec, dict) and k in rec}
+
+
 def main(argv=None, runtime=None, json_fd=None):
     rt = runtime or GpuRuntime()
     ap = argparse.ArgumentParser()
@@ -235,6 +255,8 @@ def main(argv=None, runtime=None, json_fd=None):
     ap.add_argument("--no-f32-child", action="store_true", help="skip the MS_PRECISION=f32 child run")
     ap.add_argument("--no-frontend", action="store_true", help="skip the waveform -> MFCC side measurement")
     ap.add_argument("--no-ragged", action="store_true", help="skip the ragged-length leg")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the other BASELINE configs / BASELINE.md 3 legs (DS1, CTC loss, CTC beam, RNN-T, streaming)")
     ap.add_argument("--in-flight", type=int, choices=[1, 2], default=2,
                     help="batches in flight per GPU for the headline figure: 2 (default) = myrtlespeech_amd.pipeline."
                          "TwoBatchesInFlight (two streams, the next batch's projection GEMMs run beside this batch's "
@@ -262,9 +284,11 @@ def main(argv=None, runtime=None, json_fd=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    f32 = None
+    f32 = stream_fp16 = None
     if world == 1 and "RANK" not in os.environ and precision_mode() == "bf16x3" and not args.no_f32_child:
         f32 = f32_child(args)          # before the first GPU call of this process
+    if world == 1 and "RANK" not in os.environ and precision_mode() == "bf16x3" and not args.no_legs:
+        stream_fp16 = fp16_stream_child()
 
     dist = None
     if world > 1 or "RANK" in os.environ:  # under torchrun (also with one rank) the collective path is exercised
@@ -553,7 +577,8 @@ def main(argv=None, runtime=None, json_fd=None):
             # one launch of lstm_persistent_wide2_kernel = 1 layer x 2 directions x 501 steps of TWO batches of 32
             pr = pair["per_launch"]["recurrence"]
             roof["two_batches_per_forward"] = {
-                "kernel": "lstm_persistent_wide2_kernel (16 hidden units per workgroup, two 32-row batch groups side by side)",
+                "kernel": ("lstm_persistent_wide2_kernel (16 hidden units per workgroup, two 32-row batch groups side by side)" if wide
+                           else kname + " (this mode has no wide-workgroup form: two launches, one per 32-row batch group)"),
                 "launch_ms": round(pr, 4), "algorithmic_bytes_per_launch": 2 * launch_bytes,
                 "achieved": round(2 * launch_bytes / (pr * 1e-3) / 1e9, 1), "frac": round(2 * launch_bytes / (pr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             wrec, wwhy = pmc_record("lstm_persistent_wide2_kernel@2groups")
@@ -630,7 +655,16 @@ def main(argv=None, runtime=None, json_fd=None):
                                     "every step's full work incl. decode completes inside the timed region; outputs "
                                     "bit-identical to the one-batch path") if pipelined else "one batch at a time",
                        "decode": "all-gather logits, batched decode on every rank" if args.gather_logits else
-                                 "per-shard decode (no data-path collective)"},
+                                 "per-shard decode (no data-path collective)",
+                       # flat scalars (the driver's record keeps scalars of `config`, not nested objects): the literal
+                       # "batch 32, one batch at a time" step and the strict-f32 figure beside the headline
+                       "headline_mode": ("two_batches_per_forward" if (pipelined and headline is paired) else
+                                         "two_batches_in_flight" if pipelined else "one_batch_in_flight"),
+                       "headline_latency_ms_per_batch": round(latency_ms if pipelined else one["span"], 3),
+                       "one_batch_ms_per_step": round(one_ms, 3),
+                       "one_batch_value": round(world * BATCH_PER_GPU * CLIP_SECONDS * args.steps / one_elapsed, 1),
+                       "f32_value": (f32 or {}).get("value"), "f32_ms_per_step": (f32 or {}).get("ms_per_step"),
+                       "f32_one_batch_ms_per_step": ((f32 or {}).get("one_batch_in_flight") or {}).get("ms_per_step")},
             "one_batch_in_flight": dict(
                 {"value": round(world * BATCH_PER_GPU * CLIP_SECONDS * args.steps / one_elapsed, 1),
                  "ms_per_step": round(one_ms, 3),
@@ -678,6 +712,32 @@ def main(argv=None, runtime=None, json_fd=None):
             out["precision_f32"] = f32
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)
+        # ---- the other BASELINE configs and BASELINE.md 3's separately reported legs (N = 1 only): every record carries its
+        # floor and its CPU baseline (tools/bench_configs.py); `legs` -- the LAST key of the line, so that it survives a
+        # record that keeps only the tail of stdout -- repeats the numbers without the prose
+        if world == 1 and dist is None and not args.no_legs:
+            from tools import bench_configs
+            del pipe, paired
+            torch.cuda.empty_cache() if torch.cuda.is_available() else None
+            detail = bench_configs.run_legs(["ctc", "beam", "ds1", "rnnt", "stream"], cpu=not args.no_cpu_baseline)
+            if stream_fp16 is not None:
+                detail["cfg5_streaming_fp16"] = stream_fp16
+            out["legs_detail"] = detail
+            num = ("ms", "ms_min", "ms_per_chunk", "ms_per_chunk_wall", "floor_ms", "frac_of_floor", "audio_sec_per_s", "utterances_per_s",
+                   "encoder_ms", "beam8_decode_ms", "greedy_decode_ms", "us_per_frame", "realtime_factor", "dtype",
+                   "transcripts_equal_oracle_fixture", "error")
+            legs = {"calibration": detail.get("calibration")}
+            for name, rec in detail.items():
+                if name == "calibration" or not isinstance(rec, dict):
+                    continue
+                legs[name] = compact(rec, num)
+                cb = rec.get("cpu_baseline")
+                if cb:
+                    legs[name]["cpu"] = compact(cb, ("value", "unit", "cores"))
+            legs["encoder_greedy"] = {"ms": round(ms_per_step, 3), "value": round(value, 1), "one_batch_ms": round(one_ms, 3),
+                                      "f32_ms": (f32 or {}).get("ms_per_step"), "roofline_frac": roof["frac"],
+                                      "cpu": compact(out.get("cpu_baseline", {}), ("value", "unit", "cores"))}
+            out["legs"] = legs
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:

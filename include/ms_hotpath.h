@@ -157,6 +157,13 @@ int ms_lookahead_forward(const float* x, const float* w, float* y, int N, int F,
                          long xs_f, long xs_t, long ys_n, long ys_f, long ys_t, int act, float act_lo,
                          float act_hi, void* stream);
 
+/* The same on a WINDOW of a stream (streaming with carried context, myrtlespeech_amd/streaming.py): x holds T_in frames,
+ * only the first T_out <= T_in output frames are computed and written (taps beyond T_in read as zero, which a caller
+ * allows only at the true end of the utterance); y has room for T_out frames. */
+int ms_lookahead_window_forward(const float* x, const float* w, float* y, int N, int F, int T_in, int T_out, int ctx,
+                                long xs_n, long xs_f, long xs_t, long ys_n, long ys_f, long ys_t, int act, float act_lo,
+                                float act_hi, void* stream);
+
 /* ---- model/rnn.py / model/hard_lstm.py ---------------------------------- */
 
 /* One layer (all directions) of torch.nn.LSTM/GRU/RNN as RNN.forward drives it
@@ -248,6 +255,11 @@ int ms_prof_read(float* out_ms_host, int* out_n_host);
  * {wall ticks, shader cycles}).  Launched on a stream of its own beside other kernels it shows the clock the chip holds
  * under their load (MI355X_MICROARCH.md, DVFS give-back item 6).  samples * spacing_us is capped at 50 ms. */
 int ms_clock_probe(unsigned long long* out_dev, int samples, int spacing_us, void* stream);
+
+/* Diagnostic (bench.py's floors for the scan kernels; not part of the reference surface): one workgroup of `threads`
+ * runs `steps` rounds of {LDS write, barrier, neighbour read, barrier}; out_dev[0] = elapsed ticks of the 100 MHz wall
+ * clock (2 * steps barrier-separated phases), out_dev[1] = a checksum. */
+int ms_barrier_chain_probe(unsigned long long* out_dev, int steps, int threads, void* stream);
 
 /* ---- loss/ctc_loss.py ---------------------------------------------------- */
 

@@ -51,6 +51,7 @@ SIGNATURES = {
     "ms_linear_split_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ms_linear_split_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
     "ms_lookahead_forward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_int, c_float, c_float, _P]),
+    "ms_lookahead_window_forward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_int, c_float, c_float, _P]),
     "ms_rnn_packed_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ms_rnn_pack": (c_int, [c_int, c_int, c_int, c_int, _PP, _PP, _PP, _PP, _P, _P]),
     "ms_rnn_workspace_bytes": (c_size_t, [c_int] * 6),
@@ -65,6 +66,7 @@ SIGNATURES = {
     "ms_prof_enable": (c_int, [c_int]),
     "ms_prof_read": (c_int, [POINTER(c_float), POINTER(c_int)]),
     "ms_clock_probe": (c_int, [_P, c_int, c_int, _P]),
+    "ms_barrier_chain_probe": (c_int, [_P, c_int, c_int, _P]),
     "ms_ctc_loss_workspace_bytes": (c_size_t, [c_int] * 4),
     "ms_ctc_loss_forward": (c_int, [_P] * 7 + [c_int] * 7 + [_P, c_size_t, _P]),
     "ms_log_softmax_axis": (c_int, [_P, _P, c_int, c_int, c_int, _P]),

@@ -101,6 +101,36 @@ extern "C" int ms_clock_probe(unsigned long long* out_dev, int samples, int spac
   return MS_OK;
 }
 
+namespace {
+// `steps` dependent rounds of {LDS write, s_barrier, LDS read of the neighbour's word} in ONE workgroup: the cost of one
+// barrier-separated step of the scan kernels (CTC alpha / beta rows, the beam search's phases), which is what their time
+// is made of -- bench.py prices their serial chains with it (floor = barriers x this).
+__global__ __launch_bounds__(1024) void barrier_chain_kernel(unsigned long long* out, int steps) {
+  __shared__ float cell[1024];
+  const int tid = threadIdx.x, nb = (tid + 1) % blockDim.x;
+  float v = (float)tid;
+  cell[tid] = v;
+  __syncthreads();
+  const unsigned long long t0 = wall_clock64();
+  for (int s = 0; s < steps; ++s) {
+    cell[tid] = v;
+    __syncthreads();
+    v = cell[nb] * 0.5f + 1.0f;
+    __syncthreads();          // the scan kernels' double buffers save this second barrier; counted as two steps below
+  }
+  const unsigned long long t1 = wall_clock64();
+  if (tid == 0) { out[0] = t1 - t0; out[1] = (unsigned long long)v; }
+}
+}  // namespace
+
+extern "C" int ms_barrier_chain_probe(unsigned long long* out_dev, int steps, int threads, void* stream) {
+  MS_REQUIRE(out_dev && steps > 0 && steps <= (1 << 22), "bad arguments");
+  MS_REQUIRE(threads >= 64 && threads <= 1024 && threads % 64 == 0, "threads must be a multiple of 64 in [64, 1024]");
+  hipLaunchKernelGGL(barrier_chain_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, out_dev, steps);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}
+
 extern "C" int ms_abi_version(void) { return MS_ABI_VERSION; }
 extern "C" const char* ms_last_error(void) {
   static thread_local std::string copy;

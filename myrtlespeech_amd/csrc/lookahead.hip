@@ -14,9 +14,9 @@ namespace {
 constexpr int LA_TB = 256;  // output frames per workgroup (time-contiguous variant)
 
 __global__ __launch_bounds__(256) void lookahead_tcontig_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                float* __restrict__ y, int F, int T, int ctx, long xs_n,
-                                                                long xs_f, long ys_n, long ys_f, long ys_t, int act,
-                                                                float lo, float hi) {
+                                                                float* __restrict__ y, int F, int T, int To, int ctx,
+                                                                long xs_n, long xs_f, long ys_n, long ys_f, long ys_t,
+                                                                int act, float lo, float hi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                 // [LA_TB + ctx - 1]
   float* ws = smem + LA_TB + ctx;   // [ctx]
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void lookahead_tcontig_kernel(const float* __r
   for (int i = tid; i < ctx; i += 256) ws[i] = w[(size_t)f * ctx + i];
   __syncthreads();
   const int t = t0 + tid;
-  if (t < T) {
+  if (t < To) {
     float acc = 0.f;
     for (int k = 0; k < ctx; ++k) acc += ws[k] * xs[tid + k];
     if (act == MS_ACT_CLAMP) acc = fminf(fmaxf(acc, lo), hi);
@@ -42,9 +42,9 @@ __global__ __launch_bounds__(256) void lookahead_tcontig_kernel(const float* __r
 constexpr int LA_TT = 32, LA_KC = 16;
 
 __global__ __launch_bounds__(256) void lookahead_strided_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                float* __restrict__ y, int F, int T, int ctx, long xs_n,
-                                                                long xs_f, long xs_t, long ys_n, long ys_f, long ys_t,
-                                                                int act, float lo, float hi) {
+                                                                float* __restrict__ y, int F, int T, int To, int ctx,
+                                                                long xs_n, long xs_f, long xs_t, long ys_n, long ys_f,
+                                                                long ys_t, int act, float lo, float hi) {
   const int f = blockIdx.x * 256 + threadIdx.x, t0 = blockIdx.y * LA_TT, n = blockIdx.z;
   if (f >= F) return;
   const float* xr = x + n * xs_n + f * xs_f;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void lookahead_strided_kernel(const float* __r
 #pragma unroll
   for (int i = 0; i < LA_TT; ++i) {
     const int t = t0 + i;
-    if (t < T) {
+    if (t < To) {
       float v = acc[i];
       if (act == MS_ACT_CLAMP) v = fminf(fmaxf(v, lo), hi);
       y[n * ys_n + f * ys_f + t * ys_t] = v;
@@ -80,23 +80,35 @@ __global__ __launch_bounds__(256) void lookahead_strided_kernel(const float* __r
 
 }  // namespace
 
-extern "C" int ms_lookahead_forward(const float* x, const float* w, float* y, int N, int F, int T, int ctx, long xs_n,
-                                    long xs_f, long xs_t, long ys_n, long ys_f, long ys_t, int act, float act_lo,
-                                    float act_hi, void* stream) {
+static int lookahead_launch(const float* x, const float* w, float* y, int N, int F, int T, int To, int ctx, long xs_n,
+                            long xs_f, long xs_t, long ys_n, long ys_f, long ys_t, int act, float act_lo, float act_hi,
+                            void* stream) {
   ms::ProfScope prof_span(MS_PROF_OTHER, (hipStream_t)stream);
   MS_REQUIRE(x && w && y, "null pointer");
-  MS_REQUIRE(N > 0 && F > 0 && T > 0 && ctx > 0, "bad shape");
+  MS_REQUIRE(N > 0 && F > 0 && T > 0 && ctx > 0 && To > 0 && To <= T, "bad shape");
   MS_REQUIRE(act == MS_ACT_NONE || act == MS_ACT_CLAMP, "bad act");
   MS_REQUIRE(N <= 65535 && F <= 65535 && T <= 65535, "dimension exceeds grid limits");
   if (xs_t == 1) {
     const size_t lds = (size_t)(LA_TB + 2 * ctx) * sizeof(float);
     MS_REQUIRE(lds <= 64 * 1024, "context too large");
-    hipLaunchKernelGGL(lookahead_tcontig_kernel, dim3(ms::cdiv(T, LA_TB), F, N), dim3(256), lds, (hipStream_t)stream, x,
-                       w, y, F, T, ctx, xs_n, xs_f, ys_n, ys_f, ys_t, act, act_lo, act_hi);
+    hipLaunchKernelGGL(lookahead_tcontig_kernel, dim3(ms::cdiv(To, LA_TB), F, N), dim3(256), lds, (hipStream_t)stream, x,
+                       w, y, F, T, To, ctx, xs_n, xs_f, ys_n, ys_f, ys_t, act, act_lo, act_hi);
   } else {
-    hipLaunchKernelGGL(lookahead_strided_kernel, dim3(ms::cdiv(F, 256), ms::cdiv(T, LA_TT), N), dim3(256), 0, (hipStream_t)stream, x, w, y,
-                       F, T, ctx, xs_n, xs_f, xs_t, ys_n, ys_f, ys_t, act, act_lo, act_hi);
+    hipLaunchKernelGGL(lookahead_strided_kernel, dim3(ms::cdiv(F, 256), ms::cdiv(To, LA_TT), N), dim3(256), 0, (hipStream_t)stream, x, w, y,
+                       F, T, To, ctx, xs_n, xs_f, xs_t, ys_n, ys_f, ys_t, act, act_lo, act_hi);
   }
   MS_LAUNCH_CHECK();
   return MS_OK;
+}
+
+extern "C" int ms_lookahead_forward(const float* x, const float* w, float* y, int N, int F, int T, int ctx, long xs_n,
+                                    long xs_f, long xs_t, long ys_n, long ys_f, long ys_t, int act, float act_lo,
+                                    float act_hi, void* stream) {
+  return lookahead_launch(x, w, y, N, F, T, T, ctx, xs_n, xs_f, xs_t, ys_n, ys_f, ys_t, act, act_lo, act_hi, stream);
+}
+
+extern "C" int ms_lookahead_window_forward(const float* x, const float* w, float* y, int N, int F, int T_in, int T_out,
+                                           int ctx, long xs_n, long xs_f, long xs_t, long ys_n, long ys_f, long ys_t,
+                                           int act, float act_lo, float act_hi, void* stream) {
+  return lookahead_launch(x, w, y, N, F, T_in, T_out, ctx, xs_n, xs_f, xs_t, ys_n, ys_f, ys_t, act, act_lo, act_hi, stream);
 }

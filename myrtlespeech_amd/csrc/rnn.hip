@@ -1367,7 +1367,8 @@ constexpr int WIDE_RED2 = 8 * 16 * WIDE_RED_STRIDE;        // 8 waves x 16 rows,
 // Uneven shares (waves 0-3 take KSC k-steps each, waves 4-7 the other 8 - KSC): the cell waves spend ~0.5 us of every
 // stream-step on the cell and the publish before they request their own operands, waves 4-7 go straight from the barrier
 // to the next request and share the SIMDs' matrix pipes with them.
-template <int KS, bool CELL, bool HARD, bool STAMP = false, bool PACKED = false>
+// F16 (MS_PRECISION=fp16): one fp16 plane of W_hh and of h (the lo planes are neither loaded nor published), one MFMA pass.
+template <int KS, bool CELL, bool HARD, bool STAMP = false, bool PACKED = false, bool F16 = false>
 __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int k0, const int32_t* __restrict__ row_off) {
   constexpr int H = 1024, KG = H / 8;
 
@@ -1393,7 +1394,7 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
   const int unit = 8 * jb + u;
 
   // this wave's share of W_hh: its K-eighth x 64 gate rows (two blocks x two column tiles), hi and lo planes, 128 VGPRs
-  u32x4 wh[2][2][KS], wl[2][2][KS];
+  u32x4 wh[2][2][KS], wl[2][2][F16 ? 1 : KS];
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const char* wsrc = reinterpret_cast<const char*>(p.whh) + ((size_t)d * p.J + 2 * jj + b) * 128 * H;
@@ -1403,8 +1404,10 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
       const char* wp = wsrc + (kg * 32 + c16) * 16;
       wh[b][0][ks] = *reinterpret_cast<const u32x4*>(wp);
       wh[b][1][ks] = *reinterpret_cast<const u32x4*>(wp + 256);
-      wl[b][0][ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512);
-      wl[b][1][ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512 + 256);
+      if (!F16) {
+        wl[b][0][ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512);
+        wl[b][1][ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512 + 256);
+      }
     }
   }
 
@@ -1426,7 +1429,7 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
       c[sg] = (valid && p.c0) ? p.c0[sidx] : 0.f;
       len_n[sg] = valid ? (p.lens ? p.lens[n_base + n] : p.steps) : 0;
       const int off = sg * STREAM + epoch_par0(d, p.steps, rs) * KG * 256 + jb * 256 + nl * 16;  // slot read by the first step
-      publish_split<false>(h[sg], epoch_tag0(d, p.steps, rs), hx_rsrc, off, PLANE + off, lane);
+      publish_split<F16>(h[sg], epoch_tag0(d, p.steps, rs), hx_rsrc, off, PLANE + off, lane);
     }
   }
   __syncthreads();
@@ -1466,13 +1469,13 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
 
       // ---- h_{t-1} of this stream: the k-steps of the wave's K share, hi and lo planes (2 KS loads of 1 KB)
       const int base = sg * STREAM + par * KG * 256 + k0 * 1024;
-      u32x4 ah[KS], al[KS];
+      u32x4 ah[KS], al[F16 ? 1 : KS];
       const unsigned long long t_wait0 = wall_clock64();
       unsigned spins = 0;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {   // first request: agent scope; the re-requests below: system scope + volatile
         ah[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, base + ks * 1024, /*aux: sc1*/ 16);
-        al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, PLANE + base + ks * 1024, /*aux: sc1*/ 16);
+        if (!F16) al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, PLANE + base + ks * 1024, /*aux: sc1*/ 16);
       }
       f32x4v acc[2][2];
 #pragma unroll
@@ -1480,14 +1483,23 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) acc[b][ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
       auto mfma_step = [&](int ks) {
+        if (F16) {
+          const f16x8v xf = __builtin_bit_cast(f16x8v, ah[ks]);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, __builtin_bit_cast(f16x8v, wh[b][0][ks]), acc[b][0], 0, 0, 0);
+            acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, __builtin_bit_cast(f16x8v, wh[b][1][ks]), acc[b][1], 0, 0, 0);
+          }
+          return;
+        }
         const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]);
-        const bf16x8 xl = __builtin_bit_cast(bf16x8, al[ks]);
+        const bf16x8 xl = __builtin_bit_cast(bf16x8, al[F16 ? 0 : ks]);
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const bf16x8 bh0 = __builtin_bit_cast(bf16x8, wh[b][0][ks]);
           const bf16x8 bh1 = __builtin_bit_cast(bf16x8, wh[b][1][ks]);
-          const bf16x8 bl0 = __builtin_bit_cast(bf16x8, wl[b][0][ks]);
-          const bf16x8 bl1 = __builtin_bit_cast(bf16x8, wl[b][1][ks]);
+          const bf16x8 bl0 = __builtin_bit_cast(bf16x8, wl[b][0][F16 ? 0 : ks]);
+          const bf16x8 bl1 = __builtin_bit_cast(bf16x8, wl[b][1][F16 ? 0 : ks]);
           acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh0, acc[b][0], 0, 0, 0);
           acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh1, acc[b][1], 0, 0, 0);
           acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh0, acc[b][0], 0, 0, 0);
@@ -1501,7 +1513,7 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) bad |= (ah[ks][e] ^ em) | (al[ks][e] ^ em);
+          for (int e = 0; e < 4; ++e) bad |= (ah[ks][e] ^ em) | (F16 ? 0u : (al[F16 ? 0 : ks][e] ^ em));
         if (!alive || !__any((bad & 0x00010001u) != 0)) break;
         if ((++spins & 63u) == 0) {
           const unsigned dead = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1515,7 +1527,7 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           ah[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, base + ks * 1024, (int)(0x80000000u | 16u));
-          al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, PLANE + base + ks * 1024, (int)(0x80000000u | 16u));
+          if (!F16) al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, PLANE + base + ks * 1024, (int)(0x80000000u | 16u));
         }
       }
       if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[0] += now - st_prev; st_prev = now; st_sum[1] += spins; }
@@ -1558,7 +1570,7 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
         c[sg] = active ? cnew : c[sg];
         h[sg] = active ? hnew : h[sg];
         const int off = sg * STREAM + ec.wpar * KG * 256 + jb * 256 + nl * 16;
-        publish_split<false>(h[sg], wtag, hx_rsrc, off, PLANE + off, lane);
+        publish_split<F16>(h[sg], wtag, hx_rsrc, off, PLANE + off, lane);
         if (n < N) {
           const size_t oidx = ((size_t)t * p.N_total + n_base + n) * (p.ndir * H) + d * H + unit;
           const float ov = active ? hnew : 0.f;
@@ -1567,9 +1579,13 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
             // row of a batch with such a row reaches and nobody reads: a select on the address instead of a branch)
             const size_t prow = active ? (size_t)(roff + n_base + n) : (size_t)p.steps * p.N_total - 1;
             const size_t pidx = PACKED ? (prow * (p.ndir * H) + d * H + unit) : oidx;
-            const unsigned hb = bf16_bits(ov);
-            p.out_hi[pidx] = (unsigned short)hb;
-            p.out_lo[pidx] = (unsigned short)bf16_bits(ov - bf16_val(hb));
+            if (F16) {
+              p.out_hi[pidx] = __builtin_bit_cast(unsigned short, (_Float16)ov);
+            } else {
+              const unsigned hb = bf16_bits(ov);
+              p.out_hi[pidx] = (unsigned short)hb;
+              p.out_lo[pidx] = (unsigned short)bf16_bits(ov - bf16_val(hb));
+            }
           } else {
             p.out[oidx] = ov;
           }
@@ -1594,13 +1610,13 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
   }
 }
 
-template <bool HARD, int KSC, bool STAMP = false, bool PACKED = false>
+template <bool HARD, int KSC, bool STAMP = false, bool PACKED = false, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p, const int32_t* __restrict__ row_off) {
   static_assert(KSC >= 1 && KSC <= 7, "both wave sets need at least one k-step");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wave < 4) wide2_wave<KSC, true, HARD, STAMP, PACKED>(p, smem, wave * KSC, row_off);
-  else wide2_wave<8 - KSC, false, HARD, STAMP, false>(p, smem, 4 * KSC + (wave - 4) * (8 - KSC), row_off);
+  if (wave < 4) wide2_wave<KSC, true, HARD, STAMP, PACKED, F16>(p, smem, wave * KSC, row_off);
+  else wide2_wave<8 - KSC, false, HARD, STAMP, false, F16>(p, smem, 4 * KSC + (wave - 4) * (8 - KSC), row_off);
 }
 
 
@@ -2264,7 +2280,7 @@ static int launch_split2(const LstmP& p, hipStream_t stream) {
 }
 
 // wide workgroups (16 units, 8 waves), `groups` batch groups of <= 32 rows side by side in one launch
-static int launch_wide2(const LstmP& p, bool hard, int groups, hipStream_t stream) {
+static int launch_wide2(const LstmP& p, bool hard, int groups, bool f16, hipStream_t stream) {
   const size_t lds = (size_t)2 * WIDE_RED2 * sizeof(float);
   static ms::DeviceOnce attr_once;
   if (attr_once.need()) {
@@ -2275,9 +2291,23 @@ static int launch_wide2(const LstmP& p, bool hard, int groups, hipStream_t strea
     MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 3, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 4, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 2, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_once.done();
   }
   const dim3 grid(groups * p.ndir * (p.J / 2));
+  if (f16) {   // MS_PRECISION=fp16: one fp16 plane of h (32 KB pulled per workgroup and stream-step) and one MFMA pass
+    // cell waves take MS_LSTM_WIDE_KSC_F16 of the 8 k-steps of a pair each (default 3, as in the bf16x3 form)
+    static const int kf = getenv("MS_LSTM_WIDE_KSC_F16") ? atoi(getenv("MS_LSTM_WIDE_KSC_F16")) : 3;
+    if (hard) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 3, false, false, true>), grid, dim3(512), lds, stream, p, p.row_off);
+    else if (kf == 4) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 4, false, false, true>), grid, dim3(512), lds, stream, p, p.row_off);
+    else if (kf == 2) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 2, false, false, true>), grid, dim3(512), lds, stream, p, p.row_off);
+    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, false, false, true>), grid, dim3(512), lds, stream, p, p.row_off);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+  }
   static const bool stamps = getenv("MS_LSTM_STAMPS") && getenv("MS_LSTM_STAMPS")[0] == '1';
   if (p.row_off != nullptr) {   // packed rows (ragged batch): xproj and the planes hold only the rows that exist
     if (hard) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 3, false, true>), grid, dim3(512), lds, stream, p, p.row_off);
@@ -2313,7 +2343,7 @@ static int launch_wide2(const LstmP& p, bool hard, int groups, hipStream_t strea
 bool use_wide(int cell, int H, int ndir, int N) {
   static const int mode = getenv("MS_LSTM_WIDE") ? atoi(getenv("MS_LSTM_WIDE")) : -1;    // -1: default (on)
   if (mode == 0) return false;
-  if (H != 1024 || N > 64 || !use_split(cell, H, ndir) || ms::precision_mode() != ms::PREC_BF16X3) return false;
+  if (H != 1024 || N > 64 || !use_split(cell, H, ndir) || ms::precision_mode() == ms::PREC_F32) return false;
   // the occupancy / LDS answer is a property of the device and is asked once; whether THIS call's grid (batch groups x
   // directions x H/16 workgroups, all of which wait for each other) fits the CUs is evaluated on every call
   static std::atomic<int> ok[64];     // per device: 0 = not asked, 1 = a workgroup fits a CU, 2 = it does not
@@ -2542,7 +2572,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
           MS_LAUNCH_CHECK();
         }
         if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.row_off - W.dbg, stream));   // the stamp area only: row_off (packed rows) follows it
-        rc = launch_wide2(p, cell == MS_CELL_HARD_LSTM, groups, stream);
+        rc = launch_wide2(p, cell == MS_CELL_HARD_LSTM, groups, use_f16(cell, H, ndir), stream);
         if (rc != MS_OK) return rc;
         break;
       }

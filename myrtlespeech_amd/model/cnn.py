@@ -111,8 +111,9 @@ class _PackedFilters:
 
 def _conv_forward(x4: torch.Tensor, seq_lens: torch.Tensor, weight4: torch.Tensor, bias: Optional[torch.Tensor],
                   packed: _PackedFilters, stride, dilation, groups: int, same: bool,
-                  act: Optional[Tuple[float, float]]):
-    """x4 [N,C,F,T] (float32, cuda, contiguous) -> y [N,Cout,Fout,Tout], new lens."""
+                  act: Optional[Tuple[float, float]], time_pads: Optional[Tuple[int, int]] = None):
+    """x4 [N,C,F,T] (float32, cuda, contiguous) -> y [N,Cout,Fout,Tout], new lens.  ``time_pads`` overrides the (left,
+    right) zero padding along time (a window of a stream carries its context as real frames, ``streaming.py``)."""
     lib = _lib.load()
     n, cin, fin, tin = x4.shape
     cout, _, kf, kt = weight4.shape
@@ -122,6 +123,8 @@ def _conv_forward(x4: torch.Tensor, seq_lens: torch.Tensor, weight4: torch.Tenso
         pf = pad_same(fin, kf, sf, df)
     else:
         pt = pf = (0, 0)
+    if time_pads is not None:
+        pt = (int(time_pads[0]), int(time_pads[1]))
     fout = (fin + sum(pf) - (df * (kf - 1) + 1)) // sf + 1
     tout = (tin + sum(pt) - (dt * (kt - 1) + 1)) // st + 1
     if fout <= 0 or tout <= 0:

@@ -8,13 +8,16 @@ from myrtlespeech_amd import _lib
 
 
 def lookahead_apply(x: torch.Tensor, weight: torch.Tensor, x_strides, n: int, f: int, t: int,
-                    out_layout: str = "nft", clamp: Optional[Tuple[float, float]] = None) -> torch.Tensor:
+                    out_layout: str = "nft", clamp: Optional[Tuple[float, float]] = None,
+                    t_out: Optional[int] = None) -> torch.Tensor:
     """Runs ``ms_lookahead_forward`` on a float32 cuda tensor addressed by element
     strides ``x_strides = (s_n, s_f, s_t)``.  ``out_layout`` "nft" -> [N,F,T]
-    contiguous, "ntf" -> [N,T,F] contiguous (what the fully connected stack reads)."""
+    contiguous, "ntf" -> [N,T,F] contiguous (what the fully connected stack reads).
+    ``t_out``: only the first ``t_out`` of the ``t`` frames are produced (a window of a stream, ``streaming.py``)."""
     lib = _lib.load()
     ctx = weight.shape[-1]
     w = _lib.f32c(weight.detach()).reshape(f, ctx)
+    t_in, t = t, (t if t_out is None else t_out)
     if out_layout == "nft":
         y = torch.empty((n, f, t), dtype=torch.float32, device="cuda")
         ys = (f * t, t, 1)
@@ -22,8 +25,8 @@ def lookahead_apply(x: torch.Tensor, weight: torch.Tensor, x_strides, n: int, f:
         y = torch.empty((n, t, f), dtype=torch.float32, device="cuda")
         ys = (t * f, 1, f)
     a, lo, hi = (_lib.ACT_NONE, 0.0, 0.0) if clamp is None else (_lib.ACT_CLAMP, clamp[0], clamp[1])
-    _lib.check(lib.ms_lookahead_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), n, f, t, ctx, x_strides[0], x_strides[1],
-                                        x_strides[2], ys[0], ys[1], ys[2], a, lo, hi, _lib.stream_ptr()),
+    _lib.check(lib.ms_lookahead_window_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), n, f, t_in, t, ctx, x_strides[0],
+                                               x_strides[1], x_strides[2], ys[0], ys[1], ys[2], a, lo, hi, _lib.stream_ptr()),
                "ms_lookahead_forward")
     return y
 

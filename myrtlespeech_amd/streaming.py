@@ -1,44 +1,316 @@
 """Chunked (streaming) Deep Speech 2 inference (new -- the reference only has the
 ``hx`` in / ``hid`` out plumbing of rnn.py:133-185 and deep_speech_2.py:123-172, no chunker).
 
-Definition (pinned by ``tests/golden/stream_*.npz``, generated with the reference itself):
-the input is cut into consecutive ``chunk_frames``-frame slices; every slice goes through the
-ordinary ``DeepSpeech2.forward`` with the recurrent state returned by the previous slice.
-Convolutions therefore see each slice on its own (SAME padding at the slice edges) and the
-backward direction of a bidirectional RNN restarts per slice -- by construction, exactly as a
-caller of the reference would get.  Utterances that have ended leave the batch (lengths are
-sorted in decreasing order, so they are a suffix); their final state is kept.
+Two contracts, both pinned by fixtures made with the reference itself:
+
+``ChunkedDeepSpeech2(model, chunk_frames)`` -- *the reference's plumbing, chunk by chunk*
+(``tests/golden/stream_*.npz``, ``cfg5_stream*_summary.npz``): the input is cut into consecutive
+``chunk_frames``-frame slices; every slice goes through the ordinary ``DeepSpeech2.forward`` with the
+recurrent state returned by the previous slice.  Convolutions therefore see each slice on its own (SAME
+padding at the slice edges) and the backward direction of a bidirectional RNN restarts per slice -- by
+construction, exactly as a caller of the reference would get.  Utterances that have ended leave the batch
+(lengths are sorted in decreasing order, so they are a suffix); their final state is kept.
+
+``ChunkedDeepSpeech2(model, chunk_frames, carry_context=True)`` -- *the full-utterance result, delivered in
+chunks* (unidirectional stacks; pinned by the reference's FULL-utterance outputs, ``ds2_tiny_gru_lookahead.npz``
+and ``ds2_shipped_summary.npz``): every convolution keeps the input frames its next output frame still needs
+(``kernel - 1 - left pad`` of them at the stride phase it has reached) and emits an output frame only once all
+of its taps have arrived; SAME padding exists only at the true start and end of the utterance, with the
+left / right split the reference computes from the batch's padded length (cnn.py:148-163); the recurrent state
+is carried; the lookahead (lookahead.py:36-70) holds back ``context - 1`` frames.  The concatenated chunk
+outputs are the logits ``DeepSpeech2.forward`` gives on the whole clip.  Algorithmic latency (frames of input
+that must have arrived before the first logit row can be emitted) is ``ChunkedDeepSpeech2.latency_frames()``: for
+the shipped config (conv 11 x stride 2, conv 11 x stride 1, lookahead 80) 174 input frames -- frame 0 itself plus
+5 (conv1's right context) + 2 * 5 (conv2's, through conv1's stride) + 2 * 79 (the lookahead's) = 1.73 s of future
+audio, 1.58 s of which are the lookahead's.
 """
-from typing import Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 
 from myrtlespeech_amd import _lib
+from myrtlespeech_amd.model.cnn import (Conv1dTo2d, Conv2dTo1d, MaskConv1d, MaskConv2d, PaddingMode, _conv_forward, _pair,
+                                        out_lens, pad_same)
+from myrtlespeech_amd.model.lookahead import Lookahead, lookahead_apply
+from myrtlespeech_amd.model.utils import activation_clamp
+
+
+class _ConvStage:
+    """One masked convolution of the stack as a stream operator over time.
+
+    Global frame indices: the layer's input is ``total_in`` frames long (the batch's padded length at this depth);
+    output frame ``u`` reads input frames ``u * stride - left + tap * dilation``; frames below 0, at or past an
+    utterance's own length (the reference's in-place mask, cnn.py:425-443) and at or past ``total_in`` read as zero.
+    ``cache`` holds the received input frames from index ``next_out * stride - left`` on."""
+
+    def __init__(self, conv, clamp, total_in: int, lens_in: torch.Tensor):
+        self.conv, self.clamp = conv, clamp
+        self.is1d = isinstance(conv, MaskConv1d)
+        kt = conv.kernel_size[0] if self.is1d else conv.kernel_size[1]
+        self.stride = conv.stride[0] if self.is1d else _pair(conv.stride)[1]
+        self.dilation = conv.dilation[0] if self.is1d else _pair(conv.dilation)[1]
+        self.span = self.dilation * (kt - 1) + 1
+        self.same = conv._padding_mode == PaddingMode.SAME
+        self.left, self.right = pad_same(total_in, kt, self.stride, self.dilation) if self.same else (0, 0)
+        self.total_in = total_in
+        self.total_out = (total_in + self.left + self.right - self.span) // self.stride + 1
+        self.lens_in = lens_in
+        self.lens_out = out_lens(lens_in, kt, self.stride, self.dilation, self.left + self.right)
+        self.next_out = 0
+        self.cache: Optional[torch.Tensor] = None     # [N, C, F, frames] (conv2d) or [N, C, frames] (conv1d)
+        self.cache_start = -self.left
+        self.skip = 0        # frames still to arrive that no output reads (stride > span: the gaps between the windows)
+
+    def push(self, new: Optional[torch.Tensor], final: bool) -> Optional[torch.Tensor]:
+        """``new``: the next input frames (time last) or None; returns the output frames that became computable."""
+        parts = []
+        if new is not None and self.skip:
+            drop = min(self.skip, new.shape[-1])
+            new, self.skip = new[..., drop:], self.skip - drop
+        if self.cache is None:
+            ref = new
+            if ref is None:
+                return None
+            if self.left:
+                parts.append(ref.new_zeros(ref.shape[:-1] + (self.left,)))
+        else:
+            parts.append(self.cache)
+        if new is not None and (new.shape[-1] or not parts):
+            parts.append(new)
+        window = parts[0] if len(parts) == 1 else torch.cat(parts, dim=-1)
+        received = self.cache_start + window.shape[-1]
+        if final:
+            if received > self.total_in:                      # frames past the batch's padded length: not part of the clip
+                window = window[..., :window.shape[-1] - (received - self.total_in)]
+                received = self.total_in
+            tail = self.total_in + self.right - received
+            if tail > 0:
+                window = torch.cat([window, window.new_zeros(window.shape[:-1] + (tail,))], dim=-1)
+        lw = window.shape[-1]
+        cnt = 0 if lw < self.span else (lw - self.span) // self.stride + 1
+        cnt = min(cnt, self.total_out - self.next_out)
+        out = None
+        if cnt > 0:
+            used = (cnt - 1) * self.stride + self.span          # the window's frames these outputs read
+            win = window[..., :used].contiguous()
+            lens_w = (self.lens_in.to(torch.int64) - self.cache_start).clamp(min=0, max=used)
+            x4 = win.unsqueeze(2) if self.is1d else win
+            w4 = self.conv.weight.unsqueeze(2) if self.is1d else self.conv.weight
+            stride = (1, self.stride) if self.is1d else _pair(self.conv.stride)
+            dil = (1, self.dilation) if self.is1d else _pair(self.conv.dilation)
+            y, _ = _conv_forward(x4, lens_w, w4, self.conv.bias, self.conv._packed, stride, dil, self.conv.groups, self.same,
+                                 self.clamp, time_pads=(0, 0))
+            out = y.squeeze(2) if self.is1d else y
+            self.next_out += cnt
+            self.cache_start += cnt * self.stride
+            if cnt * self.stride > lw:                # the next window starts at a frame that has not arrived yet
+                self.skip = cnt * self.stride - lw
+                window = window[..., lw:]
+            else:
+                window = window[..., cnt * self.stride:]
+        self.cache = window
+        return out
+
+
+class _ContextStream:
+    """State of one batch streaming through ``model`` with carried context (see the module docstring)."""
+
+    def __init__(self, model, n: int, total_frames: int, lens: torch.Tensor, hx=None):
+        from myrtlespeech_amd.model.deep_speech_2 import _is_plain_activation
+        if getattr(model.rnn, "bidirectional", False):
+            raise ValueError("carry_context=True reproduces the full-utterance result, which a bidirectional recurrent layer "
+                             "cannot give chunk by chunk (its backward direction starts at the utterance's last frame)")
+        self.model, self.n = model, n
+        self.ops: List = []                # ("conv", _ConvStage) | ("reshape", module)
+        mods = [] if model.cnn is None else (list(model.cnn) if isinstance(model.cnn, torch.nn.Sequential) else [model.cnn])
+        total, cur_lens = total_frames, lens.detach().to("cpu", torch.int64)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, (MaskConv1d, MaskConv2d)):
+                clamp = None
+                if i + 1 < len(mods) and _is_plain_activation(mods[i + 1]):
+                    clamp = activation_clamp(mods[i + 1].module)
+                    i += 1
+                st = _ConvStage(m, clamp, total, cur_lens)
+                self.ops.append(("conv", st))
+                total, cur_lens = st.total_out, st.lens_out
+            elif isinstance(m, (Conv2dTo1d, Conv1dTo2d)):
+                self.ops.append(("reshape", m))
+            elif _is_plain_activation(m) and isinstance(m.module, torch.nn.Identity):
+                pass
+            else:
+                raise ValueError(f"carry_context=True does not know how to stream {type(m).__name__}")
+            i += 1
+        self.total_out = total                       # frames the recurrent stack sees (= rows of the logits)
+        self.out_lens = cur_lens
+        self.rnn_pos = 0
+        self.full_state = None
+        if hx is not None:                           # the caller's initial state (deep_speech_2.py:123-127), one row per utterance
+            self.full_state = tuple(_lib.f32c(s).clone() for s in hx) if isinstance(hx, tuple) else _lib.f32c(hx).clone()
+        self.state = self.full_state
+        la = model.lookahead
+        self.la = self.la_clamp = None
+        if la is not None:
+            lm = list(la) if isinstance(la, torch.nn.Sequential) else [la]
+            if not isinstance(lm[0], Lookahead) or len(lm) > 2 or (len(lm) == 2 and not _is_plain_activation(lm[1])):
+                raise ValueError("carry_context=True needs the builder's Sequential(Lookahead, SeqLenWrapper(act))")
+            self.la = lm[0]
+            self.la_clamp = activation_clamp(lm[1].module) if len(lm) == 2 else None
+        self.la_cache: Optional[torch.Tensor] = None      # [frames, N, F] recurrent outputs not yet fully consumed
+        self.emitted = 0
+
+    def latency_frames(self) -> int:
+        """Input frames that must have arrived before logit row 0 can be emitted."""
+        need = 1 + (0 if self.la is None else self.la.context - 1)     # rows of the recurrent output
+        for kind, st in reversed(self.ops):
+            if kind == "conv":
+                need = (need - 1) * st.stride + st.span - st.left
+        return max(need, 0)
+
+    def push(self, chunk: Optional[torch.Tensor], final: bool) -> Optional[torch.Tensor]:
+        """``chunk [N, C, F, frames]`` (or None with ``final``): returns the logit rows ``[rows, N, V]`` that became
+        computable (None if there are none yet)."""
+        h = None if chunk is None else _lib.f32c(chunk)
+        for kind, op in self.ops:
+            if kind == "conv":
+                h = op.push(h, final)
+            elif h is not None:
+                h = op(h) if not getattr(op, "seq_len_support", False) else op((h, None))[0]
+        rows = None
+        if h is not None:
+            rows = self._recurrent(self.model._conv_to_rnn_size(h))
+        return self._output(rows, final)
+
+    def _recurrent(self, seq: torch.Tensor) -> torch.Tensor:
+        """``seq [cnt, N, CF]``: rows ``rnn_pos ..`` of the recurrent stack's input; returns ``[cnt, N, H]`` with zero rows
+        for utterances that have ended (pad_packed_sequence, rnn.py:179-183)."""
+        cnt = seq.shape[0]
+        lens_c = (self.out_lens - self.rnn_pos).clamp(min=0, max=cnt)
+        alive = int((lens_c > 0).sum())
+        self.rnn_pos += cnt
+        hidden = self.model.rnn.rnn.hidden_size
+        block = torch.zeros((cnt, self.n, hidden), dtype=torch.float32, device="cuda")
+        if alive == 0:
+            return block
+        hx = None
+        if self.state is not None:
+            hx = tuple(s[:, :alive].contiguous() for s in self.state) if isinstance(self.state, tuple) else \
+                self.state[:, :alive].contiguous()
+        (y, _), st = self.model.rnn((seq[:, :alive].contiguous(), lens_c[:alive]), hx=hx)
+        if self.full_state is None:
+            mk = lambda s: torch.zeros(s.shape[0], self.n, s.shape[2], device=s.device)  # noqa: E731
+            self.full_state = tuple(mk(s) for s in st) if isinstance(st, tuple) else mk(st)
+        for fs, s in zip(self.full_state if isinstance(st, tuple) else (self.full_state,), st if isinstance(st, tuple) else (st,)):
+            fs[:, :alive] = s
+        self.state = self.full_state
+        block[:, :alive] = y
+        return block
+
+    def _output(self, rows: Optional[torch.Tensor], final: bool) -> Optional[torch.Tensor]:
+        from myrtlespeech_amd.model.fully_connected import FullyConnected, linear_stack_plan, run_linear_stack
+        fc = self.model.fully_connected
+        if self.la is None:
+            if rows is None:
+                return None
+            ready = rows
+        else:
+            parts = [p for p in (self.la_cache, rows) if p is not None and p.shape[0]]
+            if not parts:
+                return None
+            window = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+            frames = window.shape[0]
+            emit = frames if final else max(frames - (self.la.context - 1), 0)
+            self.la_cache = window[emit:]
+            if emit == 0:
+                return None
+            window = window.contiguous()
+            f = window.shape[2]
+            ntf = lookahead_apply(window, self.la.weight, (f, 1, self.n * f), self.n, f, frames, out_layout="ntf",
+                                  clamp=self.la_clamp, t_out=emit)
+            ready = ntf.transpose(0, 1)                          # [emit, N, F] view
+        t = ready.shape[0]
+        self.emitted += t
+        if isinstance(fc, FullyConnected):
+            flat = _lib.f32c(ready).reshape(t * self.n, ready.shape[2])
+            y = run_linear_stack(flat, linear_stack_plan(fc.fully_connected, fc.training))
+            return y.reshape(t, self.n, -1)
+        out, _ = fc((ready.transpose(0, 1), self.out_lens))
+        return out.transpose(0, 1)
 
 
 class ChunkedDeepSpeech2:
-    def __init__(self, model, chunk_frames: int):
+    def __init__(self, model, chunk_frames: int, carry_context: bool = False):
         if chunk_frames <= 0:
             raise ValueError(f"chunk_frames={chunk_frames} must be > 0")
         self.model = model
         self.chunk_frames = chunk_frames
+        self.carry_context = carry_context
+        self._stream: Optional[_ContextStream] = None
 
+    # ------------------------------------------------------------------ carried context: explicit stream interface
+    def begin(self, lens: torch.Tensor, total_frames: Optional[int] = None, hx=None) -> None:
+        """Start a batch in carried-context mode: ``lens [N]`` (sorted in decreasing order) are the utterances' frame
+        counts, ``total_frames`` the batch's padded length (default ``lens[0]``) -- the reference's SAME padding splits
+        left / right by that length (cnn.py:148-163), so it has to be known up front to reproduce its output.  ``hx``: the
+        recurrent stack's initial state, as ``DeepSpeech2.forward`` takes it."""
+        _lib.require_gpu()
+        lens_cpu = lens.detach().to("cpu", torch.int64)
+        if lens_cpu.numel() > 1 and bool((lens_cpu[:-1] < lens_cpu[1:]).any()):
+            raise RuntimeError("lengths must be sorted in decreasing order")
+        total = int(lens_cpu[0]) if total_frames is None else int(total_frames)
+        self._stream = _ContextStream(self.model, int(lens_cpu.numel()), total, lens_cpu, hx)
+
+    def push(self, chunk: Optional[torch.Tensor], final: bool = False) -> Optional[torch.Tensor]:
+        """Feed the next input frames of every utterance of the batch (``[N, C, F, frames]``; utterances that have ended
+        get whatever padding the caller has -- it is masked like cnn.py:425-443) and receive the logit rows that became
+        computable, ``[rows, N, V]`` or None.  ``final=True`` flushes the held-back context (chunk may be None)."""
+        if self._stream is None:
+            raise RuntimeError("call begin(lens) first")
+        with torch.no_grad():
+            return self._stream.push(chunk, final)
+
+    def latency_frames(self, total_frames: int = 1 << 20) -> int:
+        """Algorithmic latency of the carried-context mode in input frames (see the module docstring)."""
+        s = _ContextStream(self.model, 1, total_frames, torch.tensor([total_frames]))
+        return s.latency_frames()
+
+    def _call_with_context(self, x: torch.Tensor, lens: torch.Tensor, hx=None):
+        n, t_total = x.shape[0], x.shape[-1]
+        self.begin(lens, t_total, hx)
+        st = self._stream
+        x = x if x.is_cuda else x.cuda()
+        outs = []
+        t0 = 0
+        while t0 < t_total:
+            t1 = min(t0 + self.chunk_frames, t_total)
+            y = self.push(x[..., t0:t1], final=(t1 == t_total))
+            if y is not None:
+                outs.append(y)
+            t0 = t1
+        logits = torch.cat(outs, 0)
+        assert logits.shape[0] == st.total_out, (logits.shape, st.total_out)
+        return (logits, st.out_lens.to(lens.dtype)), st.full_state
+
+    # ------------------------------------------------------------------ the reference's plumbing, slice by slice
     def step(self, chunk: torch.Tensor, chunk_lens: torch.Tensor, state=None):
         """One slice: ``chunk [n_alive, C, F, <=chunk_frames]``; returns ``((y, out_lens), new_state)``."""
         return self.model((chunk, chunk_lens), state)
 
-    def __call__(self, x: torch.Tensor, lens: torch.Tensor):
+    def __call__(self, x: torch.Tensor, lens: torch.Tensor, hx=None):
         """Whole (padded, length-sorted) batch, processed slice by slice.  Returns
         ``((logits[T_out, N, V], out_lens[N]), (h_n, c_n) | h_n)`` with T_out the sum of the
         slices' output frames and the state of every utterance at its own last slice."""
         _lib.require_gpu()
+        if self.carry_context:
+            return self._call_with_context(x, lens, hx)
         n, t_total = x.shape[0], x.shape[-1]
         lens_cpu = lens.detach().to("cpu", torch.int64)
         if n > 1 and bool((lens_cpu[:-1] < lens_cpu[1:]).any()):
             raise RuntimeError("lengths must be sorted in decreasing order")
         x = x if x.is_cuda else x.cuda()
         outs, out_lens = [], torch.zeros(n, dtype=torch.int64)
-        state = None
+        state = hx
         full_state = None
         t0 = 0
         while t0 < t_total:

@@ -74,6 +74,27 @@ def deep_speech_2_forward(x, lens, cfg: dict, sd: Dict[str, np.ndarray]):
 
 
 @torch.no_grad()
+def deep_speech_1_forward(x, lens, sd: Dict[str, np.ndarray], n_hidden: int, relu_clip: float = 20.0):
+    """model/deep_speech_1.py:138-188 in eval mode on stock torch CPU operators (torch.nn.LSTM flavour, batch_first):
+    [N, C, F, T] -> view / permute [N, T, C*F] (:175-176) -> 3 x (Linear + Hardtanh(0, clip)) -> packed BiLSTM -> Linear +
+    Hardtanh -> Linear; returns (logits [T, N, V] numpy, lens numpy)."""
+    h = torch.as_tensor(np.asarray(x, dtype=np.float32))
+    lens = torch.as_tensor(np.asarray(lens, dtype=np.int64))
+    n, c, f, t = h.shape
+    h = h.view(n, c * f, t).permute(0, 2, 1)
+    for k in (1, 2, 3):
+        h = F.hardtanh(F.linear(h, torch.as_tensor(sd[f"fc{k}.0.weight"]), torch.as_tensor(sd[f"fc{k}.0.bias"])), 0.0, relu_clip)
+    rnn = torch.nn.LSTM(2 * n_hidden, n_hidden, num_layers=1, bidirectional=True, batch_first=True)   # deep_speech_1.py:101-108
+    rnn.load_state_dict({k[len("bi_lstm.rnn."):]: torch.as_tensor(v) for k, v in sd.items() if k.startswith("bi_lstm.rnn.")})
+    packed = torch.nn.utils.rnn.pack_padded_sequence(h, lens, batch_first=True, enforce_sorted=True)     # rnn.py:170-183
+    out, _ = rnn(packed)
+    h, _ = torch.nn.utils.rnn.pad_packed_sequence(out, batch_first=True, total_length=t)
+    h = F.hardtanh(F.linear(h, torch.as_tensor(sd["fc4.0.weight"]), torch.as_tensor(sd["fc4.0.bias"])), 0.0, relu_clip)
+    h = F.linear(h, torch.as_tensor(sd["out.weight"]), torch.as_tensor(sd["out.bias"]))
+    return h.transpose(0, 1).contiguous().numpy(), lens.numpy()
+
+
+@torch.no_grad()
 def ctc_greedy_decode(x: np.ndarray, lens: np.ndarray, blank: int):
     """ctc_greedy_decoder.py:74-92 with one argmax over the batch and a host loop."""
     best = torch.as_tensor(x).argmax(dim=2).numpy()

@@ -275,6 +275,44 @@ def wide_layer(path: str, n: int = 32, steps: int = 37) -> None:
         print("stamps ok: %.0f ns per stream-step" % (float(span[0].mean()) / 4.0 / (2 * steps) * 10.0))
 
 
+def wide_fp16_vs_oracle() -> float:
+    """``MS_PRECISION=fp16`` (run in a child): the wide-workgroup recurrence's fp16 form -- one fp16 plane of ``W_hh`` and of the
+    exchanged ``h``, one MFMA pass -- on one and on two batch groups of ragged rows, two chained BiLSTM-1024 layers, against
+    the numpy oracle.  Tolerance: fp16 operands carry 2^-11 relative error per product (|h| <= 1, weights
+    ~U(-1/32, 1/32), K = 1024 + In): 3e-3 absolute on outputs and states is ~10x the observed error."""
+    from oracle import ds_oracle as O
+    from myrtlespeech_amd import _lib
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    assert os.environ.get("MS_PRECISION") == "fp16"
+    lib = _lib.load()
+    worst = 0.0
+    for n, steps in ((20, 33), (40, 29), (64, 17)):
+        assert lib.ms_rnn_layer_is_wide(0, 1024, 2, n) == 1
+        torch.manual_seed(31 + n)
+        m = RNN(RNNType.LSTM, 96, 1024, num_layers=2, bidirectional=True, forget_gate_bias=1.0).eval()
+        g = torch.Generator().manual_seed(32 + n)
+        x = torch.randn(steps, n, 96, generator=g)
+        lens = torch.sort(torch.randint(1, steps + 1, (n,), generator=g), descending=True).values
+        lens[0] = steps
+        h0 = torch.randn(4, n, 1024, generator=g) * 0.3
+        c0 = torch.randn(4, n, 1024, generator=g) * 0.3
+        with torch.no_grad():
+            (y, _), (hn, cn) = m((x.cuda(), lens), (h0.cuda(), c0.cuda()))
+        torch.cuda.synchronize()
+        sd = {k[len("rnn."):]: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        want, (wh, wc) = O.rnn_forward(O.LSTM, x.numpy(), lens.numpy(), sd, 1024, 2, True, (h0.numpy(), c0.numpy()))
+        err = max(float(np.abs(y.cpu().numpy() - want).max()), float(np.abs(hn.cpu().numpy() - wh).max()),
+                  float(np.abs(cn.cpu().numpy() - wc).max()))
+        yy = y.cpu().numpy()
+        for i, L in enumerate(lens.tolist()):
+            assert not yy[L:, i].any()
+        print(f"wide fp16 recurrence, {n} rows x {steps} steps: max err vs oracle {err:.3e}")
+        worst = max(worst, err)
+    assert worst < 3e-3, worst
+    print("wide fp16 ok %.3e" % worst)
+    return worst
+
+
 def ragged_stack(path: str, n: int = 40, steps: int = 48, layers: int = 2) -> float:
     """A chained stack of BiLSTM-1024 layers (the wide-workgroup kernel's shape, two batch groups) on a batch of RAGGED lengths:
     by default the layers work on the rows that exist only (``MS_RNN_PACKED_ROWS``: projection over sum(lens) rows, packed planes

@@ -906,3 +906,59 @@ if __name__ == "__main__" and "wer" in sys.argv[1:]:
     gen_wer()
 if __name__ == "__main__" and "ctcgraddim" in sys.argv[1:]:
     gen_ctc_grad_dim()
+
+
+def gen_stream_context():
+    """FULL-utterance reference outputs of two small unidirectional stacks, for ``ChunkedDeepSpeech2(carry_context=True)``
+    (VERDICT r3 item 3): (a) LSTM, no lookahead, an EVEN time kernel with stride 3 -- the left / right split of the SAME
+    padding then depends on the padded length (cnn.py:148-163) -- over five ragged utterances; (b) GRU + lookahead 7 with a
+    Hardtanh behind it, a conv1d block in the stack, odd total length.  Same cfg layout as the ds2_tiny fixtures."""
+    torch.manual_seed(31)
+    cnn = torch.nn.Sequential(
+        MaskConv2d(1, 4, [5, 4], [2, 3], PaddingMode.SAME), act_wrap(0.0, 20.0),
+        MaskConv2d(4, 4, [3, 3], [2, 1], PaddingMode.SAME), act_wrap(0.0, 20.0),
+    )
+    rnn = RNN(RNNType.LSTM, 4 * 4, 16, num_layers=2, bidirectional=False, forget_gate_bias=1.0)
+    fc = FullyConnected(16, 9, 1, 20, torch.nn.Hardtanh(0.0, 20.0))
+    m = DeepSpeech2(cnn, rnn, None, fc).eval()
+    x = torch.randn(5, 1, 16, 71)
+    lens_t = torch.tensor([71, 64, 40, 23, 5], dtype=torch.int64)
+    (y, ol), hid = m((x.clone(), lens_t))
+    flat, dl = ragged(CTCGreedyDecoder(8)(y, ol))
+    cfg = dict(convs=[dict(kind="conv2d", idx=0, in_channels=1, out_channels=4, kernel=[5, 4], stride=[2, 3], same=True, act=[0.0, 20.0]),
+                      dict(kind="conv2d", idx=2, in_channels=4, out_channels=4, kernel=[3, 3], stride=[2, 1], same=True, act=[0.0, 20.0])],
+               rnn=dict(kind=0, input=16, hidden=16, layers=2, bidirectional=False, forget_gate_bias=1.0),
+               lookahead=None, fc=dict(in_features=16, out_features=9, n_hidden=1, hidden=20, act=[0.0, 20.0]), blank=8)
+    arrays = {"in/x": npy(x), "in/lens": npy(lens_t), "out/y": npy(y), "out/lens": npy(ol), "out/hn": npy(hid[0]),
+              "out/cn": npy(hid[1]), "out/greedy_flat": flat, "out/greedy_lens": dl}
+    arrays.update(sd_arrays(m))
+    save("ds2_tiny_ctx_lstm_even_kernel", cfg, arrays)
+
+    torch.manual_seed(32)
+    cnn = torch.nn.Sequential(
+        MaskConv2d(1, 3, [5, 5], [2, 2], PaddingMode.SAME), act_wrap(0.0, 20.0),
+        Conv2dTo1d(),
+        MaskConv1d(3 * 6, 10, 4, 2, PaddingMode.SAME), act_wrap(0.0, 20.0),
+        Conv1dTo2d(),
+    )
+    rnn = RNN(RNNType.GRU, 10, 12, num_layers=2, bidirectional=False)
+    la = torch.nn.Sequential(Lookahead(12, 7), SeqLenWrapper(torch.nn.Hardtanh(-0.2, 0.25), torch.nn.Identity()))
+    fc = FullyConnected(12, 7, 0, None, None)
+    m = DeepSpeech2(cnn, rnn, la, fc).eval()
+    x = torch.randn(4, 1, 12, 93)
+    lens_t = torch.tensor([93, 92, 51, 14], dtype=torch.int64)
+    (y, ol), hid = m((x.clone(), lens_t))
+    flat, dl = ragged(CTCGreedyDecoder(6)(y, ol))
+    cfg = dict(convs=[dict(kind="conv2d", idx=0, in_channels=1, out_channels=3, kernel=[5, 5], stride=[2, 2], same=True, act=[0.0, 20.0]),
+                      dict(kind="conv1d", idx=3, in_channels=18, out_channels=10, kernel=4, stride=2, same=True, act=[0.0, 20.0])],
+               rnn=dict(kind=1, input=10, hidden=12, layers=2, bidirectional=False, forget_gate_bias=None),
+               lookahead=dict(context=7, act=[-0.2, 0.25]),
+               fc=dict(in_features=12, out_features=7, n_hidden=0, hidden=None, act=None), blank=6)
+    arrays = {"in/x": npy(x), "in/lens": npy(lens_t), "out/y": npy(y), "out/lens": npy(ol), "out/hn": npy(hid),
+              "out/greedy_flat": flat, "out/greedy_lens": dl}
+    arrays.update(sd_arrays(m))
+    save("ds2_tiny_ctx_gru_lookahead_act", cfg, arrays)
+
+
+if __name__ == "__main__" and "streamctx" in sys.argv[1:]:
+    gen_stream_context()

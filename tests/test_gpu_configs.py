@@ -51,6 +51,15 @@ def test_cfg5_streaming_batch64_fp16_mfma_in_subprocess():
     print(out.strip().splitlines()[-2])
 
 
+def test_wide_workgroup_lstm_fp16_form_vs_oracle_in_subprocess():
+    """VERDICT r3 missing 6: the fp16 instantiation of ``lstm_persistent_wide2_kernel`` (one 16-bit plane of ``h`` exchanged: 32 KB
+    pulled per workgroup and stream-step; up to 64 sequences in one launch) against the oracle, in a child with
+    ``MS_PRECISION=fp16``; configs[4] (batch 64) runs on it -- ``test_cfg5_streaming_batch64_fp16_mfma_in_subprocess`` above."""
+    out = _child("wide_fp16_vs_oracle()", MS_PRECISION="fp16")
+    assert "wide fp16 ok" in out
+    print([l for l in out.splitlines() if "max err" in l])
+
+
 def test_split_gemm_kernels_agree_in_both_operand_modes():
     """kernel4 (8 waves), kernel4n (4 waves, the co-tenant form of the two-in-flight pipeline) and kernel2 (register staging):
     bit-identical in the default bf16x3 mode and, in a child, in the single-pass fp16 mode of configs[4]."""

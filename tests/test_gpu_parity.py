@@ -547,6 +547,90 @@ def test_ds2_shipped_architecture_full_width_vs_reference_summary():
     print(f"shipped-architecture max |logit err| on the sub-grid: {err:.3e} (mean |logit| {float(g['out/y_abs_mean']):.3e})")
 
 
+# ----------------------------------------------------------------------------- streaming with carried context (a16)
+@pytest.mark.parametrize("name", ["ds2_tiny_gru_lookahead", "ds2_tiny_ctx_lstm_even_kernel", "ds2_tiny_ctx_gru_lookahead_act"])
+def test_streaming_with_carried_context_equals_the_full_utterance_reference(name):
+    """``ChunkedDeepSpeech2(carry_context=True)``: chunk outputs concatenated == the reference's FULL-utterance
+    ``DeepSpeech2.forward`` (deep_speech_2.py:123-172 on the whole clip; fixtures made by the reference): logits, output
+    lengths, final state, greedy transcripts -- for chunk sizes from one frame to the whole clip.  The stacks cover a conv1d
+    block, an even time kernel with stride 3 (the SAME split then depends on the padded length, cnn.py:148-163), stride-2
+    layers, ragged lengths down to 5 frames, a lookahead with and without an activation, an initial state."""
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    from myrtlespeech_amd.streaming import ChunkedDeepSpeech2
+    g = Golden(name)
+    m = load_sd(build_ds2(g.cfg), g.sd()).eval()
+    hx = T(g["in/h0"]) if g.has("in/h0") else None
+    total = g["in/x"].shape[-1]
+    for chunk in (1, 2, 5, 8, 13, 32, total):
+        st = ChunkedDeepSpeech2(m, chunk, carry_context=True)
+        (y, lens), hid = st(T(g["in/x"]), T(g["in/lens"]), hx)
+        np.testing.assert_allclose(cpu(y), g["out/y"], **TOL, err_msg=f"chunk {chunk}")
+        np.testing.assert_array_equal(cpu(lens), g["out/lens"])
+        hn = hid[0] if isinstance(hid, tuple) else hid
+        np.testing.assert_allclose(cpu(hn), g["out/hn"], **TOL)
+        if g.has("out/cn"):
+            np.testing.assert_allclose(cpu(hid[1]), g["out/cn"], **TOL)
+        if g.has("out/greedy_flat"):
+            assert CTCGreedyDecoder(g.cfg["blank"])(y, lens) == unragged(g["out/greedy_flat"], g["out/greedy_lens"])
+    # the explicit stream interface: rows come out as soon as their context has arrived, never earlier
+    st = ChunkedDeepSpeech2(m, 4, carry_context=True)
+    st.begin(T(g["in/lens"]), total, hx)
+    lat = st.latency_frames(total)
+    x = T(g["in/x"]).cuda()
+    rows, t0 = 0, 0
+    while t0 < total:
+        out = st.push(x[..., t0:t0 + 4], final=(t0 + 4 >= total))
+        t0 += 4
+        if t0 < lat and t0 < total:
+            assert out is None, (t0, lat)
+        rows += 0 if out is None else out.shape[0]
+    assert rows == g["out/y"].shape[0]
+    with pytest.raises(ValueError):
+        ChunkedDeepSpeech2(load_sd(build_ds2(Golden("ds2_tiny_bilstm").cfg), Golden("ds2_tiny_bilstm").sd()), 8,
+                           carry_context=True)(T(Golden("ds2_tiny_bilstm")["in/x"]), T(Golden("ds2_tiny_bilstm")["in/lens"]))
+
+
+def test_streaming_with_carried_context_shipped_architecture_vs_full_utterance_reference():
+    """The reference's SHIPPED config shape (2 x conv2d, 3 x GRU-2560 unidirectional, lookahead 80, FC 1 x 1024;
+    configs/deep_speech_2_en.config:19-93) streamed in 320 ms chunks with carried context against the reference's
+    full-utterance run of ``tests/golden/ds2_shipped_summary.npz``: logits on the stored sub-grid and the final state within
+    1e-3, greedy transcripts bit-exact; 174 input frames of algorithmic latency (1.58 s of it the lookahead's 79 frames)."""
+    from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+    from myrtlespeech_amd.model.deep_speech_2 import DeepSpeech2
+    from myrtlespeech_amd.model.fully_connected import FullyConnected
+    from myrtlespeech_amd.model.lookahead import Lookahead
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    from myrtlespeech_amd.model.seq_len_wrapper import SeqLenWrapper
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    from myrtlespeech_amd.streaming import ChunkedDeepSpeech2
+    g = Golden("ds2_shipped_summary")
+
+    def act():
+        return SeqLenWrapper(torch.nn.Hardtanh(0.0, 20.0), torch.nn.Identity())
+    torch.manual_seed(g.cfg["seed_weights"])
+    cnn = torch.nn.Sequential(MaskConv2d(1, 32, [41, 11], [2, 2], PaddingMode.SAME), act(),
+                              MaskConv2d(32, 32, [21, 11], [2, 1], PaddingMode.SAME), act())
+    rnn = RNN(RNNType.GRU, 640, 2560, num_layers=3, bidirectional=False)
+    la = torch.nn.Sequential(Lookahead(2560, 80), SeqLenWrapper(torch.nn.Identity(), torch.nn.Identity()))
+    fc = FullyConnected(2560, 29, 1, 1024, torch.nn.Hardtanh(0.0, 20.0))
+    model = DeepSpeech2(cnn, rnn, la, fc).eval()
+    gen = torch.Generator().manual_seed(g.cfg["seed_input"])
+    N, Tn = g.cfg["N"], g.cfg["T"]
+    x = torch.randn(N, 1, 80, Tn, generator=gen)
+    lens = torch.sort(torch.randint(150, Tn + 1, (N,), generator=gen), descending=True).values
+    lens[0] = Tn
+    np.testing.assert_array_equal(lens.numpy(), g["in/lens"])
+    st = ChunkedDeepSpeech2(model, 32, carry_context=True)
+    assert st.latency_frames() == 174
+    (y, ol), hn = st(x, lens)
+    np.testing.assert_array_equal(cpu(ol), g["out/lens"])
+    np.testing.assert_allclose(cpu(y[::10, ::2, :]), g["out/y_sub"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(cpu(hn[:, :, ::64]), g["out/hn_sub"], rtol=0, atol=1e-3)
+    assert CTCGreedyDecoder(28)(y, ol) == unragged(g["out/greedy_flat"], g["out/greedy_lens"])
+    err = float(np.abs(cpu(y[::10, ::2, :]) - g["out/y_sub"]).max())
+    print(f"shipped architecture streamed with carried context: max |logit err| vs the full-utterance reference {err:.3e}")
+
+
 # ----------------------------------------------------------------------------- CTC beam search
 def test_beam_config_size_vs_reference():
     """The reference CTCBeamDecoder at the BASELINE decode size (T = 501, V = 29, beam 8, prune 1e-3; 4 ragged utterances

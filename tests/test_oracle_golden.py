@@ -127,6 +127,16 @@ def test_torch_cpu_baseline_matches_reference_golden():
     assert TC.ctc_greedy_decode(y, nl, c["blank"]) == unragged(g["out/greedy_flat"], g["out/greedy_lens"])
 
 
+def test_torch_cpu_ds1_baseline_matches_reference_golden():
+    """The stock-torch DS1 assembly that bench.py's ``cfg1_ds1`` leg times as its CPU baseline, against the reference's output."""
+    from oracle import torch_cpu as TC
+    g = Golden("ds1_tiny")
+    c = g.cfg
+    y, nl = TC.deep_speech_1_forward(g["in/x"], g["in/lens"], g.sd(), c["n_hidden"], c["relu_clip"])
+    np.testing.assert_allclose(y, g["out/y"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(nl, g["in/lens"])
+
+
 @pytest.mark.parametrize("name", golden_names("ds1_tiny"))
 def test_ds1_tiny(name):
     g = Golden(name)
