@@ -166,6 +166,13 @@ def upload(host: torch.Tensor, dtype=None) -> torch.Tensor:
     if dtype is not None and h.dtype != dtype:
         h = h.to(dtype)
     h = h.contiguous()
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        # inside a HIP graph capture (streaming.py) a host -> device copy would bake a host address into the graph; the
+        # lengths of a steady-state chunk are all equal, and a fill kernel makes those on the device
+        flat = h.reshape(-1)
+        if flat.numel() and bool((flat == flat[0]).all()):
+            return torch.full(h.shape, flat[0].item(), dtype=h.dtype, device="cuda")
+        raise RuntimeError("host values that differ cannot be uploaded inside a HIP graph capture")
     if not _ASYNC_LENS:
         return h.cuda()
     try:

@@ -380,13 +380,18 @@ __device__ __forceinline__ void lds_dma_16(__amdgpu_buffer_rsrc_t rsrc, char* ds
 // WN = wave columns: 2 = 256 x 256 tile, 8 waves, two per SIMD (the shipped form); 1 = 256 x 128 tile, 4 waves, one per
 // SIMD: 224 VGPRs and 128 KB of LDS per workgroup, i.e. a workgroup that fits on a CU BESIDE a workgroup of the persistent
 // LSTM kernel (272 VGPRs, 20 KB) -- the co-residency experiment of DESIGN 7.0 (tools/overlap_probe.py)
-template <bool F16, int WN, int PER_STEP_ = 3, bool SPACED = false>
+// NJ = 32-column W fragments per wave: 4 (64 x 128 per wave: the forms above) or, with WN = 2, 2 -- a 256 x 128 tile on EIGHT
+// waves of 64 x 64 (round 4): twice the workgroups of the 256 x 256 form for outputs that would otherwise leave CUs idle
+// (a streaming chunk's projection is 1 024 x 8 192: 128 tiles of 256 x 256 on 256 CUs), every output still the same
+// k-ordered sum (bit-identical), 8 fragment reads per 12 MFMAs instead of 12 per 24.
+template <bool F16, int WN, int PER_STEP_ = 3, bool SPACED = false, int NJ = 4>
 __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah, const unsigned short* __restrict__ Al,
                                            const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
                                            const float* __restrict__ bias, float* __restrict__ Y, int M, int K, int N, int act,
                                            float lo, float hi, const int* __restrict__ m_eff = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  constexpr int TN = 128 * WN;
+  constexpr int TN = 32 * NJ * WN;
+  static_assert(NJ == 4 || (NJ == 2 && WN == 2), "the narrow form is the 8-wave kernel");
   // m_eff (optional): the number of rows that exist is a word in device memory (<= the M the grid was sized for): the
   // recurrent layers' packed projection, whose row count is the sum of the batch's lengths (rnn.hip).  Workgroups past
   // the tiles of that many rows leave at once.
@@ -416,11 +421,15 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
 
   // ---- this wave's DMA pieces (16 rows each): NPA pieces of x plane PA from tile row RA, NPB pieces of W plane PB from RB.
   // WN = 2: 8 waves x 8 pieces of ONE plane (F16: 4); WN = 1: 4 waves x (8 of an x plane + 4 of a W plane) (F16: 4 + 2).
-  constexpr int NPA = WN == 2 ? (F16 ? 4 : 8) : (F16 ? 4 : 8);
-  constexpr int NPB = WN == 2 ? 0 : (F16 ? 2 : 4);
+  // NJ = 2 (8 waves, 256 x 128): 32 x-pieces + 16 W-pieces per K-block = 4 + 2 per wave (F16: 2 + 1)
+  constexpr int NPA = NJ == 2 ? (F16 ? 2 : 4) : WN == 2 ? (F16 ? 4 : 8) : (F16 ? 4 : 8);
+  constexpr int NPB = NJ == 2 ? (F16 ? 1 : 2) : WN == 2 ? 0 : (F16 ? 2 : 4);
   constexpr int NP = NPA + NPB;
   int PA, RA, PB = 2, RB = 0;
-  if (WN == 2) {
+  if (NJ == 2) {
+    if (F16) { PA = 0; RA = wave * 32; PB = 2; RB = wave * 16; }
+    else { PA = wave >> 2; RA = (wave & 3) * 64; PB = 2 + (wave >> 2); RB = (wave & 3) * 32; }
+  } else if (WN == 2) {
     const int g0 = wave * NPA;                               // pieces numbered plane-major, 16 per plane
     PA = F16 ? (g0 >> 4) * 2 : (g0 >> 4);                    // 0 = x hi, 1 = x lo, 2 = W hi, 3 = W lo
     RA = (g0 & 15) * 16;
@@ -455,11 +464,11 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
     }
   };
 
-  f32x16 acc[2][4];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -467,7 +476,7 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
   const int sw = (l31 >> 2) & 3;
   const int foff0 = l31 * 64 + ((half ^ sw) * 16);           // h = 0: kg = half
   const int foff1 = l31 * 64 + (((2 + half) ^ sw) * 16);     // h = 1: kg = 2 + half
-  const int a_base = wm * 64 * 64, b_base = 2 * G4_PLANE + wn * 128 * 64;
+  const int a_base = wm * 64 * 64, b_base = 2 * G4_PLANE + wn * (32 * NJ) * 64;
 
   u32x4 fa[WN == 1 ? 1 : 2][6 + 6];   // [set][ah0 ah1 al0 al1 | bh0..3 bl0..3]: 12 granules per set
   auto read_frags = [&](int set, int stage, int h) {
@@ -478,7 +487,7 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
       if (!F16) fa[set][2 + i] = *reinterpret_cast<const u32x4*>(st + G4_PLANE + a_base + i * 32 * 64);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       fa[set][4 + j] = *reinterpret_cast<const u32x4*>(st + b_base + j * 32 * 64);
       if (!F16) fa[set][8 + j] = *reinterpret_cast<const u32x4*>(st + G4_PLANE + b_base + j * 32 * 64);
     }
@@ -491,26 +500,26 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set][4 + j]),
                                                              __builtin_bit_cast(f16x8, fa[set][i]), acc[i][j], 0, 0, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][4 + j]),
                                                               __builtin_bit_cast(bf16x8, fa[set][i]), acc[i][j], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][4 + j]),
                                                               __builtin_bit_cast(bf16x8, fa[set][2 + i]), acc[i][j], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][8 + j]),
                                                               __builtin_bit_cast(bf16x8, fa[set][i]), acc[i][j], 0, 0, 0);
     }
@@ -608,7 +617,7 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
   __builtin_amdgcn_sched_barrier(0);
 
-  constexpr int NR = F16 ? 6 : 12;          // fragment reads per half block
+  constexpr int NR = NJ == 2 ? (F16 ? 4 : 8) : (F16 ? 6 : 12);          // fragment reads per half block (NJ = 2: 12 MFMAs, 8 reads)
   constexpr int MPR = F16 ? 8 / 6 + 1 : 2;  // MFMAs issued per read in the interleave (F16: 8 MFMAs, 6 reads)
   for (int b = 0; b < nk; ++b) {
     const int cur = b & 1;
@@ -649,10 +658,10 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
     const int m = m0 + wm * 64 + i * 32 + l31;
     if (m >= M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * 128 + j * 32 + 8 * g + 4 * half;
+        const int n = n0 + wn * (32 * NJ) + j * 32 + 8 * g + 4 * half;
         f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
         if (n_vec && n + 3 < N) {
           if (bias != nullptr) {
@@ -686,6 +695,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4(const unsigned 
                                                                  int M, int K, int N, int act, float lo, float hi,
                                                                  const int* __restrict__ m_eff) {
   gemm4_body<F16, 2>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff);
+}
+
+// 256 x 128 tiles on eight waves (NJ = 2): outputs whose 256 x 256 tiles would leave CUs without a workgroup
+template <bool F16>
+__global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4h(const unsigned short* __restrict__ Ah,
+                                                                  const unsigned short* __restrict__ Al,
+                                                                  const unsigned short* __restrict__ Wh,
+                                                                  const unsigned short* __restrict__ Wl,
+                                                                  const float* __restrict__ bias, float* __restrict__ Y,
+                                                                  int M, int K, int N, int act, float lo, float hi,
+                                                                  const int* __restrict__ m_eff) {
+  gemm4_body<F16, 2, 3, false, 2>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff);
 }
 
 // the 4-wave form, capped at 208 VGPRs (the two-stream LSTM kernel allocates 304 of a SIMD's 512): experiment only
@@ -750,6 +771,8 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4h<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4h<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     attr_once.done();
   }
   static const bool small_tile = getenv("MS_GEMM_TILE128") && getenv("MS_GEMM_TILE128")[0] == '1';
@@ -758,6 +781,18 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
   // (narrow outputs, e.g. N = 512: 2 column tiles); both kernels accumulate in the same order, results are identical
   const long tiles256 = (long)cdiv(M, S2_M) * cdiv(N, S2_N);
   const bool starved = tiles256 * 4 < (long)num_cus() * 3 && (long)cdiv(M, SB_M) * cdiv(N, SB_N) > tiles256;
+  // round 4: a starved output of at least a million elements takes 256 x 128 tiles on the LDS-DMA kernel (8 waves of 64 x 64)
+  // instead of falling back to the round-1 register-staged kernel (or, in fp16 mode, half-filling the chip with 256 x 256
+  // tiles): a streaming chunk's projection, 1 024 x 8 192.  MS_GEMM_HALF_TILE=0 keeps the old routing (A/B runs).
+  static const bool half_off = getenv("MS_GEMM_HALF_TILE") && getenv("MS_GEMM_HALF_TILE")[0] == '0';
+  if (!half_off && !small_tile && starved && m_eff == nullptr && (long)M * N >= 1024L * 1024 &&
+      g_gemm_variant.load(std::memory_order_relaxed) == 0 && (size_t)std::max(M, N) * K * 2 < ((size_t)1 << 31)) {
+    auto k4h = f16 ? gemm_nt_bf16x3_kernel4h<true> : gemm_nt_bf16x3_kernel4h<false>;
+    hipLaunchKernelGGL(k4h, dim3(cdiv(M, S2_M) * cdiv(N, 128)), dim3(512), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi,
+                       m_eff);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+  }
   if (f16 || (!small_tile && !starved && (long)M * N >= 4L * 1024 * 1024)) {
     const int nwg2 = cdiv(M, S2_M) * cdiv(N, S2_N);
     auto kern = f16 ? gemm_nt_bf16x3_kernel2<true> : gemm_nt_bf16x3_kernel2<false>;

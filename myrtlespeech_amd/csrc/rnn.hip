@@ -2131,6 +2131,12 @@ struct PersistentTurn {
   explicit PersistentTurn(hipStream_t s) : stream(s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { rc = MS_ERR_HIP; return; }
+    // A launch that is being CAPTURED into a HIP graph (streaming.py replays a chunk's launches as one graph) is not chained:
+    // nothing runs now, and the capture stream is not the stream the graph will be launched on.  A graph that holds
+    // persistent launches must therefore not be replayed beside persistent launches of another stream of this process.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive) return;
+    (void)hipGetLastError();
     c = &g_chain[dev & 63];
     c->mu.lock();
     if (c->any && c->last != stream) {

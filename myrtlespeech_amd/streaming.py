@@ -239,14 +239,60 @@ class _ContextStream:
         return out.transpose(0, 1)
 
 
+class _ChunkGraph:
+    """One steady-state slice -- ``alive`` utterances, all with a full ``frames``-frame slice, state carried -- captured once as
+    a HIP graph (``torch.cuda.CUDAGraph``) and replayed per chunk: the ~45 launches of a slice then cost the host one
+    ``hipGraphLaunch`` instead of ~1 ms of Python / ctypes work per chunk, and the device does exactly
+    the launches the eager call enqueues (same kernels, same order, same buffers: bit-identical results).  The recurrent
+    state lives in the graph's own static tensors and is chained inside the graph (state_in <- state_out)."""
+
+    def __init__(self, model, alive: int, shape, state):
+        self.x = torch.empty((alive,) + tuple(shape[1:]), dtype=torch.float32, device="cuda")
+        self.state = tuple(torch.zeros_like(s[:, :alive]) for s in state) if isinstance(state, tuple) else \
+            torch.zeros_like(state[:, :alive])
+        frames = shape[-1]
+        host = torch.full((alive,), frames, dtype=torch.int64)
+        self.lens = _lib.attach_host(torch.full((alive,), frames, dtype=torch.int64, device="cuda"), host)
+        self.graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            (y, ol), st = model((self.x, self.lens), self.state)
+            if isinstance(st, tuple):
+                for a, b in zip(self.state, st):
+                    a.copy_(b)
+            else:
+                self.state.copy_(st)
+        self.y, self.out_lens_host = y, _lib.host_lens(ol).clone()
+
+    def load_state(self, state, alive: int):
+        if isinstance(state, tuple):
+            for a, b in zip(self.state, state):
+                a.copy_(b[:, :alive])
+        else:
+            self.state.copy_(state[:, :alive])
+
+    def run(self, xc: torch.Tensor):
+        self.x.copy_(xc)
+        self.graph.replay()
+        return self.y
+
+
 class ChunkedDeepSpeech2:
-    def __init__(self, model, chunk_frames: int, carry_context: bool = False):
+    def __init__(self, model, chunk_frames: int, carry_context: bool = False, use_graph: Optional[bool] = None):
+        """``use_graph`` (default: on unless ``MS_STREAM_GRAPH=0``): replay steady-state slices as a captured HIP graph
+        (reference-plumbing mode only; any slice that is not steady state -- ragged lengths inside the slice, a short last
+        slice -- and any capture failure fall back to the eager call)."""
         if chunk_frames <= 0:
             raise ValueError(f"chunk_frames={chunk_frames} must be > 0")
         self.model = model
         self.chunk_frames = chunk_frames
         self.carry_context = carry_context
         self._stream: Optional[_ContextStream] = None
+        import os
+        self.use_graph = (os.environ.get("MS_STREAM_GRAPH") != "0") if use_graph is None else bool(use_graph)
+        self._graphs = {}
+        self.graph_error: Optional[str] = None
+        self.graph_replays = 0
 
     # ------------------------------------------------------------------ carried context: explicit stream interface
     def begin(self, lens: torch.Tensor, total_frames: Optional[int] = None, hx=None) -> None:
@@ -312,29 +358,64 @@ class ChunkedDeepSpeech2:
         outs, out_lens = [], torch.zeros(n, dtype=torch.int64)
         state = hx
         full_state = None
+        active = None            # the _ChunkGraph whose static tensors hold the current state, if any
+        check_was = getattr(self.model.rnn, "check_status", None)
         t0 = 0
         while t0 < t_total:
             alive = int((lens_cpu > t0).sum())
             if alive == 0:
                 break
-            xc = x[:alive, :, :, t0:t0 + self.chunk_frames].contiguous()
+            xc = x[:alive, :, :, t0:t0 + self.chunk_frames]
             lc = (lens_cpu[:alive] - t0).clamp(max=xc.shape[-1])
-            hx = None
-            if state is not None:
-                hx = tuple(s[:, :alive].contiguous() for s in state) if isinstance(state, tuple) else \
-                    state[:, :alive].contiguous()
-            (y, ol), state = self.step(xc, lc, hx)
+            steady = (self.use_graph and self.graph_error is None and state is not None and xc.shape[-1] == self.chunk_frames
+                      and int(lc.min()) == self.chunk_frames)
+            y = ol_host = None
+            if steady:
+                key = (alive, tuple(xc.shape[1:]))
+                cg = self._graphs.get(key)
+                if cg is None:
+                    try:
+                        if check_was is not None:
+                            self.model.rnn.check_status = False      # ms_rnn_status synchronises: not inside a capture
+                        cur = active.state if active is not None else state
+                        cg = _ChunkGraph(self.model, alive, xc.shape, cur)
+                        self._graphs[key] = cg
+                    except Exception as e:  # noqa: BLE001 -- capture is an optimisation: the eager path below is the definition
+                        self.graph_error = f"{type(e).__name__}: {e}"[:300]
+                        cg = None
+                        torch.cuda.synchronize()
+                    finally:
+                        if check_was is not None:
+                            self.model.rnn.check_status = check_was
+                if cg is not None:
+                    if active is not cg:
+                        cg.load_state(active.state if active is not None else state, alive)
+                        active = cg
+                    y, ol_host = cg.run(xc), cg.out_lens_host
+                    state = cg.state
+                    self.graph_replays += 1
+            if y is None:
+                if active is not None:       # leave the graph: its static state is the current state
+                    state, active = active.state, None
+                hx_c = None
+                if state is not None:
+                    hx_c = tuple(s_[:, :alive].contiguous() for s_ in state) if isinstance(state, tuple) else \
+                        state[:, :alive].contiguous()
+                (y, ol), state = self.step(xc.contiguous(), lc, hx_c)
+                ol_host = _lib.host_lens(ol)   # host values ride along with the device tensor: no read-back
             if full_state is None:
-                full_state = tuple(torch.zeros(s.shape[0], n, s.shape[2], device=s.device) for s in state) \
+                full_state = tuple(torch.zeros(s_.shape[0], n, s_.shape[2], device=s_.device) for s_ in state) \
                     if isinstance(state, tuple) else torch.zeros(state.shape[0], n, state.shape[2], device=state.device)
             if isinstance(state, tuple):
-                for fs, s in zip(full_state, state):
-                    fs[:, :alive] = s
+                for fs, s_ in zip(full_state, state):
+                    fs[:, :alive] = s_
             else:
                 full_state[:, :alive] = state
             block = torch.zeros((y.shape[0], n, y.shape[2]), dtype=y.dtype, device=y.device)
             block[:, :alive] = y
             outs.append(block)
-            out_lens[:alive] += _lib.host_lens(ol)   # host values ride along with the device tensor: no read-back
+            out_lens[:alive] += ol_host
             t0 += self.chunk_frames
+        if self.graph_replays and check_was:
+            _lib.check(_lib.load().ms_rnn_status(_lib.ptr(self.model.rnn._workspace.buf), _lib.stream_ptr()), "ms_rnn_layer_forward")
         return (torch.cat(outs, 0), out_lens.to(lens.dtype)), full_state

@@ -216,7 +216,10 @@ def gemm_variants_equal() -> None:
     bit-identical outputs, ragged edges included."""
     from myrtlespeech_amd import _lib
     lib = _lib.load()
-    for M, K, N, act in ((2100, 96, 2052, 0), (4100, 32, 1026, 1), (3000, 640, 2048, 0)):
+    # (the first three shapes leave CUs without a 256 x 256 tile: variant 0 is then the 256 x 128 eight-wave kernel of round 4;
+    # (4100, 64, 4100) fills the chip: variant 0 = the 256 x 256 kernel; (1024, 2048, 8192) is a streaming chunk's projection)
+    for M, K, N, act in ((2100, 96, 2052, 0), (4100, 32, 1026, 1), (3000, 640, 2048, 0), (4100, 64, 4100, 1), (1024, 2048, 8192, 0),
+                         (700, 640, 1500, 1)):
         g = torch.Generator().manual_seed(M + K + N)
         x = torch.randn(M, K, generator=g).cuda()
         w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()

@@ -315,6 +315,7 @@ def leg_stream(ctx, chunks=16):
            "dtype": mode, "ms_per_chunk": round(per_chunk, 4), "ms_per_chunk_min": round(ms_min / chunks, 4),
            "ms_per_chunk_wall": round(per_chunk_wall, 4), "realtime_factor": round(N * 0.32 / per_chunk * 1e3, 1),
            "ms": round(per_chunk, 4), "floor_ms": round(floor, 4), "frac_of_floor": round(floor / per_chunk, 3),
+           "hip_graph_replays": stream.graph_replays, "hip_graph_error": stream.graph_error,
            "floor": f"per chunk: {w_bytes / 1e6:.0f} MB of weights streamed once at 8 TB/s + 5 layers x 16 sequential steps x "
                     f"{step_us:.2f} us (the persistent recurrence's step at batch 64 in this mode, measured in this run); a BiLSTM "
                     "layer's projection needs the whole layer below, so the five recurrences are in series"}
