@@ -52,7 +52,7 @@ LSTM_STEP_FLOP = 2 * BATCH_PER_GPU * HIDDEN * 4 * HIDDEN            # 268.4 MFLO
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 / fp16 MFMA
 MFMA_F32_PEAK_TF = 157.3    # float32-input MFMA
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc_bench.json")
 
 
 def precision_mode():
@@ -79,7 +79,7 @@ KERNEL_SOURCES = {"lstm": ("rnn.hip", "common.h"), "gemm_nt_bf16x3": ("gemm_spli
 
 
 def source_sha16(names=None):
-    """Digests of the kernel source files the timed binary was built from ({file: sha16}); profiles/r03_pmc_bench.json
+    """Digests of the kernel source files the timed binary was built from ({file: sha16}); profiles/r04_pmc_bench.json
     records the digests its counters were taken on, so a stale counter file is detected instead of being quoted."""
     csrc = os.path.join(ROOT, "myrtlespeech_amd", "csrc")
     out = {}
@@ -96,13 +96,13 @@ def pmc_record(kernel_key):
         with open(PMC_PROFILE) as f:
             prof = json.load(f)
     except Exception:
-        return None, "profiles/r03_pmc_bench.json not found"
+        return None, "profiles/r04_pmc_bench.json not found"
     if prof.get("precision") != precision_mode():
         return None, f"counters were taken in {prof.get('precision')} mode"
     files = next((v for k, v in KERNEL_SOURCES.items() if kernel_key.startswith(k)), None)
     now = source_sha16(files)
     if any(prof.get("source_sha16", {}).get(f) != d for f, d in now.items()):
-        return None, f"{', '.join(now)} changed since the counter passes (profiles/r03_pmc_bench.json is stale for this kernel)"
+        return None, f"{', '.join(now)} changed since the counter passes (profiles/r04_pmc_bench.json is stale for this kernel)"
     rec = prof.get("kernels", {}).get(kernel_key)
     return (rec, None) if rec else (None, f"no counters for {kernel_key}")
 
@@ -341,7 +341,12 @@ def main(argv=None, runtime=None, json_fd=None):
             dist.barrier()
         rt.synchronize()
 
-    pipelined = args.in_flight == 2 and not (args.gather_logits and dist is not None)
+    # Throughput modes.  With --gather-logits (batched decode behind an RCCL all-gather) the two-batches-per-forward mode
+    # stays on: its `post` runs on the calling thread in batch order, so every rank issues the collectives in the same order.
+    # The threaded two-in-flight pipeline calls `post` from two worker threads, whose interleaving may differ between ranks
+    # (a collective order mismatch = a hang), so it is not timed under --gather-logits.
+    gathering = args.gather_logits and dist is not None
+    pipelined = args.in_flight == 2
     pipe = paired = None
     if pipelined:
         starts = {}
@@ -351,12 +356,16 @@ def main(argv=None, runtime=None, json_fd=None):
             starts[k].record()
 
         def post(out):
-            pending = decoder.launch(out[0][0], out[0][1])
+            logits, out_lens = out[0][0], out[0][1]
+            if gathering:        # this batch's shard of logits from every rank, then the batched decode on every rank
+                from myrtlespeech_amd.parallel import gather_logits
+                logits, out_lens = gather_logits(logits, out_lens)
+            pending = decoder.launch(logits, out_lens)
             end = rt.event()
             end.record()
             return pending, end
 
-        pipe = rt.pipe(model, post, pre)
+        pipe = None if gathering else rt.pipe(model, post, pre)
         paired = rt.paired(model, post, pre)
 
     STAGES = ("projection", "recurrence", "gemm_k_large", "gemm_k_small", "conv", "layout", "linear", "greedy", "other")
@@ -393,7 +402,7 @@ def main(argv=None, runtime=None, json_fd=None):
         barrier()
         lib.ms_prof_read(ms, cnt)
         lib.ms_prof_enable(0)
-        rt.check_status(list(pipe.models) if (two is True or two is pipe) else [model])
+        rt.check_status(list(pipe.models) if (pipe is not None and (two is True or two is pipe)) else [model])
         t_max = torch.tensor([elapsed], dtype=torch.float64, device=rt.device)
         if dist is not None:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -443,7 +452,8 @@ def main(argv=None, runtime=None, json_fd=None):
     # one-batch figure (already measured) is reported instead, with the reason.
     pipeline_error = None
     two = None
-    if pipelined:
+    elapsed = latency_ms = None
+    if pipelined and pipe is not None:
         try:
             # untimed: the pipeline's own warm-up.  A call keeps every batch's outputs until the caller has collected them, so
             # the caching allocator only reaches its steady state after a call of the timed call's length: with a shorter
@@ -453,19 +463,20 @@ def main(argv=None, runtime=None, json_fd=None):
             elapsed, latency_ms = two["elapsed"], two["latency"]
         except Exception as e:  # noqa: BLE001
             pipeline_error = f"{type(e).__name__}: {e}"[:300]
-            pipelined = False
+            pipe = None
             two = None
             lib.ms_gemm_set_variant(0)
             rt.synchronize()
     two_in_flight = None
-    if pipelined:
+    if two is not None:
         two_in_flight = {"value": round(world * BATCH_PER_GPU * CLIP_SECONDS * args.steps / elapsed, 1),
                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "latency_ms_per_batch": round(latency_ms, 3)}
         two_in_flight.update(stage_report(two, True))
     # leg 3 (the other throughput mode, round 3): two batches per forward (pipeline.PairedBatches -> one stream, the two
     # batches' recurrences side by side in one launch of the wide-workgroup kernel)
     pair = per_forward = None
-    headline = pipe if pipelined else None          # the runner whose figure is `value`
+    headline = pipe if two is not None else None          # the runner whose figure is `value`
+    pipelined = headline is not None
     if paired is not None:
         try:
             paired([(x, lens_full)] * max(2, args.warmup, min(args.steps, 24)))
@@ -597,7 +608,7 @@ def main(argv=None, runtime=None, json_fd=None):
             roof["mfma_frac"] = round(rec["mfma_flop"] / (rec_ms * 1e-3) / 1e12 / mfma_peak, 4)
             roof["mfma_busy_frac_pmc"] = rec.get("mfma_busy_frac")
             roof["l2_hit_rate_pmc"] = rec.get("l2_hit_rate")
-            roof["pmc_source"] = "profiles/r03_pmc_bench.json (rocprofv3 --pmc passes over this bench, same kernel sources)"
+            roof["pmc_source"] = "profiles/r04_pmc_bench.json (rocprofv3 --pmc passes over this bench, same kernel sources)"
         else:
             roof["traffic"] = None
             roof["pmc_note"] = why

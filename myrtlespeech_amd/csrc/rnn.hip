@@ -804,14 +804,16 @@ __global__ __launch_bounds__(256) void split_planes_packed_kernel(const float* _
 // Layout of a direction: ... [parity][slab_bytes] ..., i.e. parity = (byte offset / slab_bytes) & 1.
 // The same launch clears the per-call status word and the epoch flags (`zero_words` words at `zero_base`), which used to
 // be a memset of its own before every layer call and between batch groups.
+// `ndir` regions of words_per_dir words follow each other; region r belongs to direction r % dir_mod (the wide path lays
+// out [group][direction], so one launch initialises every batch group: ndir = groups * dir_mod).
 __global__ void hx_init_kernel(unsigned* __restrict__ hx, size_t words_per_dir, size_t slab_words, int ndir, int steps,
-                               int rs, unsigned* __restrict__ zero_base, int zero_words) {
+                               int rs, unsigned* __restrict__ zero_base, int zero_words, int dir_mod) {
   const size_t total = words_per_dir * ndir;
   const int mask = (1 << rs) - 1;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)zero_words; i += (size_t)gridDim.x * blockDim.x)
     zero_base[i] = 0u;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int d = (int)(i / words_per_dir);
+    const int d = (int)(i / words_per_dir) % dir_mod;
     const int par = (int)(((i % words_per_dir) / slab_words) & mask);
     int first_u;  // first clock value at which slot `par` is read (forward: counting up from 0; backward: down from steps-1)
     if (d == 0) first_u = par;
@@ -2571,12 +2573,12 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
           static const bool on = getenv("MS_LSTM_WIDE_XCD") && getenv("MS_LSTM_WIDE_XCD")[0] == '1';
           p.xcd_map = (on && groups == 2 && ndir == 2 && p.J == 128) ? 1 : 0;
         }
-        for (int g = 0; g < groups; ++g) {
-          hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir)), dim3(256), 0, stream,
-                             (unsigned*)(ws + W.hx) + (size_t)g * ndir * words_per_dir, words_per_dir, (size_t)8 * H, ndir, steps, rs,
-                             zero_base(0), g == 0 ? zero_words(0) : 0);
-          MS_LAUNCH_CHECK();
-        }
+        // one launch for all batch groups: a group's exchange region is `ndir` directions long, so group g's direction d is
+        // "direction" g * ndir + d of a region with groups * ndir of them, and the tag a slot starts with depends on the
+        // direction's parity only (hx_init_kernel: d & 1 -- forward / backward -- when ndir == 2, forward when ndir == 1)
+        hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir * groups)), dim3(256), 0, stream,
+                           (unsigned*)(ws + W.hx), words_per_dir, (size_t)8 * H, ndir * groups, steps, rs, zero_base(0), zero_words(0), ndir);
+        MS_LAUNCH_CHECK();
         if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.row_off - W.dbg, stream));   // the stamp area only: row_off (packed rows) follows it
         rc = launch_wide2(p, cell == MS_CELL_HARD_LSTM, groups, use_f16(cell, H, ndir), stream);
         if (rc != MS_OK) return rc;
@@ -2594,7 +2596,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
           const size_t words_per_dir = two_stream ? ((size_t)32 * H << rs) : (size_t)2 * H * p.NPAD;
           p.ring_shift = rs;
           hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir)), dim3(256), 0, stream,
-                             (unsigned*)(ws + W.hx), words_per_dir, slab_words, ndir, steps, rs, zero_base(n0), zero_words(n0));
+                             (unsigned*)(ws + W.hx), words_per_dir, slab_words, ndir, steps, rs, zero_base(n0), zero_words(n0), ndir);
           MS_LAUNCH_CHECK();
         }
         if (two_stream) {
@@ -2613,7 +2615,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       if (f32x2) {
         // every word of every slot starts with the tag that is NOT the first one expected there (also between groups)
         hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for((size_t)64 * H * ndir)), dim3(256), 0, stream,
-                           (unsigned*)(ws + W.hx), (size_t)64 * H, (size_t)16 * H, ndir, steps, 1, zero_base(n0), zero_words(n0));
+                           (unsigned*)(ws + W.hx), (size_t)64 * H, (size_t)16 * H, ndir, steps, 1, zero_base(n0), zero_words(n0), ndir);
         MS_LAUNCH_CHECK();
         rc = launch_f32x2_any(p, hard, stream);
         if (rc != MS_OK) return rc;
@@ -2645,7 +2647,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
     for (int n0 = 0; n0 < N; n0 += 32) {
       const int rs = lstm_ring_shift();
       hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(((size_t)32 * H << rs) * ndir)), dim3(256), 0, stream,
-                         (unsigned*)(ws + W.hx), (size_t)32 * H << rs, (size_t)8 * H, ndir, steps, rs, zero_base(n0), zero_words(n0));
+                         (unsigned*)(ws + W.hx), (size_t)32 * H << rs, (size_t)8 * H, ndir, steps, rs, zero_base(n0), zero_words(n0), ndir);
       MS_LAUNCH_CHECK();
       GruP g;
       g.xproj = xproj;

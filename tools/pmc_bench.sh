@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 pass() {
   local name=$1; shift
   echo "[pmc_bench] pass $name: $*"
-  timeout -k 10 240 rocprofv3 --pmc "$@" -d $OUT/$name -o $name --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-child --no-frontend --no-ragged --in-flight 1 > $OUT.$name.log 2>&1 || { echo "[pmc_bench] pass $name failed or timed out"; tail -5 $OUT.$name.log; return 1; }
+  timeout -k 10 240 rocprofv3 --pmc "$@" -d $OUT/$name -o $name --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-child --no-frontend --no-ragged --no-legs --in-flight 1 > $OUT.$name.log 2>&1 || { echo "[pmc_bench] pass $name failed or timed out"; tail -5 $OUT.$name.log; return 1; }
 }
 mkdir -p $OUT
 pass p1 FETCH_SIZE || exit 1
