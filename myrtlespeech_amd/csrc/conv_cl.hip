@@ -16,6 +16,7 @@
 //   _mask_ / _pad of cnn.py:391-443 are load predicates; bias + clamp in the epilogue; the
 //   output is f32 NCHW (time contiguous) like conv.hip.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -199,6 +200,154 @@ __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned shor
       }
     }
   }
+}
+
+
+// ---- short inputs (round 4): a 320 ms streaming chunk reaches the second DS2 convolution as 16 frames x 40 rows x 32 channels
+// per utterance.  The tiled kernel above then runs 192 workgroups whose 32-frame MFMA tiles are half padding and whose
+// per-kernel-row staging (three barriers per kf, nothing in flight across them) is fully exposed at less than one workgroup
+// per CU: 177 us for 29 GFLOP (profiles/r04e_cfg5_kernel_stats.csv).  This form: Cin = 32 -- one v_mfma_f32_16x16x32 contracts
+// all channels of a tap --, a 16-frame x 16-cout MFMA tile per output feature row, every input row a workgroup needs staged
+// ONCE (all kf rows: (RB - 1) SF + (KF - 1) DF + 1 rows x (16 + KT - 1) frames x 64 B per plane), no barrier in the tap
+// loop: a wave owns every fourth kernel row for all of the block's output rows and streams its filter granules (the MFMA's
+// A operand, 16 couts x 32 channels = 1 KB per plane and tap) straight from L2 into registers, a kernel row ahead.
+// Workgroup = (utterance, 16 output channels, RB output feature rows); grid sized to about one workgroup per CU.
+constexpr int SH_RB = 12;     // output feature rows per workgroup, at most
+constexpr int SH_KT = 11;     // time taps held in registers per kernel row (DS2: 11)
+
+template <bool F16>
+__global__ __launch_bounds__(256, 1) void maskconv_cl_short_kernel(const unsigned short* __restrict__ xh,
+                                                                   const unsigned short* __restrict__ xl,
+                                                                   const int32_t* __restrict__ lens,
+                                                                   const unsigned short* __restrict__ wp,
+                                                                   const float* __restrict__ bias, float* __restrict__ y, ClP p,
+                                                                   int RB, int RIN) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q = lane >> 4;
+  const int fo0 = blockIdx.x * RB, cb = blockIdx.y, n = blockIdx.z;
+  const int PW = p.PW;                                   // staged frames per row: Tout + KT - 1 (ST = DT = 1)
+  const int row_bytes = PW * 64;
+  char* Ph = lds;
+  char* Pl = lds + (size_t)RIN * row_bytes;
+  const int len = lens ? min(lens[n], p.Tin) : p.Tin;
+  const int fin_lo = fo0 * p.SF - p.pad_f;
+
+  // ---- stage every input row of this block once (masked, zero padded): granule (row, frame, kg), 4 lanes = one frame's 64 B
+  for (int i = tid; i < RIN * PW * 4; i += 256) {
+    const int kg = i & 3, rq = i >> 2;
+    const int r = rq / PW, fq = rq - r * PW;
+    const int fin = fin_lo + r, tin = fq - p.pad_t;
+    u32x4 vh = {0u, 0u, 0u, 0u}, vl = {0u, 0u, 0u, 0u};
+    if (fin >= 0 && fin < p.Fin && tin >= 0 && tin < len) {
+      const size_t off = (((size_t)n * p.Fin + fin) * p.Tin + tin) * 32 + kg * 8;
+      vh = *reinterpret_cast<const u32x4*>(xh + off);
+      if (!F16) vl = *reinterpret_cast<const u32x4*>(xl + off);
+    }
+    *reinterpret_cast<u32x4*>(Ph + r * row_bytes + fq * 64 + kg * 16) = vh;
+    if (!F16) *reinterpret_cast<u32x4*>(Pl + r * row_bytes + fq * 64 + kg * 16) = vl;
+  }
+  __syncthreads();
+
+  // A wave owns every fourth KERNEL ROW (kf = wave, wave + 4, ...) for ALL output rows of the block: its filter granules are
+  // then nobody else's, so the workgroup reads each filter byte once (when the waves split the OUTPUT rows instead, every
+  // wave streamed all 462 KB of a cout-half's filters: 473 MB out of L2 per call, and the call ran at the L2's pace, 115 us).
+  // The four partial sums per output meet in LDS at the end and are added in wave order.
+  ms::f32x4 acc[SH_RB];
+#pragma unroll
+  for (int i = 0; i < SH_RB; ++i) acc[i] = ms::f32x4{0.f, 0.f, 0.f, 0.f};
+  const int cout_pad = p.co_tiles * 32;
+  const size_t wplane = (size_t)p.KF * p.KT * 4 * cout_pad * 8;            // elements
+  const unsigned short* wa = wp + (size_t)q * cout_pad * 8 + (cb * 16 + c16) * 8;   // this lane's granule of tap 0
+  const size_t tap_stride = (size_t)4 * cout_pad * 8;
+  // the filters of one kernel row (KT taps x hi, lo) sit in registers and the wave's NEXT row is requested before this row's
+  // MFMAs (up to 12 output rows x KT taps x 3: thousands of cycles, an L2 round trip is a few hundred)
+  u32x4 fh[2][SH_KT], fl[2][SH_KT];
+  auto load_row = [&](auto set, int kf) {
+#pragma unroll
+    for (int kt = 0; kt < SH_KT; ++kt)
+      if (kt < p.KT) {
+        const unsigned short* src = wa + (size_t)(kf * p.KT + kt) * tap_stride;
+        fh[set][kt] = *reinterpret_cast<const u32x4*>(src);
+        if (!F16) fl[set][kt] = *reinterpret_cast<const u32x4*>(src + wplane);
+      }
+  };
+  auto compute_row = [&](auto set, int kf) {
+#pragma unroll
+    for (int i = 0; i < SH_RB; ++i) {
+      const int fo = fo0 + i;
+      const int fin = fo * p.SF - p.pad_f + kf * p.DF;
+      if (i < RB && fo < p.Fout && fin >= 0 && fin < p.Fin) {     // wave-uniform
+        const int rbase = (fin - fin_lo) * row_bytes + c16 * 64 + q * 16;
+#pragma unroll
+        for (int kt = 0; kt < SH_KT; ++kt)
+          if (kt < p.KT) {
+            const u32x4 bh = *reinterpret_cast<const u32x4*>(Ph + rbase + kt * 64);
+            if (F16) {
+              acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fh[set][kt]), __builtin_bit_cast(f16x8, bh), acc[i], 0, 0, 0);
+            } else {
+              const u32x4 bl = *reinterpret_cast<const u32x4*>(Pl + rbase + kt * 64);
+              acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fh[set][kt]), __builtin_bit_cast(bf16x8, bh), acc[i], 0, 0, 0);
+              acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fl[set][kt]), __builtin_bit_cast(bf16x8, bh), acc[i], 0, 0, 0);
+              acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fh[set][kt]), __builtin_bit_cast(bf16x8, bl), acc[i], 0, 0, 0);
+            }
+          }
+      }
+    }
+  };
+  constexpr std::integral_constant<int, 0> S0{};
+  constexpr std::integral_constant<int, 1> S1{};
+  if (wave < p.KF) load_row(S0, wave);
+  for (int kf = wave; kf < p.KF; kf += 8) {
+    if (kf + 4 < p.KF) load_row(S1, kf + 4);
+    compute_row(S0, kf);
+    if (kf + 8 < p.KF) load_row(S0, kf + 8);
+    if (kf + 4 < p.KF) compute_row(S1, kf + 4);
+  }
+
+  // ---- the four waves' partial sums: [wave][row][lane] float4 in the (now free) staging area, added in wave order
+  __syncthreads();
+  ms::f32x4* part = reinterpret_cast<ms::f32x4*>(lds);
+#pragma unroll
+  for (int i = 0; i < SH_RB; ++i)
+    if (i < RB) part[(wave * SH_RB + i) * 64 + lane] = acc[i];
+  __syncthreads();
+  // D[cout = 4 q + r][frame = c16]; wave w finishes rows w, w + 4, w + 8
+#pragma unroll
+  for (int j = 0; j < SH_RB / 4; ++j) {
+    const int i = wave + 4 * j, fo = fo0 + i;
+    if (i >= RB || fo >= p.Fout) continue;
+    ms::f32x4 v = part[(0 * SH_RB + i) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += part[(w * SH_RB + i) * 64 + lane];
+    if (c16 < p.Tout) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cb * 16 + 4 * q + r;
+        if (co < p.Cout) {
+          float o = v[r] + (bias ? bias[co] : 0.f);
+          if (p.act == MS_ACT_CLAMP) o = fminf(fmaxf(o, p.lo), p.hi);
+          y[(((size_t)n * p.Cout + co) * p.Fout + fo) * p.Tout + c16] = o;
+        }
+      }
+    }
+  }
+}
+
+// Does the short-input form serve this problem, and with which block of output rows?  (MS_CONV_SHORT=0: never; tests and A/B runs)
+int conv_cl_short_plan(const ClP& p, bool f16, int* RB, int* RIN, size_t* lds) {
+  static const bool off = getenv("MS_CONV_SHORT") && getenv("MS_CONV_SHORT")[0] == '0';
+  if (off || p.Cin != 32 || p.Tout > 16 || p.ST != 1 || p.DT != 1 || p.FP != 0 || p.N > 65535 || p.KT > SH_KT) return 0;
+  const int cbs = ms::cdiv(p.Cout, 16);
+  int nblk = std::max(1, std::min(ms::cdiv(p.Fout, 4), ms::cdiv(ms::num_cus(), p.N * cbs)));
+  while (ms::cdiv(p.Fout, nblk) > SH_RB) ++nblk;
+  for (; nblk <= p.Fout; ++nblk) {
+    const int rb = ms::cdiv(p.Fout, nblk);
+    const int rin = (rb - 1) * p.SF + (p.KF - 1) * p.DF + 1;
+    const size_t bytes = std::max((size_t)(f16 ? 1 : 2) * rin * (p.Tout + p.KT - 1) * 64, (size_t)4 * SH_RB * 64 * 16);
+    if (bytes <= 156 * 1024) { *RB = rb; *RIN = rin; *lds = bytes; return 1; }
+  }
+  return 0;
 }
 
 // f32 NCHW [N][C][F][T] -> channels-last bf16 hi / lo planes [N][F][T][C]  (C % 8 == 0)
@@ -441,5 +590,25 @@ extern "C" int ms_maskconv_cl_forward(const float* x, const int32_t* lens, const
   hipLaunchKernelGGL(nchw_to_cl_split_kernel, dim3(ms::cdiv(Tin, 32), ms::cdiv(Cin, 32), N * Fin), dim3(32, 8), 0, stream, x,
                      xh, xl, Cin, Fin, Tin, f16 ? 1 : 0);
   MS_LAUNCH_CHECK();
+  {
+    int RB = 0, RIN = 0;
+    size_t slds = 0;
+    if (conv_cl_short_plan(p, f16, &RB, &RIN, &slds)) {
+      static ms::DeviceOnce attr_once;
+      if (attr_once.need()) {
+        MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_short_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_short_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_once.done();
+      }
+      ClP ps = p;
+      ps.PW = Tout + KT - 1;
+      const dim3 grid(ms::cdiv(Fout, RB), ms::cdiv(Cout, 16), N);
+      const unsigned short* wq = (const unsigned short*)packed_w;
+      if (f16) hipLaunchKernelGGL(maskconv_cl_short_kernel<true>, grid, dim3(256), slds, stream, xh, xl, lens, wq, bias, y, ps, RB, RIN);
+      else hipLaunchKernelGGL(maskconv_cl_short_kernel<false>, grid, dim3(256), slds, stream, xh, xl, lens, wq, bias, y, ps, RB, RIN);
+      MS_LAUNCH_CHECK();
+      return MS_OK;
+    }
+  }
   return conv_cl_launch<false>(p, wf, lds, xh, xl, lens, packed_w, bias, y, stream);
 }

@@ -1206,6 +1206,34 @@ def test_conv_cl_second_row_staging_when_the_last_iteration_is_partial(monkeypat
         np.testing.assert_array_equal(cpu(nl), wl)
 
 
+def test_conv_cl_short_input_kernel_vs_oracle(monkeypatch):
+    """``maskconv_cl_short_kernel`` (round 4: 32 input channels, at most 16 output frames, time stride 1 -- a streaming chunk at
+    DS2's second convolution): 16-frame x 16-cout MFMA tiles, every input row of a block staged once, filters streamed from L2.
+    Kernel heights / widths, feature strides and dilations, SAME and no padding, output channels that are not a multiple of
+    16, ragged lengths (the mask, cnn.py:425-443), 1 .. 70 utterances (different row-block plans), against the oracle; the
+    tiled kernel (MS_CONV_SHORT=0 is read once per process, so it is compared through the oracle, not in-process)."""
+    from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+    monkeypatch.setenv("MS_CONV_MFMA_MIN_FLOPS", "0")
+    rng = np.random.default_rng(11)
+    cases = [  # (cout, kf, kt, sf, df, same, F, T, N)
+        (32, 21, 11, 2, 1, True, 40, 16, 64), (32, 21, 11, 2, 1, True, 40, 16, 3), (16, 3, 3, 1, 1, True, 7, 16, 5),
+        (29, 5, 4, 2, 1, True, 23, 13, 2), (48, 4, 5, 1, 2, True, 12, 9, 6), (40, 7, 1, 3, 1, False, 50, 16, 1),
+        (32, 1, 7, 1, 1, False, 5, 22, 4), (33, 9, 2, 2, 2, False, 41, 10, 70), (32, 21, 11, 2, 1, True, 40, 1, 2),
+    ]
+    for cout, kf, kt, sf, df, same, F, Tn, N in cases:
+        torch.manual_seed(3)
+        m = MaskConv2d(32, cout, [kf, kt], [sf, 1], PaddingMode.SAME if same else PaddingMode.NONE, dilation=[df, 1]).eval()
+        x = (rng.normal(size=(N, 32, F, Tn)) + 1.0).astype(np.float32)
+        lens = np.sort(rng.integers(1, Tn + 1, size=N))[::-1].copy()
+        lens[0] = Tn
+        y, nl = m((T(x), T(lens)), fused_activation=(0.0, 20.0))
+        want, wl = O.mask_conv2d(x, lens, cpu(m.weight), cpu(m.bias), (sf, 1), same, dilation=(df, 1))
+        want = np.clip(want, 0.0, 20.0)
+        assert y.shape[-1] <= 16
+        np.testing.assert_allclose(cpu(y), want, rtol=1e-4, atol=2e-3, err_msg=str((cout, kf, kt, sf, df, same, F, Tn, N)))
+        np.testing.assert_array_equal(cpu(nl), wl)
+
+
 @pytest.mark.parametrize("H,bidir,N,Tn", [(256, True, 37, 9), (512, False, 5, 12), (1024, True, 32, 6)])
 def test_lstm_stack_plane_chaining_is_bit_identical_to_single_layers(H, bidir, N, Tn):
     """A two-stream LSTM stack hands each layer's output to the next layer as GEMM operand planes inside the workspace
