@@ -420,6 +420,94 @@ def stream_case(seed):
     np.testing.assert_allclose(h_c.cpu().numpy(), h_w.cpu().numpy(), rtol=1e-4, atol=1e-4, err_msg=str(("stream state", seed)))
 
 
+
+def stream_ctx_case(seed):
+    """Streaming with carried context (round 4): a random UNIDIRECTIONAL DeepSpeech2 (1-2 conv2d layers with time kernels up to 7
+    and strides 1-3, optional lookahead, 0-1 hidden FC layers) fed in chunks of a random size against the ORACLE's
+    full-utterance forward (which is pinned to the reference's): logits on every frame an utterance owns, lengths, final
+    states."""
+    global _build_ds2
+    from myrtlespeech_amd.streaming import ChunkedDeepSpeech2
+    if _build_ds2 is None:
+        ds2_case(seed)
+    rng = np.random.default_rng(seed)
+    F, Tn, N = int(rng.integers(8, 25)), int(rng.integers(4, 120)), int(rng.integers(1, 7))
+    convs, cin, f = [], 1, F
+    for i in range(int(rng.integers(1, 3))):
+        cout = int(rng.integers(2, 9))
+        k = [int(rng.integers(1, 6)), int(rng.integers(1, 8))]
+        st = [int(rng.integers(1, 3)), int(rng.integers(1, 4))]
+        convs.append(dict(kind="conv2d", idx=2 * i, in_channels=cin, out_channels=cout, kernel=k, stride=st, same=True,
+                          act=(0.0, 20.0) if rng.random() < 0.7 else None))
+        f = -(-f // st[0]) if convs[-1]["same"] else (f - k[0]) // st[0] + 1
+        cin = cout
+        if f < 1:
+            return
+    # without SAME padding a layer may leave no frames for short inputs: keep the case only if every layer has output
+    t = Tn
+    for c in convs:
+        t = -(-t // c["stride"][1]) if c["same"] else (t - c["kernel"][1]) // c["stride"][1] + 1
+        if t < 1:
+            return
+    H = int(rng.choice([32, 64, 96]))
+    kind = int(rng.integers(0, 3))
+    rnn = dict(kind=kind, input=cin * f, hidden=H, layers=int(rng.integers(1, 3)), bidirectional=False,
+               forget_gate_bias=1.0 if kind == 0 else None)
+    la = dict(context=int(rng.integers(1, 12)), act=(0.0, 20.0) if rng.random() < 0.5 else None) if rng.random() < 0.6 else None
+    nh = int(rng.integers(0, 2))
+    fc = dict(in_features=H, out_features=int(rng.integers(5, 31)), n_hidden=nh, hidden=int(rng.integers(16, 49)) if nh else None,
+              act=(0.0, 20.0) if nh else None)
+    cfg = dict(convs=convs, rnn=rnn, lookahead=la, fc=fc)
+    torch.manual_seed(seed)
+    m = _build_ds2(cfg).eval()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    x = rng.normal(size=(N, 1, F, Tn)).astype(np.float32)
+    lens = np.sort(rng.integers(1, Tn + 1, size=N))[::-1].copy()
+    lens[0] = Tn
+    # (without SAME padding an utterance shorter than a kernel has no output frames: the reference's pack_padded_sequence
+    # rejects it; keep lengths that leave every utterance at least one frame)
+    want, wl, whid = O.deep_speech_2_forward(x, lens, cfg, sd)
+    if int(np.min(wl)) < 1:
+        return
+    chunk = int(rng.integers(1, 40))
+    (ys, ysl), hids = ChunkedDeepSpeech2(m, chunk, carry_context=True)(torch.from_numpy(x.copy()), torch.from_numpy(lens))
+    assert ysl.tolist() == [int(v) for v in wl], ("stream ctx lens", seed)
+    yc = ys.cpu().numpy()
+    assert yc.shape == want.shape, ("stream ctx shape", seed, yc.shape, want.shape)
+    for n in range(N):
+        np.testing.assert_allclose(yc[:wl[n], n], want[:wl[n], n], rtol=2e-4, atol=2e-4, err_msg=str(("stream ctx", seed, n, chunk, cfg)))
+    h_c = hids[0] if isinstance(hids, tuple) else hids
+    h_w = whid[0] if isinstance(whid, tuple) else whid
+    np.testing.assert_allclose(h_c.cpu().numpy(), h_w, rtol=2e-4, atol=2e-4, err_msg=str(("stream ctx state", seed)))
+
+
+def conv_short_case(seed):
+    """``maskconv_cl_short_kernel`` (32 input channels, <= 16 output frames, time stride 1) on random geometry against the oracle."""
+    from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+    os.environ["MS_CONV_MFMA_MIN_FLOPS"] = "0"
+    rng = np.random.default_rng(seed)
+    cout = int(rng.integers(1, 70))
+    kf, kt = int(rng.integers(1, 24)), int(rng.integers(1, 12))
+    sf, df = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    same = bool(rng.random() < 0.6)
+    F = int(rng.integers(df * (kf - 1) + 1, df * (kf - 1) + 45))
+    Tn = int(rng.integers(1, 17)) if same else int(rng.integers(kt, kt + 16))
+    N = int(rng.integers(1, 80))
+    torch.manual_seed(seed)
+    m = MaskConv2d(32, cout, [kf, kt], [sf, 1], PaddingMode.SAME if same else PaddingMode.NONE, dilation=[df, 1]).eval()
+    x = (rng.normal(size=(N, 32, F, Tn)) + 0.5).astype(np.float32)
+    lens = np.sort(rng.integers(1, Tn + 1, size=N))[::-1].copy()
+    lens[0] = Tn
+    act = (0.0, 20.0) if rng.random() < 0.5 else None
+    y, nl = m((torch.from_numpy(x.copy()), torch.from_numpy(lens)), fused_activation=act)
+    want, wl = O.mask_conv2d(x, lens, m.weight.detach().cpu().numpy(), m.bias.detach().cpu().numpy(), (sf, 1), same, dilation=(df, 1))
+    if act is not None:
+        want = np.clip(want, *act)
+    assert y.shape[-1] <= 16 or not same
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-4, atol=3e-3, err_msg=str(("conv short", seed, cout, kf, kt, sf, df, same, F, Tn, N)))
+    assert np.array_equal(nl.cpu().numpy(), wl)
+
+
 family("ctc loss+grad vs oracle", ctc_case)
 family("front-end vs oracle", frontend_case)
 family("ctc beam vs oracle", beam_case)
@@ -436,4 +524,6 @@ family("lookahead vs oracle", lookahead_case)
 family("whole random DS2 vs oracle", ds2_case)
 family("whole random DS1 vs oracle", ds1_case)
 family("chunked streaming vs whole", stream_case)
+family("carried-context streaming vs oracle", stream_ctx_case)
+family("short-input conv vs oracle", conv_short_case)
 print("soak ok")
