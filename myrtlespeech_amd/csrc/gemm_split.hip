@@ -453,10 +453,16 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
       voff[p] = min(row, rows - 1) * (K * 2) + kgs * 16;
     }
   }
+  // LDS stages.  bf16x3: two stages of four planes (x hi, x lo, W hi, W lo).  fp16 on the 8-wave forms (round 4): the lo planes
+  // are never written, so their space holds two MORE stages -- stage s lives at (s & 1) * G4_STAGE + (s >> 1) * G4_PLANE -- and
+  // a K-block's DMA is issued FOUR blocks ahead instead of two: an fp16 block is 8 MFMAs per wave (~260 cycles), less than
+  // an L2 round trip, so with two stages every block waited for its successor's operands (0.73 PF/s at the chunk's projection).
+  constexpr int RING = (F16 && WN == 2) ? 4 : 2;
+  auto stage_off = [&](int stage) { return RING == 4 ? (stage & 1) * G4_STAGE + (stage >> 1) * G4_PLANE : stage * G4_STAGE; };
   auto dma_block = [&](int kb, int stage) {                  // all pieces of K-block kb
     const int soff = __builtin_amdgcn_readfirstlane(kb * (SB_K * 2));
-    char* dst_a = lds + stage * G4_STAGE + PA * G4_PLANE + RA * 64;
-    char* dst_b = lds + stage * G4_STAGE + PB * G4_PLANE + RB * 64;
+    char* dst_a = lds + stage_off(stage) + PA * G4_PLANE + RA * 64;
+    char* dst_b = lds + stage_off(stage) + PB * G4_PLANE + RB * 64;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       if (p < NPA) lds_dma_16(rsrc_a, dst_a + p * 1024, voff[p], soff);
@@ -480,7 +486,7 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
 
   u32x4 fa[WN == 1 ? 1 : 2][6 + 6];   // [set][ah0 ah1 al0 al1 | bh0..3 bl0..3]: 12 granules per set
   auto read_frags = [&](int set, int stage, int h) {
-    const char* st = lds + stage * G4_STAGE + (h ? foff1 : foff0);
+    const char* st = lds + stage_off(stage) + (h ? foff1 : foff0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       fa[set][i] = *reinterpret_cast<const u32x4*>(st + a_base + i * 32 * 64);
@@ -528,6 +534,10 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
   const int nk = K / SB_K;
   dma_block(0, 0);
   dma_block(min(1, nk - 1), 1);
+  if (RING == 4) {
+    dma_block(min(2, nk - 1), 2);
+    dma_block(min(3, nk - 1), 3);
+  }
   // (waits are the builtin, not inline asm: the compiler's own wait insertion then knows the fragment sets are complete
   // and does not wait again at their first use, which would also cover the reads issued in between)
   __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
@@ -620,7 +630,7 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
   constexpr int NR = NJ == 2 ? (F16 ? 4 : 8) : (F16 ? 6 : 12);          // fragment reads per half block (NJ = 2: 12 MFMAs, 8 reads)
   constexpr int MPR = F16 ? 8 / 6 + 1 : 2;  // MFMAs issued per read in the interleave (F16: 8 MFMAs, 6 reads)
   for (int b = 0; b < nk; ++b) {
-    const int cur = b & 1;
+    const int cur = b & (RING - 1), nxt = (b + 1) & (RING - 1);
     // ---- top: frags(b, half 1) -> set 1 under the MFMAs on set 0
     read_frags(1, cur, 1);
     mfma_set(0);
@@ -630,13 +640,16 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
       __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0070);   // lgkmcnt(0): set 1 complete; vmcnt(0): this wave's pieces of block b+1 landed
+    // lgkmcnt(0): set 1 complete; this wave's pieces of block b+1 landed: vmcnt(0) with two stages, vmcnt(2 NP) with four
+    // (blocks b+2 and b+3, issued later, may still be in flight; DMA pieces complete in issue order)
+    if (RING == 4) __builtin_amdgcn_s_waitcnt(0x0070 | (2 * NP));
+    else __builtin_amdgcn_s_waitcnt(0x0070);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    // ---- mid: block b+2 -> the stage just drained; frags(b+1, half 0) -> set 0 under the MFMAs on set 1
+    // ---- mid: block b+RING -> the stage just drained; frags(b+1, half 0) -> set 0 under the MFMAs on set 1
     // (the tail re-loads the last block into a stage nobody reads again and reads fragments nobody uses: no branches)
-    dma_block(min(b + 2, nk - 1), cur);
-    read_frags(0, cur ^ 1, 0);
+    dma_block(min(b + RING, nk - 1), cur);
+    read_frags(0, nxt, 0);
     mfma_set(1);
 #pragma unroll
     for (int i = 0; i < NR; ++i) {

@@ -370,6 +370,7 @@ class ChunkedDeepSpeech2:
             steady = (self.use_graph and self.graph_error is None and state is not None and xc.shape[-1] == self.chunk_frames
                       and int(lc.min()) == self.chunk_frames)
             y = ol_host = None
+            cg_used = False
             if steady:
                 key = (alive, tuple(xc.shape[1:]))
                 cg = self._graphs.get(key)
@@ -393,6 +394,7 @@ class ChunkedDeepSpeech2:
                         active = cg
                     y, ol_host = cg.run(xc), cg.out_lens_host
                     state = cg.state
+                    cg_used = True
                     self.graph_replays += 1
             if y is None:
                 if active is not None:       # leave the graph: its static state is the current state
@@ -403,19 +405,27 @@ class ChunkedDeepSpeech2:
                         state[:, :alive].contiguous()
                 (y, ol), state = self.step(xc.contiguous(), lc, hx_c)
                 ol_host = _lib.host_lens(ol)   # host values ride along with the device tensor: no read-back
-            if full_state is None:
-                full_state = tuple(torch.zeros(s_.shape[0], n, s_.shape[2], device=s_.device) for s_ in state) \
-                    if isinstance(state, tuple) else torch.zeros(state.shape[0], n, state.shape[2], device=state.device)
-            if isinstance(state, tuple):
-                for fs, s_ in zip(full_state, state):
-                    fs[:, :alive] = s_
+            # the returned state holds every utterance's state at ITS last slice: rows are copied out of the running state only
+            # when utterances are about to leave the batch (and once at the end), not per slice
+            t_next = t0 + self.chunk_frames
+            alive_next = int((lens_cpu > t_next).sum()) if t_next < t_total else 0
+            if alive_next < alive:
+                if full_state is None:
+                    full_state = tuple(torch.zeros(s_.shape[0], n, s_.shape[2], device=s_.device) for s_ in state) \
+                        if isinstance(state, tuple) else torch.zeros(state.shape[0], n, state.shape[2], device=state.device)
+                if isinstance(state, tuple):
+                    for fs, s_ in zip(full_state, state):
+                        fs[:, alive_next:alive] = s_[:, alive_next:alive]
+                else:
+                    full_state[:, alive_next:alive] = state[:, alive_next:alive]
+            if alive == n:
+                block = y.clone() if cg_used else y
             else:
-                full_state[:, :alive] = state
-            block = torch.zeros((y.shape[0], n, y.shape[2]), dtype=y.dtype, device=y.device)
-            block[:, :alive] = y
+                block = torch.zeros((y.shape[0], n, y.shape[2]), dtype=y.dtype, device=y.device)
+                block[:, :alive] = y
             outs.append(block)
             out_lens[:alive] += ol_host
-            t0 += self.chunk_frames
+            t0 = t_next
         if self.graph_replays and check_was:
             _lib.check(_lib.load().ms_rnn_status(_lib.ptr(self.model.rnn._workspace.buf), _lib.stream_ptr()), "ms_rnn_layer_forward")
         return (torch.cat(outs, 0), out_lens.to(lens.dtype)), full_state
