@@ -141,6 +141,17 @@ int ms_clamp(const float* x, float* y, size_t n, float lo, float hi, void* strea
 int ms_linear_forward(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
                       float act_lo, float act_hi, void* stream);
 
+/* Same contract as ms_linear_forward (exact float32 MFMA) for layers with few output COLUMNS (N <= 64, K >= 512: the
+ * 29-symbol output layer, fully_connected.py:164 / deep_speech_1.py:118-120): one 32-column tile per 128 rows leaves a
+ * streaming chunk's 1 024 rows on eight workgroups that each walk all of K, so the contraction is cut into min(8, K / 128)
+ * slices whose partial sums land in the workspace and are added in slice order (deterministic; the slice count depends on
+ * (K, N) only, so a row's result does not depend on the batch it is in; the rounding differs from ms_linear_forward's single
+ * k-ordered chain by a few ulp).  ms_linear_splitk_workspace_bytes() == 0 means the shape is not such a layer: the call then
+ * IS ms_linear_forward and needs no workspace. */
+size_t ms_linear_splitk_workspace_bytes(int M, int K, int N);
+int ms_linear_splitk_forward(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
+                             float act_lo, float act_hi, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Same contract as ms_linear_forward for K % 32 == 0, computed with float32 operands split
  * into bf16 hi + lo (x.w ~= x_hi.w_hi + x_lo.w_hi + x_hi.w_lo, f32 accumulate; relative error
  * ~2^-17 per product).  The workspace holds the four bf16 planes. */

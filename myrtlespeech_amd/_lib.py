@@ -48,6 +48,8 @@ SIGNATURES = {
     "ms_nct_to_tnc": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ms_clamp": (c_int, [_P, _P, c_size_t, c_float, c_float, _P]),
     "ms_linear_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
+    "ms_linear_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ms_linear_splitk_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
     "ms_linear_split_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ms_linear_split_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
     "ms_lookahead_forward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_int, c_float, c_float, _P]),

@@ -199,7 +199,53 @@ int linear_splitk_launch(const float* x, const float* w, const float* bias, floa
   return launch_cfg<4, 1, 1, 1>(x, w, bias, y_parts, M, K, N, MS_ACT_NONE, 0.f, 0.f, stream, ksplit);
 }
 
+// y = act(sum over the K slices, in slice order, + nothing else: the bias went into slice 0)
+__global__ void splitk_reduce_kernel(const float* __restrict__ parts, float* __restrict__ y, size_t mn, int ksplit, int act, float lo,
+                                     float hi) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (size_t)gridDim.x * blockDim.x) {
+    float v = parts[i];
+    for (int z = 1; z < ksplit; ++z) v += parts[(size_t)z * mn + i];
+    if (act == MS_ACT_CLAMP) v = fminf(fmaxf(v, lo), hi);
+    y[i] = v;
+  }
+}
+
+// K slices for a GEMM with few output COLUMNS (an output layer: 29 symbols = one 32-column tile per 128 rows, so a chunk's
+// 1 024 rows are eight workgroups each walking all of K).  The slice count depends on (K, N) only, never on the number of
+// rows: an utterance's logits must not depend on what it is batched with (utterance shards reproduce the whole batch bit for
+// bit).  0 = the plain kernel.
+int linear_splitk_slices(int M, int K, int N) {
+  (void)M;
+  if (N > 64 || K < 512) return 0;
+  return std::min(8, K / 128);
+}
+
 }  // namespace ms
+
+extern "C" size_t ms_linear_splitk_workspace_bytes(int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 0;
+  const int ks = ms::linear_splitk_slices(M, K, N);
+  return ks ? ms::align_up((size_t)ks * M * N * sizeof(float), 256) : 0;
+}
+
+extern "C" int ms_linear_splitk_forward(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
+                                        float act_lo, float act_hi, void* workspace, size_t workspace_bytes, void* stream_) {
+  ms::ProfScope prof_span(MS_PROF_LINEAR, (hipStream_t)stream_);
+  MS_REQUIRE(x && w && y, "null pointer");
+  MS_REQUIRE(M > 0 && K > 0 && N > 0, "bad shape");
+  MS_REQUIRE(act == MS_ACT_NONE || act == MS_ACT_CLAMP, "bad act");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int ks = ms::linear_splitk_slices(M, K, N);
+  if (ks == 0) return ms::linear_launch(x, w, bias, y, M, K, N, act, act_lo, act_hi, stream);
+  MS_REQUIRE(workspace && workspace_bytes >= ms_linear_splitk_workspace_bytes(M, K, N), "workspace too small");
+  int rc = ms::linear_splitk_launch(x, w, bias, (float*)workspace, M, K, N, ks, stream);
+  if (rc != MS_OK) return rc;
+  const size_t mn = (size_t)M * N;
+  hipLaunchKernelGGL(ms::splitk_reduce_kernel, dim3((unsigned)std::min<size_t>((mn + 255) / 256, 2048)), dim3(256), 0, stream,
+                     (const float*)workspace, y, mn, ks, act, act_lo, act_hi);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
+}
 
 extern "C" int ms_linear_forward(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
                                  int act, float act_lo, float act_hi, void* stream) {

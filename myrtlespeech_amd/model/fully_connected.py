@@ -6,6 +6,7 @@ state_dict keys (``fully_connected.{0,2,..}.weight``) and repr match; the module
 are parameter containers -- the forward pass runs each Linear (+ its clamp) as one
 MFMA GEMM with a fused epilogue (``ms_linear_forward``).
 """
+import os
 from collections import OrderedDict
 from typing import List, Optional, Tuple, Union
 
@@ -36,6 +37,7 @@ def linear_stack_plan(module: Union[torch.nn.Linear, torch.nn.Sequential], train
 
 
 _SPLIT_MIN_FLOPS = 2e9  # below this the two plane-split passes cost more than they save
+_SPLITK = os.environ.get("MS_LINEAR_SPLITK") != "0"   # K slices for exact-f32 layers with few output tiles (A/B runs: 0)
 # Operand-plane scratch of the split GEMM, one per HIP stream: work on one stream is ordered, so successive layers may share
 # a buffer, but two streams (pipeline.BatchesInFlight) must not -- one stream's planes would be overwritten under the other's GEMM.
 _split_ws = OrderedDict()
@@ -77,8 +79,12 @@ def run_linear_stack(x2d: torch.Tensor, plan) -> torch.Tensor:
             _lib.check(lib.ms_linear_split_forward(_lib.ptr(h), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), m, k, n, a, lo, hi,
                                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "ms_linear_split_forward")
         else:
-            _lib.check(lib.ms_linear_forward(_lib.ptr(h), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), m, k, n, a, lo, hi,
-                                             _lib.stream_ptr()), "ms_linear_forward")
+            # an output layer (<= 64 columns): K slices, added in slice order (ms_linear_splitk_forward); 0 bytes = not such a
+            # layer, and the call is ms_linear_forward
+            nb = lib.ms_linear_splitk_workspace_bytes(m, k, n) if _SPLITK else 0
+            ws = _stream_workspace().get(nb) if nb else None
+            _lib.check(lib.ms_linear_splitk_forward(_lib.ptr(h), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), m, k, n, a, lo, hi,
+                                                    _lib.ptr(ws), nb, _lib.stream_ptr()), "ms_linear_splitk_forward")
         h = y
     return h
 
