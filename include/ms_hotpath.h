@@ -147,7 +147,7 @@ int ms_linear_forward(const float* x, const float* w, const float* bias, float* 
  * slices whose partial sums land in the workspace and are added in slice order (deterministic; the slice count depends on
  * (K, N) only, so a row's result does not depend on the batch it is in; the rounding differs from ms_linear_forward's single
  * k-ordered chain by a few ulp).  ms_linear_splitk_workspace_bytes() == 0 means the shape is not such a layer: the call then
- * IS ms_linear_forward and needs no workspace. */
+ * IS ms_linear_forward and needs no workspace; a NULL workspace selects ms_linear_forward for any shape. */
 size_t ms_linear_splitk_workspace_bytes(int M, int K, int N);
 int ms_linear_splitk_forward(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
                              float act_lo, float act_hi, void* workspace, size_t workspace_bytes, void* stream);

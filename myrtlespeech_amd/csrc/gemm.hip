@@ -236,8 +236,9 @@ extern "C" int ms_linear_splitk_forward(const float* x, const float* w, const fl
   MS_REQUIRE(act == MS_ACT_NONE || act == MS_ACT_CLAMP, "bad act");
   hipStream_t stream = (hipStream_t)stream_;
   const int ks = ms::linear_splitk_slices(M, K, N);
-  if (ks == 0) return ms::linear_launch(x, w, bias, y, M, K, N, act, act_lo, act_hi, stream);
-  MS_REQUIRE(workspace && workspace_bytes >= ms_linear_splitk_workspace_bytes(M, K, N), "workspace too small");
+  // (no workspace = the caller asks for the plain kernel: MS_LINEAR_SPLITK=0 in the Python layer, A/B runs)
+  if (ks == 0 || workspace == nullptr) return ms::linear_launch(x, w, bias, y, M, K, N, act, act_lo, act_hi, stream);
+  MS_REQUIRE(workspace_bytes >= ms_linear_splitk_workspace_bytes(M, K, N), "workspace too small");
   int rc = ms::linear_splitk_launch(x, w, bias, (float*)workspace, M, K, N, ks, stream);
   if (rc != MS_OK) return rc;
   const size_t mn = (size_t)M * N;
