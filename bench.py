@@ -730,12 +730,12 @@ def main(argv=None, runtime=None, json_fd=None):
             from tools import bench_configs
             del pipe, paired
             torch.cuda.empty_cache() if torch.cuda.is_available() else None
-            detail = bench_configs.run_legs(["ctc", "beam", "ds1", "rnnt", "stream"], cpu=not args.no_cpu_baseline)
+            detail = bench_configs.run_legs(["ctc", "beam", "ds1", "rnnt", "stream", "streamctx"], cpu=not args.no_cpu_baseline)
             if stream_fp16 is not None:
                 detail["cfg5_streaming_fp16"] = stream_fp16
             out["legs_detail"] = detail
             num = ("ms", "ms_min", "ms_per_chunk", "ms_per_chunk_wall", "floor_ms", "frac_of_floor", "audio_sec_per_s", "utterances_per_s",
-                   "encoder_ms", "beam8_decode_ms", "greedy_decode_ms", "us_per_frame", "realtime_factor", "dtype",
+                   "encoder_ms", "beam8_decode_ms", "greedy_decode_ms", "us_per_frame", "realtime_factor", "dtype", "latency_frames",
                    "transcripts_equal_oracle_fixture", "error")
             legs = {"calibration": detail.get("calibration")}
             for name, rec in detail.items():

@@ -342,6 +342,65 @@ def leg_stream(ctx, chunks=16):
     return out
 
 
+def leg_stream_context(ctx, chunks=24):
+    """The reference's SHIPPED architecture (configs/deep_speech_2_en.config:19-93: 2 x conv2d, 3 x GRU-2560 unidirectional, lookahead
+    80, FC 1024) streamed in 320 ms chunks WITH carried convolution / lookahead context (``carry_context=True``: the chunks'
+    outputs concatenated are the full-utterance logits), 32 streams.  Steady-state chunks only (the first six hold back the
+    174-frame latency); eager launches (no graph replay in this mode yet), so ``ms_per_chunk_wall`` includes the host."""
+    from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+    from myrtlespeech_amd.model.deep_speech_2 import DeepSpeech2
+    from myrtlespeech_amd.model.fully_connected import FullyConnected
+    from myrtlespeech_amd.model.lookahead import Lookahead
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    from myrtlespeech_amd.model.seq_len_wrapper import SeqLenWrapper
+    from myrtlespeech_amd.streaming import ChunkedDeepSpeech2
+
+    def act():
+        return SeqLenWrapper(torch.nn.Hardtanh(0.0, 20.0), torch.nn.Identity())
+    torch.manual_seed(7)
+    cnn = torch.nn.Sequential(MaskConv2d(1, 32, [41, 11], [2, 2], PaddingMode.SAME), act(),
+                              MaskConv2d(32, 32, [21, 11], [2, 1], PaddingMode.SAME), act())
+    rnn = RNN(RNNType.GRU, 640, 2560, num_layers=3, bidirectional=False)
+    la = torch.nn.Sequential(Lookahead(2560, 80), SeqLenWrapper(torch.nn.Identity(), torch.nn.Identity()))
+    fc = FullyConnected(2560, 29, 1, 1024, torch.nn.Hardtanh(0.0, 20.0))
+    m = DeepSpeech2(cnn, rnn, la, fc).eval()
+    m.rnn.check_status = False
+    N, chunk = 32, 32
+    total = chunk * (chunks + 8)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(N, 1, 80, total, generator=g).cuda()
+    lens = torch.full((N,), total, dtype=torch.int64)
+    st = ChunkedDeepSpeech2(m, chunk, carry_context=True)
+    lat = st.latency_frames()
+    with torch.no_grad():
+        st.begin(lens, total)
+        t0 = 0
+        for _ in range(8):                                   # warm-up: fills the held-back context, reaches steady state
+            st.push(x[..., t0:t0 + chunk])
+            t0 += chunk
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0 = time.perf_counter()
+        a.record()
+        rows = 0
+        for k in range(chunks):
+            out = st.push(x[..., t0:t0 + chunk], final=(k == chunks - 1))
+            rows += 0 if out is None else out.shape[0]
+            t0 += chunk
+        b.record()
+        b.synchronize()
+        wall = (time.perf_counter() - w0) / chunks * 1e3
+    ms = a.elapsed_time(b) / chunks
+    step_us = 7.8                                               # persistent GRU-2560 at 32 rows (DESIGN 4, profiles/r01d)
+    w_bytes = (3 * 3 * 2560 * (2560 + 2560) - 3 * 2560 * (2560 - 640)) * 4 + (2560 * 1024 + 1024 * 29) * 4
+    floor = w_bytes / (HBM_GBS * 1e6) + 3 * 16 * step_us * 1e-3
+    return {"workload": f"shipped DS2 (3xGRU-2560 + lookahead 80) streamed with carried context, {N} streams, {chunk}-frame chunks",
+            "ms_per_chunk": round(ms, 4), "ms_per_chunk_wall": round(wall, 4), "ms": round(ms, 4),
+            "realtime_factor": round(N * 0.32 / ms * 1e3, 1), "latency_frames": lat, "rows_per_chunk": round(rows / chunks, 2),
+            "floor_ms": round(floor, 4), "frac_of_floor": round(floor / ms, 3),
+            "floor": f"per chunk: {w_bytes / 1e6:.0f} MB of weights once at 8 TB/s + 3 layers x 16 dependent GRU steps x {step_us} us"}
+
+
 def leg_frontend(ctx):
     from myrtlespeech_amd.data.preprocess import MFCC, MFCCLegacy, Standardize
     w = (torch.randn(32, 160000) * 0.1).cuda()
@@ -360,7 +419,8 @@ def leg_frontend(ctx):
 
 
 LEGS = {"ds1": ("cfg1_ds1", leg_ds1), "ctc": ("ctc_loss", leg_ctc_loss), "beam": ("ctc_beam_decode", leg_ctc_beam),
-        "rnnt": ("cfg4_rnnt", leg_rnnt), "stream": ("cfg5_streaming", leg_stream), "frontend": ("frontend", leg_frontend)}
+        "rnnt": ("cfg4_rnnt", leg_rnnt), "stream": ("cfg5_streaming", leg_stream), "streamctx": ("stream_carried_context", leg_stream_context),
+        "frontend": ("frontend", leg_frontend)}
 
 
 def context(cpu=True, which=None):
