@@ -239,6 +239,18 @@ class _ContextStream:
         return out.transpose(0, 1)
 
 
+def _workspace_slots(model):
+    """(owner, attribute name) of every grow-only scratch buffer a forward pass of ``model`` uses."""
+    slots = []
+    for m in model.modules():
+        if isinstance(getattr(m, "_workspace", None), _lib.Workspace):
+            slots.append((m, "_workspace"))
+        pk = getattr(m, "_packed", None)
+        if pk is not None and isinstance(getattr(pk, "workspace", None), _lib.Workspace):
+            slots.append((pk, "workspace"))
+    return slots
+
+
 class _ChunkGraph:
     """One steady-state slice -- ``alive`` utterances, all with a full ``frames``-frame slice, state carried -- captured once as
     a HIP graph (``torch.cuda.CUDAGraph``) and replayed per chunk: the ~45 launches of a slice then cost the host one
@@ -247,22 +259,41 @@ class _ChunkGraph:
     state lives in the graph's own static tensors and is chained inside the graph (state_in <- state_out)."""
 
     def __init__(self, model, alive: int, shape, state):
-        self.x = torch.empty((alive,) + tuple(shape[1:]), dtype=torch.float32, device="cuda")
+        self.x = torch.zeros((alive,) + tuple(shape[1:]), dtype=torch.float32, device="cuda")
         self.state = tuple(torch.zeros_like(s[:, :alive]) for s in state) if isinstance(state, tuple) else \
             torch.zeros_like(state[:, :alive])
         frames = shape[-1]
         host = torch.full((alive,), frames, dtype=torch.int64)
         self.lens = _lib.attach_host(torch.full((alive,), frames, dtype=torch.int64, device="cuda"), host)
         self.graph = torch.cuda.CUDAGraph()
-        torch.cuda.synchronize()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            (y, ol), st = model((self.x, self.lens), self.state)
-            if isinstance(st, tuple):
-                for a, b in zip(self.state, st):
-                    a.copy_(b)
-            else:
-                self.state.copy_(st)
+        # The graph records POINTERS.  The model's grow-only scratch buffers (recurrent workspace, convolution planes) may be
+        # re-allocated by a later, larger call of the same model -- the graph would then write into freed memory -- so the
+        # graph gets scratch buffers of its own: fresh Workspace objects are swapped in, one eager forward sizes them (and
+        # does every first-use set-up of the library outside the capture), the capture records them, and the model's own
+        # objects are put back.  (Packed weights are keyed on the parameters' versions: ChunkedDeepSpeech2 drops its graphs
+        # when a parameter changes.)
+        import os
+        slots = _workspace_slots(model) if os.environ.get("MS_STREAM_GRAPH_OWN_WS") != "0" else []     # (0: A/B runs only)
+        self._own = [_lib.Workspace() for _ in slots]
+        saved = [getattr(o, a) for o, a in slots]
+        try:
+            for (o, a), w in zip(slots, self._own):
+                setattr(o, a, w)
+            model((self.x, self.lens), self.state)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                (y, ol), st = model((self.x, self.lens), self.state)
+                if isinstance(st, tuple):
+                    for a_, b_ in zip(self.state, st):
+                        a_.copy_(b_)
+                else:
+                    self.state.copy_(st)
+        finally:
+            for (o, a), w in zip(slots, saved):
+                setattr(o, a, w)
         self.y, self.out_lens_host = y, _lib.host_lens(ol).clone()
+        rnn_ws = [w for (o, a), w in zip(slots, self._own) if o is getattr(model, "rnn", None)]
+        self.rnn_ws = rnn_ws[0] if rnn_ws else None      # holds the sticky time-out word of this graph's recurrent launches
 
     def load_state(self, state, alive: int):
         if isinstance(state, tuple):
@@ -291,6 +322,7 @@ class ChunkedDeepSpeech2:
         import os
         self.use_graph = (os.environ.get("MS_STREAM_GRAPH") != "0") if use_graph is None else bool(use_graph)
         self._graphs = {}
+        self._graph_sig = None
         self.graph_error: Optional[str] = None
         self.graph_replays = 0
 
@@ -359,6 +391,12 @@ class ChunkedDeepSpeech2:
         state = hx
         full_state = None
         active = None            # the _ChunkGraph whose static tensors hold the current state, if any
+        if self.use_graph:       # a graph holds the packed weights' addresses: a parameter that changed invalidates every graph
+            sig = tuple((p_.data_ptr(), _lib.version_of(p_)) for p_ in self.model.parameters())
+            if sig != self._graph_sig:
+                self._graphs.clear()
+                self._graph_sig = sig
+        used = set()
         check_was = getattr(self.model.rnn, "check_status", None)
         t0 = 0
         while t0 < t_total:
@@ -395,6 +433,7 @@ class ChunkedDeepSpeech2:
                     y, ol_host = cg.run(xc), cg.out_lens_host
                     state = cg.state
                     cg_used = True
+                    used.add(cg)
                     self.graph_replays += 1
             if y is None:
                 if active is not None:       # leave the graph: its static state is the current state
@@ -426,6 +465,8 @@ class ChunkedDeepSpeech2:
             outs.append(block)
             out_lens[:alive] += ol_host
             t0 = t_next
-        if self.graph_replays and check_was:
-            _lib.check(_lib.load().ms_rnn_status(_lib.ptr(self.model.rnn._workspace.buf), _lib.stream_ptr()), "ms_rnn_layer_forward")
+        if check_was:            # the graphs' recurrent launches report through the graphs' own workspaces
+            for cg in used:
+                if cg.rnn_ws is not None and cg.rnn_ws.buf is not None:
+                    _lib.check(_lib.load().ms_rnn_status(_lib.ptr(cg.rnn_ws.buf), _lib.stream_ptr()), "ms_rnn_layer_forward")
         return (torch.cat(outs, 0), out_lens.to(lens.dtype)), full_state

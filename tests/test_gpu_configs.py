@@ -87,6 +87,21 @@ def test_streaming_hip_graph_replay_equals_the_eager_slices():
     for a, b in ((y0, y1), (h0, h1), (c0, c1), (y0, y2), (h0, h2), (c0, c2)):
         assert torch.equal(a, b)
     assert torch.equal(l0, l1) and torch.equal(l0, l2)
+    # a graph records pointers: (i) a later, LARGER call of the same model re-allocates the model's grow-only scratch buffers --
+    # the graphs own theirs, so their replays are unaffected; (ii) a parameter edited in place re-packs the weights into new
+    # buffers -- the streamer drops its graphs and captures again
+    with torch.no_grad():
+        big = torch.randn(48, 1, 80, 32 * 12, generator=g).cuda()
+        m((big, torch.full((48,), 32 * 12)))
+        (y3, _), (h3, c3) = graph(x.clone(), lens)
+        assert torch.equal(y0, y3) and torch.equal(h0, h3) and torch.equal(c0, c3)
+        m.rnn.rnn.weight_hh_l0.mul_(1.25)
+        m.fully_connected.fully_connected[2].bias.add_(0.5)
+        (y4, _), (h4, c4) = ChunkedDeepSpeech2(m, 32, use_graph=False)(x.clone(), lens)
+        (y5, _), (h5, c5) = graph(x.clone(), lens)
+    assert not torch.equal(y0, y4)
+    assert torch.equal(y4, y5) and torch.equal(h4, h5) and torch.equal(c4, c5)
+    assert graph.graph_error is None, graph.graph_error
 
 
 def test_wide_workgroup_lstm_fp16_form_vs_oracle_in_subprocess():
