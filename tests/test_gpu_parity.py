@@ -219,6 +219,42 @@ def test_wide_workgroup_lstm_two_groups_vs_oracle(hard, bidir, N):
             torch.testing.assert_close(cn[:, lo:hi], cn2, rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("bidir,N,steps", [(True, 1, 23), (True, 9, 14), (False, 16, 11), (True, 17, 9), (True, 41, 9), (False, 48, 7)])
+def test_wide_workgroup_lstm_small_groups_vs_oracle(bidir, N, steps):
+    """``lstm_persistent_wide2_kernel`` on small batch groups: single clips (N = 1: BASELINE configs[0]'s recurrence), N = 16
+    (configs[3]'s encoder), 17 rows, and two groups of which the SECOND is small (41 = 32 + 9, 48 = 32 + 16) -- two chained
+    layers, ragged lengths and an initial state, against the oracle; and the rows of a small batch equal, bit for bit, the same
+    rows computed inside a batch of 32 (an utterance's result does not depend on its batch).  (Round 4 built a
+    one-row-stream form for groups of <= 16 rows -- the second stream is all padding there -- and measured 3.19 against 3.24 us
+    per step: one stream's step IS the publish -> visible -> pull -> cell chain that two interleaved streams hide in each
+    other; not kept, EXPERIMENTS.md.)"""
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    H, In = 1024, 32
+    torch.manual_seed(100 + N)
+    m = RNN(RNNType.LSTM, In, H, num_layers=2, bidirectional=bidir, forget_gate_bias=1.0).eval()
+    rng = np.random.default_rng(100 + N)
+    x = rng.normal(size=(steps, N, In)).astype(np.float32)
+    lens = np.sort(rng.integers(1, steps + 1, size=N))[::-1].copy()
+    lens[0] = steps
+    D = 2 if bidir else 1
+    h0 = (rng.normal(size=(2 * D, N, H)) * 0.3).astype(np.float32)
+    c0 = (rng.normal(size=(2 * D, N, H)) * 0.3).astype(np.float32)
+    (out, _), (hn, cn) = m((T(x), T(lens)), hx=(T(h0).cuda(), T(c0).cuda()))
+    sd = {k[len("rnn."):]: cpu(v) for k, v in m.state_dict().items()}
+    want, (whn, wcn) = O.rnn_forward(O.LSTM, x, lens, sd, H, 2, bidir, hx=(h0, c0))
+    np.testing.assert_allclose(cpu(out), want, rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(cpu(hn), whn, rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(cpu(cn), wcn, rtol=1e-4, atol=3e-5)
+    if N <= 16:
+        # the same utterances as rows 0 .. N-1 of a batch of 32 (two row streams): identical bits
+        xb = np.concatenate([x, rng.normal(size=(steps, 32 - N, In)).astype(np.float32)], 1)
+        lb = np.concatenate([lens, np.ones(32 - N, dtype=lens.dtype)])
+        hb = np.concatenate([h0, np.zeros((2 * D, 32 - N, H), np.float32)], 1)
+        cb = np.concatenate([c0, np.zeros((2 * D, 32 - N, H), np.float32)], 1)
+        (ob, _), (hnb, cnb) = m((T(xb), T(lb)), hx=(T(hb).cuda(), T(cb).cuda()))
+        assert torch.equal(ob[:, :N], out) and torch.equal(hnb[:, :N], hn) and torch.equal(cnb[:, :N], cn)
+
+
 # ----------------------------------------------------------------------------- conv
 @pytest.mark.parametrize("name", golden_names("conv2d_"))
 def test_conv2d_golden(name):
