@@ -864,7 +864,7 @@ typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 // F16: the hi plane carries tagged fp16 values and the lo plane is not used.
 template <bool F16 = false>
 __device__ __forceinline__ void publish_split(float hval, unsigned tag, __amdgpu_buffer_rsrc_t rsrc, int off_hi, int off_lo,
-                                              int lane) {
+                                              int lane, bool row_exists = true) {
   unsigned hi, lo;
   if (F16) {
     hi = ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)hval) & 0xFFFEu) | tag;
@@ -878,7 +878,7 @@ __device__ __forceinline__ void publish_split(float hval, unsigned tag, __amdgpu
   g[0] = v;
   g[1] = row_shl<1>(v); g[2] = row_shl<2>(v); g[3] = row_shl<3>(v); g[4] = row_shl<4>(v);
   g[5] = row_shl<5>(v); g[6] = row_shl<6>(v); g[7] = row_shl<7>(v);
-  if ((lane & 7) == 0) {
+  if ((lane & 7) == 0 && row_exists) {   // (a padding row of the wide kernel is neither published nor pulled)
     u32x4 oh, ol;
     oh[0] = (g[0] & 0xFFFFu) | (g[1] << 16); oh[1] = (g[2] & 0xFFFFu) | (g[3] << 16);
     oh[2] = (g[4] & 0xFFFFu) | (g[5] << 16); oh[3] = (g[6] & 0xFFFFu) | (g[7] << 16);
@@ -1431,13 +1431,18 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
       c[sg] = (valid && p.c0) ? p.c0[sidx] : 0.f;
       len_n[sg] = valid ? (p.lens ? p.lens[n_base + n] : p.steps) : 0;
       const int off = sg * STREAM + epoch_par0(d, p.steps, rs) * KG * 256 + jb * 256 + nl * 16;  // slot read by the first step
-      publish_split<F16>(h[sg], epoch_tag0(d, p.steps, rs), hx_rsrc, off, PLANE + off, lane);
+      publish_split<F16>(h[sg], epoch_tag0(d, p.steps, rs), hx_rsrc, off, PLANE + off, lane, valid);
     }
   }
   __syncthreads();
 
   const int xcols = p.ndir * 4 * H;
   const int lane_off = q * 256 + c16 * 16;
+  // Rows past the group's last sequence are padding of the 16-row MFMA tile: their lanes request an offset beyond the
+  // buffer (a raw buffer load then returns zeros without touching memory) and take no part in the tag check, and nobody
+  // publishes them: a single clip pulls 4 KB of h per stream-step instead of 64 KB (round 4; a full group is unchanged).
+  const bool row_ok[2] = {c16 < N, 16 + c16 < N};
+  const int loff[2] = {row_ok[0] ? lane_off : 0x40000000, row_ok[1] ? lane_off : 0x40000000};
   bool alive = true;
   // diagnostic build: [0] wait for h (first request .. tags fresh), [1] repeated requests (a count), [2] MFMAs + partial sums
   // to LDS, [3] wait at the barrier, [4] reduce + cell + publish (cell waves); summed per wave class over the launch
@@ -1476,8 +1481,8 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
       unsigned spins = 0;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {   // first request: agent scope; the re-requests below: system scope + volatile
-        ah[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, base + ks * 1024, /*aux: sc1*/ 16);
-        if (!F16) al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, PLANE + base + ks * 1024, /*aux: sc1*/ 16);
+        ah[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, loff[sg], base + ks * 1024, /*aux: sc1*/ 16);
+        if (!F16) al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, loff[sg], PLANE + base + ks * 1024, /*aux: sc1*/ 16);
       }
       f32x4v acc[2][2];
 #pragma unroll
@@ -1516,7 +1521,7 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int e = 0; e < 4; ++e) bad |= (ah[ks][e] ^ em) | (F16 ? 0u : (al[F16 ? 0 : ks][e] ^ em));
-        if (!alive || !__any((bad & 0x00010001u) != 0)) break;
+        if (!alive || !__any(row_ok[sg] && (bad & 0x00010001u) != 0)) break;
         if ((++spins & 63u) == 0) {
           const unsigned dead = __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (dead != 0 || wall_clock64() - t_wait0 > SPIN_LIMIT_TICKS) {
@@ -1528,8 +1533,8 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
         for (int z = 0; z < p.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          ah[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, base + ks * 1024, (int)(0x80000000u | 16u));
-          if (!F16) al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, lane_off, PLANE + base + ks * 1024, (int)(0x80000000u | 16u));
+          ah[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, loff[sg], base + ks * 1024, (int)(0x80000000u | 16u));
+          if (!F16) al[ks] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, loff[sg], PLANE + base + ks * 1024, (int)(0x80000000u | 16u));
         }
       }
       if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[0] += now - st_prev; st_prev = now; st_sum[1] += spins; }
@@ -1572,7 +1577,7 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
         c[sg] = active ? cnew : c[sg];
         h[sg] = active ? hnew : h[sg];
         const int off = sg * STREAM + ec.wpar * KG * 256 + jb * 256 + nl * 16;
-        publish_split<F16>(h[sg], wtag, hx_rsrc, off, PLANE + off, lane);
+        publish_split<F16>(h[sg], wtag, hx_rsrc, off, PLANE + off, lane, n < N);
         if (n < N) {
           const size_t oidx = ((size_t)t * p.N_total + n_base + n) * (p.ndir * H) + d * H + unit;
           const float ov = active ? hnew : 0.f;
