@@ -90,7 +90,7 @@ DecLayout dec_layout(int T, int N, int V, int D, int H, int L, int J, int w, int
   W.pp = take((size_t)W.slots * J * 4);
   W.pp_tmp = take((size_t)KSPLIT * R * J * 4);
   const int in_max = (D > H ? D : H) + H;
-  W.xrow = take((size_t)R * in_max * 4);
+  W.xrow = take((size_t)((R + 31) / 32 * 32) * in_max * 6);   // float32 rows, or three bf16 planes of whole 32-row groups (6 B)
   W.gates = take((size_t)KSPLIT * R * 4 * H * 4);
   W.htop = take((size_t)R * H * 4);
   W.logp = take((size_t)R * (greedy ? GREEDY_CHUNK : 1) * V1 * 4);
@@ -101,7 +101,7 @@ DecLayout dec_layout(int T, int N, int V, int D, int H, int L, int J, int w, int
     wc += (size_t)4 * H * ((l == 0 ? D : H) + H);
     bc += (size_t)4 * H;
   }
-  W.wcat = take(wc * 4);
+  W.wcat = take(wc * 6);      // float32 rows [4H][K] (4 B per weight) or three bf16 planes of them (6 B): sized for the planes
   W.bcat = take(bc * 4);
   W.total = o;
   return W;
@@ -132,19 +132,147 @@ __global__ void pack_cat_kernel(const float* __restrict__ w_ih, const float* __r
   if (threadIdx.x == 0) bcat[row] = (b_ih ? b_ih[row] : 0.f) + (b_hh ? b_hh[row] : 0.f);
 }
 
+
+// ---- the predictor's gate GEMMs as an error-free bf16 split (round 4).  gates[R <= 128.., 4H] = x[R, K] . Wcat[4H, K]^T with
+// R = utterances x beam width hypothesis rows (128 at configs[3]) ran as exact-f32 MFMA in 128 x 32 tiles and eight K slices:
+// 17.6 us per launch, four launches per frame, 45 % of the decode (profiles/r04e_cfg4_kernel_stats.csv) -- float32 MFMA issues
+// 1/16 of the bf16 rate.  Here every float32 operand is written as THREE bf16 values h + m + l (8 + 8 + 8 significand bits: an
+// exact decomposition) and the product keeps the six terms down to 2^-24 relative (hh, hm, mh, mm, hl, lh), accumulated in float32:
+// float32-grade products at 6/16 of the float32 MFMA time.  The weights are split once per decode call (pack_cat3_kernel), the
+// rows by the kernels that produce them (pred_gather_kernel, lstm_cell_kernel: store_split3), both into FRAGMENT-MAJOR planes
+// (frag_off): a wave's operand load is one contiguous 1 KB block.  No LDS, no barrier: a wave owns 32 rows x 32 gate columns x
+// one K slice, four k-steps of operands in flight; partial sums per K slice as before (lstm_cell_kernel adds them in slice
+// order).  Measured (configs[3], same box): a gate GEMM 22.5 -> 17.8 us (the exact-f32 kernel's 51 426 launches average 17.6 us
+// over gate AND the smaller pred_proj GEMMs), beam-8 decode 122 -> 112 ms, greedy 70 -> 60 ms.  Not the ~6 us its MFMA time
+// would allow: 6 bytes per weight now come from beyond L2 per launch (50 MB at K = 2048) -- two W planes instead of three or a
+// deeper prefetch moved it by 4 % / 0 % (EXPERIMENTS.md).  MS_RNNT_GATES_F32=1 keeps the exact-f32 MFMA path.
+// Fragment-major operand layouts of the split gate GEMM: element (row, k) of a [rows, K] matrix sits where the lane that
+// needs it (row % 32, (k % 16) / 8) finds its 8 consecutive k next to the other 63 lanes' -- a wave's operand load is then
+// one contiguous block (1 KB of bf16, 2 KB of float32) instead of 32 row segments of 32 / 64 bytes (row-major operands made
+// the kernel address-coalescing-bound: 32 us per launch).
+__host__ __device__ __forceinline__ size_t frag_off(int row, int k, int K) {
+  return ((((size_t)(row >> 5) * (K >> 4) + (k >> 4)) * 2 + ((k >> 3) & 1)) * 32 + (row & 31)) * 8 + (k & 7);
+}
+typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
+// x = h + m + l (three bf16 values, exact) written to the three planes of a fragment-major operand
+__device__ __forceinline__ void store_split3(unsigned short* planes, size_t plane_stride, size_t off, float x) {
+  const unsigned h = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x);
+  const float r1 = x - __uint_as_float(h << 16);
+  const unsigned m = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)r1);
+  const unsigned l = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)(r1 - __uint_as_float(m << 16)));
+  planes[off] = (unsigned short)h;
+  planes[plane_stride + off] = (unsigned short)m;
+  planes[2 * plane_stride + off] = (unsigned short)l;
+}
+typedef __bf16 bf16x8r __attribute__((ext_vector_type(8)));
+typedef float f32x16r __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ unsigned bf16_rne(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
+
+__global__ void pack_cat3_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh, const float* __restrict__ b_ih,
+                                 const float* __restrict__ b_hh, unsigned short* __restrict__ planes, float* __restrict__ bcat,
+                                 int H, int In) {
+  const int row = blockIdx.x;  // 4H rows
+  const int K = In + H;
+  const size_t plane = (size_t)4 * H * K;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const float x = k < In ? w_ih[(size_t)row * In + k] : w_hh[(size_t)row * H + (k - In)];
+    const unsigned h = bf16_rne(x);
+    const float r1 = x - __uint_as_float(h << 16);
+    const unsigned m = bf16_rne(r1);
+    const unsigned l = bf16_rne(r1 - __uint_as_float(m << 16));
+    const size_t o = frag_off(row, k, K);
+    planes[o] = (unsigned short)h;
+    planes[plane + o] = (unsigned short)m;
+    planes[2 * plane + o] = (unsigned short)l;
+  }
+  if (threadIdx.x == 0) bcat[row] = (b_ih ? b_ih[row] : 0.f) + (b_hh ? b_hh[row] : 0.f);
+}
+
+// grid (N4 / 64, nsplit, cdiv(R, 128)), 512 threads; parts [nsplit][R][N4]; K % (16 * nsplit) == 0, N4 % 64 == 0.
+// Eight waves: wave = (row group of 32, column tile of 32); with eight K slices that is four waves per SIMD, which is what
+// hides the L2 latency of a k-step's operands (a first form with four waves of 32 x 64 and one k-step of prefetch ran at the
+// latency: 31.8 us per launch against 17.6 for the exact-f32 kernel).
+__global__ __launch_bounds__(512) void pred_gates_split_kernel(const unsigned short* __restrict__ x, size_t xplane,
+                                                               const unsigned short* __restrict__ wp,
+                                                               const float* __restrict__ bias, float* __restrict__ parts, int R,
+                                                               int K, int N4, int nsplit) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int rg = wave & 3, nt = wave >> 2;
+  const int n0 = blockIdx.x * 64 + nt * 32, z = blockIdx.y;
+  const int m = blockIdx.z * 128 + rg * 32 + l31;             // this lane's x row
+  const int kslice = K / nsplit, k0 = z * kslice;
+  const size_t wplane = (size_t)N4 * K;
+  const unsigned short* xp = x + frag_off(m, k0 + half * 8, K);          // x and W: three bf16 planes each, fragment-major
+  const unsigned short* w0 = wp + frag_off(n0 + l31, k0 + half * 8, K);
+  const bool row_ok = m < R;
+
+  f32x16r acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  constexpr int PF = 4;                                        // k-steps of operands in flight (the weights come from beyond L2)
+  u32x4r xf[PF][3], wf[PF][3];
+  auto load = [&](int slot, int ks) {                           // one k-step further: 2 halves x 32 rows x 8 elements
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      xf[slot][pl] = u32x4r{0u, 0u, 0u, 0u};
+      if (row_ok) xf[slot][pl] = *reinterpret_cast<const u32x4r*>(xp + (size_t)pl * xplane + (size_t)ks * 512);
+      wf[slot][pl] = *reinterpret_cast<const u32x4r*>(w0 + (size_t)pl * wplane + (size_t)ks * 512);
+    }
+  };
+  auto step = [&](int slot) {
+    const bf16x8r bh = __builtin_bit_cast(bf16x8r, wf[slot][0]), bm = __builtin_bit_cast(bf16x8r, wf[slot][1]);
+    const bf16x8r bl = __builtin_bit_cast(bf16x8r, wf[slot][2]);
+    const bf16x8r xh = __builtin_bit_cast(bf16x8r, xf[slot][0]), xm = __builtin_bit_cast(bf16x8r, xf[slot][1]);
+    const bf16x8r xl = __builtin_bit_cast(bf16x8r, xf[slot][2]);
+    // smallest terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc, 0, 0, 0);
+  };
+  const int nks = kslice / 16;
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+    if (j < nks) load(j, j);
+  for (int ks = 0; ks < nks; ks += PF) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+      if (ks + j < nks) {
+        step(j);
+        if (ks + j + PF < nks) load(j, ks + j + PF);
+      }
+  }
+  // D[row = (r & 3) + 8 (r >> 2) + 4 half of the wave's 32][col = l31]
+  float* out = parts + (size_t)z * R * N4;
+  const int n = n0 + l31;
+  const float bv = (z == 0 && bias != nullptr) ? bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int mr = blockIdx.z * 128 + rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (mr < R) out[(size_t)mr * N4 + n] = acc[r] + bv;
+  }
+}
+
 // x0[r] = [embedding[label_r] | h[src_r][layer 0]]; rows without a request are zero.
 __global__ void pred_gather_kernel(const float* __restrict__ embedding, const int32_t* __restrict__ ext_label,
                                    const int32_t* __restrict__ ext_src, const int32_t* __restrict__ ext_dst,
-                                   const float* __restrict__ st_h, float* __restrict__ xrow, int D, int H, int L, int V1) {
+                                   const float* __restrict__ st_h, float* __restrict__ xrow, int D, int H, int L, int V1,
+                                   int frag, size_t xplane) {
   const int r = blockIdx.x;
   const bool valid = ext_dst[r] >= 0;
   const int src = ext_src[r];
   const int lab = min(max(ext_label[r], 0), V1 - 1);
-  float* x = xrow + (size_t)r * (D + H);
-  for (int k = threadIdx.x; k < D + H; k += blockDim.x) {
+  const int K = D + H;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
     float v = 0.f;
     if (valid) v = k < D ? embedding[(size_t)lab * D + k] : (src >= 0 ? st_h[((size_t)src * L + 0) * H + (k - D)] : 0.f);
-    x[k] = v;
+    if (frag) store_split3(reinterpret_cast<unsigned short*>(xrow), xplane, frag_off(r, k, K), v);
+    else xrow[(size_t)r * K + k] = v;
   }
 }
 
@@ -152,7 +280,8 @@ __global__ void pred_gather_kernel(const float* __restrict__ embedding, const in
 // [h' | h[src][l+1]] or, after the last layer, the row of `htop`.
 __global__ void lstm_cell_kernel(const float* __restrict__ gates, const int32_t* __restrict__ ext_src,
                                  const int32_t* __restrict__ ext_dst, float* __restrict__ st_h, float* __restrict__ st_c,
-                                 float* __restrict__ xnext, float* __restrict__ htop, int H, int L, int l, int R) {
+                                 float* __restrict__ xnext, float* __restrict__ htop, int H, int L, int l, int R, int nsplit,
+                                 int frag, size_t xplane) {
   const int r = blockIdx.x;
   const int src = ext_src[r], dst = ext_dst[r];
   const float* g = gates + (size_t)r * 4 * H;
@@ -162,9 +291,13 @@ __global__ void lstm_cell_kernel(const float* __restrict__ gates, const int32_t*
     float pre[4];
 #pragma unroll
     for (int gate = 0; gate < 4; ++gate) {
-      float v = g[gate * H + u];
+      float pz[KSPLIT];
 #pragma unroll
-      for (int z = 1; z < KSPLIT; ++z) v += g[z * part + gate * H + u];
+      for (int z = 0; z < KSPLIT; ++z) pz[z] = z < nsplit ? g[z * part + gate * H + u] : 0.f;   // independent loads ...
+      float v = pz[0];
+#pragma unroll
+      for (int z = 1; z < KSPLIT; ++z)
+        if (z < nsplit) v += pz[z];                                                            // ... added in slice order
       pre[gate] = v;
     }
     const float gi = 1.f / (1.f + expf(-pre[0])), gf = 1.f / (1.f + expf(-pre[1]));
@@ -178,8 +311,13 @@ __global__ void lstm_cell_kernel(const float* __restrict__ gates, const int32_t*
       st_c[((size_t)dst * L + l) * H + u] = c_new;
     }
     if (l + 1 < L) {
-      xnext[(size_t)r * 2 * H + u] = dst >= 0 ? h_new : 0.f;
-      xnext[(size_t)r * 2 * H + H + u] = h_next_src;
+      if (frag) {
+        store_split3(reinterpret_cast<unsigned short*>(xnext), xplane, frag_off(r, u, 2 * H), dst >= 0 ? h_new : 0.f);
+        store_split3(reinterpret_cast<unsigned short*>(xnext), xplane, frag_off(r, H + u, 2 * H), h_next_src);
+      } else {
+        xnext[(size_t)r * 2 * H + u] = dst >= 0 ? h_new : 0.f;
+        xnext[(size_t)r * 2 * H + H + u] = h_next_src;
+      }
     } else {
       htop[(size_t)r * H + u] = dst >= 0 ? h_new : 0.f;
     }
@@ -681,6 +819,28 @@ struct Net {
 
 // One prediction-network step for the R request rows described by ext_label / ext_src / ext_dst.
 // The pred_proj GEMM leaves its K-slice partial sums in pp_tmp; joint_slots_kernel adds and commits them.
+// the split form needs K slices of whole 16-deep k-steps and whole 64-column tiles; all layers of a call take the same path
+// K slices of the split form: MS_RNNT_GATES_KSPLIT (2, 4 or 8); default 4 -- 64 column tiles x 4 slices = 256 workgroups of 8 waves,
+// and half the partial sums for the cell kernel to add (measured 111 .. 114 ms per decode against 114 .. 119 with 8)
+int gates_split_slices() {
+  static const int v = [] {
+    const char* e = getenv("MS_RNNT_GATES_KSPLIT");
+    const int k = e ? atoi(e) : 4;
+    return (k == 2 || k == 4 || k == 8) ? k : 4;
+  }();
+  return v;
+}
+bool gates_split_ok(const Net& n, int l) {
+  static const bool off = getenv("MS_RNNT_GATES_F32") && getenv("MS_RNNT_GATES_F32")[0] == '1';
+  if (off) return false;
+  for (int i = 0; i < n.L; ++i) {
+    const int K = (i == 0 ? n.D : n.H) + n.H;
+    if (K % (16 * KSPLIT) != 0 || (4 * n.H) % 64 != 0) return false;
+  }
+  (void)l;
+  return true;
+}
+
 int predictor_step(const Net& n, const DecLayout& W, char* ws, hipStream_t s) {
   const int R = W.R, H = n.H, L = n.L;
   int32_t* ext_label = (int32_t*)(ws + W.ext_label);
@@ -691,16 +851,28 @@ int predictor_step(const Net& n, const DecLayout& W, char* ws, hipStream_t s) {
   float* xrow = (float*)(ws + W.xrow);
   float* gates = (float*)(ws + W.gates);
   float* htop = (float*)(ws + W.htop);
+  const int frag = gates_split_ok(n, 0) ? 1 : 0;
+  const size_t xplane = (size_t)((R + 31) / 32 * 32) * ((n.D > H ? n.D : H) + H);   // elements between the three x planes
   hipLaunchKernelGGL(pred_gather_kernel, dim3(R), dim3(256), 0, s, n.embedding, ext_label, ext_src, ext_dst, st_h, xrow, n.D,
-                     H, L, n.V + 1);
+                     H, L, n.V + 1, frag, xplane);
   MS_LAUNCH_CHECK();
   for (int l = 0; l < L; ++l) {
     const int K = (l == 0 ? n.D : H) + H;
-    int rc = ms::linear_splitk_launch(xrow, (const float*)(ws + W.wcat) + W.wcat_off[l],
-                                      (const float*)(ws + W.bcat) + W.bcat_off[l], gates, R, K, 4 * H, KSPLIT, s);
-    if (rc != MS_OK) return rc;
+    int nsplit = KSPLIT;
+    if (gates_split_ok(n, l)) {
+      // three bf16 planes of [W_ih | W_hh] (pack_cat3_kernel), plane l at 3 x wcat_off[l] elements of 2 bytes
+      nsplit = gates_split_slices();
+      const unsigned short* planes = (const unsigned short*)(ws + W.wcat) + 3 * W.wcat_off[l];
+      hipLaunchKernelGGL(pred_gates_split_kernel, dim3(4 * H / 64, nsplit, (R + 127) / 128), dim3(512), 0, s, reinterpret_cast<const unsigned short*>(xrow), xplane, planes,
+                         (const float*)(ws + W.bcat) + W.bcat_off[l], gates, R, K, 4 * H, nsplit);
+      MS_LAUNCH_CHECK();
+    } else {
+      int rc = ms::linear_splitk_launch(xrow, (const float*)(ws + W.wcat) + W.wcat_off[l],
+                                        (const float*)(ws + W.bcat) + W.bcat_off[l], gates, R, K, 4 * H, KSPLIT, s);
+      if (rc != MS_OK) return rc;
+    }
     hipLaunchKernelGGL(lstm_cell_kernel, dim3(R), dim3(256), 0, s, gates, ext_src, ext_dst, st_h, st_c, xrow, htop, H, L, l,
-                       R);
+                       R, nsplit, frag, xplane);
     MS_LAUNCH_CHECK();
   }
   return ms::linear_splitk_launch(htop, n.w_pred, nullptr, (float*)(ws + W.pp_tmp), R, H, n.J, KSPLIT, s);
@@ -738,8 +910,12 @@ extern "C" int ms_rnnt_decode(const float* enc_p, const int32_t* lens, const flo
 
   for (int l = 0; l < L; ++l) {
     MS_REQUIRE(w_ih[l] && w_hh[l], "null layer weights");
-    hipLaunchKernelGGL(pack_cat_kernel, dim3(4 * H), dim3(256), 0, s, w_ih[l], w_hh[l], b_ih[l], b_hh[l],
-                       (float*)(ws + W.wcat) + W.wcat_off[l], (float*)(ws + W.bcat) + W.bcat_off[l], H, l == 0 ? D : H);
+    if (gates_split_ok(net, l))
+      hipLaunchKernelGGL(pack_cat3_kernel, dim3(4 * H), dim3(256), 0, s, w_ih[l], w_hh[l], b_ih[l], b_hh[l],
+                         (unsigned short*)(ws + W.wcat) + 3 * W.wcat_off[l], (float*)(ws + W.bcat) + W.bcat_off[l], H, l == 0 ? D : H);
+    else
+      hipLaunchKernelGGL(pack_cat_kernel, dim3(4 * H), dim3(256), 0, s, w_ih[l], w_hh[l], b_ih[l], b_hh[l],
+                         (float*)(ws + W.wcat) + W.wcat_off[l], (float*)(ws + W.bcat) + W.bcat_off[l], H, l == 0 ? D : H);
     MS_LAUNCH_CHECK();
   }
   const size_t joint_lds = (size_t)(J + V1) * 4;

@@ -139,7 +139,9 @@ def _conv_forward(x4: torch.Tensor, seq_lens: torch.Tensor, weight4: torch.Tenso
     b = None if bias is None else _lib.f32c(bias.detach())
     # below ~1 GFLOP the exact-f32 tap kernel wins (no layout pass); MS_CONV_MFMA_MIN_FLOPS moves the threshold (tests)
     big = 2.0 * y.numel() * cin * kf * kt >= float(os.environ.get("MS_CONV_MFMA_MIN_FLOPS", "1e9"))
-    if _lib.split_precision() and groups == 1 and fin == 1 and kf == 1 and cin * kt >= 64 and big:
+    # (a 2-D convolution over ONE feature row only is that row's 1-D convolution if the row is not padded away: with a
+    # feature stride > 1 the reference's SAME padding puts a zero row in front of it, cnn.py:148-163 -- found by tests/soak.py)
+    if _lib.split_precision() and groups == 1 and fin == 1 and kf == 1 and sf == 1 and pf == (0, 0) and cin * kt >= 64 and big:
         # conv1d with many input channels: im2col (mask and padding as load predicates) + split-bf16 GEMM (conv1d_gemm.hip)
         pk = packed.get_gemm1d(weight4)
         nbytes = lib.ms_maskconv1d_gemm_workspace_bytes(n, cin, tout, cout, kt)

@@ -1255,6 +1255,9 @@ def test_conv_cl_short_input_kernel_vs_oracle(monkeypatch):
         (32, 21, 11, 2, 1, True, 40, 16, 64), (32, 21, 11, 2, 1, True, 40, 16, 3), (16, 3, 3, 1, 1, True, 7, 16, 5),
         (29, 5, 4, 2, 1, True, 23, 13, 2), (48, 4, 5, 1, 2, True, 12, 9, 6), (40, 7, 1, 3, 1, False, 50, 16, 1),
         (32, 1, 7, 1, 1, False, 5, 22, 4), (33, 9, 2, 2, 2, False, 41, 10, 70), (32, 21, 11, 2, 1, True, 40, 1, 2),
+        # ONE feature row, feature stride 3, SAME: the reference's padding puts a zero row in front of the only real one
+        # (cnn.py:148-163), so every output is the bias -- this shape used to be routed to the conv1d lowering (soak 81000307)
+        (33, 1, 5, 3, 2, True, 1, 14, 7), (16, 1, 3, 2, 1, True, 1, 9, 3),
     ]
     for cout, kf, kt, sf, df, same, F, Tn, N in cases:
         torch.manual_seed(3)
