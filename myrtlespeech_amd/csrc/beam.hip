@@ -52,8 +52,8 @@ BeamLayout beam_layout(int T, int V, int W) {
   L.node_len = take((size_t)L.NN * 4);
   L.node_nw = take((size_t)L.NN * 4);
   L.node_cslot = take((size_t)L.NN * 4);
-  L.node_tidx = take((size_t)2 * L.NN * 4);
-  L.node_tstamp = take((size_t)2 * L.NN * 4);
+  L.node_tidx = take((size_t)2 * L.NN * 8);     // {frame stamp, table index} pairs, [2][NN] (one 8-byte load per look-up)
+  L.node_tstamp = L.node_tidx;
   L.childtab = take((size_t)L.CS * V * 4);
   L.per_utt = ms::align_up(o, 256);
   return L;
@@ -101,6 +101,10 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
   int* par_rank = reinterpret_cast<int*>(par_val + W);
   int* newbeam = par_rank + W;
   int* sh = newbeam + W;  // [0]=B, [1]=k_count, [2]=n_nodes, [3]=n_cslots
+  // this frame's and the previous frame's candidate tables Pb / Pnb (ctc_beam_decoder.py:182-192) live in LDS (round 4: they
+  // were a dependent global load at the end of every look-up chain); they go back to the workspace when the call ends
+  float* l_tbl_pb = reinterpret_cast<float*>(sh + 8);       // [2][M]
+  float* l_tbl_pnb = l_tbl_pb + 2 * M;                      // [2][M]
 
   // ---- global state of this utterance
   char* u = p.ws + (size_t)n * p.L.per_utt;
@@ -115,8 +119,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
   int* node_len = reinterpret_cast<int*>(u + p.L.node_len);
   int* node_nw = reinterpret_cast<int*>(u + p.L.node_nw);
   int* node_cslot = reinterpret_cast<int*>(u + p.L.node_cslot);
-  int* node_tidx = reinterpret_cast<int*>(u + p.L.node_tidx);
-  int* node_tstamp = reinterpret_cast<int*>(u + p.L.node_tstamp);
+  int2* node_tt = reinterpret_cast<int2*>(u + p.L.node_tidx);   // [2][NN] {stamp, index}
   int* childtab = reinterpret_cast<int*>(u + p.L.childtab);
   const int NN = p.L.NN;
 
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
     // Pb[-1][()] = 1, Pnb[-1][()] = 0, A_prev = [()]   (ctc_beam_decoder.py:182-192)
     if (tid == 0) {
       node_parent[0] = -1; node_sym[0] = -1; node_len[0] = 0; node_nw[0] = 0; node_cslot[0] = 0;
-      node_tstamp[0] = -1; node_tstamp[NN] = -1; node_tidx[0] = 0; node_tidx[NN] = 0;
+      node_tt[0] = make_int2(-1, 0); node_tt[NN] = make_int2(-1, 0);
       bm_node[0] = 0; bm_pb[0] = 1.0f; bm_pnb[0] = 0.0f;
       sh[0] = 1; sh[2] = 1; sh[3] = 1;
     }
@@ -132,7 +135,16 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
   } else {
     if (tid == 0) { sh[0] = hdr[2]; sh[2] = hdr[0]; sh[3] = hdr[1]; }
     for (int w = tid; w < W; w += 256) { bm_node[w] = g_beam_node[w]; bm_pb[w] = g_beam_pb[w]; bm_pnb[w] = g_beam_pnb[w]; }
+    for (int i = tid; i < 2 * M; i += 256) { l_tbl_pb[i] = tbl_pb[i]; l_tbl_pnb[i] = tbl_pnb[i]; }
   }
+  __syncthreads();
+  // the beam entries' last symbol / length / word count / child-table slot ride along in LDS from frame to frame (S6 knows
+  // them when it builds the next beam); only a call's first frame fetches them from the trie
+  for (int w = tid; w < W; w += 256)
+    if (w < sh[0]) {
+      const int nd = bm_node[w];
+      bm_last[w] = node_sym[nd]; bm_len[w] = node_len[nd]; bm_nw[w] = node_nw[nd]; bm_cslot[w] = node_cslot[nd];
+    }
   __syncthreads();
 
   const int len = min(max(p.lens[n], 0), p.T);
@@ -143,13 +155,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
     const int cp = t & 1, pp = cp ^ 1;
     const float* row = p.probs + ((size_t)t * p.N + n) * V;
     for (int v = tid; v < V; v += 256) prow[v] = row[v];
-    for (int w = tid; w < W; w += 256) {
-      if (w < B) {
-        const int nd = bm_node[w];
-        bm_last[w] = node_sym[nd]; bm_len[w] = node_len[nd]; bm_nw[w] = node_nw[nd]; bm_cslot[w] = node_cslot[nd];
-      }
-      par_present[w] = 0;
-    }
+    for (int w = tid; w < W; w += 256) par_present[w] = 0;
     if (tid == 0) sh[1] = 0;
     __syncthreads();
     const float p_blank = prow[p.blank];
@@ -174,9 +180,9 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
             par_val[w2] = a; par_rank[w2] = i * 4; par_present[w2] = 1;
           } else {
             float pb_c = 0.f, pnb_c = 0.f;
-            if (child >= 0 && node_tstamp[pp * NN + child] == t) {
-              const int idx = node_tidx[pp * NN + child];
-              pb_c = tbl_pb[pp * M + idx]; pnb_c = tbl_pnb[pp * M + idx];
+            if (child >= 0) {
+              const int2 tt = node_tt[pp * NN + child];
+              if (tt.x == t) { pb_c = l_tbl_pb[pp * M + tt.y]; pnb_c = l_tbl_pnb[pp * M + tt.y]; }
             }
             const float bterm = pc * pnb_c;
             const float pnb_new = a + bterm;
@@ -269,30 +275,41 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
         nd = atomicAdd(&sh[2], 1);
         node_parent[nd] = bm_node[w]; node_sym[nd] = c; node_len[nd] = bm_len[w] + 1;
         node_nw[nd] = bm_nw[w] + ((c == p.sep && bm_last[w] != p.sep) ? 1 : 0);
-        node_cslot[nd] = -1; node_tstamp[nd] = -1; node_tstamp[NN + nd] = -1;
+        node_cslot[nd] = -1; node_tt[nd] = make_int2(-1, 0); node_tt[NN + nd] = make_int2(-1, 0);
         childtab[(size_t)bm_cslot[w] * V + c] = nd;
         c_child[i] = nd;
       }
-      tbl_pb[cp * M + i] = c_pb[i]; tbl_pnb[cp * M + i] = c_pnb[i];
-      node_tidx[cp * NN + nd] = i; node_tstamp[cp * NN + nd] = t + 1;
+      l_tbl_pb[cp * M + i] = c_pb[i]; l_tbl_pnb[cp * M + i] = c_pnb[i];
+      node_tt[cp * NN + nd] = make_int2(t + 1, i);
     }
     __syncthreads();
 
     // ---- S6: A_prev <- best beam_width candidates
     const int Bn = min(K, W);
-    int nb_node = -1;
+    int nb_node = -1, nb_last = -1, nb_len = 0, nb_nw = 0, nb_cslot = 0;
     float nb_pb = 0.f, nb_pnb = 0.f;
     if (tid < Bn) {
       const int i = newbeam[tid];
       nb_node = c_child[i]; nb_pb = c_pb[i]; nb_pnb = c_pnb[i];
-      if (node_cslot[nb_node] < 0) {
-        const int cs = atomicAdd(&sh[3], 1);
-        node_cslot[nb_node] = cs;
-        for (int v = 0; v < V; ++v) childtab[(size_t)cs * V + v] = -1;
+      if (i < W) {                     // a beam entry that stays: it has had its child-table slot since it entered the beam
+        nb_last = bm_last[i]; nb_len = bm_len[i]; nb_nw = bm_nw[i]; nb_cslot = bm_cslot[i];
+      } else {                         // an extension l + c (its node exists since S5 at the latest)
+        const int w = (i - W) / V, c = (i - W) - w * V;
+        nb_last = c; nb_len = bm_len[w] + 1;
+        nb_nw = bm_nw[w] + ((c == p.sep && bm_last[w] != p.sep) ? 1 : 0);
+        nb_cslot = node_cslot[nb_node];
+        if (nb_cslot < 0) {
+          nb_cslot = atomicAdd(&sh[3], 1);
+          node_cslot[nb_node] = nb_cslot;
+          for (int v = 0; v < V; ++v) childtab[(size_t)nb_cslot * V + v] = -1;
+        }
       }
     }
     __syncthreads();
-    if (tid < Bn) { bm_node[tid] = nb_node; bm_pb[tid] = nb_pb; bm_pnb[tid] = nb_pnb; }
+    if (tid < Bn) {
+      bm_node[tid] = nb_node; bm_pb[tid] = nb_pb; bm_pnb[tid] = nb_pnb;
+      bm_last[tid] = nb_last; bm_len[tid] = nb_len; bm_nw[tid] = nb_nw; bm_cslot[tid] = nb_cslot;
+    }
     if (tid == 0) sh[0] = Bn;
     __syncthreads();
   }
@@ -300,6 +317,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
   // ---- persist state, emit results
   const int B = sh[0];
   if (tid == 0) { hdr[0] = sh[2]; hdr[1] = sh[3]; hdr[2] = B; }
+  for (int i = tid; i < 2 * M; i += 256) { tbl_pb[i] = l_tbl_pb[i]; tbl_pnb[i] = l_tbl_pnb[i]; }
   for (int w = tid; w < W; w += 256)
     if (w < B) { g_beam_node[w] = bm_node[w]; g_beam_pb[w] = bm_pb[w]; g_beam_pnb[w] = bm_pnb[w]; }
   if (p.finish && tid == 0) {
@@ -324,7 +342,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
 
 size_t beam_lds_bytes(int V, int W) {
   const size_t M = (size_t)W * (V + 1);
-  return (size_t)V * 4 + M * 8 * 4 + (size_t)W * 11 * 4 + 8 * 4;
+  return (size_t)V * 4 + M * 8 * 4 + (size_t)W * 11 * 4 + 8 * 4 + 4 * M * 4;
 }
 
 }  // namespace
