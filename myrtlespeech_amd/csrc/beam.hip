@@ -105,6 +105,10 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
   // were a dependent global load at the end of every look-up chain); they go back to the workspace when the call ends
   float* l_tbl_pb = reinterpret_cast<float*>(sh + 8);       // [2][M]
   float* l_tbl_pnb = l_tbl_pb + 2 * M;                      // [2][M]
+  // the kept candidates' (score, order key) pairs, compacted: the ranking loop of S4 reads them in sequence
+  float* k_score = l_tbl_pnb + 2 * M;                       // [M]
+  int* k_key = reinterpret_cast<int*>(k_score + M);         // [M]
+  int* c_cslot = k_key + M;                                 // [M] child-table slot of an extension's node (-1: none yet)
 
   // ---- global state of this utterance
   char* u = p.ws + (size_t)n * p.L.per_utt;
@@ -149,12 +153,18 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
 
   const int len = min(max(p.lens[n], 0), p.T);
   const int t_stop = min(p.t_end, len);
+  // the frame's probabilities do not depend on the search: thread v holds p[t + 1][v] a frame ahead (alphabets beyond 256
+  // symbols fetch the rest in the frame itself)
+  float p_next = 0.f;
+  if (p.t_begin < t_stop && tid < V) p_next = p.probs[((size_t)p.t_begin * p.N + n) * V + tid];
   for (int t = p.t_begin; t < t_stop; ++t) {
     const int B = sh[0];
     if (B == 0) break;  // an empty beam stays empty (ctc_beam_decoder.py:258)
     const int cp = t & 1, pp = cp ^ 1;
     const float* row = p.probs + ((size_t)t * p.N + n) * V;
-    for (int v = tid; v < V; v += 256) prow[v] = row[v];
+    if (tid < V) prow[tid] = p_next;
+    for (int v = tid + 256; v < V; v += 256) prow[v] = row[v];
+    if (t + 1 < t_stop && tid < V) p_next = p.probs[((size_t)(t + 1) * p.N + n) * V + tid];
     for (int w = tid; w < W; w += 256) par_present[w] = 0;
     if (tid == 0) sh[1] = 0;
     __syncthreads();
@@ -180,10 +190,13 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
             par_val[w2] = a; par_rank[w2] = i * 4; par_present[w2] = 1;
           } else {
             float pb_c = 0.f, pnb_c = 0.f;
+            int cslot_c = -1;
             if (child >= 0) {
               const int2 tt = node_tt[pp * NN + child];
+              cslot_c = node_cslot[child];          // beside the stamp, not behind it: S6 needs it if this candidate survives
               if (tt.x == t) { pb_c = l_tbl_pb[pp * M + tt.y]; pnb_c = l_tbl_pnb[pp * M + tt.y]; }
             }
+            c_cslot[slot] = cslot_c;
             const float bterm = pc * pnb_c;
             const float pnb_new = a + bterm;
             const float pb_new = p_blank * (pb_c + pnb_c);
@@ -246,24 +259,43 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
           score = score * p.word_factor[nw];
         }
         c_score[i] = score;
-        k_idx[atomicAdd(&sh[1], 1)] = i;
+        const int j = atomicAdd(&sh[1], 1);
+        k_idx[j] = i; k_score[j] = score; k_key[j] = c_key[i];
       }
     }
     __syncthreads();
     const int K = sh[1];
 
-    // ---- S4: stable descending order, keep beam_width
-    for (int j = tid; j < K; j += 256) {
-      const int ij = k_idx[j];
-      const float sj = c_score[ij];
-      const int kj = c_key[ij];
-      int pos = 0;
-      for (int m = 0; m < K; ++m) {
-        const int im = k_idx[m];
-        const float sm = c_score[im];
-        pos += (sm > sj || (sm == sj && c_key[im] < kj)) ? 1 : 0;
+    // ---- S4: stable descending order, keep beam_width.  Rank of candidate j = candidates that sort before it; the pairs are
+    // read in sequence (round 4: the loop went through k_idx[m] -> c_score / c_key, two dependent LDS round trips per
+    // comparison, and was 3.6 of the frame's 7 us)
+    if (K <= 64) {
+      // the usual case (22 kept candidates on average at V = 29, W = 8): one wave, candidate j in lane j, the others'
+      // pairs broadcast from registers (v_readlane) -- no LDS traffic in the loop
+      if (tid < 64) {
+        const bool have = tid < K;
+        const float sj = have ? k_score[tid] : 0.f;
+        const int kj = have ? k_key[tid] : 0;
+        int pos = 0;
+        for (int m = 0; m < K; ++m) {
+          const float sm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sj), m));   // m is wave-uniform: v_readlane
+          const int km = __builtin_amdgcn_readlane(kj, m);
+          pos += (sm > sj || (sm == sj && km < kj)) ? 1 : 0;
+        }
+        if (have && pos < W) newbeam[pos] = k_idx[tid];
       }
-      if (pos < W) newbeam[pos] = ij;
+    } else {
+      for (int j = tid; j < K; j += 256) {
+        const float sj = k_score[j];
+        const int kj = k_key[j];
+        int pos = 0;
+#pragma unroll 8
+        for (int m = 0; m < K; ++m) {
+          const float sm = k_score[m];
+          pos += (sm > sj || (sm == sj && k_key[m] < kj)) ? 1 : 0;
+        }
+        if (pos < W) newbeam[pos] = k_idx[j];
+      }
     }
 
     // ---- S5: trie nodes + this frame's tables for every present candidate
@@ -297,7 +329,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
         const int w = (i - W) / V, c = (i - W) - w * V;
         nb_last = c; nb_len = bm_len[w] + 1;
         nb_nw = bm_nw[w] + ((c == p.sep && bm_last[w] != p.sep) ? 1 : 0);
-        nb_cslot = node_cslot[nb_node];
+        nb_cslot = c_cslot[i];               // -1: the node was made this frame or has never been in the beam
         if (nb_cslot < 0) {
           nb_cslot = atomicAdd(&sh[3], 1);
           node_cslot[nb_node] = nb_cslot;
@@ -342,7 +374,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
 
 size_t beam_lds_bytes(int V, int W) {
   const size_t M = (size_t)W * (V + 1);
-  return (size_t)V * 4 + M * 8 * 4 + (size_t)W * 11 * 4 + 8 * 4 + 4 * M * 4;
+  return (size_t)V * 4 + M * 8 * 4 + (size_t)W * 11 * 4 + 8 * 4 + 4 * M * 4 + 3 * M * 4;
 }
 
 }  // namespace
