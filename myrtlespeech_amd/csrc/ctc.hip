@@ -4,6 +4,7 @@
 //   ms_ctc_loss_forward   <- loss/ctc_loss.py:95-101 (LogSoftmax + torch.nn.CTCLoss)
 //   ms_ctc_greedy_decode  <- post_process/ctc_greedy_decoder.py:74-92
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -118,6 +119,284 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_kernel(const float* __r
     nll[n] = -ll;
   }
 }
+
+// ---- the alpha recursion as a four-wave systolic pipeline (round 4).  The kernel above spends 0.43 us per frame, almost all
+// of it the round trip "alpha row to LDS -> barrier -> three dependent LDS reads" that every frame pays.  Here a lane keeps
+// its K consecutive states' alphas in REGISTERS for the whole utterance, the neighbours' alpha(s-1) / alpha(s-2) arrive by DPP
+// (wave_shr:1), and only the two states at a wave's upper edge cross to the next wave, through an LDS mailbox with one entry per
+// frame: wave w computes frame t as soon as wave w-1 has published frame t-1, so the waves run
+// skewed by about one frame and nobody waits at a barrier.  The mailbox read for frame t is issued a frame ahead (the upstream
+// wave is ahead: the LDS latency is off the chain).  Dependencies only run upwards (wave 0 never waits) and every wave is
+// resident (one workgroup), so the waits terminate whatever the data.
+// An utterance has ONE wave per SIMD, which issues one instruction of any kind per four cycles: a frame costs its instruction
+// count, so the frame is written for few instructions --
+//   * phase 1 (all threads, a frame's symbols in registers) writes the frame's log-probabilities once, normalised, in the log2
+//     domain and clamped to a finite "log zero" (CTC_NEG) into the workspace: the recursion is max3 / sub / v_exp / add /
+//     v_log / add on finite numbers, no -inf cases, no per-frame normaliser, no multiplications by log2(e) / ln 2;
+//   * a state's log-probability arrives through a D-deep register ring, one buffer load per frame whose frame offset is a
+//     scalar register (an L2 round trip is ~8 frames long);
+//   * the main loop runs whole blocks of D frames with no exit inside (an exit per frame makes the compiler rotate the ring
+//     through copies, and a copy waits for every load in flight); the last < D frames run predicated and fetch nothing;
+//   * the edge waves are separate instantiations (no upstream / no downstream code at all).
+// Natural-log losses differ from ctc_alpha_kernel's by rounding only (1e-6 relative in tests/test_gpu_parity.py, which also
+// holds both against the oracle).  K = states per lane: S <= 256 K.
+constexpr float CTC_NEG = -1.0e30f;
+
+struct alignas(8) MbEntry { float top, below; };
+
+template <int K, int D, bool UP, bool DOWN>
+__device__ __forceinline__ void alpha_wave_body(const float* __restrict__ lpn, const int32_t* __restrict__ tg, float* fin,
+                                                MbEntry* mb, int T, int Tn, int V, int S, int blank, int tid) {
+#define CTC_FENCE() asm volatile("" ::: "memory")
+  const int lane = tid & 63, w = tid >> 6;
+  const int s0 = tid * K;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lpn), 0, (int)((size_t)T * V * sizeof(float)), 0x00020000);
+  const int V4 = V * 4;
+  int voff[K];
+  bool skip[K];
+  float own[K], ring[D][K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const int s = s0 + j;
+    const bool act = s < S;
+    const int lab = (act && (s & 1)) ? tg[s >> 1] : blank;
+    skip[j] = act && (s & 1) && s >= 3 && lab != blank && lab != tg[(s >> 1) - 1];
+    voff[j] = lab * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      ring[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], min(i, T - 1) * V4, 0));
+  // byte offset of the next frame to fetch, kept inside the utterance's rows: the scalar offset of a buffer load is NOT part
+  // of the range check (the last row is then fetched again; those values are never used)
+  const int soff_last = (T - 1) * V4;
+  int soff = min(D * V4, soff_last);
+  float a1in = CTC_NEG, a2in = CTC_NEG;
+  MbEntry pv{CTC_NEG, CTC_NEG};
+  const MbEntry* mb_up = mb + (size_t)(UP ? w - 1 : 0) * T;
+  MbEntry* mb_me = mb + (size_t)(DOWN ? w : 0) * T;
+  // The mailbox: entry [t] of wave w = the alphas of its two topmost states after frame t, written ONCE by its lane 63 over
+  // words that phase 1 set to all ones -- a bit pattern no alpha can have (the log-probabilities are clamped to finite values
+  // in phase 1, NaN included, so the recursion stays finite; an arithmetic NaN would be 0x7fc00000 anyway).  An entry is valid
+  // when neither word is the sentinel: no counter, one LDS write and one LDS read per frame.  The accesses are plain LDS
+  // operations fenced for the COMPILER (volatile turns them into flat accesses that drain the vector-memory queue, i.e. the ring)
+  // (two 32-bit reads: a 64-bit one lands in a register pair, and the pair then has to be copied apart for the DPP's tied
+  // operands -- a copy that waits for the read where it is issued)
+  auto fetch = [&](int t) {
+    CTC_FENCE();
+    pv.top = reinterpret_cast<const float*>(mb_up + t)[0];
+    pv.below = reinterpret_cast<const float*>(mb_up + t)[1];
+    CTC_FENCE();
+  };
+
+  // nw[] = this frame's alphas -> own[]; the edge values move on (DPP inside the wave, mailbox across waves)
+  auto exchange = [&](int t, const float (&nw)[K]) {
+    float ex = CTC_NEG, ey = CTC_NEG;
+    if (UP) {
+      // One asm statement, tied to the frame's result, so that the look at the entry stays BEHIND the arithmetic (left to
+      // itself the compiler tests right after the request: the LDS latency exposed and the publication missed).  The spin is
+      // bounded (~0.5 s): a wave that does not get its entry goes on with what it has instead of hanging the queue.
+      // The hazard recogniser does not see into the statement: gfx950 needs one wait state between a VALU write of a VGPR
+      // and a v_readfirstlane of it (without it the test reads the OLD register and lets a sentinel through -- measured).
+      unsigned x = __float_as_uint(pv.top), y = __float_as_uint(pv.below), tmp;
+      int spins;
+      const unsigned addr = (unsigned)(size_t)(mb_up + t);   // LDS byte address (the low 32 bits of the generic pointer)
+      asm volatile(
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "v_max_u32 %[tmp], %[x], %[y]\n\t"
+          "s_mov_b32 %[spins], 0\n\t"   // also the wait state gfx950 wants between a VALU write and a v_readfirstlane of it
+          "v_readfirstlane_b32 vcc_lo, %[tmp]\n\t"
+          "s_cmp_eq_u32 vcc_lo, -1\n\t"
+          "s_cbranch_scc0 1f\n\t"
+          "0:\n\t"
+          "s_sleep 1\n\t"
+          "ds_read_b32 %[x], %[addr]\n\t"
+          "ds_read_b32 %[y], %[addr] offset:4\n\t"
+          "s_add_u32 %[spins], %[spins], 1\n\t"
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "v_max_u32 %[tmp], %[x], %[y]\n\t"
+          "s_bitcmp1_b32 %[spins], 22\n\t"
+          "s_cbranch_scc1 1f\n\t"
+          "v_readfirstlane_b32 vcc_lo, %[tmp]\n\t"
+          "s_cmp_eq_u32 vcc_lo, -1\n\t"
+          "s_cbranch_scc1 0b\n\t"
+          "1:\n\t"
+          : [x] "+v"(x), [y] "+v"(y), [tmp] "=&v"(tmp), [spins] "=&s"(spins)
+          : [addr] "v"(addr), "v"(nw[K - 1])
+          : "vcc", "scc", "memory");
+      ex = __uint_as_float(x);
+      ey = __uint_as_float(y);
+    }
+    const float top = nw[K - 1];
+    float below;
+    a1in = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ex), __float_as_int(top), 0x138, 0xf, 0xf, false));
+    if (K >= 2) {
+      below = nw[K >= 2 ? K - 2 : 0];
+      a2in = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ey), __float_as_int(below), 0x138, 0xf, 0xf, false));
+    } else {
+      a2in = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ey), __float_as_int(a1in), 0x138, 0xf, 0xf, false));
+      below = a1in;   // lane 63: the alpha of lane 62's state
+    }
+    if (DOWN && lane == 63) {
+      CTC_FENCE();
+      mb_me[t] = MbEntry{top, below};
+      CTC_FENCE();
+    }
+    if (UP) fetch(t + 1);   // the next frame's entry, a frame ahead (after the last frame: a word inside the allocation, not used)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      own[j] = nw[j];
+      // the next frame's arithmetic starts from here, i.e. BEHIND the request above (asm statements keep their order; without
+      // this the compiler sinks the request to just in front of its test and exposes the LDS latency)
+      if (UP) asm volatile("" : "+v"(own[j]));
+    }
+  };
+  auto frame = [&](int t, float (&slot)[K], bool refill) {
+    float nw[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const float lp = slot[j];
+      const float a0 = own[j];
+      const float a1 = (j >= 1) ? own[j >= 1 ? j - 1 : 0] : a1in;
+      if (K % 2 == 0 && j % 2 == 0) {
+        // an even state of an even K is a blank: two terms, one of them exp2(0)
+        const float m = fmaxf(a0, a1);
+        const float e = __builtin_amdgcn_exp2f(-fabsf(a0 - a1));
+        nw[j] = (__builtin_amdgcn_logf(1.f + e) + m) + lp;
+      } else {
+        const float a2r = (j >= 2) ? own[j >= 2 ? j - 2 : 0] : (j == 1 ? a1in : a2in);
+        const float a2 = skip[j] ? a2r : CTC_NEG;
+        const float m = fmaxf(fmaxf(a0, a1), a2);
+        const float e = (__builtin_amdgcn_exp2f(a0 - m) + __builtin_amdgcn_exp2f(a1 - m)) + __builtin_amdgcn_exp2f(a2 - m);
+        nw[j] = (__builtin_amdgcn_logf(e) + m) + lp;
+      }
+    }
+    // the slot is refilled once its value has been USED (requested earlier, the new value would need a second register
+    // while the old one is still live, and the compiler then copies the ring back at every block end -- behind a vmcnt(0))
+    if (refill) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        asm volatile("" : : "v"(nw[j]));
+        slot[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], soff, 0));
+      }
+      soff = min(soff + V4, soff_last);
+    }
+    exchange(t, nw);
+  };
+  {  // frame 0: only the first blank and the first label can start a path
+    float nw[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int s = s0 + j;
+      nw[j] = (s < 2 && s < S) ? ring[0][j] : CTC_NEG;
+      ring[0][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], soff, 0));
+    }
+    soff = min(soff + V4, soff_last);
+    if (UP) fetch(0);
+    exchange(0, nw);
+  }
+  int tb = 1;   // frame t's log-probabilities sit in ring slot t % D
+  for (; tb + D <= Tn; tb += D) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) frame(tb + i, ring[(1 + i) % D], true);
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+    if (tb + i < Tn) frame(tb + i, ring[(1 + i) % D], false);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    if (s0 + j == S - 1) fin[0] = own[j];
+    if (s0 + j == S - 2) fin[1] = own[j];
+  }
+#undef CTC_FENCE
+}
+
+// phase 1 of the pipeline kernel: lpn[t][v] = clamp((x[t, n, v] - logsumexp_v x[t, n, :]) log2(e), +-CTC_NEG) (NaN -> CTC_NEG); a thread takes
+// a frame with its VB >= V symbols in registers (every load of the frame in flight at once)
+template <int VB>
+__device__ __forceinline__ void alpha_wave_normalise(const float* __restrict__ logits, float* __restrict__ lpn, int n, int Tn,
+                                                     int N, int V, int log_probs_in, int tid) {
+  constexpr float LOG2E = 1.4426950408889634f;
+  for (int t = tid; t < Tn; t += CTC_THREADS) {
+    const float* row = logits + ((size_t)t * N + n) * V;
+    float* out = lpn + (size_t)t * V;
+    float r[VB];
+#pragma unroll
+    for (int v = 0; v < VB; ++v) r[v] = v < V ? row[v] : neg_inf();
+    float lz = 0.f;
+    if (!log_probs_in) {
+      float m = neg_inf();
+#pragma unroll
+      for (int v = 0; v < VB; ++v) m = fmaxf(m, r[v]);
+      float sum = 0.f;
+#pragma unroll
+      for (int v = 0; v < VB; ++v) sum += expf(r[v] - m);
+      lz = logf(sum) + m;
+    }
+#pragma unroll
+    for (int v = 0; v < VB; ++v)
+      if (v < V) out[v] = fminf(fmaxf((r[v] - lz) * LOG2E, CTC_NEG), -CTC_NEG);
+  }
+}
+
+template <int K, int D>
+__global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float* __restrict__ logits,
+                                                                     const int32_t* __restrict__ in_lens,
+                                                                     const int32_t* __restrict__ targets,
+                                                                     const int32_t* __restrict__ tgt_offsets,
+                                                                     const int32_t* __restrict__ tgt_lens,
+                                                                     float* __restrict__ nll, float* __restrict__ lpn_ws,
+                                                                     int T, int N, int V, int blank, int log_probs_in) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
+  MbEntry* mb = reinterpret_cast<MbEntry*>(smem);   // [3][T] {alpha(top), alpha(top - 1)} of waves 0..2, per frame
+  float* fin = smem + (size_t)6 * T;                // [2]
+  const int Tn = min(max(in_lens[n], 0), T);
+  const int L = max(tgt_lens[n], 0);
+  const int S = 2 * L + 1;
+  const int32_t* tg = targets + tgt_offsets[n];
+  float* lpn = lpn_ws + (size_t)n * T * V;
+
+  if (V <= 32) alpha_wave_normalise<32>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
+  else if (V <= 64) alpha_wave_normalise<64>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
+  else {
+    for (int t = tid; t < Tn; t += CTC_THREADS) {
+      const float* row = logits + ((size_t)t * N + n) * V;
+      float lz = 0.f;
+      if (!log_probs_in) {
+        float m = neg_inf();
+        for (int v = 0; v < V; ++v) m = fmaxf(m, row[v]);
+        float sum = 0.f;
+        for (int v = 0; v < V; ++v) sum += expf(row[v] - m);
+        lz = logf(sum) + m;
+      }
+      for (int v = 0; v < V; ++v) lpn[(size_t)t * V + v] = fminf(fmaxf((row[v] - lz) * 1.4426950408889634f, CTC_NEG), -CTC_NEG);
+    }
+  }
+  for (int i = tid; i < 3 * T; i += CTC_THREADS) mb[i] = MbEntry{__uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu)};
+  if (tid < 2) fin[tid] = CTC_NEG;
+  __syncthreads();   // the workgroup's own stores (one CU, one L1) are visible to its loads behind this
+  if (Tn == 0) {
+    if (tid == 0) nll[n] = (S == 1) ? -0.f : INFINITY;
+    return;
+  }
+  if (w * 64 * K < S) {   // wave-uniform: a wave without states has nothing downstream of it either
+    if (w == 0) alpha_wave_body<K, D, false, true>(lpn, tg, fin, mb, T, Tn, V, S, blank, tid);
+    else if (w == 3) alpha_wave_body<K, D, true, false>(lpn, tg, fin, mb, T, Tn, V, S, blank, tid);
+    else alpha_wave_body<K, D, true, true>(lpn, tg, fin, mb, T, Tn, V, S, blank, tid);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float l1 = fin[0], l2 = fin[1];   // log2 domain; CTC_NEG or below = no path
+    const float m = fmaxf(l1, l2);
+    const float ll2 = log2f(exp2f(l1 - m) + exp2f(l2 - m)) + m;
+    nll[n] = (m < 0.5f * CTC_NEG) ? INFINITY : -(ll2 * 0.6931471805599453f);
+  }
+}
+
+size_t alpha_wave_lds(int T) { return ((size_t)6 * T + 2) * sizeof(float); }
 
 // Gradient of the per-utterance losses with respect to the logits (alpha-beta posteriors; loss/ctc_loss.py:95-101 under
 // autograd = LogSoftmax backward o torch ctc_loss backward, which at valid frames collapses to one expression):
@@ -334,9 +613,10 @@ __global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict
 }  // namespace
 
 extern "C" size_t ms_ctc_loss_workspace_bytes(int T, int N, int V, int S_max) {
-  (void)V; (void)S_max;
-  if (T <= 0 || N <= 0) return 0;
-  return ms::align_up((size_t)T * N * sizeof(float), 256);
+  (void)S_max;
+  if (T <= 0 || N <= 0 || V <= 0) return 0;
+  // per-frame normalisers [T][N] (ctc_alpha_kernel) + the normalised log-probabilities [N][T][V] of the pipeline kernel
+  return ms::align_up((size_t)T * N * sizeof(float), 256) + ms::align_up((size_t)T * N * V * sizeof(float), 256);
 }
 
 extern "C" int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, const int32_t* targets,
@@ -358,11 +638,33 @@ extern "C" int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, 
   static ms::DeviceOnce attr_once;
   if (attr_once.need()) {
     MS_HIP(hipFuncSetAttribute((const void*)ctc_alpha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MS_HIP(hipFuncSetAttribute((const void*)ctc_alpha_wave_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MS_HIP(hipFuncSetAttribute((const void*)ctc_alpha_wave_kernel<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MS_HIP(hipFuncSetAttribute((const void*)ctc_alpha_wave_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.done();
   }
-  hipLaunchKernelGGL(ctc_alpha_kernel, dim3(N), dim3(CTC_THREADS), lds, (hipStream_t)stream, logits, in_lens, targets,
-                     tgt_offsets, tgt_lens, nll, (float*)workspace, T, N, V, S_max, blank,
-                     (zero_infinity & MS_CTC_LOG_PROBS_IN) ? 1 : 0);
+  const int lpi = (zero_infinity & MS_CTC_LOG_PROBS_IN) ? 1 : 0;
+  // the four-wave pipeline: alphas in registers (targets of <= 511 labels), the per-frame mailbox in LDS (T <= ~5 800 frames);
+  // MS_CTC_WAVE=0 (read per call: an A/B switch for the tests) keeps the LDS-row kernel
+  const char* we = getenv("MS_CTC_WAVE");
+  const bool wave_ok = !(we && we[0] == '0') && S_max <= 1024 && alpha_wave_lds(T) <= 160 * 1024 &&
+                       (size_t)T * V * sizeof(float) < (1ull << 31);
+  float* lpn_ws = (float*)((char*)workspace + ms::align_up((size_t)T * N * sizeof(float), 256));
+  if (wave_ok) {
+    const size_t wl = alpha_wave_lds(T);
+    if (S_max <= 256)
+      hipLaunchKernelGGL((ctc_alpha_wave_kernel<1, 16>), dim3(N), dim3(CTC_THREADS), wl, (hipStream_t)stream, logits, in_lens,
+                         targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi);
+    else if (S_max <= 512)
+      hipLaunchKernelGGL((ctc_alpha_wave_kernel<2, 16>), dim3(N), dim3(CTC_THREADS), wl, (hipStream_t)stream, logits, in_lens,
+                         targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi);
+    else
+      hipLaunchKernelGGL((ctc_alpha_wave_kernel<4, 8>), dim3(N), dim3(CTC_THREADS), wl, (hipStream_t)stream, logits, in_lens,
+                         targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi);
+  } else {
+    hipLaunchKernelGGL(ctc_alpha_kernel, dim3(N), dim3(CTC_THREADS), lds, (hipStream_t)stream, logits, in_lens, targets,
+                       tgt_offsets, tgt_lens, nll, (float*)workspace, T, N, V, S_max, blank, lpi);
+  }
   MS_LAUNCH_CHECK();
   zero_infinity &= 1;
   if (reduction != 0 || zero_infinity) {

@@ -106,27 +106,39 @@ class CTCLoss(torch.nn.Module):
         yl = y_lens.detach().to("cpu", torch.int64)
         if xl.numel() != n or yl.numel() != n:
             raise RuntimeError("input_lengths and target_lengths must be of size batch_size")
-        if xl.numel() and (int(xl.max()) > t or int(xl.min()) < 0):
+        xl_list, yl_list = xl.tolist(), yl.tolist()
+        if n and (max(xl_list) > t or min(xl_list) < 0):
             raise RuntimeError("input lengths must be in [0, max_seq_len]")
+        yl_max = max(yl_list) if n else 0
         if y.dim() == 2:  # padded [N, S]
             s_pad = y.shape[1]
-            if yl.numel() and int(yl.max()) > s_pad:
+            if yl_max > s_pad:
                 raise RuntimeError("target length exceeds the padded target width")
             offsets = torch.arange(n, dtype=torch.int64) * s_pad
         elif y.dim() == 1:  # concatenated
             offsets = torch.cumsum(yl, 0) - yl
-            if int(yl.sum()) > y.numel():
+            if sum(yl_list) > y.numel():
                 raise RuntimeError("sum(target_lengths) exceeds the number of targets")
         else:
             raise RuntimeError("targets must be [batch, max_target_len] or 1-D")
-        s_max = 2 * int(yl.max() if yl.numel() else 0) + 1
-        y_dev = y.detach().to(device="cuda", dtype=torch.int32).contiguous().reshape(-1)
-        if y_dev.numel() == 0:
+        s_max = 2 * yl_max + 1
+        # ONE staged upload for everything that starts on the host (lengths, offsets and -- when the caller keeps them
+        # there -- the targets): four separate small copies cost more host time than the loss kernel takes
+        host_parts = [xl.to(torch.int32), offsets.to(torch.int32), yl.to(torch.int32)]
+        y_on_host = not y.is_cuda
+        if y_on_host and y.numel():
+            host_parts.append(y.detach().to(torch.int32).reshape(-1))
+        packed = _lib.upload(torch.cat(host_parts))
+        xl_dev, off_dev, yl_dev = packed[:n], packed[n:2 * n], packed[2 * n:3 * n]
+        if y_on_host and y.numel():
+            y_dev = packed[3 * n:]
+        elif y.numel():
+            y_dev = y.detach().to(dtype=torch.int32).contiguous().reshape(-1)
+        else:
             y_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
         red = _REDUCTION[self.ctc_loss.reduction]
         zero_inf = int(bool(self.ctc_loss.zero_infinity))
         fwd_flags = zero_inf | log_probs_in
-        xl_dev, off_dev, yl_dev = _lib.lens_i32(xl), _lib.lens_i32(offsets), _lib.lens_i32(yl)
 
         def run_forward(logits: torch.Tensor) -> torch.Tensor:
             if log_probs is not None:

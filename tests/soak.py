@@ -174,6 +174,39 @@ def ctc_case(seed):
     np.testing.assert_allclose(xt.grad.cpu().numpy(), O.ctc_grad(x, xl, y, yl, gn, blank, True), rtol=1e-3, atol=1e-4)
 
 
+def ctc_long_case(seed):
+    """The four-wave alpha pipeline at sizes that use all of its waves and every states-per-lane form (targets of up to 520
+    labels: S <= 256 / 512 / 1024 and the LDS-row kernel beyond), ragged inputs: against the LDS-row kernel (MS_CTC_WAVE=0)
+    on every case and against the oracle on every fourth."""
+    from myrtlespeech_amd.loss.ctc_loss import CTCLoss
+    rng = np.random.default_rng(seed)
+    L = int(rng.choice([int(rng.integers(1, 128)), int(rng.integers(128, 256)), int(rng.integers(256, 521))]))
+    T_ = int(rng.integers(max(2, L // 2), 2 * L + 40))
+    N, V = int(rng.integers(1, 6)), int(rng.integers(3, 40))
+    blank = int(rng.integers(0, V))
+    labels = [v for v in range(V) if v != blank]
+    x = (rng.normal(size=(T_, N, V)) * float(rng.uniform(0.5, 6))).astype(np.float32)
+    xl = rng.integers(1, T_ + 1, size=N)
+    xl[0] = T_
+    y = rng.choice(labels, size=(N, L)).astype(np.int32)
+    yl = rng.integers(0, L + 1, size=N).astype(np.int32)
+    yl[0] = L
+    loss = CTCLoss(blank=blank, reduction="none")
+    args = ((torch.from_numpy(x), torch.from_numpy(xl)), (torch.from_numpy(y), torch.from_numpy(yl)))
+    os.environ["MS_CTC_WAVE"] = "0"
+    old = loss(*args).cpu().numpy()
+    os.environ["MS_CTC_WAVE"] = "1"
+    got = loss(*args).cpu().numpy()
+    fin = np.isfinite(old)
+    assert (np.isfinite(got) == fin).all(), (seed, got, old)
+    np.testing.assert_array_equal(got[~fin], old[~fin])
+    np.testing.assert_allclose(got[fin], old[fin], rtol=3e-6, atol=3e-5)
+    if seed % 4 == 0:
+        want = O.ctc_loss(x, xl, y, yl, blank, "none")
+        assert (np.isfinite(want) == fin).all(), (seed, got, want)
+        np.testing.assert_allclose(got[fin], want[fin], rtol=2e-4, atol=1e-2)
+
+
 def frontend_case(seed):
     from oracle import frontend_oracle as FO
     from myrtlespeech_amd.data.preprocess import AddContextFrames, MFCC, MFCCLegacy, Standardize
@@ -509,6 +542,7 @@ def conv_short_case(seed):
 
 
 family("ctc loss+grad vs oracle", ctc_case)
+family("ctc loss, long targets (alpha pipeline)", ctc_long_case)
 family("front-end vs oracle", frontend_case)
 family("ctc beam vs oracle", beam_case)
 family("ctc greedy vs oracle", greedy_case)

@@ -512,6 +512,46 @@ def test_ctc_loss_full_size_vs_oracle():
     np.testing.assert_allclose(cpu(got), want, rtol=2e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize("Tn,N,V,L", [(501, 32, 29, 120), (64, 9, 29, 20), (17, 4, 5, 3), (16, 3, 7, 8), (15, 3, 7, 7),
+                                      (33, 5, 29, 16), (2, 3, 4, 1), (1, 2, 4, 1), (700, 6, 40, 255), (300, 5, 29, 128),
+                                      (400, 4, 29, 200), (900, 3, 33, 400), (1200, 2, 29, 511), (1300, 2, 29, 600)])
+def test_ctc_alpha_wave_pipeline_vs_the_lds_row_kernel_and_the_oracle(Tn, N, V, L, monkeypatch):
+    """The four-wave pipeline (alphas in registers, DPP + a per-frame LDS mailbox; csrc/ctc.hip) against the LDS-row kernel it
+    replaced (MS_CTC_WAVE=0, read per call) and against the oracle.  (Its first form shared lse3 with that kernel and was
+    bit-identical to it on these shapes: the exchange logic was checked that way before the arithmetic was changed.)
+    Shapes walk the states-per-lane instantiations (S <= 256 / 512 / 1024 and the fallback beyond), ring boundaries
+    (T = 15, 16, 17, 33), ragged and empty inputs, empty targets and repeated labels."""
+    from myrtlespeech_amd.loss.ctc_loss import CTCLoss
+    rng = np.random.default_rng(Tn * 7 + L)
+    x = (rng.normal(size=(Tn, N, V)) * 3).astype(np.float32)
+    xl = rng.integers(max(1, Tn // 2), Tn + 1, size=N).astype(np.int32)
+    xl[0] = Tn
+    if N > 2:
+        xl[-1] = 0
+    yl = rng.integers(0, L + 1, size=N).astype(np.int32)
+    yl[0] = L
+    if N > 1:
+        yl[1] = 0
+    y = rng.integers(0, V - 1, size=(N, max(L, 1))).astype(np.int32)
+    for i in range(1, y.shape[1]):                                # repeated labels: the skip transition is off there
+        y[:, i] = np.where(rng.random(N) < 0.2, y[:, i - 1], y[:, i])
+    loss = CTCLoss(blank=V - 1, reduction="none")
+    monkeypatch.setenv("MS_CTC_WAVE", "0")
+    old = cpu(loss((T(x), T(xl)), (T(y), T(yl))))
+    monkeypatch.setenv("MS_CTC_WAVE", "1")
+    got = cpu(loss((T(x), T(xl)), (T(y), T(yl))))
+    # the pipeline works in the log2 domain on the hardware exp2 / log2 and a finite "log zero": rounding differs, nothing else
+    fin_old = np.isfinite(old)
+    np.testing.assert_array_equal(np.isfinite(got), fin_old)
+    np.testing.assert_array_equal(got[~fin_old], old[~fin_old])
+    np.testing.assert_allclose(got[fin_old], old[fin_old], rtol=2e-6, atol=2e-5)
+    if Tn * L <= 501 * 130:
+        want = O.ctc_loss(x, xl, y, yl, V - 1, "none")
+        fin = np.isfinite(want)
+        assert (np.isfinite(got) == fin).all()
+        np.testing.assert_allclose(got[fin], want[fin], rtol=2e-4, atol=1e-2)
+
+
 def test_greedy_golden():
     from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
     g = Golden("greedy_ties")
