@@ -182,6 +182,109 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel(const unsigned s
   }
 }
 
+// ---- 64 x 64 x 32, 4 waves of 32 x 32 (round 4): outputs too small to give the 256-row tiles a workgroup on most CUs -- a
+// streaming chunk's hidden FC layer is 512 x 1 024 (16 tiles of 256 x 128: 144 us on the kernel above, 9 % of a chunk of the
+// shipped architecture) -- get 64 x 64 tiles: 128 .. 512 workgroups, each K-block 6 MFMAs per wave between ONE barrier.
+// Operands go global -> registers -> LDS; the registers form a ring of four K-blocks (a block's loads are issued three
+// blocks before it is consumed: an L2 round trip is longer than a block's 192 MFMA cycles) and the LDS has two stages.
+// Fragment layout, operand roles and the per-element order of the products (hi.hi, lo.hi, hi.lo per 16-deep half, halves and
+// blocks in k order) are gemm_nt_bf16x3_kernel's: bit-identical results (tests/test_gpu_gemm.py).
+constexpr int T6 = 64;
+constexpr int T6_PLANE = T6 * 16 + 32;            // bytes per k-group plane (+32 B: conflict-free ds_write_b128)
+constexpr int T6_TILE = 4 * T6_PLANE;             // one operand plane (hi or lo) of a K-block
+constexpr int T6_STAGE = 4 * T6_TILE;             // x hi, x lo, W hi, W lo
+constexpr int T6_LDS = 2 * T6_STAGE;
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_tile64_kernel(const unsigned short* __restrict__ Ah,
+                                                                       const unsigned short* __restrict__ Al,
+                                                                       const unsigned short* __restrict__ Wh,
+                                                                       const unsigned short* __restrict__ Wl,
+                                                                       const float* __restrict__ bias, float* __restrict__ Y,
+                                                                       int M, int K, int N, int act, float lo, float hi) {
+  __shared__ __attribute__((aligned(16))) char lds[T6_LDS];
+  const int nbn = (N + T6 - 1) / T6, nbm = (M + T6 - 1) / T6;
+  const int nwg = nbn * nbm;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int bn = bid % nbn, bm = bid / nbn;     // consecutive workgroups of an XCD share the x rows
+  const int m0 = bm * T6, n0 = bn * T6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int kg = tid & 3, r_in = tid >> 2;      // loader: thread = (row r_in of the tile, k-group kg), both operands, both planes
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  const unsigned short* pa_h = Ah + (size_t)min(m0 + r_in, M - 1) * K + kg * 8;
+  const unsigned short* pa_l = Al + (size_t)min(m0 + r_in, M - 1) * K + kg * 8;
+  const unsigned short* pb_h = Wh + (size_t)min(n0 + r_in, N - 1) * K + kg * 8;
+  const unsigned short* pb_l = Wl + (size_t)min(n0 + r_in, N - 1) * K + kg * 8;
+  const int nk = K / SB_K;
+  u32x4 ring[4][4];                             // [block % 4][x hi, x lo, W hi, W lo]
+  auto load_block = [&](int kb, u32x4 (&r)[4]) {
+    const int k0 = min(kb, nk - 1) * SB_K;      // past the end: the last block again (never stored)
+    r[0] = *reinterpret_cast<const u32x4*>(pa_h + k0);
+    r[1] = *reinterpret_cast<const u32x4*>(pa_l + k0);
+    r[2] = *reinterpret_cast<const u32x4*>(pb_h + k0);
+    r[3] = *reinterpret_cast<const u32x4*>(pb_l + k0);
+  };
+  auto store_block = [&](int stage, const u32x4 (&r)[4]) {
+    char* st = lds + stage * T6_STAGE + kg * T6_PLANE + r_in * 16;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(st + p * T6_TILE) = r[p];
+  };
+  auto compute = [&](int stage) {
+    const char* st = lds + stage * T6_STAGE;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int g = 2 * s2 + half;
+      const int offa = g * T6_PLANE + (wm * 32 + l31) * 16, offb = g * T6_PLANE + (wn * 32 + l31) * 16;
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + offa));
+      const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + T6_TILE + offa));
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + 2 * T6_TILE + offb));
+      const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + 3 * T6_TILE + offb));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    }
+  };
+  load_block(0, ring[0]);
+  load_block(1, ring[1]);
+  load_block(2, ring[2]);
+  store_block(0, ring[0]);
+  __syncthreads();
+  // iteration kt: request block kt + 3, compute block kt from stage kt & 1, put block kt + 1 into the other stage (free since
+  // the barrier that ended iteration kt - 1), barrier.  Unrolled by four so that the ring's slots are static registers.
+  for (int kb = 0; kb < nk; kb += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kt = kb + u;
+      if (kt < nk) {
+        load_block(kt + 3, ring[(u + 3) & 3]);
+        compute(kt & 1);
+        if (kt + 1 < nk) store_block((kt + 1) & 1, ring[(u + 1) & 3]);
+        __syncthreads();
+      }
+    }
+  }
+  const int n = n0 + wn * 32 + l31;
+  const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + mfma32_row(r, lane);
+    if (m < M && n < N) {
+      float v = acc[r] + bv;
+      if (act == MS_ACT_CLAMP) v = fminf(fmaxf(v, lo), hi);
+      Y[(size_t)m * N + n] = v;
+    }
+  }
+}
+
 // ---- 256x256 block tile, 8 waves (4 along M x 2 along N, each 64x128), BK = 32, LDS double buffered:
 // per K-block one barrier; the next block's ds_writes and the block-after-next's global loads are
 // issued ahead of the MFMAs of the current block.
@@ -798,6 +901,19 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
   // instead of falling back to the round-1 register-staged kernel (or, in fp16 mode, half-filling the chip with 256 x 256
   // tiles): a streaming chunk's projection, 1 024 x 8 192.  MS_GEMM_HALF_TILE=0 keeps the old routing (A/B runs).
   static const bool half_off = getenv("MS_GEMM_HALF_TILE") && getenv("MS_GEMM_HALF_TILE")[0] == '0';
+  // ... and one whose 256 x 128 tiles would still leave three quarters of the CUs idle takes 64 x 64 tiles (a chunk's hidden
+  // FC layer at 64 streams: 1 024 x 1 024 = 32 tiles of 256 x 128, 256 of 64 x 64)
+  auto tile64 = [&]() {
+    const char* e = getenv("MS_GEMM_TILE64");
+    return !(e && e[0] == '0') && !f16 && !small_tile && m_eff == nullptr && g_gemm_variant.load(std::memory_order_relaxed) == 0 &&
+           (long)cdiv(M, T6) * cdiv(N, T6) <= 2L * num_cus();
+  };
+  if (tile64() && (long)cdiv(M, S2_M) * cdiv(N, 128) * 4 <= (long)num_cus()) {
+    hipLaunchKernelGGL(gemm_nt_bf16x3_tile64_kernel, dim3(cdiv(M, T6) * cdiv(N, T6)), dim3(256), 0, stream, ah, al, wh, wl, bias, y, M, K,
+                       N, act, lo, hi);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+  }
   if (!half_off && !small_tile && starved && m_eff == nullptr && (long)M * N >= 1024L * 1024 &&
       g_gemm_variant.load(std::memory_order_relaxed) == 0 && (size_t)std::max(M, N) * K * 2 < ((size_t)1 << 31)) {
     auto k4h = f16 ? gemm_nt_bf16x3_kernel4h<true> : gemm_nt_bf16x3_kernel4h<false>;
@@ -846,6 +962,14 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
   if (m_eff != nullptr) {
     set_error("gemm_bf16x3_launch_rows: this shape does not run on the kernels that take the row count from the device");
     return MS_ERR_UNSUPPORTED;
+  }
+  // small outputs (round 4): 64 x 64 tiles when they give at most two workgroups per CU -- the same sums, bit for bit.
+  // MS_GEMM_TILE64=0 (read per call: the tests' A/B switch) keeps the 256 x 128 register-staged kernel
+  if (tile64()) {
+    hipLaunchKernelGGL(gemm_nt_bf16x3_tile64_kernel, dim3(cdiv(M, T6) * cdiv(N, T6)), dim3(256), 0, stream, ah, al, wh, wl, bias, y, M, K,
+                       N, act, lo, hi);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
   }
   const int nwg = cdiv(M, SB_M) * cdiv(N, SB_N);
   hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, dim3(nwg), dim3(256), SPLIT_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);

@@ -39,36 +39,44 @@ __global__ __launch_bounds__(256) void lookahead_tcontig_kernel(const float* __r
 // of LA_KC: per chunk the LA_KC weights sit in registers and each of the LA_TT + LA_KC - 1 input frames is loaded
 // ONCE and fanned out to the outputs it contributes to (all indices static after unrolling) -- 7 loads per output
 // instead of one weight + one input load per tap (160 at context 80).
+// (round 4) The inputs of a chunk are requested TOGETHER, unconditionally (frames past the end: the last frame's address,
+// the value replaced by zero afterwards) -- behind a per-load predicate the compiler waited for every load before issuing the
+// next, one L2 round trip per input frame: 92 us for a streaming window of 16 output frames.  TT = 16 for such windows (half
+// the loads and no outputs computed for nothing); the per-output order of the products is the same for every TT.
 constexpr int LA_TT = 32, LA_KC = 16;
 
+template <int TT>
 __global__ __launch_bounds__(256) void lookahead_strided_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 float* __restrict__ y, int F, int T, int To, int ctx,
                                                                 long xs_n, long xs_f, long xs_t, long ys_n, long ys_f,
                                                                 long ys_t, int act, float lo, float hi) {
-  const int f = blockIdx.x * 256 + threadIdx.x, t0 = blockIdx.y * LA_TT, n = blockIdx.z;
+  const int f = blockIdx.x * 256 + threadIdx.x, t0 = blockIdx.y * TT, n = blockIdx.z;
   if (f >= F) return;
   const float* xr = x + n * xs_n + f * xs_f;
   const float* wr = w + (size_t)f * ctx;
-  float acc[LA_TT];
+  float acc[TT];
 #pragma unroll
-  for (int i = 0; i < LA_TT; ++i) acc[i] = 0.f;
+  for (int i = 0; i < TT; ++i) acc[i] = 0.f;
   for (int k0 = 0; k0 < ctx; k0 += LA_KC) {
-    float wk[LA_KC];
+    float wk[LA_KC], xv[TT + LA_KC - 1];
 #pragma unroll
-    for (int k = 0; k < LA_KC; ++k) wk[k] = (k0 + k < ctx) ? wr[k0 + k] : 0.f;
+    for (int j = 0; j < TT + LA_KC - 1; ++j) xv[j] = xr[(long)min(t0 + k0 + j, T - 1) * xs_t];
 #pragma unroll
-    for (int j = 0; j < LA_TT + LA_KC - 1; ++j) {
-      const int tt = t0 + k0 + j;
-      const float xv = tt < T ? xr[(long)tt * xs_t] : 0.f;
+    for (int k = 0; k < LA_KC; ++k) wk[k] = wr[min(k0 + k, ctx - 1)];
 #pragma unroll
-      for (int i = 0; i < LA_TT; ++i) {
+    for (int k = 0; k < LA_KC; ++k) wk[k] = (k0 + k < ctx) ? wk[k] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TT + LA_KC - 1; ++j) {
+      const float v = (t0 + k0 + j < T) ? xv[j] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TT; ++i) {
         const int k = j - i;  // static after unrolling
-        if (k >= 0 && k < LA_KC) acc[i] += wk[k] * xv;
+        if (k >= 0 && k < LA_KC) acc[i] += wk[k] * v;
       }
     }
   }
 #pragma unroll
-  for (int i = 0; i < LA_TT; ++i) {
+  for (int i = 0; i < TT; ++i) {
     const int t = t0 + i;
     if (t < To) {
       float v = acc[i];
@@ -94,8 +102,12 @@ static int lookahead_launch(const float* x, const float* w, float* y, int N, int
     hipLaunchKernelGGL(lookahead_tcontig_kernel, dim3(ms::cdiv(To, LA_TB), F, N), dim3(256), lds, (hipStream_t)stream, x,
                        w, y, F, T, To, ctx, xs_n, xs_f, ys_n, ys_f, ys_t, act, act_lo, act_hi);
   } else {
-    hipLaunchKernelGGL(lookahead_strided_kernel, dim3(ms::cdiv(F, 256), ms::cdiv(To, LA_TT), N), dim3(256), 0, (hipStream_t)stream, x, w, y,
-                       F, T, To, ctx, xs_n, xs_f, xs_t, ys_n, ys_f, ys_t, act, act_lo, act_hi);
+    if (To <= 16)
+      hipLaunchKernelGGL(lookahead_strided_kernel<16>, dim3(ms::cdiv(F, 256), 1, N), dim3(256), 0, (hipStream_t)stream, x, w, y, F, T, To,
+                         ctx, xs_n, xs_f, xs_t, ys_n, ys_f, ys_t, act, act_lo, act_hi);
+    else
+      hipLaunchKernelGGL(lookahead_strided_kernel<LA_TT>, dim3(ms::cdiv(F, 256), ms::cdiv(To, LA_TT), N), dim3(256), 0,
+                         (hipStream_t)stream, x, w, y, F, T, To, ctx, xs_n, xs_f, xs_t, ys_n, ys_f, ys_t, act, act_lo, act_hi);
   }
   MS_LAUNCH_CHECK();
   return MS_OK;

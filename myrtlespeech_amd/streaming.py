@@ -109,6 +109,9 @@ class _ConvStage:
             else:
                 window = window[..., cnt * self.stride:]
         self.cache = window
+        # what this push did, for the steady-state test of the graph path: (cache frames before, after, outputs, frames read)
+        self.last = (lw - (0 if new is None else new.shape[-1]), window.shape[-1], cnt,
+                     (cnt - 1) * self.stride + self.span if cnt > 0 else 0, self.skip, final)
         return out
 
 
@@ -159,6 +162,9 @@ class _ContextStream:
             self.la_clamp = activation_clamp(lm[1].module) if len(lm) == 2 else None
         self.la_cache: Optional[torch.Tensor] = None      # [frames, N, F] recurrent outputs not yet fully consumed
         self.emitted = 0
+        self.last_push = None        # (chunk shape, rows into the recurrent stack, rows emitted) of the last eager push
+        self.graph = None            # the _ContextGraph this stream is attached to
+        self.graph_ok = True         # False once the stream has left steady state (or a capture failed)
 
     def latency_frames(self) -> int:
         """Input frames that must have arrived before logit row 0 can be emitted."""
@@ -180,7 +186,32 @@ class _ContextStream:
         rows = None
         if h is not None:
             rows = self._recurrent(self.model._conv_to_rnn_size(h))
-        return self._output(rows, final)
+        out = self._output(rows, final)
+        self.last_push = None if (chunk is None or final) else \
+            (tuple(chunk.shape), 0 if rows is None else rows.shape[0], 0 if out is None else out.shape[0])
+        return out
+
+    def conv_stages(self):
+        return [op for kind, op in self.ops if kind == "conv"]
+
+    def steady_signature(self, chunk_shape):
+        """Key of the steady state this stream is in, or None: the last (eager) push took a chunk of this shape, every
+        convolution gave outputs and was left with as many cached frames as it started with (nothing skipped), the recurrent
+        stack got rows and the lookahead passed on as many rows as it received -- the next push of the same shape then does the
+        same launches on the same shapes, provided no utterance ends inside it (``_ContextGraph.can_replay``)."""
+        lp = self.last_push
+        if lp is None or lp[0] != tuple(chunk_shape) or lp[1] == 0 or lp[1] != lp[2] or self.full_state is None:
+            return None
+        sig = [tuple(chunk_shape), self.n, lp[1]]
+        for st in self.conv_stages():
+            before, after, cnt, used, skip, final = st.last
+            if final or skip or cnt == 0 or before != after or st.cache is None:
+                return None
+            sig.append((after, cnt, used))
+        if self.la is not None:
+            if self.la_cache is None or self.la_cache.shape[0] != self.la.context - 1:
+                return None
+        return tuple(sig)
 
     def _recurrent(self, seq: torch.Tensor) -> torch.Tensor:
         """``seq [cnt, N, CF]``: rows ``rnn_pos ..`` of the recurrent stack's input; returns ``[cnt, N, H]`` with zero rows
@@ -251,6 +282,138 @@ def _workspace_slots(model):
     return slots
 
 
+class _ContextGraph:
+    """One steady-state ``push`` of a carried-context stream -- every utterance alive, a whole chunk, every convolution's
+    cache and the lookahead's held-back rows at their steady sizes -- captured once as a HIP graph and replayed per chunk.
+    The eager push is ~40 launches plus the Python of the stream operators (concatenations, slices, length uploads): about a
+    millisecond of host time per chunk around ~0.5 ms of kernels; a replay costs the host one input copy, one
+    ``hipGraphLaunch`` and one clone of the logit rows.
+
+    What a push carries from chunk to chunk lives in STATIC tensors the graph owns: the convolutions' cached input frames,
+    the lookahead's held-back rows, the recurrent state.  The capture records ``push`` itself (same kernels, same order, same
+    shapes as the eager call: ``torch.equal`` results) followed by copies of the new caches back into the static tensors; a
+    capture executes nothing, so the stream's host-side counters are put back afterwards and advanced per replay by the
+    amounts the captured push advanced them.  A stream attaches to a graph of its signature by copying its caches / state in;
+    it leaves the graph (for good) at the first push that is not steady -- an utterance ending inside it, the final flush."""
+
+    def __init__(self, stream: "_ContextStream", chunk_shape):
+        import os
+        model = stream.model
+        self.chunk_shape = tuple(chunk_shape)
+        self.x = torch.zeros(self.chunk_shape, dtype=torch.float32, device="cuda")
+        stages = stream.conv_stages()
+        self.caches = [st.cache.contiguous().clone() for st in stages]
+        self.la_cache = None if stream.la is None else stream.la_cache.contiguous().clone()
+        fs = stream.full_state
+        self.state = tuple(s_.clone() for s_ in fs) if isinstance(fs, tuple) else fs.clone()
+        self.attach(stream, copy=False)
+        snap = self._counters(stream)
+        slots = _workspace_slots(model) if os.environ.get("MS_STREAM_GRAPH_OWN_WS") != "0" else []
+        self._own = [_lib.Workspace() for _ in slots]
+        saved = [getattr(o, a) for o, a in slots]
+        for w_, old in zip(self._own, saved):          # sized like the model's (grown by the eager pushes before this one):
+            if old.buf is not None:                    # no allocation, hence no zero-fill node, inside the capture
+                w_.get(old.buf.numel())
+        check_was = getattr(model.rnn, "check_status", None)
+        self.graph = torch.cuda.CUDAGraph()
+        try:
+            for (o, a), w_ in zip(slots, self._own):
+                setattr(o, a, w_)
+            if check_was is not None:
+                model.rnn.check_status = False          # ms_rnn_status synchronises: not inside a capture
+            torch.cuda.synchronize()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                y = stream.push(self.x, False)
+                for st, c in zip(stages, self.caches):
+                    c.copy_(st.cache)
+                if self.la_cache is not None:
+                    self.la_cache.copy_(stream.la_cache)
+            if y is None or any(st.cache.shape != c.shape for st, c in zip(stages, self.caches)):
+                raise RuntimeError("the captured push was not a steady-state push")
+        except BaseException:
+            # nothing ran on the device: the static clones still hold what the stream held, the counters go back
+            self._restore(stream, snap)
+            self.attach(stream, copy=False)
+            stream.graph = None
+            raise
+        finally:
+            for (o, a), w_ in zip(slots, saved):
+                setattr(o, a, w_)
+            if check_was is not None:
+                model.rnn.check_status = check_was
+        self.y = y
+        after = self._counters(stream)
+        self.delta = [b - a for a, b in zip(snap, after)]
+        self.used = [st.last[3] for st in stages]
+        self.cnt = [st.last[2] for st in stages]
+        self.rows = stream.last_push[1]
+        self._restore(stream, snap)
+        self.attach(stream, copy=False)
+        rnn_ws = [w_ for (o, a), w_ in zip(slots, self._own) if o is getattr(model, "rnn", None)]
+        self.rnn_ws = rnn_ws[0] if rnn_ws else None
+
+    @staticmethod
+    def _counters(stream):
+        v = []
+        for st in stream.conv_stages():
+            v += [st.next_out, st.cache_start]
+        return v + [stream.rnn_pos, stream.emitted]
+
+    @staticmethod
+    def _restore(stream, v):
+        it = iter(v)
+        for st in stream.conv_stages():
+            st.next_out, st.cache_start = next(it), next(it)
+        stream.rnn_pos, stream.emitted = next(it), next(it)
+
+    def attach(self, stream, copy=True):
+        """Point ``stream`` at this graph's static tensors (``copy``: after moving the stream's current contents in)."""
+        stages = stream.conv_stages()
+        if copy:
+            for st, c in zip(stages, self.caches):
+                c.copy_(st.cache)
+            if self.la_cache is not None:
+                self.la_cache.copy_(stream.la_cache)
+            fs = stream.full_state
+            for a_, b_ in zip(self.state if isinstance(fs, tuple) else (self.state,), fs if isinstance(fs, tuple) else (fs,)):
+                a_.copy_(b_)
+        for st, c in zip(stages, self.caches):
+            st.cache = c
+        if self.la_cache is not None:
+            stream.la_cache = self.la_cache
+        stream.full_state = stream.state = self.state
+        stream.graph = self
+
+    def detach(self, stream):
+        """The stream goes on eagerly with private copies (another stream may attach to this graph and overwrite its tensors)."""
+        for st, c in zip(stream.conv_stages(), self.caches):
+            st.cache = c.clone()
+        if self.la_cache is not None:
+            stream.la_cache = self.la_cache.clone()
+        stream.full_state = stream.state = tuple(s_.clone() for s_ in self.state) if isinstance(self.state, tuple) \
+            else self.state.clone()
+        stream.graph, stream.graph_ok = None, False
+
+    @staticmethod
+    def fits(stream, used, cnt, rows) -> bool:
+        """No utterance ends inside what a steady push reads (every length clamp of the eager push is inactive) and no
+        layer reaches the end of the clip."""
+        for st, u, c in zip(stream.conv_stages(), used, cnt):
+            if int(st.lens_in.min()) - st.cache_start < u or st.total_out - st.next_out < c:
+                return False
+        return int(stream.out_lens.min()) - stream.rnn_pos >= rows
+
+    def can_replay(self, stream, chunk) -> bool:
+        """The next push is the captured one."""
+        return tuple(chunk.shape) == self.chunk_shape and self.fits(stream, self.used, self.cnt, self.rows)
+
+    def replay(self, stream, chunk):
+        self.x.copy_(chunk)
+        self.graph.replay()
+        self._restore(stream, [a + d for a, d in zip(self._counters(stream), self.delta)])
+        return self.y.clone()
+
+
 class _ChunkGraph:
     """One steady-state slice -- ``alive`` utterances, all with a full ``frames``-frame slice, state carried -- captured once as
     a HIP graph (``torch.cuda.CUDAGraph``) and replayed per chunk: the ~45 launches of a slice then cost the host one
@@ -310,9 +473,9 @@ class _ChunkGraph:
 
 class ChunkedDeepSpeech2:
     def __init__(self, model, chunk_frames: int, carry_context: bool = False, use_graph: Optional[bool] = None):
-        """``use_graph`` (default: on unless ``MS_STREAM_GRAPH=0``): replay steady-state slices as a captured HIP graph
-        (reference-plumbing mode only; any slice that is not steady state -- ragged lengths inside the slice, a short last
-        slice -- and any capture failure fall back to the eager call)."""
+        """``use_graph`` (default: on unless ``MS_STREAM_GRAPH=0``): replay steady-state slices / pushes as a captured HIP
+        graph (both modes; any slice that is not steady state -- ragged lengths inside the slice, a short last slice, the
+        held-back context filling up or being flushed -- runs eagerly)."""
         if chunk_frames <= 0:
             raise ValueError(f"chunk_frames={chunk_frames} must be > 0")
         self.model = model
@@ -322,6 +485,7 @@ class ChunkedDeepSpeech2:
         import os
         self.use_graph = (os.environ.get("MS_STREAM_GRAPH") != "0") if use_graph is None else bool(use_graph)
         self._graphs = {}
+        self._ctx_graphs = {}
         self._graph_sig = None
         self.graph_error: Optional[str] = None
         self.graph_replays = 0
@@ -345,8 +509,55 @@ class ChunkedDeepSpeech2:
         computable, ``[rows, N, V]`` or None.  ``final=True`` flushes the held-back context (chunk may be None)."""
         if self._stream is None:
             raise RuntimeError("call begin(lens) first")
+        st = self._stream
         with torch.no_grad():
-            return self._stream.push(chunk, final)
+            if self.use_graph and st.graph_ok and self.graph_error is None:
+                y = self._push_graph(st, chunk, final)
+                if y is not None:
+                    return y
+            return st.push(chunk, final)
+
+    def _push_graph(self, st: "_ContextStream", chunk, final: bool):
+        """Steady-state pushes replay a captured HIP graph (``_ContextGraph``); returns None when this push has to run
+        eagerly.  A stream that has left its graph stays eager: what is left then is the clip's tail."""
+        g = st.graph
+        steady = chunk is not None and not final
+        if g is None and steady:
+            sig = st.steady_signature(chunk.shape)
+            if sig is None:
+                return None
+            psig = tuple((p_.data_ptr(), _lib.version_of(p_)) for p_ in self.model.parameters())
+            if psig != self._graph_sig:      # a graph holds the packed weights' addresses: a changed parameter drops them all
+                self._graphs.clear()
+                self._ctx_graphs.clear()
+                self._graph_sig = psig
+            g = self._ctx_graphs.get(sig)
+            if g is not None and not g.can_replay(st, chunk):
+                return None
+            if g is None:
+                stages = st.conv_stages()      # the capture must not record a clamped push: test before building
+                if not _ContextGraph.fits(st, [s_.last[3] for s_ in stages], [s_.last[2] for s_ in stages], st.last_push[1]):
+                    return None
+                try:
+                    g = _ContextGraph(st, chunk.shape)
+                    self._ctx_graphs[sig] = g
+                except Exception as e:  # noqa: BLE001 -- capture is an optimisation: the eager push is the definition
+                    self.graph_error = f"{type(e).__name__}: {e}"[:300]
+                    st.graph_ok = False
+                    torch.cuda.synchronize()
+                    return None
+            else:
+                g.attach(st)
+        if g is None:
+            return None
+        if steady and g.can_replay(st, chunk):
+            self.graph_replays += 1
+            return g.replay(st, chunk if chunk.is_cuda else chunk.cuda())
+        # leaving the graph: its static tensors hold the current caches / state; the eager pushes go on from copies of them
+        g.detach(st)
+        if getattr(self.model.rnn, "check_status", False) and g.rnn_ws is not None and g.rnn_ws.buf is not None:
+            _lib.check(_lib.load().ms_rnn_status(_lib.ptr(g.rnn_ws.buf), _lib.stream_ptr()), "ms_rnn_layer_forward")
+        return None
 
     def latency_frames(self, total_frames: int = 1 << 20) -> int:
         """Algorithmic latency of the carried-context mode in input frames (see the module docstring)."""

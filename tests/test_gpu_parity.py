@@ -666,6 +666,38 @@ def test_streaming_with_carried_context_equals_the_full_utterance_reference(name
                            carry_context=True)(T(Golden("ds2_tiny_bilstm")["in/x"]), T(Golden("ds2_tiny_bilstm")["in/lens"]))
 
 
+@pytest.mark.parametrize("name", ["ds2_tiny_gru_lookahead", "ds2_tiny_ctx_lstm_even_kernel", "ds2_tiny_ctx_gru_lookahead_act"])
+def test_streaming_with_carried_context_hip_graph_replay_equals_the_eager_pushes(name):
+    """Steady-state pushes of the carried-context mode replay a captured HIP graph (``streaming._ContextGraph``: the
+    convolutions' cached frames, the lookahead's held-back rows and the recurrent state in static tensors, the stream's
+    counters advanced on the host): the same launches on the same buffers as the eager push, so ``torch.equal`` logits, lengths
+    and states -- on a long clip (the fixture's input tiled in time), ragged lengths (utterances end inside the stream: the
+    tail runs eagerly), several chunk sizes, and with a second batch re-using the first one's graph."""
+    from myrtlespeech_amd.streaming import ChunkedDeepSpeech2
+    g = Golden(name)
+    m = load_sd(build_ds2(g.cfg), g.sd()).eval()
+    x0 = T(g["in/x"])
+    reps = 6
+    x = torch.cat([x0] * reps, dim=-1)
+    total = x.shape[-1]
+    n = x0.shape[0]
+    lens = torch.clamp(total - torch.arange(n) * 11, min=total // 2).to(torch.int64)     # utterances end inside the last chunks
+    replays = 0
+    for chunk in (6, 12, 16, 24):
+        eager = ChunkedDeepSpeech2(m, chunk, carry_context=True, use_graph=False)
+        (ye, le), he = eager(x.clone(), lens)
+        graph = ChunkedDeepSpeech2(m, chunk, carry_context=True, use_graph=True)
+        for batch in range(2):                       # the second batch attaches to the first one's graph
+            (yg, lg), hg = graph(x.clone(), lens)
+            assert graph.graph_error is None, graph.graph_error
+            assert torch.equal(yg, ye), f"chunk {chunk} batch {batch}: max diff {float((yg - ye).abs().max())}"
+            assert torch.equal(lg, le)
+            for a, b in zip(hg if isinstance(hg, tuple) else (hg,), he if isinstance(he, tuple) else (he,)):
+                assert torch.equal(a, b)
+        replays += graph.graph_replays
+    assert replays > 0, "no chunk size reached a steady state: the graph path was not exercised"
+
+
 def test_streaming_with_carried_context_shipped_architecture_vs_full_utterance_reference():
     """The reference's SHIPPED config shape (2 x conv2d, 3 x GRU-2560 unidirectional, lookahead 80, FC 1 x 1024;
     configs/deep_speech_2_en.config:19-93) streamed in 320 ms chunks with carried context against the reference's
@@ -800,6 +832,39 @@ def test_linear_split_bf16x3(lib, M, K, N, act):
         want = np.clip(want, *act)
     bound = 1e-5 * (np.abs(x).astype(np.float64) @ np.abs(w.T).astype(np.float64)).max() + 1e-6
     assert np.abs(cpu(y) - want).max() <= bound
+
+
+@pytest.mark.parametrize("M,K,N,act", [(512, 2560, 1024, (0.0, 20.0)),    # a chunk's hidden FC layer, shipped architecture, 32 streams
+                                       (1024, 2048, 1024, (0.0, 20.0)),   # the same at configs[4] (64 streams)
+                                       (1, 32, 1, None), (63, 64, 65, None), (130, 96, 200, (-0.5, 0.5)), (700, 640, 70, None),
+                                       (16, 1024, 2048, None), (2048, 352, 128, None)])
+def test_split_gemm_64x64_tile_kernel_is_bit_identical_to_the_256x128_kernel(lib, M, K, N, act, monkeypatch):
+    """Small outputs run on 64 x 64 tiles (``gemm_nt_bf16x3_tile64_kernel``: a four-block register ring, two LDS stages)
+    instead of 256 x 128 ones that leave most CUs without a workgroup: the same k-ordered sums, so ``torch.equal`` to the
+    kernels it replaces (``MS_GEMM_TILE64=0``, read per call), ragged edges and the guard row included; and within the split's
+    error of float64."""
+    from myrtlespeech_amd import _lib
+    rng = np.random.default_rng(M * 7 + K + N)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.normal(size=(N,)).astype(np.float32)
+    xd, wd, bd = T(x).cuda(), T(w).cuda(), T(b).cuda()
+    ws = torch.empty(lib.ms_linear_split_workspace_bytes(M, K, N), dtype=torch.uint8, device="cuda")
+    a, lo, hi = (0, 0.0, 0.0) if act is None else (1, act[0], act[1])
+    ys = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MS_GEMM_TILE64", flag)
+        y = torch.full((M + 1, N), float("nan"), dtype=torch.float32, device="cuda")
+        _lib.check(lib.ms_linear_split_forward(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), M, K, N, a, lo, hi,
+                                               _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "linear_split")
+        assert bool(torch.isnan(y[M]).all())
+        ys.append(y[:M])
+    assert torch.equal(ys[0], ys[1])
+    want = x.astype(np.float64) @ w.T.astype(np.float64) + b
+    if act is not None:
+        want = np.clip(want, *act)
+    bound = 1e-5 * (np.abs(x).astype(np.float64) @ np.abs(w.T).astype(np.float64)).max() + 1e-6
+    assert np.abs(cpu(ys[1]) - want).max() <= bound
 
 
 @pytest.mark.parametrize("M,K,N,act", [(2100, 96, 2052, None),        # ragged M edge, N % 4 == 0 but not a tile multiple

@@ -348,7 +348,8 @@ def leg_stream_context(ctx, chunks=24):
     """The reference's SHIPPED architecture (configs/deep_speech_2_en.config:19-93: 2 x conv2d, 3 x GRU-2560 unidirectional, lookahead
     80, FC 1024) streamed in 320 ms chunks WITH carried convolution / lookahead context (``carry_context=True``: the chunks'
     outputs concatenated are the full-utterance logits), 32 streams.  Steady-state chunks only (the first six hold back the
-    174-frame latency); eager launches (no graph replay in this mode yet), so ``ms_per_chunk_wall`` includes the host."""
+    174-frame latency): HIP-graph replays of the captured push (``streaming._ContextGraph``); the last push flushes the
+    held-back context eagerly."""
     from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
     from myrtlespeech_amd.model.deep_speech_2 import DeepSpeech2
     from myrtlespeech_amd.model.fully_connected import FullyConnected
@@ -399,6 +400,7 @@ def leg_stream_context(ctx, chunks=24):
     return {"workload": f"shipped DS2 (3xGRU-2560 + lookahead 80) streamed with carried context, {N} streams, {chunk}-frame chunks",
             "ms_per_chunk": round(ms, 4), "ms_per_chunk_wall": round(wall, 4), "ms": round(ms, 4),
             "realtime_factor": round(N * 0.32 / ms * 1e3, 1), "latency_frames": lat, "rows_per_chunk": round(rows / chunks, 2),
+            "hip_graph_replays": st.graph_replays, "hip_graph_error": st.graph_error,
             "floor_ms": round(floor, 4), "frac_of_floor": round(floor / ms, 3),
             "floor": f"per chunk: {w_bytes / 1e6:.0f} MB of weights once at 8 TB/s + 3 layers x 16 dependent GRU steps x {step_us} us"}
 
