@@ -160,7 +160,10 @@ def _conv_forward(x4: torch.Tensor, seq_lens: torch.Tensor, weight4: torch.Tenso
         if rc != 5:  # MS_ERR_UNSUPPORTED -> the exact-f32 kernel below
             _lib.check(rc, "ms_maskconv_cl_forward")
             return y, new_lens
-    if (_lib.split_precision() and groups == 1 and cin == 1 and df == 1 and sf % 2 == 0 and kf >= 16 and big
+    # (the feature-window form pays from ~0.2 GFLOP: a streaming window of DS2's conv1 at 32 streams is 0.59 GFLOP, 69 us on
+    # the exact-f32 kernel and 28 us here, layout pass included)
+    big_fwin = 2.0 * y.numel() * cin * kf * kt >= float(os.environ.get("MS_CONV_MFMA_MIN_FLOPS", "2e8"))
+    if (_lib.split_precision() and groups == 1 and cin == 1 and df == 1 and sf % 2 == 0 and kf >= 16 and big_fwin
             and os.environ.get("MS_CONV_FWIN") != "0"):
         # one input channel, tall filter (DS2 conv1): the feature window takes the place of the channels (conv_cl.hip)
         pk = packed.get_fwin(weight4)
