@@ -27,6 +27,7 @@
 // on the data: the host enqueues iterations ahead and every few of them fetches a device counter of finished utterances
 // (4 bytes, asynchronously, looked at two checks later so that the queue never drains).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -51,7 +52,7 @@ struct DecLayout {
   // trie
   size_t node_cnt, node_parent, node_label, child;
   // predictor state pool + scratch
-  size_t st_h, st_c, pp, pp_tmp, xrow, gates, htop, logp, wcat, bcat;
+  size_t st_h, st_c, pp, pp_tmp, xrow, xrow2, gates, htop, logp, wcat, bcat;
   size_t total;
   int R, slots, maxn, bcap;
   size_t wcat_off[8], bcat_off[8];
@@ -91,6 +92,7 @@ DecLayout dec_layout(int T, int N, int V, int D, int H, int L, int J, int w, int
   W.pp_tmp = take((size_t)KSPLIT * R * J * 4);
   const int in_max = (D > H ? D : H) + H;
   W.xrow = take((size_t)((R + 31) / 32 * 32) * in_max * 6);   // float32 rows, or three bf16 planes of whole 32-row groups (6 B)
+  W.xrow2 = take((size_t)((R + 31) / 32 * 32) * in_max * 6);  // the fused layer kernel reads one x buffer and writes the other
   W.gates = take((size_t)KSPLIT * R * 4 * H * 4);
   W.htop = take((size_t)R * H * 4);
   W.logp = take((size_t)R * (greedy ? GREEDY_CHUNK : 1) * V1 * 4);
@@ -169,14 +171,18 @@ typedef float f32x16r __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ unsigned bf16_rne(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
 
+// unit_major (the fused layer kernel): gate row g H + u is stored as row (u / 8) 32 + g 8 + u % 8, so that the 32 rows of a
+// 32-row fragment group are the four gates of eight hidden units
 __global__ void pack_cat3_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh, const float* __restrict__ b_ih,
                                  const float* __restrict__ b_hh, unsigned short* __restrict__ planes, float* __restrict__ bcat,
-                                 int H, int In) {
-  const int row = blockIdx.x;  // 4H rows
+                                 int H, int In, int unit_major) {
+  const int src_row = blockIdx.x;  // 4H rows
   const int K = In + H;
   const size_t plane = (size_t)4 * H * K;
+  const int gate_ = src_row / H, unit_ = src_row % H;
+  const int row = unit_major ? (unit_ >> 3) * 32 + gate_ * 8 + (unit_ & 7) : src_row;
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    const float x = k < In ? w_ih[(size_t)row * In + k] : w_hh[(size_t)row * H + (k - In)];
+    const float x = k < In ? w_ih[(size_t)src_row * In + k] : w_hh[(size_t)src_row * H + (k - In)];
     const unsigned h = bf16_rne(x);
     const float r1 = x - __uint_as_float(h << 16);
     const unsigned m = bf16_rne(r1);
@@ -186,7 +192,7 @@ __global__ void pack_cat3_kernel(const float* __restrict__ w_ih, const float* __
     planes[plane + o] = (unsigned short)m;
     planes[2 * plane + o] = (unsigned short)l;
   }
-  if (threadIdx.x == 0) bcat[row] = (b_ih ? b_ih[row] : 0.f) + (b_hh ? b_hh[row] : 0.f);
+  if (threadIdx.x == 0) bcat[row] = (b_ih ? b_ih[src_row] : 0.f) + (b_hh ? b_hh[src_row] : 0.f);
 }
 
 // grid (N4 / 64, nsplit, cdiv(R, 128)), 512 threads; parts [nsplit][R][N4]; K % (16 * nsplit) == 0, N4 % 64 == 0.
@@ -321,6 +327,109 @@ __global__ void lstm_cell_kernel(const float* __restrict__ gates, const int32_t*
     } else {
       htop[(size_t)r * H + u] = dst >= 0 ? h_new : 0.f;
     }
+  }
+}
+
+// ---- one predictor layer in ONE launch (round 4): gate GEMM + cell.  The split-K gate GEMM left 4 x R x 4H partial sums in
+// memory for a second kernel to add (8.4 MB written and read back per layer-step at configs[3], 17.8 + 9.5 us and a kernel
+// boundary, four times per frame: half of the beam decode).  Here a workgroup owns EIGHT hidden units -- their four gates are
+// the 32 rows of one fragment group of the unit-major weight planes (pack_cat3_kernel) -- and 32 RG hypothesis rows; its eight
+// waves split the rows into RG groups and K into 8 / RG slices, meet in LDS, and the workgroup applies the cell to its
+// (row, unit) pairs itself: c_old gathered from the source slot, (h, c) written to the destination slot, the next layer's
+// operand row [h' | h_src] (or the htop row) written as the GEMM wrote nothing.  Partial sums are added in slice order, slice 0
+// carrying the bias, as lstm_cell_kernel did with the K-slice launches.  256 workgroups at R = 128 (one per CU, each streaming
+// its 32 weight rows once), 128 at R <= 32.  The next layer's rows go to the OTHER x buffer: other workgroups still read this one.
+template <int RG>
+__global__ __launch_bounds__(512) void pred_layer_fused_kernel(const unsigned short* __restrict__ x, size_t xplane,
+                                                               const unsigned short* __restrict__ wp,
+                                                               const float* __restrict__ bias, const int32_t* __restrict__ ext_src,
+                                                               const int32_t* __restrict__ ext_dst, float* __restrict__ st_h,
+                                                               float* __restrict__ st_c, unsigned short* __restrict__ xnext,
+                                                               float* __restrict__ htop, int R, int K, int H, int L, int l) {
+  constexpr int KQ = 8 / RG;
+  __shared__ float red[8][32][33];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int rg = wave % RG, kq = wave / RG;
+  const int b = blockIdx.x, rb = blockIdx.y;
+  const int m = rb * 32 * RG + rg * 32 + l31;                  // this lane's x row
+  const int kslice = K / KQ, k0 = kq * kslice;
+  const size_t wplane = (size_t)4 * H * K;
+  const unsigned short* xp = x + frag_off(m, k0 + half * 8, K);
+  const unsigned short* w0 = wp + frag_off(b * 32 + l31, k0 + half * 8, K);
+  const bool row_ok = m < R;
+
+  f32x16r acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int PF = 4;
+  u32x4r xf[PF][3], wf[PF][3];
+  auto load = [&](int slot, int ks) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      xf[slot][pl] = u32x4r{0u, 0u, 0u, 0u};
+      if (row_ok) xf[slot][pl] = *reinterpret_cast<const u32x4r*>(xp + (size_t)pl * xplane + (size_t)ks * 512);
+      wf[slot][pl] = *reinterpret_cast<const u32x4r*>(w0 + (size_t)pl * wplane + (size_t)ks * 512);
+    }
+  };
+  auto step = [&](int slot) {
+    const bf16x8r bh = __builtin_bit_cast(bf16x8r, wf[slot][0]), bm = __builtin_bit_cast(bf16x8r, wf[slot][1]);
+    const bf16x8r bl = __builtin_bit_cast(bf16x8r, wf[slot][2]);
+    const bf16x8r xh = __builtin_bit_cast(bf16x8r, xf[slot][0]), xm = __builtin_bit_cast(bf16x8r, xf[slot][1]);
+    const bf16x8r xl = __builtin_bit_cast(bf16x8r, xf[slot][2]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, acc, 0, 0, 0);   // smallest terms first (pred_gates_split_kernel)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc, 0, 0, 0);
+  };
+  const int nks = kslice / 16;
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+    if (j < nks) load(j, j);
+  for (int ks = 0; ks < nks; ks += PF) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+      if (ks + j < nks) {
+        step(j);
+        if (ks + j + PF < nks) load(j, ks + j + PF);
+      }
+  }
+  // D[row = (r & 3) + 8 (r >> 2) + 4 half of the wave's 32][col = l31 = gate * 8 + unit % 8]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t >= 256 * RG) return;
+  const int rowl = t >> 3, u8 = t & 7, rgi = rowl >> 5, rr = rowl & 31;
+  const int r = rb * 32 * RG + rowl, u = b * 8 + u8;
+  if (r >= R) return;
+  float pre[4];
+#pragma unroll
+  for (int gate = 0; gate < 4; ++gate) {
+    float v = red[rgi][rr][gate * 8 + u8] + bias[b * 32 + gate * 8 + u8];      // slice 0 (wave index = kq RG + rg)
+#pragma unroll
+    for (int q = 1; q < KQ; ++q) v += red[q * RG + rgi][rr][gate * 8 + u8];
+    pre[gate] = v;
+  }
+  const int src = ext_src[r], dst = ext_dst[r];
+  const float c_old = (dst >= 0 && src >= 0) ? st_c[((size_t)src * L + l) * H + u] : 0.f;
+  const float gi = 1.f / (1.f + expf(-pre[0])), gf = 1.f / (1.f + expf(-pre[1]));
+  const float gg = tanhf(pre[2]), go = 1.f / (1.f + expf(-pre[3]));
+  const float c_new = gf * c_old + gi * gg;
+  const float h_new = go * tanhf(c_new);
+  float h_next_src = 0.f;
+  if (l + 1 < L && dst >= 0 && src >= 0) h_next_src = st_h[((size_t)src * L + l + 1) * H + u];
+  if (dst >= 0) {
+    st_h[((size_t)dst * L + l) * H + u] = h_new;
+    st_c[((size_t)dst * L + l) * H + u] = c_new;
+  }
+  if (l + 1 < L) {
+    store_split3(xnext, xplane, frag_off(r, u, 2 * H), dst >= 0 ? h_new : 0.f);
+    store_split3(xnext, xplane, frag_off(r, H + u, 2 * H), h_next_src);
+  } else {
+    htop[(size_t)r * H + u] = dst >= 0 ? h_new : 0.f;
   }
 }
 
@@ -815,6 +924,7 @@ struct Net {
   const float* w_out;
   const float* b_out;
   int V, D, H, L, J;
+  int fused;     // one launch per predictor layer (pred_layer_fused_kernel): unit-major weight planes
 };
 
 // One prediction-network step for the R request rows described by ext_label / ext_src / ext_dst.
@@ -859,6 +969,20 @@ int predictor_step(const Net& n, const DecLayout& W, char* ws, hipStream_t s) {
   for (int l = 0; l < L; ++l) {
     const int K = (l == 0 ? n.D : H) + H;
     int nsplit = KSPLIT;
+    if (n.fused) {
+      const unsigned short* planes = (const unsigned short*)(ws + W.wcat) + 3 * W.wcat_off[l];
+      const unsigned short* xin = reinterpret_cast<const unsigned short*>(ws + ((l & 1) ? W.xrow2 : W.xrow));
+      unsigned short* xout = reinterpret_cast<unsigned short*>(ws + ((l & 1) ? W.xrow : W.xrow2));
+      const float* bias = (const float*)(ws + W.bcat) + W.bcat_off[l];
+      if (R > 32)
+        hipLaunchKernelGGL(pred_layer_fused_kernel<2>, dim3(H / 8, (R + 63) / 64), dim3(512), 0, s, xin, xplane, planes, bias, ext_src,
+                           ext_dst, st_h, st_c, xout, htop, R, K, H, L, l);
+      else
+        hipLaunchKernelGGL(pred_layer_fused_kernel<1>, dim3(H / 8, 1), dim3(512), 0, s, xin, xplane, planes, bias, ext_src, ext_dst,
+                           st_h, st_c, xout, htop, R, K, H, L, l);
+      MS_LAUNCH_CHECK();
+      continue;
+    }
     if (gates_split_ok(n, l)) {
       // three bf16 planes of [W_ih | W_hh] (pack_cat3_kernel), plane l at 3 x wcat_off[l] elements of 2 bytes
       nsplit = gates_split_slices();
@@ -906,13 +1030,22 @@ extern "C" int ms_rnnt_decode(const float* enc_p, const int32_t* lens, const flo
   hipStream_t s = (hipStream_t)stream;
   char* ws = (char*)workspace;
   const int R = W.R;
-  const Net net{embedding, w_pred, w_out, b_out, V, D, H, L, J};
+  Net net{embedding, w_pred, w_out, b_out, V, D, H, L, J, 0};
+  {
+    // one launch per predictor layer where the shapes allow it (K slices of whole 16-deep k-steps for eight waves, eight
+    // units per workgroup); MS_RNNT_FUSED=0 (read per call: the tests' A/B switch) keeps gate GEMM + cell kernel
+    const char* e = getenv("MS_RNNT_FUSED");
+    bool ok = !(e && e[0] == '0') && gates_split_ok(net, 0) && H % 8 == 0;
+    for (int l = 0; l < L && ok; ++l) ok = (((l == 0 ? D : H) + H) % 128) == 0;
+    net.fused = ok ? 1 : 0;
+  }
 
   for (int l = 0; l < L; ++l) {
     MS_REQUIRE(w_ih[l] && w_hh[l], "null layer weights");
     if (gates_split_ok(net, l))
       hipLaunchKernelGGL(pack_cat3_kernel, dim3(4 * H), dim3(256), 0, s, w_ih[l], w_hh[l], b_ih[l], b_hh[l],
-                         (unsigned short*)(ws + W.wcat) + 3 * W.wcat_off[l], (float*)(ws + W.bcat) + W.bcat_off[l], H, l == 0 ? D : H);
+                         (unsigned short*)(ws + W.wcat) + 3 * W.wcat_off[l], (float*)(ws + W.bcat) + W.bcat_off[l], H, l == 0 ? D : H,
+                         net.fused);
     else
       hipLaunchKernelGGL(pack_cat_kernel, dim3(4 * H), dim3(256), 0, s, w_ih[l], w_hh[l], b_ih[l], b_hh[l],
                          (float*)(ws + W.wcat) + W.wcat_off[l], (float*)(ws + W.bcat) + W.bcat_off[l], H, l == 0 ? D : H);
