@@ -730,7 +730,7 @@ def main(argv=None, runtime=None, json_fd=None):
             from tools import bench_configs
             del pipe, paired
             torch.cuda.empty_cache() if torch.cuda.is_available() else None
-            detail = bench_configs.run_legs(["ctc", "beam", "ds1", "rnnt", "stream", "streamctx"], cpu=not args.no_cpu_baseline)
+            detail = bench_configs.run_legs(["ctc", "ctcgrad", "beam", "ds1", "rnnt", "stream", "streamctx"], cpu=not args.no_cpu_baseline)
             if stream_fp16 is not None:
                 detail["cfg5_streaming_fp16"] = stream_fp16
             out["legs_detail"] = detail

@@ -4,6 +4,7 @@
 //   ms_ctc_loss_forward   <- loss/ctc_loss.py:95-101 (LogSoftmax + torch.nn.CTCLoss)
 //   ms_ctc_greedy_decode  <- post_process/ctc_greedy_decoder.py:74-92
 #include <math.h>
+#include <algorithm>
 #include <stdlib.h>
 
 #include "common.h"
@@ -144,35 +145,51 @@ constexpr float CTC_NEG = -1.0e30f;
 
 struct alignas(8) MbEntry { float top, below; };
 
-template <int K, int D, bool UP, bool DOWN>
+// REV (the beta recursion): the same recursion on the time-reversed, label-reversed utterance -- frame t' reads row
+// Tn - 1 - t', state s' carries the label of state S - 1 - s' -- which IS the beta recursion of loss/ctc_loss.py's backward
+// (beta_t(s) = lp[t, l'_s] + lse(beta_{t+1}(s), beta_{t+1}(s+1), [skip] beta_{t+1}(s+2)), started from the last two states).
+// ROWS: every frame's values are also written to rows[t][s] (unreversed indices) for the gradient kernel.
+template <int K, int D, bool UP, bool DOWN, bool ROWS>
 __device__ __forceinline__ void alpha_wave_body(const float* __restrict__ lpn, const int32_t* __restrict__ tg, float* fin,
-                                                MbEntry* mb, int T, int Tn, int V, int S, int blank, int tid) {
+                                                MbEntry* mb, int T, int Tn, int V, int S, int blank, int tid, float* rows,
+                                                int S_max, int rev) {
 #define CTC_FENCE() asm volatile("" ::: "memory")
   const int lane = tid & 63, w = tid >> 6;
   const int s0 = tid * K;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lpn), 0, (int)((size_t)T * V * sizeof(float)), 0x00020000);
   const int V4 = V * 4;
-  int voff[K];
+  const int L = (S - 1) >> 1;
+  int voff[K], voff_st[K];
   bool skip[K];
   float own[K], ring[D][K];
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     const int s = s0 + j;
     const bool act = s < S;
-    const int lab = (act && (s & 1)) ? tg[s >> 1] : blank;
-    skip[j] = act && (s & 1) && s >= 3 && lab != blank && lab != tg[(s >> 1) - 1];
+    const int li = s >> 1;                                             // label index of an odd state, in recursion order
+    const int lab = (act && (s & 1)) ? tg[rev ? L - 1 - li : li] : blank;
+    skip[j] = act && (s & 1) && s >= 3 && lab != blank && lab != tg[rev ? L - li : li - 1];
     voff[j] = lab * 4;
+    voff_st[j] = act ? (rev ? S - 1 - s : s) * 4 : 0x7fffffff;         // states past S: dropped by the buffer's range check
   }
+  // frame t' of the recursion reads row t' (or Tn - 1 - t'); the scalar offset of a buffer access is NOT part of the range
+  // check, so it is kept inside the utterance's rows (the edge row is then fetched again; those values are never used)
+  const int dV4 = rev ? -V4 : V4;
+  const int soff_lo = 0, soff_hi = (T - 1) * V4;
+  auto clamp_off = [&](int o) { return min(max(o, soff_lo), soff_hi); };
+  const int soff0 = rev ? (Tn - 1) * V4 : 0;
 #pragma unroll
   for (int i = 0; i < D; ++i)
 #pragma unroll
     for (int j = 0; j < K; ++j)
-      ring[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], min(i, T - 1) * V4, 0));
-  // byte offset of the next frame to fetch, kept inside the utterance's rows: the scalar offset of a buffer load is NOT part
-  // of the range check (the last row is then fetched again; those values are never used)
-  const int soff_last = (T - 1) * V4;
-  int soff = min(D * V4, soff_last);
+      ring[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], clamp_off(soff0 + i * dV4), 0));
+  int soff = clamp_off(soff0 + D * dV4);     // byte offset of the next frame to fetch
+  // row store: rows[t][s], t = t' or Tn - 1 - t'
+  const __amdgpu_buffer_rsrc_t rsrc_st =
+      __builtin_amdgcn_make_buffer_rsrc(rows, 0, ROWS ? (int)((size_t)T * S_max * sizeof(float)) : 0, 0x00020000);
+  const int dS4 = (rev ? -S_max : S_max) * 4;
+  int soff_st = rev ? (Tn - 1) * S_max * 4 : 0;
   float a1in = CTC_NEG, a2in = CTC_NEG;
   MbEntry pv{CTC_NEG, CTC_NEG};
   const MbEntry* mb_up = mb + (size_t)(UP ? w - 1 : 0) * T;
@@ -245,6 +262,11 @@ __device__ __forceinline__ void alpha_wave_body(const float* __restrict__ lpn, c
       CTC_FENCE();
     }
     if (UP) fetch(t + 1);   // the next frame's entry, a frame ahead (after the last frame: a word inside the allocation, not used)
+    if (ROWS) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nw[j]), rsrc_st, voff_st[j], soff_st, 0);
+      soff_st = max(soff_st + dS4, 0);
+    }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       own[j] = nw[j];
@@ -281,7 +303,7 @@ __device__ __forceinline__ void alpha_wave_body(const float* __restrict__ lpn, c
         asm volatile("" : : "v"(nw[j]));
         slot[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], soff, 0));
       }
-      soff = min(soff + V4, soff_last);
+      soff = clamp_off(soff + dV4);
     }
     exchange(t, nw);
   };
@@ -293,7 +315,7 @@ __device__ __forceinline__ void alpha_wave_body(const float* __restrict__ lpn, c
       nw[j] = (s < 2 && s < S) ? ring[0][j] : CTC_NEG;
       ring[0][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], soff, 0));
     }
-    soff = min(soff + V4, soff_last);
+    soff = clamp_off(soff + dV4);
     if (UP) fetch(0);
     exchange(0, nw);
   }
@@ -341,14 +363,20 @@ __device__ __forceinline__ void alpha_wave_normalise(const float* __restrict__ l
   }
 }
 
-template <int K, int D>
+// mode: bit 0 = the reversed recursion (beta), bit 1 = the workspace already holds this call's normalised log-probabilities
+// (a second launch of the same backward).  ROWS: rows_ws [N][T][S_max] receives every frame's values; ll2_out [N] the
+// log2-domain log-likelihood (CTC_NEG or below: no path).
+template <int K, int D, bool ROWS = false>
 __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float* __restrict__ logits,
                                                                      const int32_t* __restrict__ in_lens,
                                                                      const int32_t* __restrict__ targets,
                                                                      const int32_t* __restrict__ tgt_offsets,
                                                                      const int32_t* __restrict__ tgt_lens,
                                                                      float* __restrict__ nll, float* __restrict__ lpn_ws,
-                                                                     int T, int N, int V, int blank, int log_probs_in) {
+                                                                     int T, int N, int V, int blank, int log_probs_in,
+                                                                     float* __restrict__ rows_ws = nullptr, int S_max = 0,
+                                                                     int mode = 0, float* __restrict__ ll2_out = nullptr,
+                                                                     float* __restrict__ rows_ws_rev = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
   MbEntry* mb = reinterpret_cast<MbEntry*>(smem);   // [3][T] {alpha(top), alpha(top - 1)} of waves 0..2, per frame
@@ -358,8 +386,14 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
   const int S = 2 * L + 1;
   const int32_t* tg = targets + tgt_offsets[n];
   float* lpn = lpn_ws + (size_t)n * T * V;
+  // a grid of (N, 2) runs the forward recursion (y = 0) and the reversed one (y = 1: beta, rows to rows_ws_rev) side by side:
+  // both normalise the utterance's log-probabilities into the same workspace rows (the same bits from either)
+  if (blockIdx.y == 1) { mode |= 1; rows_ws = rows_ws_rev; ll2_out = nullptr; nll = nullptr; }
+  float* rows = ROWS ? rows_ws + (size_t)n * T * S_max : nullptr;
+  const int rev = mode & 1;
 
-  if (V <= 32) alpha_wave_normalise<32>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
+  if (mode & 2) {
+  } else if (V <= 32) alpha_wave_normalise<32>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
   else if (V <= 64) alpha_wave_normalise<64>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
   else {
     for (int t = tid; t < Tn; t += CTC_THREADS) {
@@ -379,20 +413,114 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
   if (tid < 2) fin[tid] = CTC_NEG;
   __syncthreads();   // the workgroup's own stores (one CU, one L1) are visible to its loads behind this
   if (Tn == 0) {
-    if (tid == 0) nll[n] = (S == 1) ? -0.f : INFINITY;
+    if (tid == 0) {
+      if (nll != nullptr) nll[n] = (S == 1) ? -0.f : INFINITY;
+      if (ll2_out != nullptr) ll2_out[n] = (S == 1) ? 0.f : CTC_NEG;
+    }
     return;
   }
   if (w * 64 * K < S) {   // wave-uniform: a wave without states has nothing downstream of it either
-    if (w == 0) alpha_wave_body<K, D, false, true>(lpn, tg, fin, mb, T, Tn, V, S, blank, tid);
-    else if (w == 3) alpha_wave_body<K, D, true, false>(lpn, tg, fin, mb, T, Tn, V, S, blank, tid);
-    else alpha_wave_body<K, D, true, true>(lpn, tg, fin, mb, T, Tn, V, S, blank, tid);
+    if (w == 0) alpha_wave_body<K, D, false, true, ROWS>(lpn, tg, fin, mb, T, Tn, V, S, blank, tid, rows, S_max, rev);
+    else if (w == 3) alpha_wave_body<K, D, true, false, ROWS>(lpn, tg, fin, mb, T, Tn, V, S, blank, tid, rows, S_max, rev);
+    else alpha_wave_body<K, D, true, true, ROWS>(lpn, tg, fin, mb, T, Tn, V, S, blank, tid, rows, S_max, rev);
   }
   __syncthreads();
   if (tid == 0) {
     const float l1 = fin[0], l2 = fin[1];   // log2 domain; CTC_NEG or below = no path
     const float m = fmaxf(l1, l2);
     const float ll2 = log2f(exp2f(l1 - m) + exp2f(l2 - m)) + m;
-    nll[n] = (m < 0.5f * CTC_NEG) ? INFINITY : -(ll2 * 0.6931471805599453f);
+    if (nll != nullptr) nll[n] = (m < 0.5f * CTC_NEG) ? INFINITY : -(ll2 * 0.6931471805599453f);
+    if (ll2_out != nullptr) ll2_out[n] = (m < 0.5f * CTC_NEG) ? CTC_NEG : ll2;
+  }
+}
+
+// ---- the gradient rows (round 4).  With alpha and beta of every frame in the workspace (two launches of the pipeline kernel:
+// forward, and reversed = beta) a frame's gradient row is independent of every other frame:
+//   grad[t, n, k] = go[n] (2^lp2[t, k] - 2^(log2 sum_{s: l'_s = k} 2^(alpha_t(s) + beta_t(s)) - ll2 - lp2[t, k]))
+// (everything in the log2 domain the pipeline works in; alpha and beta both contain lp2[t, l'_s]).  One wave per frame: its
+// lanes hold the frame's states, the blank's states (every even s) are summed by a wave reduction, a label's few occurrences
+// by the lane of that label walking its occurrence list (built once per workgroup in LDS) -- fixed orders, so the result does not
+// depend on scheduling.  Sums are taken relative to the frame's maximum of alpha + beta: a bucket more than 2^-126 below it
+// contributes nothing, as it does to any float32 result.  ctc_grad_kernel did this with V threads each scanning all S states twice
+// between three barriers per frame, serially over the frames: 26 ms at [501, 32, 29] x 120 labels (52 us per frame).
+constexpr int GR_FRAMES = 4;    // frames per wave (several waves per SIMD: a frame is a chain of dependent loads and reductions)
+
+__global__ __launch_bounds__(CTC_THREADS) void ctc_grad_rows_kernel(const float* __restrict__ lpn_ws, const float* __restrict__ alpha_ws,
+                                                                    const float* __restrict__ beta_ws, const float* __restrict__ ll2,
+                                                                    const int32_t* __restrict__ in_lens,
+                                                                    const int32_t* __restrict__ targets,
+                                                                    const int32_t* __restrict__ tgt_offsets,
+                                                                    const int32_t* __restrict__ tgt_lens,
+                                                                    const float* __restrict__ grad_nll, float* __restrict__ grad,
+                                                                    int T, int N, int V, int S_max, int blank, int zero_infinity) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int Tn = min(max(in_lens[n], 0), T);
+  const int L = max(tgt_lens[n], 0), S = 2 * L + 1;
+  const int32_t* tg = targets + tgt_offsets[n];
+  int* occ = reinterpret_cast<int*>(smem);              // [L] label positions grouped by label
+  int* start = occ + S_max;                              // [V + 1]
+  float* ab = smem + S_max + (V + 1) + (size_t)w * S_max;   // [4][S_max] this wave's alpha + beta row
+  // occurrence lists: the positions of label k in the target, in order (a few entries each; built once per workgroup)
+  for (int k = tid; k <= V; k += CTC_THREADS) {
+    int c = 0;
+    if (k < V && k != blank)
+      for (int i = 0; i < L; ++i) c += (tg[i] == k) ? 1 : 0;
+    start[k] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int c = 0;
+    for (int k = 0; k <= V; ++k) { const int cnt = start[k]; start[k] = c; c += cnt; }
+  }
+  __syncthreads();
+  for (int k = tid; k < V; k += CTC_THREADS) {
+    if (k == blank) continue;
+    int c = start[k];
+    for (int i = 0; i < L; ++i)
+      if (tg[i] == k) occ[c++] = i;
+  }
+  __syncthreads();
+  const float go = grad_nll[n];
+  const float l2 = ll2[n];
+  const bool infeasible = l2 < 0.5f * CTC_NEG;
+  const float* lpn = lpn_ws + (size_t)n * T * V;
+  const float* al = alpha_ws + (size_t)n * T * S_max;
+  const float* be = beta_ws + (size_t)n * T * S_max;
+  const int t0 = (blockIdx.x * 4 + w) * GR_FRAMES;
+  for (int t = t0; t < min(t0 + GR_FRAMES, T); ++t) {
+    float* grow = grad + ((size_t)t * N + n) * V;
+    if (t >= Tn || (infeasible && zero_infinity)) {       // padding frames (and, with zero_infinity, impossible targets): zeros
+      for (int k = lane; k < V; k += 64) grow[k] = 0.f;
+      continue;
+    }
+    // alpha + beta of the frame's states into LDS, their maximum and the blank's sum by wave reductions
+    float m = CTC_NEG;
+    for (int s = lane; s < S; s += 64) {
+      const float v = al[(size_t)t * S_max + s] + be[(size_t)t * S_max + s];
+      ab[s] = v;
+      m = fmaxf(m, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    // (the row is this wave's own: a wave's LDS operations execute in order, no barrier between its writes and reads)
+    float bsum = 0.f;
+    for (int s = 2 * lane; s < S; s += 128) bsum += __builtin_amdgcn_exp2f(ab[s] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bsum += __shfl_xor(bsum, o, 64);
+    const bool dead = m < 0.5f * CTC_NEG;                  // no state of this frame lies on a path (an impossible target)
+    for (int k = lane; k < V; k += 64) {
+      const float lp2 = lpn[(size_t)t * V + k];
+      float res = __builtin_amdgcn_exp2f(lp2);
+      if (!dead) {
+        float sum = 0.f;
+        if (k == blank) sum = bsum;
+        else
+          for (int i = start[k]; i < start[k + 1]; ++i) sum += __builtin_amdgcn_exp2f(ab[2 * occ[i] + 1] - m);
+        if (sum > 0.f) res -= __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(sum) + m - l2 - lp2);
+      }
+      grow[k] = res * go;
+    }
   }
 }
 
@@ -741,9 +869,11 @@ extern "C" int ms_ctc_greedy_decode(const float* x, const int32_t* lens, int32_t
 }
 
 extern "C" size_t ms_ctc_loss_backward_workspace_bytes(int T, int N, int V, int S_max) {
-  (void)V;
-  if (T <= 0 || N <= 0 || S_max < 1) return 0;
-  return ms::align_up((size_t)T * N * sizeof(float), 256) + ms::align_up((size_t)T * N * S_max * sizeof(float), 256);
+  if (T <= 0 || N <= 0 || S_max < 1 || V <= 0) return 0;
+  // normalisers [T][N] + alpha rows [N][T][S_max] (ctc_grad_kernel); + beta rows, the normalised log-probabilities [N][T][V] and
+  // the log-likelihoods [N] of the pipeline path
+  return ms::align_up((size_t)T * N * sizeof(float), 256) + 2 * ms::align_up((size_t)T * N * S_max * sizeof(float), 256) +
+         ms::align_up((size_t)T * N * V * sizeof(float), 256) + ms::align_up((size_t)N * sizeof(float), 256);
 }
 
 extern "C" int ms_ctc_loss_backward(const float* logits, const int32_t* in_lens, const int32_t* targets,
@@ -757,6 +887,48 @@ extern "C" int ms_ctc_loss_backward(const float* logits, const int32_t* in_lens,
   if (workspace_bytes < ms_ctc_loss_backward_workspace_bytes(T, N, V, S_max)) {
     ms::set_error("ms_ctc_loss_backward: workspace too small");
     return MS_ERR_WORKSPACE;
+  }
+  {
+    // the pipeline path: alpha rows and beta rows (the same kernel on the reversed utterance) in one launch, then one wave per
+    // frame for the gradient rows.  MS_CTC_WAVE=0 (read per call) keeps ctc_grad_kernel.
+    const char* we = getenv("MS_CTC_WAVE");
+    const size_t rows_lds = ((size_t)5 * S_max + V + 1) * sizeof(float);
+    if (!(we && we[0] == '0') && S_max <= 1024 && alpha_wave_lds(T) <= 160 * 1024 && rows_lds <= 64 * 1024 &&
+        (size_t)T * std::max(V, S_max) * sizeof(float) < (1ull << 31)) {
+      static ms::DeviceOnce once;
+      if (once.need()) {
+        MS_HIP(hipFuncSetAttribute((const void*)ctc_alpha_wave_kernel<1, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MS_HIP(hipFuncSetAttribute((const void*)ctc_alpha_wave_kernel<2, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MS_HIP(hipFuncSetAttribute((const void*)ctc_alpha_wave_kernel<4, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MS_HIP(hipFuncSetAttribute((const void*)ctc_grad_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        once.done();
+      }
+      char* wsb = (char*)workspace;
+      const size_t rows_bytes = ms::align_up((size_t)T * N * S_max * sizeof(float), 256);
+      float* alpha_rows = (float*)(wsb + ms::align_up((size_t)T * N * sizeof(float), 256));
+      float* beta_rows = (float*)((char*)alpha_rows + rows_bytes);
+      float* lpn = (float*)((char*)beta_rows + rows_bytes);
+      float* ll2 = (float*)((char*)lpn + ms::align_up((size_t)T * N * V * sizeof(float), 256));
+      const int lpi = (zero_infinity & MS_CTC_LOG_PROBS_IN) ? 1 : 0;
+      const size_t wl = alpha_wave_lds(T);
+      hipStream_t st = (hipStream_t)stream;
+      // alpha and beta (= the reversed recursion) side by side: grid (N, 2)
+      if (S_max <= 256)
+        hipLaunchKernelGGL((ctc_alpha_wave_kernel<1, 16, true>), dim3(N, 2), dim3(CTC_THREADS), wl, st, logits, in_lens, targets,
+                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows);
+      else if (S_max <= 512)
+        hipLaunchKernelGGL((ctc_alpha_wave_kernel<2, 16, true>), dim3(N, 2), dim3(CTC_THREADS), wl, st, logits, in_lens, targets,
+                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows);
+      else
+        hipLaunchKernelGGL((ctc_alpha_wave_kernel<4, 8, true>), dim3(N, 2), dim3(CTC_THREADS), wl, st, logits, in_lens, targets,
+                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows);
+      MS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(ctc_grad_rows_kernel, dim3(ms::cdiv(T, 4 * GR_FRAMES), N), dim3(CTC_THREADS), rows_lds, st, lpn, alpha_rows,
+                         beta_rows, ll2, in_lens, targets, tgt_offsets, tgt_lens, grad_nll, grad_logits, T, N, V, S_max, blank,
+                         zero_infinity & 1);
+      MS_LAUNCH_CHECK();
+      return MS_OK;
+    }
   }
   const size_t lds = (size_t)4 * S_max * sizeof(float);
   constexpr size_t GRAD_LDS_MAX = 160 * 1024 - 256;   // the kernel also has a static word

@@ -552,6 +552,54 @@ def test_ctc_alpha_wave_pipeline_vs_the_lds_row_kernel_and_the_oracle(Tn, N, V, 
         np.testing.assert_allclose(got[fin], want[fin], rtol=2e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize("Tn,N,V,L,zi", [(501, 8, 29, 120, False), (64, 9, 29, 20, True), (17, 4, 5, 3, False), (16, 3, 7, 8, True),
+                                         (33, 5, 29, 16, False), (2, 3, 4, 1, True), (1, 2, 4, 1, False), (300, 5, 29, 128, False),
+                                         (400, 4, 29, 200, True), (700, 3, 33, 400, False)])
+def test_ctc_gradient_pipeline_vs_the_lds_row_kernel_and_the_oracle(Tn, N, V, L, zi, monkeypatch):
+    """The backward of the loss on the pipeline path (alpha rows, beta rows = the same kernel on the reversed utterance,
+    then one wave per frame for the gradient row; csrc/ctc.hip) against ``ctc_grad_kernel`` (MS_CTC_WAVE=0, read per call) and
+    against the oracle: ragged and empty inputs, empty and impossible targets (with and without ``zero_infinity``), repeated
+    labels, every states-per-lane form."""
+    from myrtlespeech_amd.loss.ctc_loss import CTCLoss
+    rng = np.random.default_rng(Tn * 11 + L)
+    x = (rng.normal(size=(Tn, N, V)) * 2).astype(np.float32)
+    xl = rng.integers(max(1, Tn // 2), Tn + 1, size=N).astype(np.int32)
+    xl[0] = Tn
+    if N > 2:
+        xl[-1] = 0
+    yl = rng.integers(0, L + 1, size=N).astype(np.int32)
+    yl[0] = L
+    if N > 1:
+        yl[1] = 0
+    if N > 3:
+        xl[2], yl[2] = max(1, L // 2), L            # more labels than frames: no path
+    y = rng.integers(0, V - 1, size=(N, max(L, 1))).astype(np.int32)
+    for i in range(1, y.shape[1]):
+        y[:, i] = np.where(rng.random(N) < 0.2, y[:, i - 1], y[:, i])
+    wts = rng.uniform(0.5, 1.5, size=N).astype(np.float32)
+    loss = CTCLoss(blank=V - 1, reduction="none", zero_infinity=zi)
+    grads = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MS_CTC_WAVE", flag)
+        xt = T(x).cuda().requires_grad_(True)
+        out = loss((xt, T(xl)), (T(y), T(yl)))
+        fin = torch.isfinite(out)
+        (out[fin] * T(wts).cuda()[fin]).sum().backward()
+        grads.append(cpu(xt.grad))
+    old, got = grads
+    assert np.isfinite(got).all() == np.isfinite(old).all()
+    # float32 log-domain values of magnitude ~T carry ~T 2^-24 of absolute error into a posterior (both kernels, and the
+    # reference's float32 path): 1e-4 at a few hundred frames, 1e-3 at 501 (the tolerance of the config-size tests)
+    # (measured against the float64 oracle, tools/ctc_grad_err.py: both kernels 6e-4 .. 2.6e-3 at 501 frames, 1e-4 at 64)
+    tol = 3e-4 if Tn <= 128 else 4e-3
+    np.testing.assert_allclose(got, old, rtol=1e-4, atol=2 * tol)
+    if Tn * L <= 501 * 130:
+        nll = O.ctc_loss(x, xl, y, yl, V - 1, "none")
+        ok = np.isfinite(nll)                      # utterances with a path (the others: zeros or softmax rows, checked above)
+        want = O.ctc_grad(x[:, ok], xl[ok], y[ok], yl[ok], wts[ok], V - 1, zi)
+        np.testing.assert_allclose(got[:, ok], want, rtol=1e-3, atol=tol)
+
+
 def test_greedy_golden():
     from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
     g = Golden("greedy_ties")

@@ -176,6 +176,49 @@ def leg_ctc_loss(ctx):
     return out
 
 
+def leg_ctc_grad(ctx):
+    """CTC loss forward + backward (the alpha-beta posteriors = the gradient with respect to the logits; loss/ctc_loss.py:95-101
+    under autograd), [501, 32, 29], targets 32 x 120, reduction sum."""
+    from myrtlespeech_amd.loss.ctc_loss import CTCLoss
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(501, 32, 29, generator=g).cuda().requires_grad_(True)
+    lens = torch.full((32,), 501, dtype=torch.int32)
+    tgt = torch.randint(0, 28, (32, 120), dtype=torch.int32, generator=g)
+    tl = torch.full((32,), 120, dtype=torch.int32)
+    loss = CTCLoss(blank=28, reduction="sum")
+
+    def step():
+        logits.grad = None
+        loss((logits, lens), (tgt, tl)).backward()
+    ms, ms_min = ev_timed(step, 3, 20)
+    b_us = ctx["barrier_step_us"]
+    rows = 501 * 32 * 241 * 4
+    floor = 2 * 501 * b_us * 1e-3 + (4 * rows + 3 * 501 * 32 * 29 * 4) / (HBM_GBS * 1e6)
+    out = {"workload": "CTC loss forward + backward, logits [501,32,29], targets 32 x 120, reduction sum",
+           "ms": round(ms, 4), "ms_min": round(ms_min, 4), "floor_ms": round(floor, 4), "frac_of_floor": round(floor / ms, 3),
+           "floor": f"two dependent chains (alpha, beta) of 501 frames x {b_us:.3f} us (measured barrier phase) + alpha / beta rows "
+                    "written and read once + logits read, gradient written, at 8 TB/s.  Kernels: the forward pipeline, the same "
+                    "kernel twice more with row stores (alpha, and reversed = beta), one wave per frame for the gradient rows "
+                    "(csrc/ctc.hip); the LDS-row kernel this replaced took 26 ms"}
+    if ctx.get("cpu"):
+        x = logits.detach().cpu().requires_grad_(True)
+        f = torch.nn.CTCLoss(blank=28, reduction="sum")
+        lsm = torch.nn.LogSoftmax(dim=-1)
+
+        def cpu_step():
+            x.grad = None
+            f(lsm(x), tgt, lens, tl).backward()
+        cpu_step()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            cpu_step()
+        dt = (time.perf_counter() - t0) / reps
+        out["cpu_baseline"] = {"value": round(dt * 1e3, 3), "unit": "ms", "cores": ctx["cores"], "kind": "port",
+                               "sample": f"{reps} forward + backward passes of LogSoftmax + torch.nn.CTCLoss on the same tensors"}
+    return out
+
+
 def leg_ctc_beam(ctx):
     """CTC prefix beam search, softmax(randn(501, 32, 29) * 12), beam 8 (ctc_beam_decoder.py:175-258)."""
     from myrtlespeech_amd.post_process.ctc_beam_decoder import CTCBeamDecoder
@@ -422,7 +465,8 @@ def leg_frontend(ctx):
             "ms": round(ms, 3), "audio_sec_per_s": round(320.0 / ms * 1e3, 0), "legacy_mfcc26_32x4s_ms": round(ms_l, 3)}
 
 
-LEGS = {"ds1": ("cfg1_ds1", leg_ds1), "ctc": ("ctc_loss", leg_ctc_loss), "beam": ("ctc_beam_decode", leg_ctc_beam),
+LEGS = {"ds1": ("cfg1_ds1", leg_ds1), "ctc": ("ctc_loss", leg_ctc_loss), "ctcgrad": ("ctc_loss_backward", leg_ctc_grad),
+        "beam": ("ctc_beam_decode", leg_ctc_beam),
         "rnnt": ("cfg4_rnnt", leg_rnnt), "stream": ("cfg5_streaming", leg_stream), "streamctx": ("stream_carried_context", leg_stream_context),
         "frontend": ("frontend", leg_frontend)}
 
