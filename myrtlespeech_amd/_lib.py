@@ -160,6 +160,40 @@ def f32c(t):
 _ASYNC_LENS = os.environ.get("MS_ASYNC_LENS") != "0"
 
 
+# Constant length tensors for HIP-graph captures.  A captured forward (streaming.py) sees only lengths that are all equal (a
+# steady-state chunk); made by ``torch.full`` inside the capture they become fill NODES that run at every replay -- about
+# seven ~4.6 us launches per chunk (1 055 us).  The eager warm-up pass that precedes every capture leaves the constants here
+# (made outside any capture, so they belong to no graph's pool), and the capture picks them up instead of recording fills.
+# Entries are keyed on (shape, dtype, value) and dropped if somebody edited the tensor in place.
+_const_lens = {}
+
+
+def _const_tensor(shape, dtype, value, make: bool):
+    key = (tuple(shape), dtype, int(value))
+    rec = _const_lens.get(key)
+    if rec is not None:
+        t, version = rec
+        if version_of(t) == version:
+            return t
+        del _const_lens[key]
+    if not make:
+        return None
+    if len(_const_lens) > 512:
+        _const_lens.clear()
+    t = torch.full(tuple(shape), int(value), dtype=dtype, device="cuda")
+    _const_lens[key] = (t, version_of(t))
+    return t
+
+
+def _all_equal_value(h: torch.Tensor):
+    """The common value of a small integer host tensor whose elements are all equal, else None."""
+    if h.numel() == 0 or h.numel() > 4096 or h.dtype not in (torch.int32, torch.int64):
+        return None
+    flat = h.reshape(-1)
+    v = int(flat[0])
+    return v if bool((flat == v).all()) else None
+
+
 def upload(host: torch.Tensor, dtype=None) -> torch.Tensor:
     """Small host tensor -> device without stalling the host: a pageable ``.cuda()`` is stream-ordered AND blocks the host
     until the device gets there, i.e. it drains the launch queue in the middle of a forward.  Pinned + non_blocking does
@@ -173,8 +207,13 @@ def upload(host: torch.Tensor, dtype=None) -> torch.Tensor:
         # lengths of a steady-state chunk are all equal, and a fill kernel makes those on the device
         flat = h.reshape(-1)
         if flat.numel() and bool((flat == flat[0]).all()):
-            return torch.full(h.shape, flat[0].item(), dtype=h.dtype, device="cuda")
+            c = _const_tensor(h.shape, h.dtype, flat[0].item(), make=False) if h.dtype in (torch.int32, torch.int64) else None
+            return c if c is not None else torch.full(h.shape, flat[0].item(), dtype=h.dtype, device="cuda")
         raise RuntimeError("host values that differ cannot be uploaded inside a HIP graph capture")
+    if torch.cuda.is_available():
+        v = _all_equal_value(h)
+        if v is not None:
+            _const_tensor(h.shape, h.dtype, v, make=True)      # for a capture of the same forward that may follow
     if not _ASYNC_LENS:
         return h.cuda()
     try:
@@ -233,6 +272,15 @@ def lens_to_device(lens: torch.Tensor) -> torch.Tensor:
 def lens_i32(lens):
     """int32 device copy of a lengths tensor."""
     if lens.is_cuda:
+        if lens.dtype == torch.int32 and lens.is_contiguous():
+            return lens
+        h = cached_host(lens) if _ASYNC_LENS else None
+        if h is not None:                      # the conversion kernel of a captured forward is a node of every replay
+            v = _all_equal_value(h)
+            if v is not None:
+                c = _const_tensor(lens.shape, torch.int32, v, make=not torch.cuda.is_current_stream_capturing())
+                if c is not None and torch.cuda.is_current_stream_capturing():
+                    return c
         return lens.to(torch.int32).contiguous()
     return upload(lens, torch.int32)
 
@@ -260,8 +308,11 @@ class Workspace:
     def __init__(self):
         self.buf = None
 
-    def get(self, nbytes):
+    def get(self, nbytes, zero: bool = True):
         if self.buf is None or self.buf.numel() < nbytes:
-            # zero-filled: the recurrent layers keep a sticky time-out word in the first bytes (ms_rnn_status)
-            self.buf = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device="cuda")
+            # zero-filled: the recurrent layers keep a sticky time-out word in the first bytes (ms_rnn_status); pure scratch
+            # (``zero=False``: the linear layers' operand planes) is not -- allocated inside a HIP-graph capture the fill
+            # would be a node of every replay
+            make = torch.zeros if zero else torch.empty
+            self.buf = make(max(int(nbytes), 256), dtype=torch.uint8, device="cuda")
         return self.buf

@@ -186,6 +186,9 @@ def _mask_in_place(acts: torch.Tensor, seq_lens: torch.Tensor):
     """MaskConv*._mask_ (cnn.py:280-293, 425-443) on the caller's tensor."""
     if acts.is_cuda and acts.dtype == torch.float32 and acts.is_contiguous():
         n, t = acts.shape[0], acts.shape[-1]
+        h = _lib.host_lens(seq_lens)
+        if h.numel() == n and n and int(h.min()) >= t:
+            return True          # every sequence fills the tensor: nothing to zero (a steady-state streaming chunk)
         inner = acts.numel() // (n * t)
         lens_dev = _lib.lens_i32(seq_lens)  # keep alive until the launch is enqueued
         _lib.check(_lib.load().ms_mask_time_(_lib.ptr(acts), _lib.ptr(lens_dev), n, inner, t, _lib.stream_ptr()),

@@ -75,14 +75,14 @@ def run_linear_stack(x2d: torch.Tensor, plan) -> torch.Tensor:
         w = _lib.f32c(lin.weight.detach())
         b = None if lin.bias is None else _lib.f32c(lin.bias.detach())
         if _lib.split_precision() and k % 32 == 0 and 2.0 * m * k * n >= _SPLIT_MIN_FLOPS:
-            ws = _stream_workspace().get(lib.ms_linear_split_workspace_bytes(m, k, n))
+            ws = _stream_workspace().get(lib.ms_linear_split_workspace_bytes(m, k, n), zero=False)
             _lib.check(lib.ms_linear_split_forward(_lib.ptr(h), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), m, k, n, a, lo, hi,
                                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "ms_linear_split_forward")
         else:
             # an output layer (<= 64 columns): K slices, added in slice order (ms_linear_splitk_forward); 0 bytes = not such a
             # layer, and the call is ms_linear_forward
             nb = lib.ms_linear_splitk_workspace_bytes(m, k, n) if _SPLITK else 0
-            ws = _stream_workspace().get(nb) if nb else None
+            ws = _stream_workspace().get(nb, zero=False) if nb else None
             _lib.check(lib.ms_linear_splitk_forward(_lib.ptr(h), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), m, k, n, a, lo, hi,
                                                     _lib.ptr(ws), nb, _lib.stream_ptr()), "ms_linear_splitk_forward")
         h = y
