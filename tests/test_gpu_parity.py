@@ -746,6 +746,37 @@ def test_streaming_with_carried_context_hip_graph_replay_equals_the_eager_pushes
     assert replays > 0, "no chunk size reached a steady state: the graph path was not exercised"
 
 
+@pytest.mark.parametrize("kt,st,chunk", [(1, 3, 5), (1, 3, 6), (2, 3, 5), (3, 2, 7), (5, 1, 4)])
+def test_streaming_carried_context_graph_with_strides_wider_than_kernels(kt, st, chunk):
+    """A time stride wider than the kernel leaves gaps between a convolution's windows: a push that STARTED inside a gap
+    consumed fewer frames than the next push of the same size will, and must not be taken for the steady state a graph is
+    captured from (tests/soak.py seed 94000234: kernel 1, stride 3, chunks of 5).  Graph replay == eager pushes == the oracle's
+    full-utterance forward."""
+    from myrtlespeech_amd.streaming import ChunkedDeepSpeech2
+    cfg = dict(convs=[dict(kind="conv2d", idx=0, in_channels=1, out_channels=6, kernel=[3, kt], stride=[2, st], same=True,
+                           act=(0.0, 20.0)),
+                      dict(kind="conv2d", idx=2, in_channels=6, out_channels=7, kernel=[5, 1], stride=[1, 1], same=True,
+                           act=(0.0, 20.0))],
+               rnn=dict(kind=0, input=84, hidden=64, layers=1, bidirectional=False, forget_gate_bias=1.0),
+               lookahead=dict(context=4, act=None),
+               fc=dict(in_features=64, out_features=5, n_hidden=1, hidden=19, act=(0.0, 20.0)))
+    torch.manual_seed(kt * 100 + st * 10 + chunk)
+    m = build_ds2(cfg).eval()
+    rng = np.random.default_rng(chunk)
+    N, Tn = 3, 97
+    x = rng.normal(size=(N, 1, 24, Tn)).astype(np.float32)
+    lens = np.array([Tn, Tn - 9, Tn - 30])
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    want, wl, _ = O.deep_speech_2_forward(x, lens, cfg, sd)
+    (ye, le), _ = ChunkedDeepSpeech2(m, chunk, carry_context=True, use_graph=False)(T(x.copy()), T(lens))
+    g = ChunkedDeepSpeech2(m, chunk, carry_context=True, use_graph=True)
+    (yg, lg), _ = g(T(x.copy()), T(lens))
+    assert g.graph_error is None, g.graph_error
+    assert torch.equal(yg, ye) and torch.equal(lg, le)
+    for n in range(N):
+        np.testing.assert_allclose(cpu(yg)[:wl[n], n], want[:wl[n], n], rtol=2e-4, atol=2e-4)
+
+
 def test_streaming_with_carried_context_shipped_architecture_vs_full_utterance_reference():
     """The reference's SHIPPED config shape (2 x conv2d, 3 x GRU-2560 unidirectional, lookahead 80, FC 1 x 1024;
     configs/deep_speech_2_en.config:19-93) streamed in 320 ms chunks with carried context against the reference's
