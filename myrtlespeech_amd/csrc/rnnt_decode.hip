@@ -590,7 +590,6 @@ struct BeamP {
 // surgery then runs in LDS, and the trie insertions of the picked extensions go out in parallel.
 __global__ __launch_bounds__(256) void beam_round_kernel(BeamP p, int t, int region, int first, int last) {
   extern __shared__ __attribute__((aligned(16))) float cand[];  // [w * V1] log-probabilities, then candidate scores
-  __shared__ float wv[4];
   __shared__ int wi[4];
   __shared__ int pick_idx[32];
   __shared__ float pick_val[32];
@@ -659,35 +658,35 @@ __global__ __launch_bounds__(256) void beam_round_kernel(BeamP p, int t, int reg
     cand[c] = (k == blank || !isfinite(s)) ? -INFINITY : s;
   }
   __syncthreads();
-  for (int q = 0; q < w; ++q) {
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int c = tid; c < C; c += 256) {
-      const float v = cand[c];
-      if (v > bv) { bv = v; bi = c; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    if (lane == 0) { wv[wave] = bv; wi[wave] = bi; }
-    __syncthreads();
-    if (tid == 0) {
-      float fv = wv[0];
-      int fi = wi[0];
-      for (int x = 1; x < 4; ++x)
-        if (wv[x] > fv || (wv[x] == fv && wi[x] < fi)) { fv = wv[x]; fi = wi[x]; }
-      if (fi != 0x7fffffff && fv > -INFINITY) {
-        pick_idx[n_pick] = fi;
-        pick_val[n_pick] = fv;
-        cand[fi] = -INFINITY;
-        ++n_pick;
+  // the w best, one after the other, by ONE wave (round 4: all four waves with two barriers and a serial merge per pick took
+  // most of the kernel's 14.7 us): a lane scans its candidates, the wave reduces (value desc, ties -> lowest flat index), lane 0
+  // records the pick and removes it -- a wave's LDS operations execute in order, so the next scan sees the removal
+  if (wave == 0) {
+    int npk = 0;
+    for (int q = 0; q < w; ++q) {
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int c = lane; c < C; c += 64) {
+        const float v = cand[c];
+        if (v > bv) { bv = v; bi = c; }
       }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if (bi == 0x7fffffff || !(bv > -INFINITY)) break;      // wave-uniform: nothing finite is left
+      if (lane == 0) {
+        pick_idx[npk] = bi;
+        pick_val[npk] = bv;
+        cand[bi] = -INFINITY;
+      }
+      ++npk;
     }
-    __syncthreads();
+    if (lane == 0) n_pick = npk;
   }
+  __syncthreads();
   const int np = n_pick;
   if (tid < np) {
     // distinct picks are distinct (parent, label) pairs, so their trie insertions are independent; node numbers are
