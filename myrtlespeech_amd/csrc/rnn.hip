@@ -105,13 +105,19 @@ bool use_split_gemm(int cell, int H, int ndir, int In) {
 // GRU whose recurrent weights fit the register files when cut into 10-unit workgroups (one per CU): H in {1280, 2560}
 // -- the reference's shipped DS2 config is 3 x GRU-2560, unidirectional.  MS_GRU_PERSISTENT=0 falls back to the per-step
 // streamed-weights kernel.
-constexpr int GRU_U = 10;
+// Hidden sizes of the persistent GRU and their tiling: U units per workgroup (3 U gate rows <= 32), KS = H / 128 k-steps per
+// wave.  2560 and 1280 (the reference's shipped width and half of it) since round 1; the other multiples of 128 (round 4)
+// because a GRU of any other width fell to one launch per step: GRU-1024 bidirectional 10.9 ms against 3.1 for the LSTM.
+constexpr int gru_units(int H) {
+  return (H == 2560 || H == 1280) ? 10 : (H == 2048 || H == 1536 || H == 1024 || H == 768 || H == 512) ? 8 : 0;
+}
 bool use_gru_persistent(int cell, int H, int ndir) {
   static const bool off = getenv("MS_GRU_PERSISTENT") && getenv("MS_GRU_PERSISTENT")[0] == '0';
   if (off || force_generic() || !want_split() || cell != MS_CELL_GRU) return false;
-  if (H != 1280 && H != 2560) return false;
+  const int U = gru_units(H);
+  if (U == 0) return false;
   const int cus = ms::num_cus();
-  return cus > 0 && ndir * (H / GRU_U) <= cus * std::min(1, persistent_blocks_per_cu(true));
+  return cus > 0 && ndir * (H / U) <= cus * std::min(1, persistent_blocks_per_cu(true));
 }
 
 // MS_LSTM_RING=<slots> (power of two, 2..128; default 2): exchange slots per (stream, plane) of the two-stream LSTM kernel
@@ -137,7 +143,7 @@ PackLayout pack_layout(int cell, int In, int H, int ndir) {
   L.wih = o; o += ms::align_up(ndir * GH * In * sizeof(float), 256);
   L.bias_x = o; o += ms::align_up(ndir * GH * sizeof(float), 256);
   size_t whh_bytes = ndir * GH * H * sizeof(float);
-  if (use_gru_persistent(cell, H, ndir)) whh_bytes = (size_t)ndir * (H / GRU_U) * 128 * H;  // 32 packed rows per workgroup
+  if (use_gru_persistent(cell, H, ndir)) whh_bytes = (size_t)ndir * (H / gru_units(H)) * 128 * H;  // 32 packed rows per workgroup
   L.whh = o; o += ms::align_up(whh_bytes, 256);
   L.bhh = o; o += ms::align_up(ndir * GH * sizeof(float), 256);
   L.total = o;
@@ -1859,8 +1865,8 @@ __device__ __forceinline__ void publish_elem(float hval, unsigned tag, __amdgpu_
 
 template <int KS, int U>
 __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
-  constexpr int H = 128 * KS, KG = H / 8, CH = 5, NCH = KS / CH;
-  static_assert(KS % CH == 0 && 3 * U <= 32 && 16 * U <= 256, "unsupported GRU tiling");
+  constexpr int H = 128 * KS, KG = H / 8, CH = KS % 5 == 0 ? 5 : KS % 4 == 0 ? 4 : 3, NCH = KS / CH;
+  static_assert(KS % CH == 0 && 3 * U <= 32 && 16 * U <= 256 && H % U == 0, "unsupported GRU tiling");
   constexpr int RED2 = 4 * 16 * RED_STRIDE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* red = smem;  // [stream][4 waves][16 rows][RED_STRIDE]
@@ -2093,9 +2099,11 @@ int persistent_blocks_per_cu(bool gru) {
     const size_t red = (size_t)RED_FLOATS * sizeof(float), big = ((size_t)1024 * 32 + RED_FLOATS) * sizeof(float);
     int nb;
     if (gru) {
-      const PersistentKernel ks[] = {{(const void*)gru_persistent_kernel<20, GRU_U>, red},
-                                     {(const void*)gru_persistent_kernel<10, GRU_U>, red}};
-      nb = min_blocks_per_cu(ks, 2);
+      const PersistentKernel ks[] = {{(const void*)gru_persistent_kernel<20, 10>, red}, {(const void*)gru_persistent_kernel<10, 10>, red},
+                                     {(const void*)gru_persistent_kernel<16, 8>, red},  {(const void*)gru_persistent_kernel<12, 8>, red},
+                                     {(const void*)gru_persistent_kernel<8, 8>, red},   {(const void*)gru_persistent_kernel<6, 8>, red},
+                                     {(const void*)gru_persistent_kernel<4, 8>, red}};
+      nb = min_blocks_per_cu(ks, 7);
     } else {
       // the heaviest instantiation of every LSTM family (all are __launch_bounds__(256, 1); registers and LDS are
       // what the API prices): LDS-resident weights at H = 1024, register-resident split / f32 weights at H = 1024
@@ -2238,9 +2246,10 @@ extern "C" int ms_rnn_pack(int cell, int In, int H, int ndir, const float* const
       }
       hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH)), dim3(256), 0, stream, bi, bx_d, GH);
       if (use_gru_persistent(cell, H, ndir)) {
-        unsigned short* dst = (unsigned short*)(base + L.whh) + (size_t)d * (H / GRU_U) * 64 * H;
-        hipLaunchKernelGGL(pack_whh_gru_kernel, dim3(blocks_for((size_t)(H / GRU_U) * (H / 8) * 256)), dim3(256), 0, stream,
-                           w_hh[d], dst, H, GRU_U);
+        const int U = gru_units(H);
+        unsigned short* dst = (unsigned short*)(base + L.whh) + (size_t)d * (H / U) * 64 * H;
+        hipLaunchKernelGGL(pack_whh_gru_kernel, dim3(blocks_for((size_t)(H / U) * (H / 8) * 256)), dim3(256), 0, stream,
+                           w_hh[d], dst, H, U);
       } else {
         hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d], whh_d, GH * H);
       }
@@ -2667,17 +2676,21 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       }
       g.hx = (float*)(ws + W.hx);
       g.status = (unsigned*)(ws + W.status);
-      g.steps = steps; g.N = std::min(32, N - n0); g.n_base = n0; g.N_total = N; g.ndir = ndir; g.J = H / GRU_U;
+      g.steps = steps; g.N = std::min(32, N - n0); g.n_base = n0; g.N_total = N; g.ndir = ndir; g.J = H / gru_units(H);
       g.ring_shift = rs;
       {
         static const int ps = getenv("MS_LSTM_POLL_SLEEP") ? atoi(getenv("MS_LSTM_POLL_SLEEP")) : 1;
         g.poll_sleep = ps > 0 ? ps : 1;
       }
       const size_t lds = (size_t)RED_FLOATS * sizeof(float);
-      if (H == 2560)
-        hipLaunchKernelGGL((gru_persistent_kernel<20, GRU_U>), dim3(ndir * g.J), dim3(256), lds, stream, g);
-      else
-        hipLaunchKernelGGL((gru_persistent_kernel<10, GRU_U>), dim3(ndir * g.J), dim3(256), lds, stream, g);
+      switch (H) {
+#define MS_GRU_CASE(HH, KS_, U_) \
+        case HH: hipLaunchKernelGGL((gru_persistent_kernel<KS_, U_>), dim3(ndir * g.J), dim3(256), lds, stream, g); break;
+        MS_GRU_CASE(2560, 20, 10) MS_GRU_CASE(1280, 10, 10) MS_GRU_CASE(2048, 16, 8) MS_GRU_CASE(1536, 12, 8)
+        MS_GRU_CASE(1024, 8, 8) MS_GRU_CASE(768, 6, 8) MS_GRU_CASE(512, 4, 8)
+#undef MS_GRU_CASE
+        default: ms::set_error("persistent GRU: unsupported hidden size"); return MS_ERR_UNSUPPORTED;
+      }
       MS_LAUNCH_CHECK();
     }
     return MS_OK;

@@ -103,7 +103,12 @@ def test_lstm_persistent_vs_oracle(H, N, T_, bidir):
                                                   ("GRU", 256, 70, 4, False, 64), ("BASIC_RNN", 64, 5, 6, True, 20),
                                                   ("BASIC_RNN", 192, 33, 3, False, 32), ("LSTM", 1280, 9, 3, False, 32),
                                                   ("GRU", 2560, 32, 3, False, 96), ("GRU", 1280, 40, 5, True, 64),
-                                                  ("GRU", 2560, 7, 4, False, 32)])
+                                                  ("GRU", 2560, 7, 4, False, 32),
+                                                  # round 4: the persistent GRU at the other multiples of 128 (8 units per workgroup)
+                                                  ("GRU", 1024, 32, 6, True, 64), ("GRU", 1024, 45, 4, False, 32),
+                                                  ("GRU", 512, 32, 7, True, 48), ("GRU", 768, 20, 5, True, 64),
+                                                  ("GRU", 1536, 33, 4, False, 32), ("GRU", 2048, 32, 3, False, 64),
+                                                  ("GRU", 2048, 9, 3, True, 32)])
 def test_streamed_weights_step_kernel_vs_oracle(kind, H, N, T_, bidir, In):
     """Cells / sizes outside the persistent LSTM: the MFMA step kernel that streams W_hh per step (H % 64 == 0: GRU,
     tanh-RNN, wide LSTM; 1, 2 and 4 batch tiles, a batch beyond 64) and the persistent register-resident GRU
