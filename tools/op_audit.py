@@ -34,7 +34,8 @@ def main():
     rows = []
     with torch.no_grad():
         for kind, H, bi, inp in [(RNNType.LSTM, 1024, True, 2048), (RNNType.LSTM, 512, True, 1024), (RNNType.LSTM, 768, False, 768),
-                                 (RNNType.LSTM, 320, True, 640), (RNNType.LSTM, 1000, True, 1000), (RNNType.GRU, 2560, False, 2560),
+                                 (RNNType.LSTM, 320, True, 640), (RNNType.LSTM, 1000, True, 1000), (RNNType.LSTM, 1280, True, 1280),
+                                 (RNNType.LSTM, 1536, True, 1536), (RNNType.LSTM, 2048, True, 2048), (RNNType.LSTM, 2048, False, 2048), (RNNType.GRU, 2560, False, 2560),
                                  (RNNType.GRU, 1280, True, 1280), (RNNType.GRU, 800, True, 800), (RNNType.GRU, 1024, True, 1024),
                                  (RNNType.BASIC_RNN, 1024, True, 1024)]:
             m = RNN(kind, inp, H, num_layers=1, bidirectional=bi, forget_gate_bias=1.0 if kind == RNNType.LSTM else None).eval()
