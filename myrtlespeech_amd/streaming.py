@@ -504,6 +504,12 @@ class ChunkedDeepSpeech2:
         if lens_cpu.numel() > 1 and bool((lens_cpu[:-1] < lens_cpu[1:]).any()):
             raise RuntimeError("lengths must be sorted in decreasing order")
         total = int(lens_cpu[0]) if total_frames is None else int(total_frames)
+        if self.use_graph:           # a graph holds the packed weights' addresses: a parameter that changed drops every graph
+            psig = tuple((p_.data_ptr(), _lib.version_of(p_)) for p_ in self.model.parameters())
+            if psig != self._graph_sig:
+                self._graphs.clear()
+                self._ctx_graphs.clear()
+                self._graph_sig = psig
         self._stream = _ContextStream(self.model, int(lens_cpu.numel()), total, lens_cpu, hx)
 
     def push(self, chunk: Optional[torch.Tensor], final: bool = False) -> Optional[torch.Tensor]:
@@ -529,12 +535,7 @@ class ChunkedDeepSpeech2:
             sig = st.steady_signature(chunk.shape)
             if sig is None:
                 return None
-            psig = tuple((p_.data_ptr(), _lib.version_of(p_)) for p_ in self.model.parameters())
-            if psig != self._graph_sig:      # a graph holds the packed weights' addresses: a changed parameter drops them all
-                self._graphs.clear()
-                self._ctx_graphs.clear()
-                self._graph_sig = psig
-            g = self._ctx_graphs.get(sig)
+            g = self._ctx_graphs.get(sig)        # (begin() dropped the graphs of an older parameter set)
             if g is not None and not g.can_replay(st, chunk):
                 return None
             if g is None:
