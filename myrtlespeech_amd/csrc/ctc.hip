@@ -156,9 +156,14 @@ __device__ __forceinline__ void alpha_wave_body(const float* __restrict__ lpn, c
 #define CTC_FENCE() asm volatile("" ::: "memory")
   const int lane = tid & 63, w = tid >> 6;
   const int s0 = tid * K;
+  // `lpn` rows: [T][V] log-probabilities (a state reads its label's column), or -- wide alphabets, `gathered` -- [T][S_max]
+  // with a column per STATE (a wave's load is then 256 contiguous bytes instead of 64 cache lines of a 4 KB row)
+  const int gathered = S_max < 0;
+  const int RS = gathered ? -S_max : V;
+  S_max = gathered ? -S_max : S_max;
   const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lpn), 0, (int)((size_t)T * V * sizeof(float)), 0x00020000);
-  const int V4 = V * 4;
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lpn), 0, (int)((size_t)T * RS * sizeof(float)), 0x00020000);
+  const int V4 = RS * 4;
   const int L = (S - 1) >> 1;
   int voff[K], voff_st[K];
   bool skip[K];
@@ -170,7 +175,7 @@ __device__ __forceinline__ void alpha_wave_body(const float* __restrict__ lpn, c
     const int li = s >> 1;                                             // label index of an odd state, in recursion order
     const int lab = (act && (s & 1)) ? tg[rev ? L - 1 - li : li] : blank;
     skip[j] = act && (s & 1) && s >= 3 && lab != blank && lab != tg[rev ? L - li : li - 1];
-    voff[j] = lab * 4;
+    voff[j] = gathered ? (act ? (rev ? S - 1 - s : s) : 0) * 4 : lab * 4;
     voff_st[j] = act ? (rev ? S - 1 - s : s) * 4 : 0x7fffffff;         // states past S: dropped by the buffer's range check
   }
   // frame t' of the recursion reads row t' (or Tn - 1 - t'); the scalar offset of a buffer access is NOT part of the range
@@ -376,7 +381,8 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
                                                                      int T, int N, int V, int blank, int log_probs_in,
                                                                      float* __restrict__ rows_ws = nullptr, int S_max = 0,
                                                                      int mode = 0, float* __restrict__ ll2_out = nullptr,
-                                                                     float* __restrict__ rows_ws_rev = nullptr) {
+                                                                     float* __restrict__ rows_ws_rev = nullptr,
+                                                                     float* __restrict__ lps_ws = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
   MbEntry* mb = reinterpret_cast<MbEntry*>(smem);   // [3][T] {alpha(top), alpha(top - 1)} of waves 0..2, per frame
@@ -391,22 +397,64 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
   if (blockIdx.y == 1) { mode |= 1; rows_ws = rows_ws_rev; ll2_out = nullptr; nll = nullptr; }
   float* rows = ROWS ? rows_ws + (size_t)n * T * S_max : nullptr;
   const int rev = mode & 1;
+  const bool wide_v = V > 64;                       // the recursion reads a per-state copy (lps) of the log-probabilities
+  float* lps = wide_v ? lps_ws + (size_t)n * T * S_max : nullptr;
 
   if (mode & 2) {
   } else if (V <= 32) alpha_wave_normalise<32>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
   else if (V <= 64) alpha_wave_normalise<64>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
   else {
-    for (int t = tid; t < Tn; t += CTC_THREADS) {
+    // wide alphabets (word pieces): a WAVE per frame, lanes across the symbols (coalesced row reads, wave reductions), a
+    // lane's share of the row in registers with every load of the row in flight at once -- a thread per frame, or one load
+    // per loop iteration, waited for each L2 round trip in turn: 1.07 ms per launch at V = 1 000, 0.3 ms now.  Rows beyond
+    // 64 x 16 symbols are walked in slabs of that size, the later passes re-reading them.  The recursion then reads a
+    // per-STATE copy of the row (lps: a wave's load is 256 contiguous bytes, not 64 cache lines of a 4 KB row)
+    const int lane = tid & 63;
+    constexpr int NV = 16;
+    for (int t = w; t < Tn; t += CTC_THREADS / 64) {
       const float* row = logits + ((size_t)t * N + n) * V;
       float lz = 0.f;
+      float r[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) r[i] = (lane + 64 * i < V) ? row[lane + 64 * i] : neg_inf();
       if (!log_probs_in) {
         float m = neg_inf();
-        for (int v = 0; v < V; ++v) m = fmaxf(m, row[v]);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) m = fmaxf(m, r[i]);
+        for (int v0 = 64 * NV; v0 < V; v0 += 64 * NV) {
+          float q[NV];
+#pragma unroll
+          for (int i = 0; i < NV; ++i) q[i] = (v0 + lane + 64 * i < V) ? row[v0 + lane + 64 * i] : neg_inf();
+#pragma unroll
+          for (int i = 0; i < NV; ++i) m = fmaxf(m, q[i]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
         float sum = 0.f;
-        for (int v = 0; v < V; ++v) sum += expf(row[v] - m);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sum += expf(r[i] - m);
+        for (int v0 = 64 * NV; v0 < V; v0 += 64 * NV) {
+          float q[NV];
+#pragma unroll
+          for (int i = 0; i < NV; ++i) q[i] = (v0 + lane + 64 * i < V) ? row[v0 + lane + 64 * i] : neg_inf();
+#pragma unroll
+          for (int i = 0; i < NV; ++i) sum += expf(q[i] - m);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
         lz = logf(sum) + m;
       }
-      for (int v = 0; v < V; ++v) lpn[(size_t)t * V + v] = fminf(fmaxf((row[v] - lz) * 1.4426950408889634f, CTC_NEG), -CTC_NEG);
+      if (ROWS) {                                   // every symbol's value: only the gradient kernel reads these
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          if (lane + 64 * i < V) lpn[(size_t)t * V + lane + 64 * i] = fminf(fmaxf((r[i] - lz) * 1.4426950408889634f, CTC_NEG), -CTC_NEG);
+        for (int v = 64 * NV + lane; v < V; v += 64)
+          lpn[(size_t)t * V + v] = fminf(fmaxf((row[v] - lz) * 1.4426950408889634f, CTC_NEG), -CTC_NEG);
+      }
+      for (int s2 = lane; s2 < S; s2 += 64) {
+        const int lab = (s2 & 1) ? tg[s2 >> 1] : blank;
+        lps[(size_t)t * S_max + s2] = fminf(fmaxf((row[lab] - lz) * 1.4426950408889634f, CTC_NEG), -CTC_NEG);
+      }
     }
   }
   for (int i = tid; i < 3 * T; i += CTC_THREADS) mb[i] = MbEntry{__uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu)};
@@ -420,9 +468,9 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
     return;
   }
   if (w * 64 * K < S) {   // wave-uniform: a wave without states has nothing downstream of it either
-    if (w == 0) alpha_wave_body<K, D, false, true, ROWS>(lpn, tg, fin, mb, T, Tn, V, S, blank, tid, rows, S_max, rev);
-    else if (w == 3) alpha_wave_body<K, D, true, false, ROWS>(lpn, tg, fin, mb, T, Tn, V, S, blank, tid, rows, S_max, rev);
-    else alpha_wave_body<K, D, true, true, ROWS>(lpn, tg, fin, mb, T, Tn, V, S, blank, tid, rows, S_max, rev);
+    if (w == 0) alpha_wave_body<K, D, false, true, ROWS>(wide_v ? lps : lpn, tg, fin, mb, T, Tn, V, S, blank, tid, rows, wide_v ? -S_max : S_max, rev);
+    else if (w == 3) alpha_wave_body<K, D, true, false, ROWS>(wide_v ? lps : lpn, tg, fin, mb, T, Tn, V, S, blank, tid, rows, wide_v ? -S_max : S_max, rev);
+    else alpha_wave_body<K, D, true, true, ROWS>(wide_v ? lps : lpn, tg, fin, mb, T, Tn, V, S, blank, tid, rows, wide_v ? -S_max : S_max, rev);
   }
   __syncthreads();
   if (tid == 0) {
@@ -744,7 +792,9 @@ extern "C" size_t ms_ctc_loss_workspace_bytes(int T, int N, int V, int S_max) {
   (void)S_max;
   if (T <= 0 || N <= 0 || V <= 0) return 0;
   // per-frame normalisers [T][N] (ctc_alpha_kernel) + the normalised log-probabilities [N][T][V] of the pipeline kernel
-  return ms::align_up((size_t)T * N * sizeof(float), 256) + ms::align_up((size_t)T * N * V * sizeof(float), 256);
+  // (wide alphabets, V > 64: the recursion reads a per-state copy [N][T][S_max] instead)
+  return ms::align_up((size_t)T * N * sizeof(float), 256) +
+         ms::align_up((size_t)T * N * (V > 64 ? std::max(S_max, 1) : V) * sizeof(float), 256);
 }
 
 extern "C" int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, const int32_t* targets,
@@ -782,13 +832,16 @@ extern "C" int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, 
     const size_t wl = alpha_wave_lds(T);
     if (S_max <= 256)
       hipLaunchKernelGGL((ctc_alpha_wave_kernel<1, 16>), dim3(N), dim3(CTC_THREADS), wl, (hipStream_t)stream, logits, in_lens,
-                         targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi);
+                         targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi, (float*)nullptr, S_max, 0, (float*)nullptr,
+                         (float*)nullptr, lpn_ws);
     else if (S_max <= 512)
       hipLaunchKernelGGL((ctc_alpha_wave_kernel<2, 16>), dim3(N), dim3(CTC_THREADS), wl, (hipStream_t)stream, logits, in_lens,
-                         targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi);
+                         targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi, (float*)nullptr, S_max, 0, (float*)nullptr,
+                         (float*)nullptr, lpn_ws);
     else
       hipLaunchKernelGGL((ctc_alpha_wave_kernel<4, 8>), dim3(N), dim3(CTC_THREADS), wl, (hipStream_t)stream, logits, in_lens,
-                         targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi);
+                         targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi, (float*)nullptr, S_max, 0, (float*)nullptr,
+                         (float*)nullptr, lpn_ws);
   } else {
     hipLaunchKernelGGL(ctc_alpha_kernel, dim3(N), dim3(CTC_THREADS), lds, (hipStream_t)stream, logits, in_lens, targets,
                        tgt_offsets, tgt_lens, nll, (float*)workspace, T, N, V, S_max, blank, lpi);
@@ -872,7 +925,7 @@ extern "C" size_t ms_ctc_loss_backward_workspace_bytes(int T, int N, int V, int 
   if (T <= 0 || N <= 0 || S_max < 1 || V <= 0) return 0;
   // normalisers [T][N] + alpha rows [N][T][S_max] (ctc_grad_kernel); + beta rows, the normalised log-probabilities [N][T][V] and
   // the log-likelihoods [N] of the pipeline path
-  return ms::align_up((size_t)T * N * sizeof(float), 256) + 2 * ms::align_up((size_t)T * N * S_max * sizeof(float), 256) +
+  return ms::align_up((size_t)T * N * sizeof(float), 256) + (V > 64 ? 3 : 2) * ms::align_up((size_t)T * N * S_max * sizeof(float), 256) +
          ms::align_up((size_t)T * N * V * sizeof(float), 256) + ms::align_up((size_t)N * sizeof(float), 256);
 }
 
@@ -909,19 +962,20 @@ extern "C" int ms_ctc_loss_backward(const float* logits, const int32_t* in_lens,
       float* beta_rows = (float*)((char*)alpha_rows + rows_bytes);
       float* lpn = (float*)((char*)beta_rows + rows_bytes);
       float* ll2 = (float*)((char*)lpn + ms::align_up((size_t)T * N * V * sizeof(float), 256));
+      float* lps = (float*)((char*)ll2 + ms::align_up((size_t)N * sizeof(float), 256));     // wide alphabets only
       const int lpi = (zero_infinity & MS_CTC_LOG_PROBS_IN) ? 1 : 0;
       const size_t wl = alpha_wave_lds(T);
       hipStream_t st = (hipStream_t)stream;
       // alpha and beta (= the reversed recursion) side by side: grid (N, 2)
       if (S_max <= 256)
         hipLaunchKernelGGL((ctc_alpha_wave_kernel<1, 16, true>), dim3(N, 2), dim3(CTC_THREADS), wl, st, logits, in_lens, targets,
-                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows);
+                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows, lps);
       else if (S_max <= 512)
         hipLaunchKernelGGL((ctc_alpha_wave_kernel<2, 16, true>), dim3(N, 2), dim3(CTC_THREADS), wl, st, logits, in_lens, targets,
-                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows);
+                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows, lps);
       else
         hipLaunchKernelGGL((ctc_alpha_wave_kernel<4, 8, true>), dim3(N, 2), dim3(CTC_THREADS), wl, st, logits, in_lens, targets,
-                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows);
+                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows, lps);
       MS_LAUNCH_CHECK();
       hipLaunchKernelGGL(ctc_grad_rows_kernel, dim3(ms::cdiv(T, 4 * GR_FRAMES), N), dim3(CTC_THREADS), rows_lds, st, lpn, alpha_rows,
                          beta_rows, ll2, in_lens, targets, tgt_offsets, tgt_lens, grad_nll, grad_logits, T, N, V, S_max, blank,

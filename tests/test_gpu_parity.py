@@ -519,7 +519,8 @@ def test_ctc_loss_full_size_vs_oracle():
 
 @pytest.mark.parametrize("Tn,N,V,L", [(501, 32, 29, 120), (64, 9, 29, 20), (17, 4, 5, 3), (16, 3, 7, 8), (15, 3, 7, 7),
                                       (33, 5, 29, 16), (2, 3, 4, 1), (1, 2, 4, 1), (700, 6, 40, 255), (300, 5, 29, 128),
-                                      (400, 4, 29, 200), (900, 3, 33, 400), (1200, 2, 29, 511), (1300, 2, 29, 600)])
+                                      (400, 4, 29, 200), (900, 3, 33, 400), (1200, 2, 29, 511), (1300, 2, 29, 600),
+                                      (120, 3, 100, 30), (90, 2, 300, 25), (60, 2, 65, 12)])     # wide alphabets: a wave per frame
 def test_ctc_alpha_wave_pipeline_vs_the_lds_row_kernel_and_the_oracle(Tn, N, V, L, monkeypatch):
     """The four-wave pipeline (alphas in registers, DPP + a per-frame LDS mailbox; csrc/ctc.hip) against the LDS-row kernel it
     replaced (MS_CTC_WAVE=0, read per call) and against the oracle.  (Its first form shared lse3 with that kernel and was
@@ -559,7 +560,8 @@ def test_ctc_alpha_wave_pipeline_vs_the_lds_row_kernel_and_the_oracle(Tn, N, V, 
 
 @pytest.mark.parametrize("Tn,N,V,L,zi", [(501, 8, 29, 120, False), (64, 9, 29, 20, True), (17, 4, 5, 3, False), (16, 3, 7, 8, True),
                                          (33, 5, 29, 16, False), (2, 3, 4, 1, True), (1, 2, 4, 1, False), (300, 5, 29, 128, False),
-                                         (400, 4, 29, 200, True), (700, 3, 33, 400, False)])
+                                         (400, 4, 29, 200, True), (700, 3, 33, 400, False), (100, 3, 130, 20, False),
+                                         (80, 2, 70, 15, True)])
 def test_ctc_gradient_pipeline_vs_the_lds_row_kernel_and_the_oracle(Tn, N, V, L, zi, monkeypatch):
     """The backward of the loss on the pipeline path (alpha rows, beta rows = the same kernel on the reversed utterance,
     then one wave per frame for the gradient row; csrc/ctc.hip) against ``ctc_grad_kernel`` (MS_CTC_WAVE=0, read per call) and
