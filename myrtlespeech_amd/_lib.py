@@ -175,11 +175,14 @@ def _const_tensor(shape, dtype, value, make: bool):
         t, version = rec
         if version_of(t) == version:
             return t
+        # edited in place by somebody: graphs that hold it read the edited values (as they would with a tensor of their own);
+        # the entry is kept alive but no longer handed out
+        _const_lens[("stale", len(_const_lens)) + key] = rec
         del _const_lens[key]
-    if not make:
+    if not make or len(_const_lens) >= 4096:
+        # (full: no new entries -- a captured graph holds the ADDRESS of every constant it picked up, so entries are never
+        # evicted; a capture that finds none records a fill node as before)
         return None
-    if len(_const_lens) > 512:
-        _const_lens.clear()
     t = torch.full(tuple(shape), int(value), dtype=dtype, device="cuda")
     _const_lens[key] = (t, version_of(t))
     return t
