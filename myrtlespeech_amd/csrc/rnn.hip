@@ -70,11 +70,19 @@ bool force_generic() {
 // and run by the per-step kernels, which need no co-residency.
 int persistent_blocks_per_cu(bool gru);
 
+// LSTM widths beyond 1024 (round 4): the two-stream kernel with a wave's K-quarter of 32 gate rows x H in 16 H / 128 VGPRs per
+// lane (256 at H = 2048) -- bf16x3 operands only, H / 8 workgroups per direction, the directions of a bidirectional layer in
+// two launches when they do not fit the CUs together.  They had one launch per step: 15 .. 21 ms per layer at [501, 32, H].
+bool wide_lstm_h(int H) { return H == 1280 || H == 1536 || H == 2048; }
 bool use_fast(int cell, int H, int ndir) {
   if (force_generic()) return false;
   if (!(cell == MS_CELL_LSTM || cell == MS_CELL_HARD_LSTM)) return false;
-  if (H % 32 != 0 || H > 1024) return false;
   const int cus = ms::num_cus();
+  if (H > 1024) {
+    if (!wide_lstm_h(H) || cell != MS_CELL_LSTM || ms::precision_mode() != ms::PREC_BF16X3) return false;
+    return cus > 0 && (H / 8) <= cus * std::min(1, persistent_blocks_per_cu(false));
+  }
+  if (H % 32 != 0) return false;
   return cus > 0 && ndir * (H / 8) <= cus * std::min(1, persistent_blocks_per_cu(false));
 }
 
@@ -83,7 +91,7 @@ bool use_fast(int cell, int H, int ndir) {
 // hi*lo accumulated in f32 (relative error ~2^-17 per product instead of 2^-24).
 bool want_split() { return ms::precision_mode() != ms::PREC_F32; }
 bool use_split(int cell, int H, int ndir) { return use_fast(cell, H, ndir) && want_split() && H % 64 == 0; }
-bool two_stream_shape(int H) { return H == 256 || H == 512 || H == 768 || H == 1024; }
+bool two_stream_shape(int H) { return H == 256 || H == 512 || H == 768 || H == 1024 || wide_lstm_h(H); }
 // MS_PRECISION=f32 on the two-stream shapes: float32-MFMA two-stream kernel with register-resident W_hh; h crosses
 // workgroups with its mantissa LSB used as the epoch tag (MS_LSTM_F32_ONE_STREAM=1 keeps the one-stream LDS-weights
 // kernel, whose exchange is bit-exact)
@@ -512,6 +520,7 @@ struct LstmP {
   unsigned* status;     // [0]: nonzero = a wait timed out
   unsigned long long* dbg;  // [ndir*J][8] stamp sums (diagnostic build only; the wide kernel: [workgroup][16])
   int steps, N, n_base, N_total, H, ndir, J, NPAD;
+  int d_base;      // two-stream kernel: direction of workgroup 0 (a bidirectional layer whose directions run as two launches)
   int poll_sleep;  // s_sleep(1) repetitions between polls of the exchange buffer
   int xcd_map;     // wide kernel: (group, direction) -> XCD pair (two groups, two directions, J / 2 = 64)
   int ring_shift;  // two-stream kernel: log2 of the number of exchange slots per (stream, plane) (1 = two slots)
@@ -1141,14 +1150,14 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 template <int KS, bool HARD, bool STAMP = false, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p) {
-  constexpr int H = 128 * KS, KG = H / 8;  // KS k-steps (K = 32) per wave; H in {256, 512, 768, 1024}
+  constexpr int H = 128 * KS, KG = H / 8;  // KS k-steps (K = 32) per wave; H in {256, 512, 768, 1024, 1280, 1536, 2048}
   constexpr int RED2 = 4 * 16 * RED_STRIDE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* red = smem;  // [stream][4 waves][16 rows][RED_STRIDE]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
-  const int d = blockIdx.x / p.J, j = blockIdx.x % p.J;
+  const int d = p.d_base + blockIdx.x / p.J, j = blockIdx.x % p.J;
   const int nl = (tid >> 3) & 15, u = tid & 7;  // cell threads are waves 0 and 1
   const int unit = 8 * j + u;
   const int N = p.N;
@@ -2113,6 +2122,7 @@ int persistent_blocks_per_cu(bool gru) {
           {(const void*)lstm_persistent_split_kernel<1, 4, false>, big},
           {(const void*)lstm_persistent_split_kernel<2, 0, false>, big},
           {(const void*)lstm_persistent_split2_kernel<8, false>, red},
+          {(const void*)lstm_persistent_split2_kernel<16, false>, red},
           {(const void*)lstm_persistent_split2_kernel<8, true>, red},
           {(const void*)lstm_persistent_split2_kernel<8, false, false, true>, red},
           {(const void*)lstm_persistent_f32x2_kernel<16, false>, red},
@@ -2296,6 +2306,16 @@ static int launch_split(const LstmP& p, hipStream_t stream) {
 template <int KS, bool HARD, bool STAMP = false, bool F16 = false>
 static int launch_split2(const LstmP& p, hipStream_t stream) {
   const size_t lds = (size_t)RED_FLOATS * sizeof(float);
+  if (p.ndir * p.J > ms::num_cus()) {
+    // every workgroup of a launch has to be resident: the directions of a wide bidirectional layer run one after the other
+    for (int d = 0; d < p.ndir; ++d) {
+      LstmP q = p;
+      q.d_base = d;
+      hipLaunchKernelGGL((lstm_persistent_split2_kernel<KS, HARD, STAMP, F16>), dim3(p.J), dim3(256), lds, stream, q);
+      MS_LAUNCH_CHECK();
+    }
+    return MS_OK;
+  }
   hipLaunchKernelGGL((lstm_persistent_split2_kernel<KS, HARD, STAMP, F16>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
   MS_LAUNCH_CHECK();
   return MS_OK;
@@ -2415,6 +2435,9 @@ static int launch_split2_any(const LstmP& p, bool hard, bool stamps, bool f16, h
     case 256: return hard ? launch_split2<2, true>(p, stream) : launch_split2<2, false>(p, stream);
     case 512: return hard ? launch_split2<4, true>(p, stream) : launch_split2<4, false>(p, stream);
     case 768: return hard ? launch_split2<6, true>(p, stream) : launch_split2<6, false>(p, stream);
+    case 1280: return launch_split2<10, false>(p, stream);      // (use_fast admits the wide shapes for the plain LSTM cell only)
+    case 1536: return launch_split2<12, false>(p, stream);
+    case 2048: return launch_split2<16, false>(p, stream);
     default:
       if (stamps && !hard) return launch_split2<8, false, true>(p, stream);
       return hard ? launch_split2<8, true>(p, stream) : launch_split2<8, false>(p, stream);
@@ -2565,6 +2588,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       p.flags = (unsigned*)(ws + W.flags);
       p.status = (unsigned*)(ws + W.status);
       p.steps = steps; p.N = ng; p.n_base = n0; p.N_total = N; p.H = H; p.ndir = ndir; p.J = H / 8;
+      p.d_base = 0;
       p.NPAD = ms::cdiv(ng, 32) * 32;
       {
         static const int ps = getenv("MS_LSTM_POLL_SLEEP") ? atoi(getenv("MS_LSTM_POLL_SLEEP")) : 1;
@@ -2602,7 +2626,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
         const bool hard_ = (cell == MS_CELL_HARD_LSTM);
         if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.row_off - W.dbg, stream));
         static const bool one_stream = getenv("MS_LSTM_ONE_STREAM") && getenv("MS_LSTM_ONE_STREAM")[0] == '1';
-        const bool two_stream = p.NPAD == 32 && two_stream_shape(H) && (!one_stream || use_f16(cell, H, ndir));
+        const bool two_stream = p.NPAD == 32 && two_stream_shape(H) && (!one_stream || use_f16(cell, H, ndir) || H > 1024);
         {
           // every word of every slot starts with the tag that is NOT the first one expected there
           const int rs = two_stream ? lstm_ring_shift() : 1;

@@ -108,7 +108,10 @@ def test_lstm_persistent_vs_oracle(H, N, T_, bidir):
                                                   ("GRU", 1024, 32, 6, True, 64), ("GRU", 1024, 45, 4, False, 32),
                                                   ("GRU", 512, 32, 7, True, 48), ("GRU", 768, 20, 5, True, 64),
                                                   ("GRU", 1536, 33, 4, False, 32), ("GRU", 2048, 32, 3, False, 64),
-                                                  ("GRU", 2048, 9, 3, True, 32)])
+                                                  ("GRU", 2048, 9, 3, True, 32),
+                                                  # ... and the two-stream LSTM beyond 1024 (a bidirectional layer's directions in two launches)
+                                                  ("LSTM", 1280, 32, 5, True, 64), ("LSTM", 1536, 20, 4, False, 32),
+                                                  ("LSTM", 2048, 32, 4, True, 64), ("LSTM", 2048, 40, 3, False, 32)])
 def test_streamed_weights_step_kernel_vs_oracle(kind, H, N, T_, bidir, In):
     """Cells / sizes outside the persistent LSTM: the MFMA step kernel that streams W_hh per step (H % 64 == 0: GRU,
     tanh-RNN, wide LSTM; 1, 2 and 4 batch tiles, a batch beyond 64) and the persistent register-resident GRU
@@ -1464,7 +1467,8 @@ def test_conv_cl_short_input_kernel_vs_oracle(monkeypatch):
         np.testing.assert_array_equal(cpu(nl), wl)
 
 
-@pytest.mark.parametrize("H,bidir,N,Tn", [(256, True, 37, 9), (512, False, 5, 12), (1024, True, 32, 6)])
+@pytest.mark.parametrize("H,bidir,N,Tn", [(256, True, 37, 9), (512, False, 5, 12), (1024, True, 32, 6), (1280, True, 20, 5),
+                                          (2048, False, 32, 4)])
 def test_lstm_stack_plane_chaining_is_bit_identical_to_single_layers(H, bidir, N, Tn):
     """A two-stream LSTM stack hands each layer's output to the next layer as GEMM operand planes inside the workspace
     (MS_RNN_OUT_PLANES_TO_WS / MS_RNN_X_PLANES_IN_WS); the same weights run as single-layer modules (float32 hand-over,
