@@ -195,6 +195,7 @@ constexpr int T6_TILE = 4 * T6_PLANE;             // one operand plane (hi or lo
 constexpr int T6_STAGE = 4 * T6_TILE;             // x hi, x lo, W hi, W lo
 constexpr int T6_LDS = 2 * T6_STAGE;
 
+template <bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_tile64_kernel(const unsigned short* __restrict__ Ah,
                                                                        const unsigned short* __restrict__ Al,
                                                                        const unsigned short* __restrict__ Wh,
@@ -229,14 +230,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_tile64_kernel(const uns
   auto load_block = [&](int kb, u32x4 (&r)[4]) {
     const int k0 = min(kb, nk - 1) * SB_K;      // past the end: the last block again (never stored)
     r[0] = *reinterpret_cast<const u32x4*>(pa_h + k0);
-    r[1] = *reinterpret_cast<const u32x4*>(pa_l + k0);
     r[2] = *reinterpret_cast<const u32x4*>(pb_h + k0);
-    r[3] = *reinterpret_cast<const u32x4*>(pb_l + k0);
+    if (!F16) {                                  // fp16 mode (MS_PRECISION=fp16): one plane per operand, one MFMA per half
+      r[1] = *reinterpret_cast<const u32x4*>(pa_l + k0);
+      r[3] = *reinterpret_cast<const u32x4*>(pb_l + k0);
+    }
   };
   auto store_block = [&](int stage, const u32x4 (&r)[4]) {
     char* st = lds + stage * T6_STAGE + kg * T6_PLANE + r_in * 16;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(st + p * T6_TILE) = r[p];
+    for (int p = 0; p < 4; ++p)
+      if (!F16 || (p & 1) == 0) *reinterpret_cast<u32x4*>(st + p * T6_TILE) = r[p];
   };
   auto compute = [&](int stage) {
     const char* st = lds + stage * T6_STAGE;
@@ -244,6 +248,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_tile64_kernel(const uns
     for (int s2 = 0; s2 < 2; ++s2) {
       const int g = 2 * s2 + half;
       const int offa = g * T6_PLANE + (wm * 32 + l31) * 16, offb = g * T6_PLANE + (wn * 32 + l31) * 16;
+      if (F16) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(st + offa));
+        const f16x8 bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(st + 2 * T6_TILE + offb));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        continue;
+      }
       const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + offa));
       const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + T6_TILE + offa));
       const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + 2 * T6_TILE + offb));
@@ -905,12 +915,19 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
   // FC layer at 64 streams: 1 024 x 1 024 = 32 tiles of 256 x 128, 256 of 64 x 64)
   auto tile64 = [&]() {
     const char* e = getenv("MS_GEMM_TILE64");
-    return !(e && e[0] == '0') && !f16 && !small_tile && m_eff == nullptr && g_gemm_variant.load(std::memory_order_relaxed) == 0 &&
+    return !(e && e[0] == '0') && !small_tile && m_eff == nullptr && g_gemm_variant.load(std::memory_order_relaxed) == 0 &&
            (long)cdiv(M, T6) * cdiv(N, T6) <= 2L * num_cus();
   };
+  auto launch_tile64 = [&]() {
+    if (f16)
+      hipLaunchKernelGGL(gemm_nt_bf16x3_tile64_kernel<true>, dim3(cdiv(M, T6) * cdiv(N, T6)), dim3(256), 0, stream, ah, al, wh, wl, bias, y,
+                         M, K, N, act, lo, hi);
+    else
+      hipLaunchKernelGGL(gemm_nt_bf16x3_tile64_kernel<false>, dim3(cdiv(M, T6) * cdiv(N, T6)), dim3(256), 0, stream, ah, al, wh, wl, bias, y,
+                         M, K, N, act, lo, hi);
+  };
   if (tile64() && (long)cdiv(M, S2_M) * cdiv(N, 128) * 4 <= (long)num_cus()) {
-    hipLaunchKernelGGL(gemm_nt_bf16x3_tile64_kernel, dim3(cdiv(M, T6) * cdiv(N, T6)), dim3(256), 0, stream, ah, al, wh, wl, bias, y, M, K,
-                       N, act, lo, hi);
+    launch_tile64();
     MS_LAUNCH_CHECK();
     return MS_OK;
   }
@@ -966,8 +983,7 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
   // small outputs (round 4): 64 x 64 tiles when they give at most two workgroups per CU -- the same sums, bit for bit.
   // MS_GEMM_TILE64=0 (read per call: the tests' A/B switch) keeps the 256 x 128 register-staged kernel
   if (tile64()) {
-    hipLaunchKernelGGL(gemm_nt_bf16x3_tile64_kernel, dim3(cdiv(M, T6) * cdiv(N, T6)), dim3(256), 0, stream, ah, al, wh, wl, bias, y, M, K,
-                       N, act, lo, hi);
+    launch_tile64();
     MS_LAUNCH_CHECK();
     return MS_OK;
   }

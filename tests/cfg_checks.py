@@ -362,3 +362,30 @@ def ds2_ragged_logits(path: str) -> None:
     torch.cuda.synchronize()
     np.savez(path, y=y.cpu().numpy(), ol=ol.cpu().numpy(), hn=hn.cpu().numpy(), cn=cn.cpu().numpy())
     print("ds2 ragged logits saved:", "all rows" if os.environ.get("MS_RNN_PACKED") == "0" else "packed rows")
+
+
+def tile64_matches_other_kernels(shapes=((512, 2560, 1024), (1024, 2048, 1024), (130, 96, 200))):
+    """The 64 x 64-tile split GEMM against the kernels it replaces (``MS_GEMM_TILE64=0``) in the PROCESS's precision mode
+    (run with ``MS_PRECISION=fp16`` for the single-pass fp16 form): the same k-ordered sums, ``torch.equal``."""
+    import os
+    import numpy as np
+    import torch
+    from myrtlespeech_amd import _lib
+    lib = _lib.load()
+    for M, K, N in shapes:
+        rng = np.random.default_rng(M + K + N)
+        x = torch.from_numpy(rng.normal(size=(M, K)).astype(np.float32)).cuda()
+        w = torch.from_numpy((rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)).cuda()
+        b = torch.from_numpy(rng.normal(size=(N,)).astype(np.float32)).cuda()
+        ws = torch.empty(lib.ms_linear_split_workspace_bytes(M, K, N), dtype=torch.uint8, device="cuda")
+        ys = []
+        for flag in ("0", "1"):
+            os.environ["MS_GEMM_TILE64"] = flag
+            y = torch.full((M + 1, N), float("nan"), dtype=torch.float32, device="cuda")
+            _lib.check(lib.ms_linear_split_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), M, K, N, 1, 0.0, 20.0,
+                                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "linear_split")
+            assert bool(torch.isnan(y[M]).all())
+            ys.append(y[:M])
+        assert torch.equal(ys[0], ys[1]), (M, K, N, float((ys[0] - ys[1]).abs().max()))
+        want = (x.double() @ w.double().T + b.double()).clamp(0.0, 20.0)
+        print(f"tile64 {M}x{K}x{N}: max err vs float64 {float((ys[1].double() - want).abs().max()):.3e}")

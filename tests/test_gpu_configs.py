@@ -51,6 +51,13 @@ def test_cfg5_streaming_batch64_fp16_mfma_in_subprocess():
     print(out.strip().splitlines()[-2])
 
 
+def test_split_gemm_64x64_tiles_fp16_form_in_subprocess():
+    """``MS_PRECISION=fp16``: the single-pass fp16 form of the 64 x 64-tile GEMM (a streaming chunk's hidden FC layer) gives the
+    bits of the fp16 kernels it replaces."""
+    out = _child("tile64_matches_other_kernels()", MS_PRECISION="fp16")
+    assert out.count("tile64 ") == 3
+
+
 def test_streaming_hip_graph_replay_equals_the_eager_slices():
     """``ChunkedDeepSpeech2`` replays steady-state slices as one captured HIP graph (``streaming._ChunkGraph``): same launches, same
     buffers, so logits, lengths and final states are bit-identical to the eager slice-by-slice call -- on a batch whose
