@@ -196,6 +196,7 @@ __device__ __forceinline__ void alpha_wave_body(const float* __restrict__ lpn, c
   const int dS4 = (rev ? -S_max : S_max) * 4;
   int soff_st = rev ? (Tn - 1) * S_max * 4 : 0;
   float a1in = CTC_NEG, a2in = CTC_NEG;
+  int gave_up = 0;
   MbEntry pv{CTC_NEG, CTC_NEG};
   const MbEntry* mb_up = mb + (size_t)(UP ? w - 1 : 0) * T;
   MbEntry* mb_me = mb + (size_t)(DOWN ? w : 0) * T;
@@ -219,7 +220,8 @@ __device__ __forceinline__ void alpha_wave_body(const float* __restrict__ lpn, c
     if (UP) {
       // One asm statement, tied to the frame's result, so that the look at the entry stays BEHIND the arithmetic (left to
       // itself the compiler tests right after the request: the LDS latency exposed and the publication missed).  The spin is
-      // bounded (~0.5 s): a wave that does not get its entry goes on with what it has instead of hanging the queue.
+      // bounded (~0.5 s): a wave that does not get its entry goes on with what it has instead of hanging the queue, and the
+      // utterance's loss comes out as NaN.
       // The hazard recogniser does not see into the statement: gfx950 needs one wait state between a VALU write of a VGPR
       // and a v_readfirstlane of it (without it the test reads the OLD register and lets a sentinel through -- measured).
       unsigned x = __float_as_uint(pv.top), y = __float_as_uint(pv.below), tmp;
@@ -250,6 +252,7 @@ __device__ __forceinline__ void alpha_wave_body(const float* __restrict__ lpn, c
           : "vcc", "scc", "memory");
       ex = __uint_as_float(x);
       ey = __uint_as_float(y);
+      gave_up |= spins;          // bit 22 set: the bounded spin ran out (the loss is then reported as NaN, not as a number)
     }
     const float top = nw[K - 1];
     float below;
@@ -337,6 +340,7 @@ __device__ __forceinline__ void alpha_wave_body(const float* __restrict__ lpn, c
     if (s0 + j == S - 1) fin[0] = own[j];
     if (s0 + j == S - 2) fin[1] = own[j];
   }
+  if ((gave_up >> 22) & 1) fin[2] = 1.f;   // an entry never arrived (cannot happen while every wave of the workgroup runs)
 #undef CTC_FENCE
 }
 
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
   MbEntry* mb = reinterpret_cast<MbEntry*>(smem);   // [3][T] {alpha(top), alpha(top - 1)} of waves 0..2, per frame
-  float* fin = smem + (size_t)6 * T;                // [2]
+  float* fin = smem + (size_t)6 * T;                // [2] the last two states' values, [2] = a wave gave up waiting
   const int Tn = min(max(in_lens[n], 0), T);
   const int L = max(tgt_lens[n], 0);
   const int S = 2 * L + 1;
@@ -459,6 +463,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
   }
   for (int i = tid; i < 3 * T; i += CTC_THREADS) mb[i] = MbEntry{__uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu)};
   if (tid < 2) fin[tid] = CTC_NEG;
+  if (tid == 2) fin[2] = 0.f;
   __syncthreads();   // the workgroup's own stores (one CU, one L1) are visible to its loads behind this
   if (Tn == 0) {
     if (tid == 0) {
@@ -474,11 +479,12 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
   }
   __syncthreads();
   if (tid == 0) {
-    const float l1 = fin[0], l2 = fin[1];   // log2 domain; CTC_NEG or below = no path
+    const float l1 = fin[0], l2 = fin[1];   // log2 domain; CTC_NEG or below = no path; NaN = a wave gave up waiting
+    const bool poisoned = fin[2] != 0.f;
     const float m = fmaxf(l1, l2);
     const float ll2 = log2f(exp2f(l1 - m) + exp2f(l2 - m)) + m;
-    if (nll != nullptr) nll[n] = (m < 0.5f * CTC_NEG) ? INFINITY : -(ll2 * 0.6931471805599453f);
-    if (ll2_out != nullptr) ll2_out[n] = (m < 0.5f * CTC_NEG) ? CTC_NEG : ll2;
+    if (nll != nullptr) nll[n] = poisoned ? __uint_as_float(0x7fc00000u) : (m < 0.5f * CTC_NEG) ? INFINITY : -(ll2 * 0.6931471805599453f);
+    if (ll2_out != nullptr) ll2_out[n] = poisoned ? __uint_as_float(0x7fc00000u) : (m < 0.5f * CTC_NEG) ? CTC_NEG : ll2;
   }
 }
 
@@ -572,7 +578,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_grad_rows_kernel(const float*
   }
 }
 
-size_t alpha_wave_lds(int T) { return ((size_t)6 * T + 2) * sizeof(float); }
+size_t alpha_wave_lds(int T) { return ((size_t)6 * T + 4) * sizeof(float); }
 
 // Gradient of the per-utterance losses with respect to the logits (alpha-beta posteriors; loss/ctc_loss.py:95-101 under
 // autograd = LogSoftmax backward o torch ctc_loss backward, which at valid frames collapses to one expression):
