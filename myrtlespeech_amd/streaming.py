@@ -474,6 +474,95 @@ class _ChunkGraph:
         return self.y
 
 
+class GraphedForward:
+    """``model((x, lens), hx)`` for inputs of ONE shape whose lengths are all equal (a single clip, a full batch) as a captured
+    HIP graph: the forward's ~20 launches cost the host one input copy and one ``hipGraphLaunch`` (DeepSpeech1 on one 4 s clip
+    is ~0.75 ms of kernels inside ~1.0 ms of eager Python: the device idles a quarter of the call).  Same launches on the
+    same buffers as the eager call, so the results are its bits (``tests/test_gpu_configs.py``).  Any other input -- ragged
+    lengths, a shape it has not seen while ``max_graphs`` are held, a capture that fails -- runs eagerly.  The graph owns its
+    scratch buffers (see ``_ChunkGraph``) and is dropped when a parameter changes.  Outputs are copies: they stay valid after
+    the next call."""
+
+    def __init__(self, model, max_graphs: int = 4):
+        self.model, self.max_graphs = model, max_graphs
+        self._graphs = {}
+        self._sig = None
+        self.graph_error: Optional[str] = None
+        self.replays = 0
+
+    class _Graph:
+        def __init__(self, model, shape, length: int, hx):
+            import os
+            n = shape[0]
+            self.x = torch.zeros(tuple(shape), dtype=torch.float32, device="cuda")
+            host = torch.full((n,), length, dtype=torch.int64)
+            self.lens = _lib.attach_host(torch.full((n,), length, dtype=torch.int64, device="cuda"), host)
+            self.hx = None if hx is None else (tuple(torch.zeros_like(_lib.f32c(s_)) for s_ in hx) if isinstance(hx, tuple)
+                                               else torch.zeros_like(_lib.f32c(hx)))
+            slots = _workspace_slots(model) if os.environ.get("MS_STREAM_GRAPH_OWN_WS") != "0" else []
+            self._own = [_lib.Workspace() for _ in slots]
+            saved = [getattr(o, a) for o, a in slots]
+            checked = [m_ for m_ in model.modules() if getattr(m_, "check_status", False) is True]
+            self.graph = torch.cuda.CUDAGraph()
+            try:
+                for (o, a), w_ in zip(slots, self._own):
+                    setattr(o, a, w_)
+                for m_ in checked:
+                    m_.check_status = False              # ms_rnn_status synchronises: not inside a capture
+                model((self.x, self.lens), self.hx)      # sizes the scratch, does the library's first-use set-up, fills the constants
+                torch.cuda.synchronize()
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    (self.y, self.out_lens), self.hid = model((self.x, self.lens), self.hx)
+            finally:
+                for (o, a), w_ in zip(slots, saved):
+                    setattr(o, a, w_)
+                for m_ in checked:
+                    m_.check_status = True
+            self.status_ws = [w_ for (o, a), w_ in zip(slots, self._own) if o in checked]
+
+        def run(self, x, hx):
+            self.x.copy_(x)
+            if hx is not None:
+                for a_, b_ in zip(self.hx if isinstance(hx, tuple) else (self.hx,), hx if isinstance(hx, tuple) else (hx,)):
+                    a_.copy_(b_)
+            self.graph.replay()
+            hid = tuple(h_.clone() for h_ in self.hid) if isinstance(self.hid, tuple) else self.hid.clone()
+            return (self.y.clone(), _lib.attach_host(self.out_lens.clone(), _lib.host_lens(self.out_lens))), hid
+
+    def __call__(self, x: torch.Tensor, lens: torch.Tensor, hx=None):
+        _lib.require_gpu()
+        lens_h = _lib.host_lens(lens)
+        same = lens_h.numel() > 0 and bool((lens_h == lens_h[0]).all())
+        if not same or self.graph_error is not None:
+            return self.model((x, lens), hx)
+        sig = tuple((p_.data_ptr(), _lib.version_of(p_)) for p_ in self.model.parameters())
+        if sig != self._sig:
+            self._graphs.clear()
+            self._sig = sig
+        key = (tuple(x.shape), int(lens_h[0]), None if hx is None else isinstance(hx, tuple))
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= self.max_graphs:
+                return self.model((x, lens), hx)
+            try:
+                with torch.no_grad():
+                    g = GraphedForward._Graph(self.model, x.shape, int(lens_h[0]), hx)
+                self._graphs[key] = g
+            except Exception as e:  # noqa: BLE001 -- capture is an optimisation: the eager forward is the definition
+                self.graph_error = f"{type(e).__name__}: {e}"[:300]
+                torch.cuda.synchronize()
+                return self.model((x, lens), hx)
+        self.replays += 1
+        return g.run(x if x.is_cuda else x.cuda(), hx)
+
+    def check_status(self):
+        """Raise if a persistent recurrence inside a replayed graph timed out (the eager call checks per forward)."""
+        for g in self._graphs.values():
+            for w_ in g.status_ws:
+                if w_.buf is not None:
+                    _lib.check(_lib.load().ms_rnn_status(_lib.ptr(w_.buf), _lib.stream_ptr()), "ms_rnn_layer_forward")
+
+
 class ChunkedDeepSpeech2:
     def __init__(self, model, chunk_frames: int, carry_context: bool = False, use_graph: Optional[bool] = None):
         """``use_graph`` (default: on unless ``MS_STREAM_GRAPH=0``): replay steady-state slices / pushes as a captured HIP

@@ -58,6 +58,46 @@ def test_split_gemm_64x64_tiles_fp16_form_in_subprocess():
     assert out.count("tile64 ") == 3
 
 
+def test_graphed_forward_equals_the_eager_forward():
+    """``streaming.GraphedForward``: a whole forward for one input shape replayed as a captured HIP graph -- DeepSpeech1 at the
+    shipped width on one 4 s clip (configs[0]) and a small DeepSpeech2 batch with an initial state: the eager call's bits;
+    ragged lengths fall back to the eager call."""
+    import torch
+    from myrtlespeech_amd.model.cnn import MaskConv2d, PaddingMode
+    from myrtlespeech_amd.model.deep_speech_1 import DeepSpeech1
+    from myrtlespeech_amd.model.deep_speech_2 import DeepSpeech2
+    from myrtlespeech_amd.model.fully_connected import FullyConnected
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    from myrtlespeech_amd.model.seq_len_wrapper import SeqLenWrapper
+    from myrtlespeech_amd.streaming import GraphedForward
+    torch.manual_seed(1)
+    with torch.no_grad():
+        m = DeepSpeech1(26, 19, 1024, 29, 0.25).eval()
+        g = GraphedForward(m)
+        for seed in (0, 1, 2):
+            x = torch.randn(1, 19, 26, 201, generator=torch.Generator().manual_seed(seed)).cuda()
+            lens = torch.tensor([201])
+            (ye, le), he = m((x.clone(), lens))
+            (yg, lg), hg = g(x.clone(), lens)
+            assert g.graph_error is None, g.graph_error
+            assert torch.equal(yg, ye) and torch.equal(lg.cpu(), le.cpu())
+            assert all(torch.equal(a, b) for a, b in zip(hg, he))
+        assert g.replays == 3
+        g.check_status()
+        cnn = torch.nn.Sequential(MaskConv2d(1, 8, [11, 5], [2, 2], PaddingMode.SAME),
+                                  SeqLenWrapper(torch.nn.Hardtanh(0.0, 20.0), torch.nn.Identity()))
+        m2 = DeepSpeech2(cnn, RNN(RNNType.LSTM, 8 * 20, 256, num_layers=2, bidirectional=True, forget_gate_bias=1.0), None,
+                         FullyConnected(512, 29, 1, 96, torch.nn.Hardtanh(0.0, 20.0))).eval()
+        g2 = GraphedForward(m2)
+        x = torch.randn(6, 1, 40, 64).cuda()
+        hx = (torch.randn(4, 6, 256).cuda() * 0.3, torch.randn(4, 6, 256).cuda() * 0.3)
+        for lens in (torch.full((6,), 64), torch.tensor([64, 60, 50, 40, 30, 9])):
+            (ye, le), he = m2((x.clone(), lens), hx)
+            (yg, lg), hg = g2(x.clone(), lens, hx)
+            assert torch.equal(yg, ye) and torch.equal(lg.cpu(), le.cpu()) and all(torch.equal(a, b) for a, b in zip(hg, he))
+        assert g2.replays == 1 and g2.graph_error is None
+
+
 def test_streaming_hip_graph_replay_equals_the_eager_slices():
     """``ChunkedDeepSpeech2`` replays steady-state slices as one captured HIP graph (``streaming._ChunkGraph``): same launches, same
     buffers, so logits, lengths and final states are bit-identical to the eager slice-by-slice call -- on a batch whose
