@@ -598,6 +598,7 @@ __global__ __launch_bounds__(256) void beam_round_kernel(BeamP p, int t, int reg
   __shared__ int b_node[128], b_slot[128];
   __shared__ float b_score[128];
   __shared__ int n_pick, next_node;
+  __shared__ int match_at[32];
   const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = p.w, V1 = p.V + 1, blank = p.V;
   const int len_i = p.lens[i], cnt = p.A_cnt[i], bc0 = first ? 0 : p.B_cnt[i], nodes0 = p.node_cnt[i];
@@ -615,28 +616,67 @@ __global__ __launch_bounds__(256) void beam_round_kernel(BeamP p, int t, int reg
   for (int c = tid; c < w * V1; c += 256) cand[c] = p.logp[(size_t)i * w * V1 + c];
   if (t >= len_i) return;
   if (tid == 0) { n_pick = 0; next_node = nodes0; }
+  if (tid < 32) match_at[tid] = -1;
   __syncthreads();
-  if (tid == 0) {
-    // blank transitions, in hypothesis order: same prefix (trie node) -> logaddexp, else append (first arrival keeps
-    // its predictor state)
-    int bc = bc0;
-    for (int j = 0; j < cnt; ++j) {
-      const float s = old_score[j] + cand[j * V1 + blank];
-      int at = -1;
-      for (int b = 0; b < bc; ++b)
-        if (b_node[b] == old_node[j]) { at = b; break; }
-      if (at >= 0) {
-        b_score[at] = logaddexp32(b_score[at], s);
-      } else if (bc < p.bcap) {
-        b_node[bc] = old_node[j];
-        b_score[bc] = s;
-        b_slot[bc] = old_slot[j];
-        ++bc;
+  // blank transitions, in hypothesis order: same prefix (trie node) -> logaddexp, else append (first arrival keeps its
+  // predictor state).  The live hypotheses' nodes are distinct (picks are distinct (parent, label) pairs, the frame's first
+  // set comes out of B, whose nodes are distinct), so the hypotheses do not interact: every (hypothesis, B entry) pair is
+  // compared at once and wave 0 merges / appends, an append's position = its rank among the unmatched (round 4: thread 0
+  // walked cnt x bc dependent LDS reads, ~10 of the kernel's 14.7 us).  Should two live hypotheses ever share a node the
+  // serial walk below does what it always did.
+  for (int idx = tid; idx < cnt * bc0; idx += 256) {
+    const int j = idx / bc0, b = idx - j * bc0;
+    if (b_node[b] == old_node[j]) match_at[j] = b;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int j = lane;
+    bool dup = false;
+    if (j < cnt)
+      for (int k = 0; k < j; ++k) dup |= old_node[k] == old_node[j];
+    if (__any(dup)) {
+      if (lane == 0) {
+        int bc = bc0;
+        for (int jj = 0; jj < cnt; ++jj) {
+          const float s = old_score[jj] + cand[jj * V1 + blank];
+          int at = -1;
+          for (int b = 0; b < bc; ++b)
+            if (b_node[b] == old_node[jj]) { at = b; break; }
+          if (at >= 0) {
+            b_score[at] = logaddexp32(b_score[at], s);
+          } else if (bc < p.bcap) {
+            b_node[bc] = old_node[jj];
+            b_score[bc] = s;
+            b_slot[bc] = old_slot[jj];
+            ++bc;
+          }
+        }
+        p.B_cnt[i] = bc;
+        wi[0] = bc;
+      }
+    } else {
+      const bool have = j < cnt;
+      const int at = have ? match_at[j] : 0;
+      const bool unmatched = have && at < 0;
+      const unsigned long long um = __ballot(unmatched);
+      const int pos = bc0 + __popcll(um & ((1ull << lane) - 1ull));
+      if (have) {
+        const float s = old_score[j] + cand[j * V1 + blank];
+        if (at >= 0) {
+          b_score[at] = logaddexp32(b_score[at], s);
+        } else if (pos < p.bcap) {
+          b_node[pos] = old_node[j];
+          b_score[pos] = s;
+          b_slot[pos] = old_slot[j];
+        }
+      }
+      if (lane == 0) {
+        const int bc = min(bc0 + (int)__popcll(um), p.bcap);
+        p.B_cnt[i] = bc;
+        wi[0] = bc;
       }
     }
-    p.B_cnt[i] = bc;
-    wi[0] = bc;
-    if (last) p.A_cnt[i] = 0;
+    if (lane == 0 && last) p.A_cnt[i] = 0;
   }
   __syncthreads();
   {
@@ -740,24 +780,40 @@ __global__ __launch_bounds__(256) void beam_frame_end_kernel(BeamP p, float* st_
   }
   if (t >= len_i) return;
   __syncthreads();
-  if (tid == 0) {
+  // the beam_width best of B, one after the other (first maximum = earliest arrival among equals), by ONE wave: a lane holds
+  // entries lane and lane + 64, the wave reduces (an entry before none, score desc, index asc), the owner marks its entry taken
+  // (round 4: thread 0 walked w x bc dependent LDS reads, ~9 us, in every one of the w x N workgroups)
+  if (tid < 64) {
+    const int lane = tid;
+    const float s0 = lane < bc ? b_score[lane] : 0.f, s1 = lane + 64 < bc ? b_score[lane + 64] : 0.f;
+    bool t0 = !(lane < bc), t1 = !(lane + 64 < bc);          // "taken" also stands for "does not exist"
     int ns = 0;
-    unsigned long long taken_lo = 0, taken_hi = 0;  // bcap <= 128
     for (int x = 0; x < w && x < bc; ++x) {
-      int best = -1;
-      for (int b = 0; b < bc; ++b) {
-        const bool taken = b < 64 ? (taken_lo >> b) & 1ull : (taken_hi >> (b - 64)) & 1ull;
-        if (taken) continue;
-        if (best < 0 || b_score[b] > b_score[best]) best = b;  // first maximum = earliest arrival among equals
+      bool have = false;
+      float bv = 0.f;
+      int bi = 0x7fffffff;
+      if (!t0) { have = true; bv = s0; bi = lane; }
+      if (!t1 && (!have || s1 > bv)) { have = true; bv = s1; bi = lane + 64; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const bool oh = __shfl_xor((int)have, o, 64) != 0;
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        // the serial walk keeps the FIRST maximum: a later entry replaces the best only if its score is greater
+        const bool take = oh && (!have || ov > bv || (!(bv > ov) && oi < bi));
+        if (take) { have = true; bv = ov; bi = oi; }
       }
-      if (best < 0) break;
-      if (best < 64) taken_lo |= 1ull << best; else taken_hi |= 1ull << (best - 64);
-      sel_src[ns] = b_slot[best];
-      sel_node[ns] = b_node[best];
-      sel_score[ns] = b_score[best];
+      if (!have) break;                                       // wave-uniform
+      if (bi == lane) t0 = true;
+      if (bi == lane + 64) t1 = true;
+      if (lane == 0) {
+        sel_src[ns] = b_slot[bi];
+        sel_node[ns] = b_node[bi];
+        sel_score[ns] = b_score[bi];
+      }
       ++ns;
     }
-    n_sel = ns;
+    if (lane == 0) n_sel = ns;
   }
   __syncthreads();
   const int ns = n_sel;
