@@ -42,11 +42,13 @@
 extern "C" {
 #endif
 
-/* 2 (round 4): ms_prof_read writes MS_PROF_KINDS = 9 entries (was 4 in version 1); the `zero_infinity` argument of the CTC
+/* 3 (round 5): ms_linear_splitk_workspace_bytes / ms_linear_splitk_forward take `flags` (MS_LINEAR_FEW_ROWS): the K-slice count
+ * no longer depends on M.
+ * 2 (round 4): ms_prof_read writes MS_PROF_KINDS = 9 entries (was 4 in version 1); the `zero_infinity` argument of the CTC
  * entry points is a bit field {1 = zero_infinity, MS_CTC_LOG_PROBS_IN} and values above 3 are rejected;
  * ms_ctc_loss_backward takes the same bit field; ms_log_softmax_axis_backward is new.  The Python binding refuses a
  * library whose ms_abi_version() differs (myrtlespeech_amd/_lib.py). */
-#define MS_ABI_VERSION 2
+#define MS_ABI_VERSION 3
 
 enum {
   MS_OK = 0,
@@ -145,12 +147,16 @@ int ms_linear_forward(const float* x, const float* w, const float* bias, float* 
  * 29-symbol output layer, fully_connected.py:164 / deep_speech_1.py:118-120): one 32-column tile per 128 rows leaves a
  * streaming chunk's 1 024 rows on eight workgroups that each walk all of K, so the contraction is cut into min(8, K / 128)
  * slices whose partial sums land in the workspace and are added in slice order (deterministic; the slice count depends on
- * (K, N) only, so a row's result does not depend on the batch it is in; the rounding differs from ms_linear_forward's single
- * k-ordered chain by a few ulp).  ms_linear_splitk_workspace_bytes() == 0 means the shape is not such a layer: the call then
- * IS ms_linear_forward and needs no workspace; a NULL workspace selects ms_linear_forward for any shape. */
-size_t ms_linear_splitk_workspace_bytes(int M, int K, int N);
+ * (K, N, flags) only -- never on M -- so a row's result does not depend on the batch or chunk it is in; the rounding differs
+ * from ms_linear_forward's single k-ordered chain by a few ulp).  flags: 0, or MS_LINEAR_FEW_ROWS = the caller states that
+ * the layer serves a handful of rows (one clip's hidden layers, deep_speech_1.py:124-136) and takes K slices for N <= 4096
+ * too; a caller that sets it for some batches and not for others gives up bit-reproducibility between them.
+ * ms_linear_splitk_workspace_bytes() == 0 means the shape is not such a layer: the call then IS ms_linear_forward and needs
+ * no workspace; a NULL workspace selects ms_linear_forward for any shape. */
+#define MS_LINEAR_FEW_ROWS 1
+size_t ms_linear_splitk_workspace_bytes(int M, int K, int N, int flags);
 int ms_linear_splitk_forward(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
-                             float act_lo, float act_hi, void* workspace, size_t workspace_bytes, void* stream);
+                             float act_lo, float act_hi, int flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Same contract as ms_linear_forward for K % 32 == 0, computed with float32 operands split
  * into bf16 hi + lo (x.w ~= x_hi.w_hi + x_lo.w_hi + x_hi.w_lo, f32 accumulate; relative error

@@ -16,11 +16,13 @@ LIB_PATH = os.environ.get("MS_HOTPATH_LIB") or os.path.join(_HERE, "libms_hotpat
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ms_hotpath.h")
 
 MS_OK = 0
-ABI_VERSION = 2    # include/ms_hotpath.h MS_ABI_VERSION this binding was written against (checked in load())
+ABI_VERSION = 3    # include/ms_hotpath.h MS_ABI_VERSION this binding was written against (checked in load())
 ERR_NAMES = {1: "MS_ERR_INVALID", 2: "MS_ERR_HIP", 3: "MS_ERR_WORKSPACE", 4: "MS_ERR_TIMEOUT", 5: "MS_ERR_UNSUPPORTED"}
 
 CELL_LSTM, CELL_GRU, CELL_RNN_TANH, CELL_HARD_LSTM = 0, 1, 2, 3
 ACT_NONE, ACT_CLAMP = 0, 1
+LINEAR_FEW_ROWS = 1   # MS_LINEAR_FEW_ROWS
+PROF_KINDS = 9        # MS_PROF_KINDS: entries ms_prof_read writes into each of its two arrays
 
 _P = c_void_p
 _PP = POINTER(c_void_p)
@@ -48,8 +50,8 @@ SIGNATURES = {
     "ms_nct_to_tnc": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ms_clamp": (c_int, [_P, _P, c_size_t, c_float, c_float, _P]),
     "ms_linear_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
-    "ms_linear_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "ms_linear_splitk_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
+    "ms_linear_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "ms_linear_splitk_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, _P, c_size_t, _P]),
     "ms_linear_split_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ms_linear_split_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
     "ms_lookahead_forward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_int, c_float, c_float, _P]),

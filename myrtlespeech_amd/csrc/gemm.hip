@@ -211,37 +211,38 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ parts, float* __r
 }
 
 // K slices for a GEMM with few output COLUMNS (an output layer: 29 symbols = one 32-column tile per 128 rows, so a chunk's
-// 1 024 rows are eight workgroups each walking all of K).  The slice count depends on (K, N) only, never on the number of
-// rows: an utterance's logits must not depend on what it is batched with (utterance shards reproduce the whole batch bit for
-// bit).  0 = the plain kernel.
-// (round 4) ... except for a handful of rows: a single clip's hidden layers (DeepSpeech1 on one 4 s clip: 201 x 1 024 x 1 024,
-// 64 workgroups walking all of K, 33 .. 61 us each) also take K slices -- M <= 256 is below every sharded batch (a shard of
-// the smallest tested batch has 2 004 rows), so shards still reproduce their batch.
-int linear_splitk_slices(int M, int K, int N) {
+// 1 024 rows are eight workgroups each walking all of K).  The slice count depends on (K, N) and the caller's flags only,
+// NEVER on the number of rows: an utterance's logits must not depend on what it is batched with (utterance shards reproduce
+// the whole batch bit for bit, streaming output does not depend on the chunking).  0 = the plain kernel.
+// MS_LINEAR_FEW_ROWS (this used to be inferred from M <= 256, which made a row's rounding depend on its batch):
+// the CALLER states that the layer serves a handful of rows (a single clip's hidden layers -- DeepSpeech1 on one 4 s clip:
+// 201 x 1 024 x 1 024, 64 workgroups walking all of K) and accepts K-slice rounding for wide layers too.
+int linear_splitk_slices(int K, int N, int flags) {
   if (K < 512) return 0;
-  if (N > 64) return (M <= 256 && N <= 4096) ? std::min(8, K / 128) : 0;
+  if (N > 64) return ((flags & MS_LINEAR_FEW_ROWS) && N <= 4096) ? std::min(8, K / 128) : 0;
   return std::min(8, K / 128);
 }
 
 }  // namespace ms
 
-extern "C" size_t ms_linear_splitk_workspace_bytes(int M, int K, int N) {
+extern "C" size_t ms_linear_splitk_workspace_bytes(int M, int K, int N, int flags) {
   if (M <= 0 || K <= 0 || N <= 0) return 0;
-  const int ks = ms::linear_splitk_slices(M, K, N);
+  const int ks = ms::linear_splitk_slices(K, N, flags);
   return ks ? ms::align_up((size_t)ks * M * N * sizeof(float), 256) : 0;
 }
 
 extern "C" int ms_linear_splitk_forward(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
-                                        float act_lo, float act_hi, void* workspace, size_t workspace_bytes, void* stream_) {
+                                        float act_lo, float act_hi, int flags, void* workspace, size_t workspace_bytes, void* stream_) {
   ms::ProfScope prof_span(MS_PROF_LINEAR, (hipStream_t)stream_);
   MS_REQUIRE(x && w && y, "null pointer");
   MS_REQUIRE(M > 0 && K > 0 && N > 0, "bad shape");
   MS_REQUIRE(act == MS_ACT_NONE || act == MS_ACT_CLAMP, "bad act");
+  MS_REQUIRE((flags & ~MS_LINEAR_FEW_ROWS) == 0, "unknown flag");
   hipStream_t stream = (hipStream_t)stream_;
-  const int ks = ms::linear_splitk_slices(M, K, N);
+  const int ks = ms::linear_splitk_slices(K, N, flags);
   // (no workspace = the caller asks for the plain kernel: MS_LINEAR_SPLITK=0 in the Python layer, A/B runs)
   if (ks == 0 || workspace == nullptr) return ms::linear_launch(x, w, bias, y, M, K, N, act, act_lo, act_hi, stream);
-  MS_REQUIRE(workspace_bytes >= ms_linear_splitk_workspace_bytes(M, K, N), "workspace too small");
+  MS_REQUIRE(workspace_bytes >= ms_linear_splitk_workspace_bytes(M, K, N, flags), "workspace too small");
   int rc = ms::linear_splitk_launch(x, w, bias, (float*)workspace, M, K, N, ks, stream);
   if (rc != MS_OK) return rc;
   const size_t mn = (size_t)M * N;

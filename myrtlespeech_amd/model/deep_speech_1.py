@@ -26,6 +26,9 @@ class DeepSpeech1(torch.nn.Module):
         self.use_cuda = torch.cuda.is_available()
         self._relu_clip = float(relu_clip)
         self._drop_prob = drop_prob
+        # single-clip serving switch (not in the reference): lets the wide exact-f32 layers take K slices
+        # (MS_LINEAR_FEW_ROWS).  Off by default: with it a clip's rounding differs from the same clip inside a batch.
+        self.few_rows = False
         self.fc1 = self._fully_connected(input_features * input_channels, n_hidden)
         self.fc2 = self._fully_connected(n_hidden, n_hidden)
         self.fc3 = self._fully_connected(n_hidden, 2 * n_hidden)
@@ -59,11 +62,11 @@ class DeepSpeech1(torch.nn.Module):
                    "ms_nct_to_tnc")
         plan = (linear_stack_plan(self.fc1, self.training) + linear_stack_plan(self.fc2, self.training)
                 + linear_stack_plan(self.fc3, self.training))
-        h = run_linear_stack(tnf.reshape(t * n, c * f), plan).reshape(t, n, -1)
+        h = run_linear_stack(tnf.reshape(t * n, c * f), plan, few_rows=self.few_rows).reshape(t, n, -1)
         # bi_lstm is batch_first; hand it the batch-major *view* of the time-major buffer
         (h, _), hid = self.bi_lstm((h.transpose(0, 1), seq_lens), hx)
         h = h.transpose(0, 1)  # back to the time-major storage the kernel wrote
         plan = linear_stack_plan(self.fc4, self.training) + linear_stack_plan(self.out, self.training)
         h = _lib.f32c(h)
-        out = run_linear_stack(h.reshape(t * n, h.shape[-1]), plan).reshape(t, n, -1)
+        out = run_linear_stack(h.reshape(t * n, h.shape[-1]), plan, few_rows=self.few_rows).reshape(t, n, -1)
         return (out, _lib.lens_to_device(seq_lens)), hid

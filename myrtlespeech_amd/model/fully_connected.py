@@ -60,9 +60,14 @@ def _stream_workspace() -> "_lib.Workspace":
     return ws
 
 
-def run_linear_stack(x2d: torch.Tensor, plan) -> torch.Tensor:
+def run_linear_stack(x2d: torch.Tensor, plan, few_rows: bool = False) -> torch.Tensor:
     """x2d [M, K] float32 cuda contiguous.  Large layers with K % 32 == 0 run as the
-    split-bf16 GEMM (unless MS_PRECISION=f32), the rest as the exact-f32 GEMM."""
+    split-bf16 GEMM (unless MS_PRECISION=f32), the rest as the exact-f32 GEMM.
+
+    ``few_rows`` (MS_LINEAR_FEW_ROWS): the caller states that this stack serves a handful of rows (a single clip) and lets wide
+    exact-f32 layers take K slices as well.  It is a property of the call site, never derived from ``M`` here: a row's bits must
+    not depend on what it is batched or chunked with."""
+    flags = _lib.LINEAR_FEW_ROWS if few_rows else 0
     lib = _lib.load()
     h = x2d
     for lin, clamp in plan:
@@ -81,10 +86,10 @@ def run_linear_stack(x2d: torch.Tensor, plan) -> torch.Tensor:
         else:
             # an output layer (<= 64 columns): K slices, added in slice order (ms_linear_splitk_forward); 0 bytes = not such a
             # layer, and the call is ms_linear_forward
-            nb = lib.ms_linear_splitk_workspace_bytes(m, k, n) if _SPLITK else 0
+            nb = lib.ms_linear_splitk_workspace_bytes(m, k, n, flags) if _SPLITK else 0
             ws = _stream_workspace().get(nb, zero=False) if nb else None
             _lib.check(lib.ms_linear_splitk_forward(_lib.ptr(h), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), m, k, n, a, lo, hi,
-                                                    _lib.ptr(ws), nb, _lib.stream_ptr()), "ms_linear_splitk_forward")
+                                                    flags, _lib.ptr(ws), nb, _lib.stream_ptr()), "ms_linear_splitk_forward")
         h = y
     return h
 

@@ -173,7 +173,8 @@ def _worker(rank, world, port, out_dir, extra):
     path = os.path.join(out_dir, f"rank{rank}.json")
     fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
     try:
-        bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--no-frontend"] + list(extra), runtime=rt, json_fd=fd)
+        bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--no-frontend", "--detail-path",
+                    os.path.join(out_dir, "detail.json")] + list(extra), runtime=rt, json_fd=fd)
     finally:
         os.close(fd)
     with open(os.path.join(out_dir, f"log{rank}.json"), "w") as f:
@@ -195,7 +196,45 @@ def _run(tmp_path, extra):
     assert (tmp_path / "rank1.json").read_text().strip() == ""        # ONE JSON line, from rank 0
     assert len(lines) == 1
     logs = [json.loads((tmp_path / f"log{r}.json").read_text()) for r in range(world)]
-    return json.loads(lines[0]), logs
+    line = _check_line(lines[0])
+    assert line["detail"] == "detail.json"
+    # the nested per-mode records live in the side file; the line carries the standard keys and numbers
+    detail = json.loads((tmp_path / "detail.json").read_text())
+    for k in ("metric", "value", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype"):
+        assert detail[k] == line[k]
+    assert "one_batch_in_flight" not in line and "legs_detail" not in line
+    return detail, logs
+
+
+def _reject_constant(name):
+    raise ValueError(f"non-strict JSON token {name}")
+
+
+def _check_line(text):
+    """What the driver's parser needs of the ONE stdout line: under 8 KB, strict JSON, the contract's keys."""
+    assert "\n" not in text.strip() and len(text.encode()) < 8192, len(text.encode())
+    line = json.loads(text, parse_constant=_reject_constant)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in line, k
+    assert isinstance(line["config"]["workload"], str) and "model" not in line["config"]
+    assert all(not isinstance(v, (dict, list)) for v in line["config"].values())       # flat scalars
+    assert isinstance(line["roofline"]["frac"], float) and line["roofline"]["bound"] in ("hbm", "mfma")
+    assert {"achieved", "peak", "unit", "traffic", "kernel"} <= set(line["roofline"])
+    assert isinstance(line["dtype"], str) and line["ms_per_step"] > 0
+    assert all(len(v) <= 120 for v in _strings(line))
+    return line
+
+
+def _strings(o):
+    if isinstance(o, dict):
+        for v in o.values():
+            yield from _strings(v)
+    elif isinstance(o, list):
+        for v in o:
+            yield from _strings(v)
+    elif isinstance(o, str):
+        yield o
 
 
 def test_bench_control_flow_two_ranks_per_shard_decode(tmp_path):
@@ -236,3 +275,44 @@ def test_bench_control_flow_two_ranks_gather_logits_unequal_shards(tmp_path):
         assert all(len(e[2]) == sum(N_RANK) for e in dec)
         full = dec[0][2]
         assert all(v <= T_RANK[0] for v in full[:N_RANK[0]]) and all(v <= T_RANK[1] for v in full[N_RANK[0]:])
+
+
+def test_bench_line_stays_parseable_whatever_the_detail_grows_to():
+    """Round 4's own 22.9 KB record (the one the driver could not parse) goes through `bench_line`: under 8 KB, strict JSON,
+    `roofline.frac`, `cpu_baseline.value`, `config.workload`, `dtype`, `ms_per_step` and the compact `legs` still there."""
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r04s7_bench_line_20steps.json")) as f:
+        old = json.loads(f.read())
+    assert len(json.dumps(old)) > 20000
+    old["legs_detail"]["ctc_loss"]["ms"] = float("nan")          # a NaN anywhere must not reach the line as a bare token
+    old["legs"]["ctc_loss"]["ms"] = float("nan")
+    line = _check_line(bench.bench_line(old, "bench_detail.json"))
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["kind"] == "port"
+    assert list(line)[-1] == "legs" and line["legs"]["cfg4_rnnt"]["beam8_decode_ms"] > 0 and line["legs"]["ctc_loss"]["ms"] is None
+    # and a record bloated far beyond anything seen still yields a line with the standard keys
+    old["legs"] = {f"leg{i}": {"ms": 1.0, "text": "x" * 100} for i in range(200)}
+    line = _check_line(bench.bench_line(old, "bench_detail.json"))
+    assert line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
+
+
+def test_bench_spawns_its_own_ranks_without_torchrun(tmp_path):
+    """`python bench.py --gpus 2` with no RANK in the environment: the parent starts the ranks under
+    torch.distributed.run before it touches a device, relays rank 0's ONE line and the exit code."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-frontend",
+           "--runtime", "tests.test_bench_flow_cpu:_CpuRuntime", "--detail-path", str(tmp_path / "detail.json")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = _check_line(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["scaling"] == "weak"
+    assert (tmp_path / "detail.json").exists()
+    # a rank that dies takes the parent's exit code with it
+    bad = subprocess.run(cmd + ["--runtime", "tests.test_bench_flow_cpu:_no_such_factory"], env=env, capture_output=True, text=True,
+                         timeout=300, cwd=root)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]

@@ -192,6 +192,24 @@ def test_split_gemm_scratch_is_pruned_when_streams_come_and_go():
     assert all(torch.equal(o, want) for o in outs)
 
 
+@pytest.mark.parametrize("n_out", [29, 1024])
+@pytest.mark.parametrize("few_rows", [False, True])
+def test_exact_f32_linear_rows_do_not_depend_on_the_row_count(n_out, few_rows):
+    """the K-slice count of the exact-f32 layers was a function of M (slices for M <= 256 only), so the same rows
+    came out with other roundings in a 200-row call than inside a 300-row call -- a one-utterance shard or a short push
+    against the whole batch.  It now depends on (K, N, caller's flag) only: straddle the old boundary and compare bits."""
+    from myrtlespeech_amd.model import fully_connected as F
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(1024, n_out).cuda()
+    x = torch.randn(700, 1024, device="cuda")
+    whole = F.run_linear_stack(x, [(lin, (0.0, 20.0))], few_rows=few_rows)
+    for m in (1, 37, 200, 256, 257, 300, 513):
+        part = F.run_linear_stack(x[:m].contiguous(), [(lin, (0.0, 20.0))], few_rows=few_rows)
+        assert torch.equal(part, whole[:m]), (m, n_out, few_rows)
+    want = torch.clamp(x.double() @ lin.weight.double().t() + lin.bias.double(), 0.0, 20.0)
+    assert float((whole.double() - want).abs().max()) < 2e-4
+
+
 def test_paired_batches_equal_the_merged_forward_and_match_the_one_batch_path():
     """``PairedBatches`` (round 3): two batches per forward.  Bit-identical to ``model`` on the merged, length-sorted batch (it
     is that call); equal to the one-batch path within float32 rounding, greedy transcripts equal; ragged lengths (the merge

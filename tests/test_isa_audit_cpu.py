@@ -35,6 +35,41 @@ kernel_with_the_fault:
 """
 GOOD = BAD.replace("	v_cmp_gt_i32_e32 vcc, s45, v34\n", "	v_cmp_gt_i32_e32 vcc, s45, v34\n	v_cmp_ne_u32_e64 s[2:3], 1, v36\n")
 
+# beam_round_kernel (csrc/rnnt_decode.hip) as hipcc emitted it in round 4: loop BB5_54 leaves compare results in s[18:19] and
+# s[22:23]; the sibling loop BB5_58 starts NEW live ranges in those registers (`implicit-def`) and keeps two loop-carried
+# per-lane booleans with the merge `(old & ~exec) | (new & exec)` -- not the signature
+MERGE = """
+beam_round_like:
+.LBB5_54:                               ; =>This Inner Loop Header: Depth=1
+	v_cmp_eq_u32_e64 s[18:19], v10, v1
+	v_cmp_eq_u32_e64 s[22:23], v13, v1
+	s_or_b64 s[10:11], s[10:11], s[18:19]
+	s_or_b64 s[8:9], s[8:9], s[22:23]
+	s_or_b64 s[96:97], vcc, s[96:97]
+	s_andn2_b64 exec, exec, s[96:97]
+	s_cbranch_execnz .LBB5_54
+; %bb.55:
+	s_or_b64 exec, exec, s[96:97]
+; %bb.57:
+	s_mov_b64 s[20:21], 0
+                                        ; implicit-def: $sgpr18_sgpr19
+                                        ; implicit-def: $sgpr22_sgpr23
+.LBB5_58:                               ; =>This Inner Loop Header: Depth=1
+	v_cmp_eq_u32_e64 s[8:9], v4, v1
+	v_cmp_eq_u32_e64 s[10:11], v5, v1
+	s_or_b64 s[12:13], s[12:13], s[10:11]
+	s_or_b64 s[14:15], s[14:15], s[8:9]
+	s_or_b64 s[20:21], vcc, s[20:21]
+	s_andn2_b64 s[6:7], s[22:23], exec
+	s_and_b64 s[8:9], s[14:15], exec
+	s_andn2_b64 s[10:11], s[18:19], exec
+	s_and_b64 s[18:19], s[12:13], exec
+	s_or_b64 s[22:23], s[6:7], s[8:9]
+	s_or_b64 s[18:19], s[10:11], s[18:19]
+	s_andn2_b64 exec, exec, s[20:21]
+	s_cbranch_execnz .LBB5_58
+"""
+
 
 def test_audit_recognises_the_signature(tmp_path):
     bad, good = tmp_path / "bad.s", tmp_path / "good.s"
@@ -43,6 +78,24 @@ def test_audit_recognises_the_signature(tmp_path):
     found = audit.audit(str(bad))
     assert len(found) == 1 and found[0][3] == "s[2:3]" and found[0][4] == "BB4_13" and found[0][7] == "BB4_20"
     assert audit.audit(str(good)) == []       # recomputed inside the second loop: fine
+
+
+def test_audit_does_not_report_new_live_ranges_or_the_per_lane_merge(tmp_path):
+    merge = tmp_path / "merge.s"
+    merge.write_text(MERGE)
+    assert audit.audit(str(merge)) == []
+    # each rule on its own: without the implicit-def comments the merge idiom alone clears it ...
+    merge.write_text("\n".join(l for l in MERGE.splitlines() if "implicit-def" not in l))
+    assert audit.audit(str(merge)) == []
+    # ... and a plain read of the stale mask in the sibling loop (no merge, no new live range) is still the signature
+    stale = "\n".join(l for l in MERGE.splitlines() if "implicit-def" not in l).replace(
+        "s_andn2_b64 s[6:7], s[22:23], exec", "s_and_b64 s[6:7], s[22:23], s[14:15]")
+    merge.write_text(stale)
+    found = audit.audit(str(merge))
+    assert len(found) == 1 and found[0][3] == "s[22:23]" and found[0][4] == "BB5_54" and found[0][7] == "BB5_58"
+    # with the implicit-def in place the same read is of a new value: not reported
+    merge.write_text(MERGE.replace("s_andn2_b64 s[6:7], s[22:23], exec", "s_and_b64 s[6:7], s[22:23], s[14:15]"))
+    assert audit.audit(str(merge)) == []
 
 
 def test_no_kernel_of_the_library_has_the_signature(tmp_path):

@@ -52,8 +52,8 @@ ROUNDS = int(os.environ.get("PROBE_ROUNDS", "6"))
 
 def run(mode, iters=4):
     """iters x (batch A, batch B); returns (ms per batch pair, mean per-batch latency ms, spans)."""
-    ms = (ctypes.c_float * 4)()
-    cnt = (ctypes.c_int * 4)()
+    ms = (ctypes.c_float * _lib.PROF_KINDS)()      # ms_prof_read writes MS_PROF_KINDS entries (ADVICE r4: 4 here overran the arrays)
+    cnt = (ctypes.c_int * _lib.PROF_KINDS)()
     torch.cuda.synchronize()
     lib.ms_prof_enable(1)
     lib.ms_prof_read(ms, cnt)
