@@ -191,6 +191,13 @@ int ms_lookahead_window_forward(const float* x, const float* w, float* y, int N,
  * w_ih[d] [G*H, In], w_hh[d] [G*H, H], b_ih[d]/b_hh[d] [G*H] or NULL (bias=False);
  * G = 4 (LSTM, gate order i,f,g,o), 3 (GRU: r,z,n), 1 (RNN).  The pointer arrays
  * themselves are HOST arrays of device pointers. */
+/* rnn.py:112-120 accepts any hidden_size (protos/rnn.proto:20); the persistent recurrence kernels exist for LSTM widths that
+ * are multiples of 64 (<= 1024) / 1280 / 1536 / 2048 and GRU widths 512 .. 2560 in steps of 256 (+ 1280).  Returns the width a
+ * caller should PAD a layer of hidden size H to (zero weight rows / columns, zero biases, zero initial state for the padded
+ * units: they stay exactly 0, so out[..., :H], h_n[..., :H], c_n[..., :H] are the unpadded layer's values with exact zeros
+ * added to their sums) so that it runs on a persistent kernel instead of one launch per step; H itself when no padding is
+ * needed or none helps.  MS_RNN_PAD_HIDDEN=0 always returns H. */
+int ms_rnn_padded_hidden(int cell, int H, int ndir);
 size_t ms_rnn_packed_bytes(int cell, int In, int H, int ndir);
 int ms_rnn_pack(int cell, int In, int H, int ndir, const float* const* w_ih_host, const float* const* w_hh_host,
                 const float* const* b_ih_host, const float* const* b_hh_host, void* packed, void* stream);

@@ -39,12 +39,17 @@ class PackedLayer:
         self.key = None
         self.buf = None
 
-    def get(self, cell: int, in_size: int, hidden: int, params: List[Tuple[Optional[torch.Tensor], ...]]):
-        """params: per direction (w_ih, w_hh, b_ih | None, b_hh | None)."""
-        key = tuple((p.data_ptr(), _lib.version_of(p)) if p is not None else None for d in params for p in d)
+    def get(self, cell: int, in_size: int, hidden: int, params: List[Tuple[Optional[torch.Tensor], ...]],
+            pad: Optional[Tuple[int, bool]] = None):
+        """params: per direction (w_ih, w_hh, b_ih | None, b_hh | None).  ``pad`` = (padded hidden size, the layer's input is
+        the padded output of the layer below): the weights are packed at the padded width (``pad_layer_params``);
+        ``in_size`` / ``hidden`` are then the PADDED sizes."""
+        key = tuple((p.data_ptr(), _lib.version_of(p)) if p is not None else None for d in params for p in d) + (pad,)
         if key != self.key:
             lib = _lib.load()
             ndir = len(params)
+            if pad is not None:
+                params = pad_layer_params(cell, params, pad[0], pad[1])
             nbytes = lib.ms_rnn_packed_bytes(cell, in_size, hidden, ndir)
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
             keep = [[None if p is None else _lib.f32c(p.detach()) for p in d] for d in params]
@@ -61,17 +66,48 @@ class PackedLayer:
         return self.buf
 
 
+def pad_layer_params(cell: int, params, hp: int, padded_input: bool):
+    """One layer's (w_ih, w_hh, b_ih, b_hh) per direction with the hidden size padded from H to ``hp``
+    (``ms_rnn_padded_hidden``): every gate block gets ``hp - H`` zero rows, ``w_hh`` as many zero columns per row, and -- for
+    a layer fed by a padded layer (``padded_input``: its input is ``ndir`` blocks of ``hp``) -- ``w_ih`` zero columns at the
+    padded positions of every direction block.  Zero weights and biases keep the padded units at exactly 0."""
+    gates = 4 if cell in (_lib.CELL_LSTM, _lib.CELL_HARD_LSTM) else (3 if cell == _lib.CELL_GRU else 1)
+    ndir = len(params)
+    out = []
+    for w_ih, w_hh, b_ih, b_hh in params:
+        h = w_hh.shape[1]
+        wi = _lib.f32c(w_ih.detach()).view(gates, h, -1)
+        if padded_input:
+            wi = torch.nn.functional.pad(wi.view(gates, h, ndir, h), (0, hp - h)).reshape(gates, h, ndir * hp)
+        wi = torch.nn.functional.pad(wi, (0, 0, 0, hp - h)).reshape(gates * hp, -1).contiguous()
+        wh = torch.nn.functional.pad(_lib.f32c(w_hh.detach()).view(gates, h, h), (0, hp - h, 0, hp - h)).reshape(gates * hp, hp).contiguous()
+        bs = [None if b is None else torch.nn.functional.pad(_lib.f32c(b.detach()).view(gates, h), (0, hp - h)).reshape(-1).contiguous()
+              for b in (b_ih, b_hh)]
+        out.append((wi, wh, bs[0], bs[1]))
+    return out
+
+
 def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max_len: int,
                layer_params: List[List[Tuple[Optional[torch.Tensor], ...]]], packed: List[PackedLayer], hidden: int,
                h0: Optional[torch.Tensor], c0: Optional[torch.Tensor], workspace: _lib.Workspace, check: bool = True,
-               ragged: bool = False):
+               ragged: bool = False, keep_padding: bool = False):
     """x [T,N,In] float32 cuda contiguous -> (out [T,N,D*H], hn, cn|None).  ``ragged``: the lengths differ -- layers that can
-    then work on the rows that exist only, like torch's packed sequences (``MS_RNN_PACKED_ROWS``; same outputs)."""
+    then work on the rows that exist only, like torch's packed sequences (``MS_RNN_PACKED_ROWS``; same outputs).
+    ``keep_padding`` (tests): return a padded stack's outputs and states at the padded width."""
     lib = _lib.load()
     t, n, _ = x.shape
     ndir = len(layer_params[0])
     nl = len(layer_params)
     lstm_like = cell in (_lib.CELL_LSTM, _lib.CELL_HARD_LSTM)
+    # a hidden size without a persistent kernel runs at the next width that has one, its extra units held at exactly 0 by zero
+    # weights (ms_rnn_padded_hidden; rnn.py:112-120 accepts any hidden_size)
+    true_hidden = hidden
+    hidden = int(lib.ms_rnn_padded_hidden(cell, true_hidden, ndir))
+    padded = hidden != true_hidden
+    if padded:
+        grow = (0, hidden - true_hidden)
+        h0 = None if h0 is None else torch.nn.functional.pad(h0, grow)
+        c0 = None if c0 is None else torch.nn.functional.pad(c0, grow)
     hn = torch.empty((nl * ndir, n, hidden), dtype=torch.float32, device="cuda")
     cn = torch.empty_like(hn) if lstm_like else None
     inp = x
@@ -86,7 +122,7 @@ def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max
                                                         for k in in_sizes)
     for layer in range(nl):
         in_size = in_sizes[layer]
-        pk = packed[layer].get(cell, in_size, hidden, layer_params[layer])
+        pk = packed[layer].get(cell, in_size, hidden, layer_params[layer], (hidden, layer > 0) if padded else None)
         flags = (1 if (chain and layer > 0) else 0) | (2 if (chain and layer < nl - 1) else 0) | (4 if pack_rows else 0)
         out = None if flags & 2 else torch.empty((t, n, ndir * hidden), dtype=torch.float32, device="cuda")
         sl = slice(layer * ndir, (layer + 1) * ndir)
@@ -104,6 +140,10 @@ def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max
             _lib.at_issue_point()   # two batches in flight: the other batch's next layer is issued here
     if check:
         _lib.check(lib.ms_rnn_status(_lib.ptr(ws), _lib.stream_ptr()), "ms_rnn_layer_forward")
+    if padded and not keep_padding:      # drop the padded units (exact zeros) of every direction
+        inp = inp.view(t, n, ndir, hidden)[..., :true_hidden].reshape(t, n, ndir * true_hidden)
+        hn = hn[..., :true_hidden].contiguous()
+        cn = None if cn is None else cn[..., :true_hidden].contiguous()
     return inp, hn, cn
 
 

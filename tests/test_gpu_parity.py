@@ -111,7 +111,13 @@ def test_lstm_persistent_vs_oracle(H, N, T_, bidir):
                                                   ("GRU", 2048, 9, 3, True, 32),
                                                   # ... and the two-stream LSTM beyond 1024 (a bidirectional layer's directions in two launches)
                                                   ("LSTM", 1280, 32, 5, True, 64), ("LSTM", 1536, 20, 4, False, 32),
-                                                  ("LSTM", 2048, 32, 4, True, 64), ("LSTM", 2048, 40, 3, False, 32)])
+                                                  ("LSTM", 2048, 32, 4, True, 64), ("LSTM", 2048, 40, 3, False, 32),
+                                                  # round 5: any hidden size -- widths without a persistent kernel are padded
+                                                  # to the next one that has one (two layers at H <= 256: padded input columns)
+                                                  ("LSTM", 200, 20, 9, True, 40), ("LSTM", 1000, 32, 5, True, 64),
+                                                  ("LSTM", 800, 33, 4, False, 32), ("LSTM", 1100, 8, 3, True, 32),
+                                                  ("GRU", 200, 20, 9, True, 40), ("GRU", 800, 32, 5, True, 64),
+                                                  ("GRU", 1000, 40, 4, False, 32), ("GRU", 2300, 8, 3, False, 32)])
 def test_streamed_weights_step_kernel_vs_oracle(kind, H, N, T_, bidir, In):
     """Cells / sizes outside the persistent LSTM: the MFMA step kernel that streams W_hh per step (H % 64 == 0: GRU,
     tanh-RNN, wide LSTM; 1, 2 and 4 batch tiles, a batch beyond 64) and the persistent register-resident GRU
@@ -138,6 +144,68 @@ def test_streamed_weights_step_kernel_vs_oracle(kind, H, N, T_, bidir, In):
         want, whn = O.rnn_forward(getattr(O, kind), x, lens, sd, H, layers, bidir, h0)
     np.testing.assert_allclose(cpu(out), want, **TOL)
     np.testing.assert_allclose(cpu(hn), whn, **TOL)
+
+
+@pytest.mark.parametrize("kind,H,Hp", [("LSTM", 200, 256), ("LSTM", 1000, 1024), ("GRU", 800, 1024), ("GRU", 200, 512)])
+def test_any_hidden_size_runs_on_a_persistent_kernel(kind, H, Hp):
+    """hidden sizes without a persistent kernel (LSTM not a multiple of 64, GRU not one of the persistent
+    widths) are padded with zero weights to the next width that has one.  The padded units stay EXACTLY zero (checked on the
+    raw padded run), the padded run equals the per-step kernels within float32 rounding (they add the same products in another
+    order) and the oracle within the usual tolerance, and it takes one recurrence launch per layer instead of one per step."""
+    import ctypes
+    import os
+    import subprocess
+    import sys
+    from myrtlespeech_amd import _lib
+    from myrtlespeech_amd.model import rnn as R
+    lib = _lib.load()
+    cell = R._CELL[getattr(R.RNNType, kind)]
+    assert lib.ms_rnn_padded_hidden(cell, H, 2) == Hp and lib.ms_rnn_padded_hidden(cell, Hp, 2) == Hp
+    torch.manual_seed(H)
+    T_, N, In = 40, 32, 96
+    m = R.RNN(getattr(R.RNNType, kind), In, H, num_layers=2, bidirectional=True).eval()
+    rng = np.random.default_rng(H)
+    lens = np.sort(rng.integers(1, T_ + 1, size=N))[::-1].copy()
+    lens[0] = T_
+    x = rng.normal(size=(T_, N, In)).astype(np.float32)
+    h0 = (rng.normal(size=(4, N, H)) * 0.3).astype(np.float32)
+    hx = (T(h0), T(h0 * 0.5)) if kind == "LSTM" else T(h0)
+    ms, cnt = (ctypes.c_float * _lib.PROF_KINDS)(), (ctypes.c_int * _lib.PROF_KINDS)()
+    lib.ms_prof_enable(1)
+    lib.ms_prof_read(ms, cnt)
+    (out, _), hid = m((T(x), T(lens)), hx)
+    torch.cuda.synchronize()
+    lib.ms_prof_read(ms, cnt)
+    lib.ms_prof_enable(0)
+    assert cnt[1] == 2, f"{cnt[1]} recurrence spans for two layers"        # MS_PROF_RECURRENCE: one per layer
+    sd = {k[len("rnn."):]: cpu(v) for k, v in m.state_dict().items()}
+    want, whid = O.rnn_forward(getattr(O, kind), x, lens, sd, H, 2, True, (h0, h0 * 0.5) if kind == "LSTM" else h0)
+    np.testing.assert_allclose(cpu(out), want, **TOL)
+    for got, w in zip(hid if kind == "LSTM" else (hid,), whid if kind == "LSTM" else (whid,)):
+        assert got.shape == (4, N, H)
+        np.testing.assert_allclose(cpu(got), w, **TOL)
+    # the raw padded run: units H .. Hp of every direction are exact zeros, in the output and in the final states
+    params = m._layer_params()
+    raw, rhn, rcn = R.run_layers(cell, T(x), _lib.lens_i32(torch.as_tensor(lens)), T_, params, [R.PackedLayer(), R.PackedLayer()], H,
+                                 T(h0), T(h0 * 0.5) if kind == "LSTM" else None, _lib.Workspace(), keep_padding=True)
+    assert raw.shape == (T_, N, 2 * Hp)
+    assert float(raw.view(T_, N, 2, Hp)[..., H:].abs().max()) == 0.0 and float(rhn[..., H:].abs().max()) == 0.0
+    assert rcn is None or float(rcn[..., H:].abs().max()) == 0.0
+    assert torch.equal(raw.view(T_, N, 2, Hp)[..., :H].reshape(T_, N, 2 * H), out)
+    # against the per-step kernels (MS_RNN_PAD_HIDDEN=0 is read once per process: a child)
+    np.savez("/tmp/pad_in_%d.npz" % H, x=x, lens=lens, h0=h0)
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from myrtlespeech_amd.model.rnn import RNN, RNNType\n"
+        "torch.manual_seed(%d); m = RNN(RNNType.%s, %d, %d, num_layers=2, bidirectional=True).eval()\n"
+        "d = np.load(sys.argv[1]); hx = torch.tensor(d['h0']).cuda()\n"
+        "hx = (hx, hx * 0.5) if %r == 'LSTM' else hx\n"
+        "(o, _), _ = m((torch.tensor(d['x']).cuda(), torch.tensor(d['lens'])), hx); np.save(sys.argv[2], o.cpu().numpy())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), H, kind, In, H, kind)
+    child = subprocess.run([sys.executable, "-c", code, "/tmp/pad_in_%d.npz" % H, "/tmp/pad_out_%d.npy" % H],
+                           env=dict(os.environ, MS_RNN_PAD_HIDDEN="0"), capture_output=True, text=True, timeout=600)
+    assert child.returncode == 0, child.stderr[-2000:]
+    np.testing.assert_allclose(cpu(out), np.load("/tmp/pad_out_%d.npy" % H), rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("cin,cout,k,s,d,T_", [(80, 512, 11, 2, 1, 1001), (512, 256, 11, 1, 1, 501), (96, 64, 5, 3, 2, 700),
