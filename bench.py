@@ -245,6 +245,31 @@ def fp16_stream_child():
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
+def gather_one_rank_child(args):
+    """the collective path's cost on hardware in every round's record.  A child process -- started before
+    this process touches the GPU -- runs the same bench as ONE rank with the collective path forced (MS_FORCE_COLLECTIVE=1:
+    RCCL init, the all-gather of the padded logits block, batched decode of the gathered batch) and `--gather-logits`.
+    One rank is all this pool can give: no statement about scaling."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(10, args.steps // 2)), "--warmup",
+           str(args.warmup), "--gather-logits", "--no-cpu-baseline", "--no-f32-child", "--no-frontend", "--no-legs", "--no-ragged",
+           "--reps", "0", "--detail-path", os.devnull]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               MS_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        c = d.get("config", {})
+        return {"ms": d.get("ms_per_step"), "value": d.get("value"), "one_batch_ms": c.get("one_batch_ms_per_step"),
+                "headline_mode": c.get("headline_mode"), "decode": c.get("decode"), "backend": "nccl (RCCL), world 1, collective forced",
+                "steps": d.get("steps")}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def compact(rec, keys):
     return {k: rec[k] for k in keys if isinstance(rec, dict) and k in rec}
 
@@ -254,7 +279,7 @@ DETAIL_FILE = os.path.join(ROOT, "bench_detail.json")
 # keys of the full record that are prose or nested detail: they live in bench_detail.json (and on stderr), not in the line
 LINE_DROP = ("legs_detail", "one_batch_in_flight", "two_batches_in_flight", "two_batches_per_forward", "precision_f32",
              "ragged_lengths", "parity", "what_binds", "definition", "launch_ms_source", "note", "latency_note", "floor",
-             "two_in_flight_note", "pmc_source", "pipeline", "kernel_note", "sample_note")
+             "two_in_flight_note", "pmc_source", "pipeline", "kernel_note", "sample_note", "chain_floor")
 # dropped, in this order, only if the line would still exceed LINE_LIMIT (it does not today: ~4 KB)
 LINE_OPTIONAL = ("stages", "projection_gemm", "kernel_ms", "timing")
 
@@ -370,8 +395,10 @@ def main(argv=None, runtime=None, json_fd=None):
     f32 = stream_fp16 = None
     if world == 1 and "RANK" not in os.environ and precision_mode() == "bf16x3" and not args.no_f32_child:
         f32 = f32_child(args)          # before the first GPU call of this process
+    gather1 = None
     if world == 1 and "RANK" not in os.environ and precision_mode() == "bf16x3" and not args.no_legs:
         stream_fp16 = fp16_stream_child()
+        gather1 = gather_one_rank_child(args)
 
     dist = None
     if world > 1 or "RANK" in os.environ:  # under torchrun (also with one rank) the collective path is exercised
@@ -844,10 +871,12 @@ def main(argv=None, runtime=None, json_fd=None):
             detail = bench_configs.run_legs(["ctc", "ctcgrad", "beam", "ds1", "rnnt", "stream", "streamctx"], cpu=not args.no_cpu_baseline)
             if stream_fp16 is not None:
                 detail["cfg5_streaming_fp16"] = stream_fp16
+            if gather1 is not None:
+                detail["gather_logits_one_rank"] = gather1
             out["legs_detail"] = detail
-            num = ("ms", "ms_min", "ms_per_chunk", "ms_per_chunk_wall", "floor_ms", "frac_of_floor", "audio_sec_per_s", "utterances_per_s",
+            num = ("ms", "ms_min", "ms_few_rows", "ms_per_chunk", "ms_per_chunk_wall", "floor_ms", "frac_of_floor", "chain_floor_ms", "frac_of_chain_floor", "audio_sec_per_s", "utterances_per_s",
                    "encoder_ms", "beam8_decode_ms", "greedy_decode_ms", "us_per_frame", "realtime_factor", "dtype", "latency_frames",
-                   "transcripts_equal_oracle_fixture", "error")
+                   "transcripts_equal_oracle_fixture", "error", "value", "one_batch_ms", "headline_mode", "steps")
             legs = {"calibration": detail.get("calibration")}
             for name, rec in detail.items():
                 if name == "calibration" or not isinstance(rec, dict):

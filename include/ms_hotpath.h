@@ -42,7 +42,8 @@
 extern "C" {
 #endif
 
-/* 3 (round 5): ms_linear_splitk_workspace_bytes / ms_linear_splitk_forward take `flags` (MS_LINEAR_FEW_ROWS): the K-slice count
+/* 3 (round 5): ms_ctc_status and ms_rnn_padded_hidden are new; the CTC workspaces start with a 256-byte status region;
+ * ms_linear_splitk_workspace_bytes / ms_linear_splitk_forward take `flags` (MS_LINEAR_FEW_ROWS): the K-slice count
  * no longer depends on M.
  * 2 (round 4): ms_prof_read writes MS_PROF_KINDS = 9 entries (was 4 in version 1); the `zero_infinity` argument of the CTC
  * entry points is a bit field {1 = zero_infinity, MS_CTC_LOG_PROBS_IN} and values above 3 are rejected;
@@ -288,6 +289,16 @@ int ms_barrier_chain_probe(unsigned long long* out_dev, int steps, int threads, 
 /* ---- loss/ctc_loss.py ---------------------------------------------------- */
 
 size_t ms_ctc_loss_workspace_bytes(int T, int N, int V, int S_max);
+
+/* The first 256 bytes of a CTC workspace (forward or backward) hold a sticky time-out word; the caller provides it zeroed
+ * before the first call and leaves it alone afterwards.  The four-wave alpha pipeline hands two values per frame from wave
+ * to wave through an LDS mailbox with a bounded (0.5 s) spin; should an entry never arrive -- it cannot while every wave of
+ * the workgroup runs -- the utterance's loss (and its gradient) is NaN AND the word is set.  ms_ctc_status synchronises
+ * `stream`, returns MS_ERR_TIMEOUT once if the word was set and clears it (the CTC twin of ms_rnn_status; ctc_loss.py has
+ * no such state: torch's kernel cannot time out).  A NaN loss WITHOUT the status is data: a frame whose log-softmax
+ * normaliser is not finite (a NaN or +inf logit, a row of -inf) gives NaN as torch.nn.CTCLoss does, also under
+ * zero_infinity. */
+int ms_ctc_status(const void* workspace, void* stream);
 
 /* CTCLoss.forward (ctc_loss.py:95-101) = LogSoftmax(dim=-1) + torch.nn.CTCLoss:
  * log-space alpha recursion per utterance.  logits [T,N,V] unnormalised;

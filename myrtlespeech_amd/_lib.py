@@ -57,6 +57,7 @@ SIGNATURES = {
     "ms_lookahead_forward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_int, c_float, c_float, _P]),
     "ms_lookahead_window_forward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_int, c_float, c_float, _P]),
     "ms_rnn_packed_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "ms_ctc_status": (c_int, [_P, _P]),
     "ms_rnn_padded_hidden": (c_int, [c_int, c_int, c_int]),
     "ms_rnn_pack": (c_int, [c_int, c_int, c_int, c_int, _PP, _PP, _PP, _PP, _P, _P]),
     "ms_rnn_workspace_bytes": (c_size_t, [c_int] * 6),

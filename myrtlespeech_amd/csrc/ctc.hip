@@ -102,8 +102,12 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_kernel(const float* __r
     }
     // LDS-only barrier: __syncthreads() also drains the vector-memory queue (its workgroup fence waits vmcnt(0)), i.e. it
     // would wait for the log-probability just requested for the NEXT frame and put the L2 latency back into every step
+    // (compiler fences on both sides: without them nothing tells the compiler that the LDS stores above must be issued before
+    // the barrier and the loads of the next frame after it -- ADVICE r4)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's alpha row is in the LDS
     __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     float* tmp = cur; cur = nxt; nxt = tmp;
   }
   __syncthreads();
@@ -142,6 +146,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_kernel(const float* __r
 // Natural-log losses differ from ctc_alpha_kernel's by rounding only (1e-6 relative in tests/test_gpu_parity.py, which also
 // holds both against the oracle).  K = states per lane: S <= 256 K.
 constexpr float CTC_NEG = -1.0e30f;
+constexpr size_t CTC_STATUS_BYTES = 256;   // sticky time-out word at the start of every CTC workspace (ms_ctc_status)
 
 struct alignas(8) MbEntry { float top, below; };
 
@@ -347,9 +352,10 @@ __device__ __forceinline__ void alpha_wave_body(const float* __restrict__ lpn, c
 // phase 1 of the pipeline kernel: lpn[t][v] = clamp((x[t, n, v] - logsumexp_v x[t, n, :]) log2(e), +-CTC_NEG) (NaN -> CTC_NEG); a thread takes
 // a frame with its VB >= V symbols in registers (every load of the frame in flight at once)
 template <int VB>
-__device__ __forceinline__ void alpha_wave_normalise(const float* __restrict__ logits, float* __restrict__ lpn, int n, int Tn,
+__device__ __forceinline__ bool alpha_wave_normalise(const float* __restrict__ logits, float* __restrict__ lpn, int n, int Tn,
                                                      int N, int V, int log_probs_in, int tid) {
   constexpr float LOG2E = 1.4426950408889634f;
+  bool bad = false;   // a frame's normaliser is NaN or infinite
   for (int t = tid; t < Tn; t += CTC_THREADS) {
     const float* row = logits + ((size_t)t * N + n) * V;
     float* out = lpn + (size_t)t * V;
@@ -365,11 +371,16 @@ __device__ __forceinline__ void alpha_wave_normalise(const float* __restrict__ l
 #pragma unroll
       for (int v = 0; v < VB; ++v) sum += expf(r[v] - m);
       lz = logf(sum) + m;
+      bad |= !(fabsf(lz) < INFINITY);
+    } else {
+#pragma unroll
+      for (int v = 0; v < VB; ++v) bad |= (v < V) && (r[v] != r[v]);
     }
 #pragma unroll
     for (int v = 0; v < VB; ++v)
       if (v < V) out[v] = fminf(fmaxf((r[v] - lz) * LOG2E, CTC_NEG), -CTC_NEG);
   }
+  return bad;
 }
 
 // mode: bit 0 = the reversed recursion (beta), bit 1 = the workspace already holds this call's normalised log-probabilities
@@ -386,9 +397,11 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
                                                                      float* __restrict__ rows_ws = nullptr, int S_max = 0,
                                                                      int mode = 0, float* __restrict__ ll2_out = nullptr,
                                                                      float* __restrict__ rows_ws_rev = nullptr,
-                                                                     float* __restrict__ lps_ws = nullptr) {
+                                                                     float* __restrict__ lps_ws = nullptr,
+                                                                     unsigned* __restrict__ status = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
+  bool bad_row = false;   // a frame whose normaliser is not finite (a NaN / +inf logit, a row of -inf): the loss is NaN (torch)
   MbEntry* mb = reinterpret_cast<MbEntry*>(smem);   // [3][T] {alpha(top), alpha(top - 1)} of waves 0..2, per frame
   float* fin = smem + (size_t)6 * T;                // [2] the last two states' values, [2] = a wave gave up waiting
   const int Tn = min(max(in_lens[n], 0), T);
@@ -405,8 +418,8 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
   float* lps = wide_v ? lps_ws + (size_t)n * T * S_max : nullptr;
 
   if (mode & 2) {
-  } else if (V <= 32) alpha_wave_normalise<32>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
-  else if (V <= 64) alpha_wave_normalise<64>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
+  } else if (V <= 32) bad_row = alpha_wave_normalise<32>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
+  else if (V <= 64) bad_row = alpha_wave_normalise<64>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
   else {
     // wide alphabets (word pieces): a WAVE per frame, lanes across the symbols (coalesced row reads, wave reductions), a
     // lane's share of the row in registers with every load of the row in flight at once -- a thread per frame, or one load
@@ -447,6 +460,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
         lz = logf(sum) + m;
+        bad_row |= !(fabsf(lz) < INFINITY);
       }
       if (ROWS) {                                   // every symbol's value: only the gradient kernel reads these
 #pragma unroll
@@ -464,7 +478,9 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
   for (int i = tid; i < 3 * T; i += CTC_THREADS) mb[i] = MbEntry{__uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu)};
   if (tid < 2) fin[tid] = CTC_NEG;
   if (tid == 2) fin[2] = 0.f;
+  if (tid == 3) fin[3] = 0.f;
   __syncthreads();   // the workgroup's own stores (one CU, one L1) are visible to its loads behind this
+  if (bad_row) fin[3] = 1.f;   // (read behind the barrier that follows the recursion)
   if (Tn == 0) {
     if (tid == 0) {
       if (nll != nullptr) nll[n] = (S == 1) ? -0.f : INFINITY;
@@ -480,7 +496,12 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
   __syncthreads();
   if (tid == 0) {
     const float l1 = fin[0], l2 = fin[1];   // log2 domain; CTC_NEG or below = no path; NaN = a wave gave up waiting
-    const bool poisoned = fin[2] != 0.f;
+    // fin[2]: an LDS mailbox entry never arrived (cannot happen while every wave of the workgroup runs) -- NaN in band AND the
+    // sticky status word, which ms_ctc_status turns into MS_ERR_TIMEOUT; fin[3]: a non-finite normaliser -- NaN, as
+    // torch.nn.CTCLoss gives for such logits (the clamp to "log zero" would otherwise turn it into +inf, which zero_infinity
+    // silently replaces by 0: ADVICE r4)
+    if (fin[2] != 0.f && status != nullptr) atomicOr(status, 1u);
+    const bool poisoned = fin[2] != 0.f || fin[3] != 0.f;
     const float m = fmaxf(l1, l2);
     const float ll2 = log2f(exp2f(l1 - m) + exp2f(l2 - m)) + m;
     if (nll != nullptr) nll[n] = poisoned ? __uint_as_float(0x7fc00000u) : (m < 0.5f * CTC_NEG) ? INFINITY : -(ll2 * 0.6931471805599453f);
@@ -546,6 +567,10 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_grad_rows_kernel(const float*
     float* grow = grad + ((size_t)t * N + n) * V;
     if (t >= Tn || (infeasible && zero_infinity)) {       // padding frames (and, with zero_infinity, impossible targets): zeros
       for (int k = lane; k < V; k += 64) grow[k] = 0.f;
+      continue;
+    }
+    if (l2 != l2) {   // a NaN loss (a non-finite log-softmax normaliser, or a wave that gave up): NaN gradients, as torch's are
+      for (int k = lane; k < V; k += 64) grow[k] = l2;
       continue;
     }
     // alpha + beta of the frame's states into LDS, their maximum and the blank's sum by wave reductions
@@ -799,8 +824,21 @@ extern "C" size_t ms_ctc_loss_workspace_bytes(int T, int N, int V, int S_max) {
   if (T <= 0 || N <= 0 || V <= 0) return 0;
   // per-frame normalisers [T][N] (ctc_alpha_kernel) + the normalised log-probabilities [N][T][V] of the pipeline kernel
   // (wide alphabets, V > 64: the recursion reads a per-state copy [N][T][S_max] instead)
-  return ms::align_up((size_t)T * N * sizeof(float), 256) +
+  return CTC_STATUS_BYTES + ms::align_up((size_t)T * N * sizeof(float), 256) +
          ms::align_up((size_t)T * N * (V > 64 ? std::max(S_max, 1) : V) * sizeof(float), 256);
+}
+
+// The first CTC_STATUS_BYTES of a CTC workspace: a sticky word the pipeline kernel sets when a wave gave up waiting for a
+// mailbox entry (the loss of that utterance is NaN).  Synchronises `stream`, returns MS_ERR_TIMEOUT once and clears the word.
+extern "C" int ms_ctc_status(const void* workspace, void* stream) {
+  MS_REQUIRE(workspace, "null pointer");
+  unsigned v = 0;
+  MS_HIP(hipMemcpyAsync(&v, workspace, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  MS_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (v == 0) return MS_OK;
+  MS_HIP(hipMemsetAsync(const_cast<void*>(workspace), 0, sizeof(unsigned), (hipStream_t)stream));
+  ms::set_error("CTC loss: a wave of the alpha pipeline gave up waiting for its neighbour's frame (0.5 s); that utterance's loss is NaN");
+  return MS_ERR_TIMEOUT;
 }
 
 extern "C" int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, const int32_t* targets,
@@ -817,6 +855,8 @@ extern "C" int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, 
     ms::set_error("ms_ctc_loss_forward: workspace too small");
     return MS_ERR_WORKSPACE;
   }
+  unsigned* status = (unsigned*)workspace;
+  workspace = (char*)workspace + CTC_STATUS_BYTES;
   const size_t lds = (size_t)3 * S_max * sizeof(float);
   MS_REQUIRE(lds <= 160 * 1024, "target too long for the LDS-resident alpha rows");
   static ms::DeviceOnce attr_once;
@@ -839,15 +879,15 @@ extern "C" int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, 
     if (S_max <= 256)
       hipLaunchKernelGGL((ctc_alpha_wave_kernel<1, 16>), dim3(N), dim3(CTC_THREADS), wl, (hipStream_t)stream, logits, in_lens,
                          targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi, (float*)nullptr, S_max, 0, (float*)nullptr,
-                         (float*)nullptr, lpn_ws);
+                         (float*)nullptr, lpn_ws, status);
     else if (S_max <= 512)
       hipLaunchKernelGGL((ctc_alpha_wave_kernel<2, 16>), dim3(N), dim3(CTC_THREADS), wl, (hipStream_t)stream, logits, in_lens,
                          targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi, (float*)nullptr, S_max, 0, (float*)nullptr,
-                         (float*)nullptr, lpn_ws);
+                         (float*)nullptr, lpn_ws, status);
     else
       hipLaunchKernelGGL((ctc_alpha_wave_kernel<4, 8>), dim3(N), dim3(CTC_THREADS), wl, (hipStream_t)stream, logits, in_lens,
                          targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi, (float*)nullptr, S_max, 0, (float*)nullptr,
-                         (float*)nullptr, lpn_ws);
+                         (float*)nullptr, lpn_ws, status);
   } else {
     hipLaunchKernelGGL(ctc_alpha_kernel, dim3(N), dim3(CTC_THREADS), lds, (hipStream_t)stream, logits, in_lens, targets,
                        tgt_offsets, tgt_lens, nll, (float*)workspace, T, N, V, S_max, blank, lpi);
@@ -931,7 +971,7 @@ extern "C" size_t ms_ctc_loss_backward_workspace_bytes(int T, int N, int V, int 
   if (T <= 0 || N <= 0 || S_max < 1 || V <= 0) return 0;
   // normalisers [T][N] + alpha rows [N][T][S_max] (ctc_grad_kernel); + beta rows, the normalised log-probabilities [N][T][V] and
   // the log-likelihoods [N] of the pipeline path
-  return ms::align_up((size_t)T * N * sizeof(float), 256) + (V > 64 ? 3 : 2) * ms::align_up((size_t)T * N * S_max * sizeof(float), 256) +
+  return CTC_STATUS_BYTES + ms::align_up((size_t)T * N * sizeof(float), 256) + (V > 64 ? 3 : 2) * ms::align_up((size_t)T * N * S_max * sizeof(float), 256) +
          ms::align_up((size_t)T * N * V * sizeof(float), 256) + ms::align_up((size_t)N * sizeof(float), 256);
 }
 
@@ -947,6 +987,8 @@ extern "C" int ms_ctc_loss_backward(const float* logits, const int32_t* in_lens,
     ms::set_error("ms_ctc_loss_backward: workspace too small");
     return MS_ERR_WORKSPACE;
   }
+  unsigned* status = (unsigned*)workspace;
+  workspace = (char*)workspace + CTC_STATUS_BYTES;
   {
     // the pipeline path: alpha rows and beta rows (the same kernel on the reversed utterance) in one launch, then one wave per
     // frame for the gradient rows.  MS_CTC_WAVE=0 (read per call) keeps ctc_grad_kernel.
@@ -975,13 +1017,13 @@ extern "C" int ms_ctc_loss_backward(const float* logits, const int32_t* in_lens,
       // alpha and beta (= the reversed recursion) side by side: grid (N, 2)
       if (S_max <= 256)
         hipLaunchKernelGGL((ctc_alpha_wave_kernel<1, 16, true>), dim3(N, 2), dim3(CTC_THREADS), wl, st, logits, in_lens, targets,
-                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows, lps);
+                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows, lps, status);
       else if (S_max <= 512)
         hipLaunchKernelGGL((ctc_alpha_wave_kernel<2, 16, true>), dim3(N, 2), dim3(CTC_THREADS), wl, st, logits, in_lens, targets,
-                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows, lps);
+                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows, lps, status);
       else
         hipLaunchKernelGGL((ctc_alpha_wave_kernel<4, 8, true>), dim3(N, 2), dim3(CTC_THREADS), wl, st, logits, in_lens, targets,
-                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows, lps);
+                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows, lps, status);
       MS_LAUNCH_CHECK();
       hipLaunchKernelGGL(ctc_grad_rows_kernel, dim3(ms::cdiv(T, 4 * GR_FRAMES), N), dim3(CTC_THREADS), rows_lds, st, lpn, alpha_rows,
                          beta_rows, ll2, in_lens, targets, tgt_offsets, tgt_lens, grad_nll, grad_logits, T, N, V, S_max, blank,

@@ -74,6 +74,17 @@ class CTCLoss(torch.nn.Module):
         self.use_cuda = torch.cuda.is_available()
         self._workspace = _lib.Workspace()
         self._bwd_workspace = _lib.Workspace()
+        # like RNN.check_status: after every forward ask ms_ctc_status (a 4-byte read-back and a stream synchronisation)
+        # whether a wave of the alpha pipeline timed out, and raise instead of handing back a NaN loss.  A caller that must
+        # not synchronise sets it to False and calls ``status()`` when it reads the loss.
+        self.check_status = True
+
+    def status(self) -> None:
+        """Synchronises the current stream; raises RuntimeError if a loss kernel of this module timed out (reported once)."""
+        lib = _lib.load()
+        for ws in (self._workspace, self._bwd_workspace):
+            if ws.buf is not None:
+                _lib.check(lib.ms_ctc_status(_lib.ptr(ws.buf), _lib.stream_ptr()), "ms_ctc_loss_forward")
 
     def forward(self, inputs: Tuple[torch.Tensor, torch.Tensor], targets: Tuple[torch.Tensor, torch.Tensor]
                 ) -> torch.Tensor:
@@ -150,6 +161,8 @@ class CTCLoss(torch.nn.Module):
                                                _lib.ptr(yl_dev), _lib.ptr(nll), _lib.ptr(reduced), t, n, v, s_max, blank,
                                                red, fwd_flags, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
                        "ms_ctc_loss_forward")
+            if self.check_status:
+                _lib.check(lib.ms_ctc_status(_lib.ptr(ws), _lib.stream_ptr()), "ms_ctc_loss_forward")
             return nll if red == 0 else reduced[0]
 
         if torch.is_grad_enabled() and x.requires_grad:

@@ -40,16 +40,16 @@ class PackedLayer:
         self.buf = None
 
     def get(self, cell: int, in_size: int, hidden: int, params: List[Tuple[Optional[torch.Tensor], ...]],
-            pad: Optional[Tuple[int, bool]] = None):
+            pad: Optional[Tuple[int, bool, int]] = None):
         """params: per direction (w_ih, w_hh, b_ih | None, b_hh | None).  ``pad`` = (padded hidden size, the layer's input is
-        the padded output of the layer below): the weights are packed at the padded width (``pad_layer_params``);
+        the padded output of the layer below, zero columns appended to the input): the weights are packed at the padded width (``pad_layer_params``);
         ``in_size`` / ``hidden`` are then the PADDED sizes."""
         key = tuple((p.data_ptr(), _lib.version_of(p)) if p is not None else None for d in params for p in d) + (pad,)
         if key != self.key:
             lib = _lib.load()
             ndir = len(params)
             if pad is not None:
-                params = pad_layer_params(cell, params, pad[0], pad[1])
+                params = pad_layer_params(cell, params, pad[0], pad[1], pad[2])
             nbytes = lib.ms_rnn_packed_bytes(cell, in_size, hidden, ndir)
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
             keep = [[None if p is None else _lib.f32c(p.detach()) for p in d] for d in params]
@@ -66,7 +66,7 @@ class PackedLayer:
         return self.buf
 
 
-def pad_layer_params(cell: int, params, hp: int, padded_input: bool):
+def pad_layer_params(cell: int, params, hp: int, padded_input: bool, in_pad: int = 0):
     """One layer's (w_ih, w_hh, b_ih, b_hh) per direction with the hidden size padded from H to ``hp``
     (``ms_rnn_padded_hidden``): every gate block gets ``hp - H`` zero rows, ``w_hh`` as many zero columns per row, and -- for
     a layer fed by a padded layer (``padded_input``: its input is ``ndir`` blocks of ``hp``) -- ``w_ih`` zero columns at the
@@ -79,7 +79,7 @@ def pad_layer_params(cell: int, params, hp: int, padded_input: bool):
         wi = _lib.f32c(w_ih.detach()).view(gates, h, -1)
         if padded_input:
             wi = torch.nn.functional.pad(wi.view(gates, h, ndir, h), (0, hp - h)).reshape(gates, h, ndir * hp)
-        wi = torch.nn.functional.pad(wi, (0, 0, 0, hp - h)).reshape(gates * hp, -1).contiguous()
+        wi = torch.nn.functional.pad(wi, (0, in_pad, 0, hp - h)).reshape(gates * hp, -1).contiguous()   # (+ in_pad zero columns)
         wh = torch.nn.functional.pad(_lib.f32c(w_hh.detach()).view(gates, h, h), (0, hp - h, 0, hp - h)).reshape(gates * hp, hp).contiguous()
         bs = [None if b is None else torch.nn.functional.pad(_lib.f32c(b.detach()).view(gates, h), (0, hp - h)).reshape(-1).contiguous()
               for b in (b_ih, b_hh)]
@@ -104,10 +104,17 @@ def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max
     true_hidden = hidden
     hidden = int(lib.ms_rnn_padded_hidden(cell, true_hidden, ndir))
     padded = hidden != true_hidden
+    in_pad = 0
     if padded:
         grow = (0, hidden - true_hidden)
         h0 = None if h0 is None else torch.nn.functional.pad(h0, grow)
         c0 = None if c0 is None else torch.nn.functional.pad(c0, grow)
+        # ... and its first layer's input to a multiple of 32 (zero columns on both sides of the product), which is what the
+        # split-bf16 projection GEMM takes; only for stacks that are being padded anyway -- an unpadded layer keeps the GEMM
+        # (and the bits) it has always had
+        if _lib.split_precision() and x.shape[2] % 32:
+            in_pad = -x.shape[2] % 32
+            x = torch.nn.functional.pad(x, (0, in_pad))
     hn = torch.empty((nl * ndir, n, hidden), dtype=torch.float32, device="cuda")
     cn = torch.empty_like(hn) if lstm_like else None
     inp = x
@@ -122,7 +129,8 @@ def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max
                                                         for k in in_sizes)
     for layer in range(nl):
         in_size = in_sizes[layer]
-        pk = packed[layer].get(cell, in_size, hidden, layer_params[layer], (hidden, layer > 0) if padded else None)
+        pk = packed[layer].get(cell, in_size, hidden, layer_params[layer],
+                               (hidden, layer > 0, in_pad if layer == 0 else 0) if padded else None)
         flags = (1 if (chain and layer > 0) else 0) | (2 if (chain and layer < nl - 1) else 0) | (4 if pack_rows else 0)
         out = None if flags & 2 else torch.empty((t, n, ndir * hidden), dtype=torch.float32, device="cuda")
         sl = slice(layer * ndir, (layer + 1) * ndir)

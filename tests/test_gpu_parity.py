@@ -186,8 +186,9 @@ def test_any_hidden_size_runs_on_a_persistent_kernel(kind, H, Hp):
         np.testing.assert_allclose(cpu(got), w, **TOL)
     # the raw padded run: units H .. Hp of every direction are exact zeros, in the output and in the final states
     params = m._layer_params()
-    raw, rhn, rcn = R.run_layers(cell, T(x), _lib.lens_i32(torch.as_tensor(lens)), T_, params, [R.PackedLayer(), R.PackedLayer()], H,
-                                 T(h0), T(h0 * 0.5) if kind == "LSTM" else None, _lib.Workspace(), keep_padding=True)
+    raw, rhn, rcn = R.run_layers(cell, T(x).cuda(), _lib.lens_i32(torch.as_tensor(lens)), T_, params, [R.PackedLayer(), R.PackedLayer()], H,
+                                 T(h0).cuda(), T(h0 * 0.5).cuda() if kind == "LSTM" else None, _lib.Workspace(), ragged=True,
+                                 keep_padding=True)
     assert raw.shape == (T_, N, 2 * Hp)
     assert float(raw.view(T_, N, 2, Hp)[..., H:].abs().max()) == 0.0 and float(rhn[..., H:].abs().max()) == 0.0
     assert rcn is None or float(rcn[..., H:].abs().max()) == 0.0
@@ -523,6 +524,46 @@ def test_ctc_loss_golden():
     for red in ("none", "mean", "sum"):
         got = CTCLoss(blank=28, reduction=red)((T(g["in/x"]), T(g["in/x_lens"])), (T(g["in/y"]), T(g["in/y_lens"])))
         np.testing.assert_allclose(cpu(got), g[f"out/{red}_0"], rtol=1e-4, atol=1e-3)
+
+
+def test_ctc_loss_nan_logits_give_nan_like_torch_and_no_timeout_status():
+    """the four-wave pipeline clamps normalised log-probabilities to a finite "log zero"; a NaN logit row used to
+    come out as nll = +inf, which ``zero_infinity`` silently turned into 0 (loss AND gradient) where torch.nn.CTCLoss gives
+    NaN.  A non-finite normaliser now poisons that utterance's loss -- and only that one's -- and is NOT a time-out."""
+    from myrtlespeech_amd import _lib
+    from myrtlespeech_amd.loss.ctc_loss import CTCLoss
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=(60, 4, 29)).astype(np.float32)
+    xl = np.array([60, 55, 50, 40], dtype=np.int32)
+    y = rng.integers(0, 28, size=(4, 12)).astype(np.int32)
+    yl = np.array([12, 10, 8, 5], dtype=np.int32)
+    bad = x.copy()
+    bad[17, 1, 3] = np.nan           # utterance 1, inside its length
+    bad[45, 3, :] = 7.0              # utterance 3, past its length (40): ignored
+    bad[45, 3, 2] = np.nan
+    bad[20, 2, 5] = np.inf           # utterance 2: log_softmax gives NaN at that symbol
+    want = torch.nn.CTCLoss(blank=28, reduction="none", zero_infinity=True)(
+        torch.log_softmax(torch.from_numpy(bad), -1), torch.from_numpy(y).long(), torch.from_numpy(xl).long(), torch.from_numpy(yl).long()).numpy()
+    assert np.isnan(want[1]) and np.isfinite(want[0]) and np.isfinite(want[3])
+    for zi in (False, True):
+        loss = CTCLoss(blank=28, reduction="none", zero_infinity=zi)      # check_status on: a time-out would raise here
+        got = cpu(loss((T(bad), T(xl)), (T(y), T(yl))))
+        assert np.isnan(got[1]) and np.isnan(got[2])
+        np.testing.assert_allclose(got[[0, 3]], want[[0, 3]], rtol=1e-4, atol=1e-4)
+        loss.status()                                                      # nothing sticky was left behind
+    # the same through autograd: the poisoned utterances' gradients are NaN, the others' match torch
+    xt = T(bad).requires_grad_(True)
+    loss = CTCLoss(blank=28, reduction="sum", zero_infinity=True)
+    loss((xt, T(xl)), (T(y), T(yl))).backward()
+    g = cpu(xt.grad)
+    assert np.isnan(g[:, 1]).any() and np.isfinite(g[:, 0]).all() and np.isfinite(g[:, 3]).all()
+    # C ABI: ms_ctc_status on a clean workspace is MS_OK; a set word is reported once as MS_ERR_TIMEOUT and cleared
+    lib = _lib.load()
+    ws = torch.zeros(lib.ms_ctc_loss_workspace_bytes(60, 4, 29, 25), dtype=torch.uint8, device="cuda")
+    assert lib.ms_ctc_status(_lib.ptr(ws), _lib.stream_ptr()) == 0
+    ws[0] = 1
+    assert lib.ms_ctc_status(_lib.ptr(ws), _lib.stream_ptr()) == 4          # MS_ERR_TIMEOUT
+    assert lib.ms_ctc_status(_lib.ptr(ws), _lib.stream_ptr()) == 0
 
 
 def test_ctc_loss_dim_golden():

@@ -27,6 +27,14 @@ import torch  # noqa: E402
 
 HBM_GBS = 8000.0
 F32_MFMA_TF = 157.3
+CLOCK_GHZ = 2.4            # MI355X peak engine clock (MI355X_MICROARCH.md)
+# The instruction-chain floor of the CTC alpha pipeline: a frame of the wave that never waits is ~40 mostly
+# DEPENDENT instructions (max3 / sub / exp2 / add / log2 / add per state group + the DPP shifts and the ring load); a wave64
+# VALU instruction issues over 4 cycles on a 16-lane SIMD, the two transcendentals over 16
+CTC_FRAME_CYCLES = 38 * 4 + 2 * 16
+CTC_CHAIN_NOTE = ("501 frames x (38 dependent VALU ops x 4 cycles + 2 transcendentals x 16) = 184 cycles per frame at 2.4 GHz on one "
+                  "wave per SIMD: what the kernel's frame is made of (measured 0.105 us = 250 cycles on the wave that never waits); "
+                  "the barrier-phase floor beside it does not bind this kernel (no barrier in its frame)")
 
 
 def host_threads():
@@ -172,11 +180,15 @@ def leg_ctc_loss(ctx):
     tgt = torch.randint(0, 28, (32, 120), dtype=torch.int32, generator=g)
     tl = torch.full((32,), 120, dtype=torch.int32)
     loss = CTCLoss(blank=28, reduction="sum")
+    loss.check_status = False          # no read-back + synchronisation per call inside the timed region; asked once below
     ms, ms_min = ev_timed(lambda: loss((logits, lens), (tgt, tl)), 3, 20)
+    loss.status()
     b_us = ctx["barrier_step_us"]
     floor = 501 * b_us * 1e-3 + 501 * 32 * 29 * 4 / (HBM_GBS * 1e6)
+    chain = 501 * CTC_FRAME_CYCLES / (CLOCK_GHZ * 1e6)
     out = {"workload": "CTC loss forward, logits [501,32,29], targets 32 x 120, reduction sum (BASELINE.md 3)",
            "ms": round(ms, 4), "ms_min": round(ms_min, 4), "floor_ms": round(floor, 4), "frac_of_floor": round(floor / ms, 3),
+           "chain_floor_ms": round(chain, 4), "frac_of_chain_floor": round(chain / ms, 3), "chain_floor": CTC_CHAIN_NOTE,
            "floor": f"501 frames x 1 barrier-separated alpha row x {b_us:.3f} us (measured barrier phase) + 1.86 MB at 8 TB/s; "
                     "one workgroup per utterance, 32 of 256 CUs busy.  The kernel (four-wave pipeline, alphas in registers, "
                     "csrc/ctc.hip) has no barrier in its frame: 0.105 us per frame on the wave that never waits, 0.15 us on "
@@ -208,15 +220,21 @@ def leg_ctc_grad(ctx):
     tl = torch.full((32,), 120, dtype=torch.int32)
     loss = CTCLoss(blank=28, reduction="sum")
 
+    loss.check_status = False
+
     def step():
         logits.grad = None
         loss((logits, lens), (tgt, tl)).backward()
     ms, ms_min = ev_timed(step, 3, 20)
+    loss.status()
     b_us = ctx["barrier_step_us"]
     rows = 501 * 32 * 241 * 4
     floor = 2 * 501 * b_us * 1e-3 + (4 * rows + 3 * 501 * 32 * 29 * 4) / (HBM_GBS * 1e6)
+    # forward's chain, then alpha and beta side by side (one more chain), then the gradient rows at HBM rate
+    chain = 2 * 501 * CTC_FRAME_CYCLES / (CLOCK_GHZ * 1e6) + (4 * rows + 3 * 501 * 32 * 29 * 4) / (HBM_GBS * 1e6)
     out = {"workload": "CTC loss forward + backward, logits [501,32,29], targets 32 x 120, reduction sum",
            "ms": round(ms, 4), "ms_min": round(ms_min, 4), "floor_ms": round(floor, 4), "frac_of_floor": round(floor / ms, 3),
+           "chain_floor_ms": round(chain, 4), "frac_of_chain_floor": round(chain / ms, 3), "chain_floor": CTC_CHAIN_NOTE,
            "floor": f"two dependent chains (alpha, beta) of 501 frames x {b_us:.3f} us (measured barrier phase) + alpha / beta rows "
                     "written and read once + logits read, gradient written, at 8 TB/s.  Kernels: the forward pipeline, the same "
                     "kernel twice more with row stores (alpha, and reversed = beta), one wave per frame for the gradient rows "
