@@ -11,10 +11,15 @@
 //   * candidates are exactly: the beam entries themselves (slot w) and their one-symbol
 //     extensions (slot W + w*V + c), an extension that is itself in the beam folds into
 //     that beam entry's slot.
-// Prefix identity is a trie in the workspace (node = parent + symbol) with a child table
-// for every node that has ever been in the beam, so "l + c" resolves to the same node no
-// matter when it is re-derived (needed for `l_plus in A_prev` and the Pb[t-1][l_plus]
-// look-ups of ctc_beam_decoder.py:232-241).
+// Prefix identity is a trie (node = parent + symbol).  Round 5: the part of it the search READS lives in LDS -- for every
+// prefix in the beam a row of its V children {node id, the child's child-table slot, where last frame's tables hold the
+// child's Pb / Pnb} (232 entries at W = 8, V = 29), double-buffered across frames and carried over by the frame end for the
+// survivors -- so a frame has no dependent global load (it had two per candidate: child table -> node stamp, 4.6 us per
+// frame).  The workspace keeps what a back-trace needs (parent, symbol, length) and, for every node that has ever been in
+// the beam, a copy of its child row (written through, read again only when a prefix that had left the beam comes back):
+// "l + c" resolves to the same node no matter when it is re-derived (`l_plus in A_prev`, ctc_beam_decoder.py:232-241).
+// Nodes are made lazily: only an extension that ENTERS the beam gets one (it needs an identity from then on); a candidate
+// that is merely present in a frame's tables is found again through its parent's row (`lc_tidx` = its slot in those tables).
 //
 // One workgroup (256 threads) per utterance, frames sequential.  Compiled with
 // -ffp-contract=off: the reference rounds after every multiply and every add.
@@ -26,35 +31,45 @@ namespace {
 
 constexpr int HDR_INTS = 16;
 enum { F_PRESENT = 1, F_KEPT = 2 };
+constexpr size_t BEAM_LDS_LIMIT = 150 * 1024;
+
+// bytes of the per-utterance working arrays (LDS; the workspace's scratch region when they do not fit)
+size_t beam_lds_bytes(int V, int W) {
+  const size_t M = (size_t)W * (V + 1), WV = (size_t)W * V;
+  return ((size_t)V + 10 * M + 6 * WV + 19 * (size_t)W + 8) * 4;
+}
 
 struct BeamLayout {
   size_t per_utt;  // bytes
-  size_t hdr, beam_node, beam_pb, beam_pnb, tbl_pb, tbl_pnb, node_parent, node_sym, node_len, node_nw, node_cslot,
-      node_tidx, node_tstamp, childtab;
-  int NN, CS, M;
+  size_t hdr, beam_node, beam_pb, beam_pnb, tbl_pb, tbl_pnb, lc_node, lc_cslot, lc_tidx, node_parent, node_sym, node_len, node_nw,
+      node_cslot, childtab, scratch;
+  int NN, CS, M, big;
 };
 
 BeamLayout beam_layout(int T, int V, int W) {
   BeamLayout L;
   L.M = W * (V + 1);
-  L.NN = 2 + T * W * V;
+  L.NN = 2 + T * W;          // a frame makes at most W nodes (the extensions that enter the beam)
   L.CS = 2 + T * W + W;
+  L.big = beam_lds_bytes(V, W) > BEAM_LDS_LIMIT ? 1 : 0;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += ms::align_up(bytes, 64); return r; };
   L.hdr = take(HDR_INTS * 4);
   L.beam_node = take((size_t)W * 4);
   L.beam_pb = take((size_t)W * 4);
   L.beam_pnb = take((size_t)W * 4);
-  L.tbl_pb = take((size_t)2 * L.M * 4);
-  L.tbl_pnb = take((size_t)2 * L.M * 4);
+  L.tbl_pb = take((size_t)L.M * 4);              // the last processed frame's tables (a call may end between frames)
+  L.tbl_pnb = take((size_t)L.M * 4);
+  L.lc_node = take((size_t)W * V * 4);           // ... and the live beam's child rows
+  L.lc_cslot = take((size_t)W * V * 4);
+  L.lc_tidx = take((size_t)W * V * 4);
   L.node_parent = take((size_t)L.NN * 4);
   L.node_sym = take((size_t)L.NN * 4);
   L.node_len = take((size_t)L.NN * 4);
   L.node_nw = take((size_t)L.NN * 4);
   L.node_cslot = take((size_t)L.NN * 4);
-  L.node_tidx = take((size_t)2 * L.NN * 8);     // {frame stamp, table index} pairs, [2][NN] (one 8-byte load per look-up)
-  L.node_tstamp = L.node_tidx;
   L.childtab = take((size_t)L.CS * V * 4);
+  L.scratch = take(L.big ? beam_lds_bytes(V, W) : 0);
   L.per_utt = ms::align_up(o, 256);
   return L;
 }
@@ -75,80 +90,87 @@ struct BeamP {
   float thr;
 };
 
+// BIG: beam_width * (alphabet + 1) too large for the LDS (~2 300 candidates; 84 prefixes at V = 29) -- the same code
+// with its working arrays in the workspace.  Slow (every phase goes through L2) but any width up to 256 decodes.
+template <bool BIG>
 __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, n = blockIdx.x;
-  const int V = p.V, W = p.W, M = p.L.M;
-  // ---- LDS carve
-  float* prow = reinterpret_cast<float*>(smem_raw);          // [V]
-  float* c_pb = prow + V;                                     // [M]
-  float* c_pnb = c_pb + M;
-  float* c_s = c_pnb + M;
-  float* c_score = c_s + M;
-  int* c_key = reinterpret_cast<int*>(c_score + M);           // [M]
+  const int V = p.V, W = p.W, M = p.L.M, WV = W * V;
+  char* u = p.ws + (size_t)n * p.L.per_utt;
+  // ---- working arrays
+  char* arr = BIG ? (u + p.L.scratch) : smem_raw;
+  float* prow = reinterpret_cast<float*>(arr);                // [V]
+  float* c_pb = prow + V;                                     // [2][M] candidate tables Pb / Pnb of this and the previous frame
+  float* c_pnb = c_pb + 2 * M;                                //        (ctc_beam_decoder.py:182-192), indexed by candidate slot
+  float* c_s = c_pnb + 2 * M;                                 // [M]
+  float* k_score = c_s + M;                                   // [M] the kept candidates' (score, order key) pairs, compacted
+  int* c_key = reinterpret_cast<int*>(k_score + M);           // [M]
   int* c_flags = c_key + M;
-  int* c_child = c_flags + M;
-  int* k_idx = c_child + M;
-  int* bm_node = k_idx + M;                                   // [W] each
-  int* bm_last = bm_node + W;
-  int* bm_len = bm_last + W;
-  int* bm_nw = bm_len + W;
-  int* bm_cslot = bm_nw + W;
-  float* bm_pb = reinterpret_cast<float*>(bm_cslot + W);
-  float* bm_pnb = bm_pb + W;
-  int* par_present = reinterpret_cast<int*>(bm_pnb + W);
+  int* k_idx = c_flags + M;
+  int* k_key = k_idx + M;
+  int* lc_node = k_key + M;                                   // [2][W][V] child rows of the live beam: node id (-1: none yet)
+  int* lc_cslot = lc_node + 2 * WV;                           //           the child's child-table slot (-1: never in the beam)
+  int* lc_tidx = lc_cslot + 2 * WV;                           //           its slot in the previous frame's tables (-1: absent)
+  int* bm_node = lc_tidx + 2 * WV;                            // [2][W] each: the beam, this frame's and the next one's
+  int* bm_last = bm_node + 2 * W;
+  int* bm_len = bm_last + 2 * W;
+  int* bm_nw = bm_len + 2 * W;
+  int* bm_cslot = bm_nw + 2 * W;
+  float* bm_pb = reinterpret_cast<float*>(bm_cslot + 2 * W);
+  float* bm_pnb = bm_pb + 2 * W;
+  int* par_present = reinterpret_cast<int*>(bm_pnb + 2 * W);  // [W] each
   float* par_val = reinterpret_cast<float*>(par_present + W);
   int* par_rank = reinterpret_cast<int*>(par_val + W);
   int* newbeam = par_rank + W;
-  int* sh = newbeam + W;  // [0]=B, [1]=k_count, [2]=n_nodes, [3]=n_cslots
-  // this frame's and the previous frame's candidate tables Pb / Pnb (ctc_beam_decoder.py:182-192) live in LDS (round 4: they
-  // were a dependent global load at the end of every look-up chain); they go back to the workspace when the call ends
-  float* l_tbl_pb = reinterpret_cast<float*>(sh + 8);       // [2][M]
-  float* l_tbl_pnb = l_tbl_pb + 2 * M;                      // [2][M]
-  // the kept candidates' (score, order key) pairs, compacted: the ranking loop of S4 reads them in sequence
-  float* k_score = l_tbl_pnb + 2 * M;                       // [M]
-  int* k_key = reinterpret_cast<int*>(k_score + M);         // [M]
-  int* c_cslot = k_key + M;                                 // [M] child-table slot of an extension's node (-1: none yet)
+  int* ent_fresh = newbeam + W;
+  int* sh = ent_fresh + W;  // [0]=B, [1]=k_count, [2]=n_nodes, [3]=n_cslots
 
   // ---- global state of this utterance
-  char* u = p.ws + (size_t)n * p.L.per_utt;
   int* hdr = reinterpret_cast<int*>(u + p.L.hdr);
   int* g_beam_node = reinterpret_cast<int*>(u + p.L.beam_node);
   float* g_beam_pb = reinterpret_cast<float*>(u + p.L.beam_pb);
   float* g_beam_pnb = reinterpret_cast<float*>(u + p.L.beam_pnb);
   float* tbl_pb = reinterpret_cast<float*>(u + p.L.tbl_pb);
   float* tbl_pnb = reinterpret_cast<float*>(u + p.L.tbl_pnb);
+  int* g_lc_node = reinterpret_cast<int*>(u + p.L.lc_node);
+  int* g_lc_cslot = reinterpret_cast<int*>(u + p.L.lc_cslot);
+  int* g_lc_tidx = reinterpret_cast<int*>(u + p.L.lc_tidx);
   int* node_parent = reinterpret_cast<int*>(u + p.L.node_parent);
   int* node_sym = reinterpret_cast<int*>(u + p.L.node_sym);
   int* node_len = reinterpret_cast<int*>(u + p.L.node_len);
   int* node_nw = reinterpret_cast<int*>(u + p.L.node_nw);
   int* node_cslot = reinterpret_cast<int*>(u + p.L.node_cslot);
-  int2* node_tt = reinterpret_cast<int2*>(u + p.L.node_tidx);   // [2][NN] {stamp, index}
   int* childtab = reinterpret_cast<int*>(u + p.L.childtab);
-  const int NN = p.L.NN;
 
+  const int b0 = p.t_begin & 1;      // buffer of the beam / child rows a frame reads = the frame's parity
   if (p.t_begin == 0) {
     // Pb[-1][()] = 1, Pnb[-1][()] = 0, A_prev = [()]   (ctc_beam_decoder.py:182-192)
     if (tid == 0) {
       node_parent[0] = -1; node_sym[0] = -1; node_len[0] = 0; node_nw[0] = 0; node_cslot[0] = 0;
-      node_tt[0] = make_int2(-1, 0); node_tt[NN] = make_int2(-1, 0);
-      bm_node[0] = 0; bm_pb[0] = 1.0f; bm_pnb[0] = 0.0f;
+      bm_node[b0 * W] = 0; bm_pb[b0 * W] = 1.0f; bm_pnb[b0 * W] = 0.0f;
+      bm_last[b0 * W] = -1; bm_len[b0 * W] = 0; bm_nw[b0 * W] = 0; bm_cslot[b0 * W] = 0;
       sh[0] = 1; sh[2] = 1; sh[3] = 1;
     }
-    for (int v = tid; v < V; v += 256) childtab[v] = -1;
+    for (int v = tid; v < V; v += 256) {
+      childtab[v] = -1;
+      lc_node[b0 * WV + v] = -1; lc_cslot[b0 * WV + v] = -1; lc_tidx[b0 * WV + v] = -1;
+    }
   } else {
     if (tid == 0) { sh[0] = hdr[2]; sh[2] = hdr[0]; sh[3] = hdr[1]; }
-    for (int w = tid; w < W; w += 256) { bm_node[w] = g_beam_node[w]; bm_pb[w] = g_beam_pb[w]; bm_pnb[w] = g_beam_pnb[w]; }
-    for (int i = tid; i < 2 * M; i += 256) { l_tbl_pb[i] = tbl_pb[i]; l_tbl_pnb[i] = tbl_pnb[i]; }
-  }
-  __syncthreads();
-  // the beam entries' last symbol / length / word count / child-table slot ride along in LDS from frame to frame (S6 knows
-  // them when it builds the next beam); only a call's first frame fetches them from the trie
-  for (int w = tid; w < W; w += 256)
-    if (w < sh[0]) {
-      const int nd = bm_node[w];
-      bm_last[w] = node_sym[nd]; bm_len[w] = node_len[nd]; bm_nw[w] = node_nw[nd]; bm_cslot[w] = node_cslot[nd];
+    const int B_in = hdr[2];
+    for (int w = tid; w < W; w += 256)
+      if (w < B_in) {
+        const int nd = g_beam_node[w];
+        bm_node[b0 * W + w] = nd; bm_pb[b0 * W + w] = g_beam_pb[w]; bm_pnb[b0 * W + w] = g_beam_pnb[w];
+        bm_last[b0 * W + w] = node_sym[nd]; bm_len[b0 * W + w] = node_len[nd]; bm_nw[b0 * W + w] = node_nw[nd];
+        bm_cslot[b0 * W + w] = node_cslot[nd];
+      }
+    for (int i = tid; i < M; i += 256) { c_pb[(b0 ^ 1) * M + i] = tbl_pb[i]; c_pnb[(b0 ^ 1) * M + i] = tbl_pnb[i]; }
+    for (int i = tid; i < WV; i += 256) {
+      lc_node[b0 * WV + i] = g_lc_node[i]; lc_cslot[b0 * WV + i] = g_lc_cslot[i]; lc_tidx[b0 * WV + i] = g_lc_tidx[i];
     }
+  }
   __syncthreads();
 
   const int len = min(max(p.lens[n], 0), p.T);
@@ -157,10 +179,22 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
   // symbols fetch the rest in the frame itself)
   float p_next = 0.f;
   if (p.t_begin < t_stop && tid < V) p_next = p.probs[((size_t)p.t_begin * p.N + n) * V + tid];
-  for (int t = p.t_begin; t < t_stop; ++t) {
+  int t = p.t_begin;
+  for (; t < t_stop; ++t) {
     const int B = sh[0];
     if (B == 0) break;  // an empty beam stays empty (ctc_beam_decoder.py:258)
-    const int cp = t & 1, pp = cp ^ 1;
+    const int cp = t & 1, pp = cp ^ 1;          // tables: this frame's / the previous frame's
+    const int cb = cp, nb = pp;                 // beam + child rows: read / built for the next frame
+    const int* bmn = bm_node + cb * W;
+    const int* bml = bm_last + cb * W;
+    const int* bmlen = bm_len + cb * W;
+    const int* bmnw = bm_nw + cb * W;
+    const int* bmcs = bm_cslot + cb * W;
+    const float* bmpb = bm_pb + cb * W;
+    const float* bmpnb = bm_pnb + cb * W;
+    int* lcn = lc_node + cb * WV;
+    int* lcc = lc_cslot + cb * WV;
+    const int* lct = lc_tidx + cb * WV;
     const float* row = p.probs + ((size_t)t * p.N + n) * V;
     if (tid < V) prow[tid] = p_next;
     for (int v = tid + 256; v < V; v += 256) prow[v] = row[v];
@@ -178,30 +212,25 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
       if (c != p.blank) {
         const float pc = prow[c];
         if (!(pc <= p.thr)) {  // `if ctc[t][c] <= prune_threshold: continue`
-          const int child = childtab[(size_t)bm_cslot[w] * V + c];
+          const int child = lcn[i];
           int w2 = -1;
           if (child >= 0)
             for (int k = 0; k < B; ++k)
-              if (bm_node[k] == child) w2 = k;
-          const bool repeat = bm_len[w] > 0 && c == bm_last[w];
-          float a = repeat ? pc * bm_pb[w] : pc * (bm_pb[w] + bm_pnb[w]);
+              if (bmn[k] == child) w2 = k;
+          const bool repeat = bmlen[w] > 0 && c == bml[w];
+          float a = repeat ? pc * bmpb[w] : pc * (bmpb[w] + bmpnb[w]);
           if (!repeat && p.lm_factor != nullptr && c == p.sep) a = a * p.lm_factor[(size_t)n * W + w];
           if (w2 >= 0) {  // l_plus in A_prev: only Pnb[t][l_plus] += a
             par_val[w2] = a; par_rank[w2] = i * 4; par_present[w2] = 1;
           } else {
             float pb_c = 0.f, pnb_c = 0.f;
-            int cslot_c = -1;
-            if (child >= 0) {
-              const int2 tt = node_tt[pp * NN + child];
-              cslot_c = node_cslot[child];          // beside the stamp, not behind it: S6 needs it if this candidate survives
-              if (tt.x == t) { pb_c = l_tbl_pb[pp * M + tt.y]; pnb_c = l_tbl_pnb[pp * M + tt.y]; }
-            }
-            c_cslot[slot] = cslot_c;
+            const int ti = lct[i];         // l_plus was a candidate of the previous frame: its Pb / Pnb (ctc_beam_decoder.py:232-241)
+            if (ti >= 0) { pb_c = c_pb[pp * M + ti]; pnb_c = c_pnb[pp * M + ti]; }
             const float bterm = pc * pnb_c;
             const float pnb_new = a + bterm;
             const float pb_new = p_blank * (pb_c + pnb_c);
             const float s = pb_new + pnb_new;
-            c_pb[slot] = pb_new; c_pnb[slot] = pnb_new; c_s[slot] = s; c_key[slot] = i * 4 + 2; c_child[slot] = child;
+            c_pb[cp * M + slot] = pb_new; c_pnb[cp * M + slot] = pnb_new; c_s[slot] = s; c_key[slot] = i * 4 + 2;
             flags = F_PRESENT | (s > 0.f ? F_KEPT : 0);
           }
         }
@@ -215,10 +244,10 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
       int flags = 0;
       if (w < B) {
         const bool in_pb = !(p_blank <= p.thr);
-        const float pb_new = in_pb ? p_blank * (bm_pb[w] + bm_pnb[w]) : 0.f;
-        const int last = bm_last[w];
-        const bool own = bm_len[w] > 0 && !(prow[last] <= p.thr);
-        const float ownv = own ? prow[last] * bm_pnb[w] : 0.f;
+        const float pb_new = in_pb ? p_blank * (bmpb[w] + bmpnb[w]) : 0.f;
+        const int last = bml[w];
+        const bool own = bmlen[w] > 0 && !(prow[last] <= p.thr);
+        const float ownv = own ? prow[last] * bmpnb[w] : 0.f;
         const bool par = par_present[w] != 0;
         const bool in_pnb = own || par;
         float pnb_new = 0.f;
@@ -237,7 +266,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
           if (par) r = min(r, par_rank[w]);
           key = 0x40000000 | r;  // keys only in Pnb[t] follow every key of Pb[t] (Counter.__add__)
         }
-        c_pb[w] = pb_new; c_pnb[w] = pnb_new; c_s[w] = s; c_key[w] = key; c_child[w] = bm_node[w];
+        c_pb[cp * M + w] = pb_new; c_pnb[cp * M + w] = pnb_new; c_s[w] = s; c_key[w] = key;
         if (in_pb || in_pnb) flags = F_PRESENT | (s > 0.f ? F_KEPT : 0);
       }
       c_flags[w] = flags;
@@ -251,14 +280,13 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
         float score = c_s[i];
         if (p.sep >= 0) {
           int nw;
-          if (i < W) nw = bm_nw[i];
+          if (i < W) nw = bmnw[i];
           else {
             const int w = (i - W) / V, c = (i - W) - w * V;
-            nw = bm_nw[w] + ((c == p.sep && bm_last[w] != p.sep) ? 1 : 0);
+            nw = bmnw[w] + ((c == p.sep && bml[w] != p.sep) ? 1 : 0);
           }
           score = score * p.word_factor[nw];
         }
-        c_score[i] = score;
         const int j = atomicAdd(&sh[1], 1);
         k_idx[j] = i; k_score[j] = score; k_key[j] = c_key[i];
       }
@@ -267,8 +295,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
     const int K = sh[1];
 
     // ---- S4: stable descending order, keep beam_width.  Rank of candidate j = candidates that sort before it; the pairs are
-    // read in sequence (round 4: the loop went through k_idx[m] -> c_score / c_key, two dependent LDS round trips per
-    // comparison, and was 3.6 of the frame's 7 us)
+    // read in sequence
     if (K <= 64) {
       // the usual case (22 kept candidates on average at V = 29, W = 8): one wave, candidate j in lane j, the others'
       // pairs broadcast from registers (v_readlane) -- no LDS traffic in the loop
@@ -297,65 +324,92 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
         if (pos < W) newbeam[pos] = k_idx[j];
       }
     }
-
-    // ---- S5: trie nodes + this frame's tables for every present candidate
-    for (int i = tid; i < nslots; i += 256) {
-      if (!(c_flags[i] & F_PRESENT)) continue;
-      int nd = c_child[i];
-      if (nd < 0) {
-        const int w = (i - W) / V, c = (i - W) - w * V;
-        nd = atomicAdd(&sh[2], 1);
-        node_parent[nd] = bm_node[w]; node_sym[nd] = c; node_len[nd] = bm_len[w] + 1;
-        node_nw[nd] = bm_nw[w] + ((c == p.sep && bm_last[w] != p.sep) ? 1 : 0);
-        node_cslot[nd] = -1; node_tt[nd] = make_int2(-1, 0); node_tt[NN + nd] = make_int2(-1, 0);
-        childtab[(size_t)bm_cslot[w] * V + c] = nd;
-        c_child[i] = nd;
-      }
-      l_tbl_pb[cp * M + i] = c_pb[i]; l_tbl_pnb[cp * M + i] = c_pnb[i];
-      node_tt[cp * NN + nd] = make_int2(t + 1, i);
-    }
     __syncthreads();
 
-    // ---- S6: A_prev <- best beam_width candidates
+    // ---- S5: an extension that enters the beam becomes a trie node (if it is not one yet) with a child-table slot (if it has
+    // never been in the beam before); both are recorded in its parent's row, here and in the workspace copy of that row
     const int Bn = min(K, W);
-    int nb_node = -1, nb_last = -1, nb_len = 0, nb_nw = 0, nb_cslot = 0;
-    float nb_pb = 0.f, nb_pnb = 0.f;
-    if (tid < Bn) {
-      const int i = newbeam[tid];
-      nb_node = c_child[i]; nb_pb = c_pb[i]; nb_pnb = c_pnb[i];
-      if (i < W) {                     // a beam entry that stays: it has had its child-table slot since it entered the beam
-        nb_last = bm_last[i]; nb_len = bm_len[i]; nb_nw = bm_nw[i]; nb_cslot = bm_cslot[i];
-      } else {                         // an extension l + c (its node exists since S5 at the latest)
-        const int w = (i - W) / V, c = (i - W) - w * V;
-        nb_last = c; nb_len = bm_len[w] + 1;
-        nb_nw = bm_nw[w] + ((c == p.sep && bm_last[w] != p.sep) ? 1 : 0);
-        nb_cslot = c_cslot[i];               // -1: the node was made this frame or has never been in the beam
-        if (nb_cslot < 0) {
-          nb_cslot = atomicAdd(&sh[3], 1);
-          node_cslot[nb_node] = nb_cslot;
-          for (int v = 0; v < V; ++v) childtab[(size_t)nb_cslot * V + v] = -1;
+    for (int j = tid; j < Bn; j += 256) {
+      const int i = newbeam[j];
+      int fresh = 0;
+      if (i >= W) {
+        const int e = i - W, w = e / V, c = e - w * V;
+        int nd = lcn[e], cs = lcc[e];
+        if (nd < 0) {
+          nd = atomicAdd(&sh[2], 1);
+          node_parent[nd] = bmn[w]; node_sym[nd] = c; node_len[nd] = bmlen[w] + 1;
+          node_nw[nd] = bmnw[w] + ((c == p.sep && bml[w] != p.sep) ? 1 : 0);
+          childtab[(size_t)bmcs[w] * V + c] = nd;
+          lcn[e] = nd;
+        }
+        if (cs < 0) {
+          cs = atomicAdd(&sh[3], 1);
+          node_cslot[nd] = cs;
+          lcc[e] = cs;
+          fresh = 1;
         }
       }
+      ent_fresh[j] = fresh;
     }
     __syncthreads();
-    if (tid < Bn) {
-      bm_node[tid] = nb_node; bm_pb[tid] = nb_pb; bm_pnb[tid] = nb_pnb;
-      bm_last[tid] = nb_last; bm_len[tid] = nb_len; bm_nw[tid] = nb_nw; bm_cslot[tid] = nb_cslot;
+
+    // ---- S6: A_prev <- best beam_width candidates; every new beam entry's child row
+    for (int idx = tid; idx < Bn * V; idx += 256) {
+      const int j = idx / V, c = idx - j * V;
+      const int i = newbeam[j];
+      int child, cs, ti = -1;
+      if (i < W) {                     // a beam entry that stays: its row moves along; a child that was a candidate of this
+        const int e = i * V + c;       // frame is found at its slot in this frame's tables
+        child = lcn[e]; cs = lcc[e];
+        if (c_flags[W + e] & F_PRESENT) ti = W + e;
+      } else {
+        const int mycs = lcc[i - W];
+        if (ent_fresh[j]) {            // never in the beam before: no children yet
+          child = -1; cs = -1;
+          childtab[(size_t)mycs * V + c] = -1;
+        } else {                       // it was in the beam once, left and comes back: its row from the workspace
+          child = childtab[(size_t)mycs * V + c];
+          cs = child >= 0 ? node_cslot[child] : -1;
+        }
+      }
+      // a child that is itself in the (old) beam is a candidate of this frame under its own beam slot
+      if (ti < 0 && child >= 0)
+        for (int k = 0; k < B; ++k)
+          if (bmn[k] == child && (c_flags[k] & F_PRESENT)) ti = k;
+      lc_node[nb * WV + idx] = child; lc_cslot[nb * WV + idx] = cs; lc_tidx[nb * WV + idx] = ti;
+    }
+    for (int j = tid; j < Bn; j += 256) {
+      const int i = newbeam[j];
+      int nd, last, ln, nw, cs;
+      if (i < W) {
+        nd = bmn[i]; last = bml[i]; ln = bmlen[i]; nw = bmnw[i]; cs = bmcs[i];
+      } else {
+        const int e = i - W, w = e / V, c = e - w * V;
+        nd = lcn[e]; cs = lcc[e];
+        last = c; ln = bmlen[w] + 1;
+        nw = bmnw[w] + ((c == p.sep && bml[w] != p.sep) ? 1 : 0);
+      }
+      bm_node[nb * W + j] = nd; bm_last[nb * W + j] = last; bm_len[nb * W + j] = ln; bm_nw[nb * W + j] = nw;
+      bm_cslot[nb * W + j] = cs; bm_pb[nb * W + j] = c_pb[cp * M + i]; bm_pnb[nb * W + j] = c_pnb[cp * M + i];
     }
     if (tid == 0) sh[0] = Bn;
     __syncthreads();
   }
 
-  // ---- persist state, emit results
+  // ---- persist state, emit results (the beam and its rows sit in the buffers of the frame the loop stopped at)
+  const int eb = t & 1;
   const int B = sh[0];
   if (tid == 0) { hdr[0] = sh[2]; hdr[1] = sh[3]; hdr[2] = B; }
-  for (int i = tid; i < 2 * M; i += 256) { tbl_pb[i] = l_tbl_pb[i]; tbl_pnb[i] = l_tbl_pnb[i]; }
+  for (int i = tid; i < M; i += 256) { tbl_pb[i] = c_pb[(eb ^ 1) * M + i]; tbl_pnb[i] = c_pnb[(eb ^ 1) * M + i]; }
+  for (int i = tid; i < WV; i += 256) {
+    g_lc_node[i] = lc_node[eb * WV + i]; g_lc_cslot[i] = lc_cslot[eb * WV + i]; g_lc_tidx[i] = lc_tidx[eb * WV + i];
+  }
   for (int w = tid; w < W; w += 256)
-    if (w < B) { g_beam_node[w] = bm_node[w]; g_beam_pb[w] = bm_pb[w]; g_beam_pnb[w] = bm_pnb[w]; }
+    if (w < B) { g_beam_node[w] = bm_node[eb * W + w]; g_beam_pb[w] = bm_pb[eb * W + w]; g_beam_pnb[w] = bm_pnb[eb * W + w]; }
   if (p.finish && tid == 0) {
     int L = 0;
     if (B > 0) {
-      int nd = bm_node[0];
+      int nd = bm_node[eb * W];
       L = node_len[nd];
       for (int i = L - 1; i >= 0; --i) { p.out_idx[(size_t)n * p.T + i] = node_sym[nd]; nd = node_parent[nd]; }
     }
@@ -363,18 +417,13 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
   }
   if (p.beam_idx_out != nullptr) {
     if (tid == 0) p.beam_len_out[n] = B;
-    if (tid < B) {
-      int nd = bm_node[tid];
+    for (int w = tid; w < B; w += 256) {
+      int nd = bm_node[eb * W + w];
       const int L = node_len[nd];
-      p.beam_plen_out[(size_t)n * W + tid] = L;
-      for (int i = L - 1; i >= 0; --i) { p.beam_idx_out[((size_t)n * W + tid) * p.T + i] = node_sym[nd]; nd = node_parent[nd]; }
+      p.beam_plen_out[(size_t)n * W + w] = L;
+      for (int i = L - 1; i >= 0; --i) { p.beam_idx_out[((size_t)n * W + w) * p.T + i] = node_sym[nd]; nd = node_parent[nd]; }
     }
   }
-}
-
-size_t beam_lds_bytes(int V, int W) {
-  const size_t M = (size_t)W * (V + 1);
-  return (size_t)V * 4 + M * 8 * 4 + (size_t)W * 11 * 4 + 8 * 4 + 4 * M * 4 + 3 * M * 4;
 }
 
 }  // namespace
@@ -403,14 +452,11 @@ extern "C" int ms_ctc_beam_decode(const float* probs, const int32_t* lens, int32
     ms::set_error("ms_ctc_beam_decode: workspace too small");
     return MS_ERR_WORKSPACE;
   }
-  const size_t lds = beam_lds_bytes(V, beam_width);
-  if (lds > 150 * 1024 || beam_width > 256) {
-    ms::set_error("ms_ctc_beam_decode: beam_width * (alphabet + 1) too large for the LDS candidate tables");
-    return MS_ERR_UNSUPPORTED;
-  }
+  MS_REQUIRE(beam_width <= 256, "beam_width must not exceed 256");
+  const size_t lds = L.big ? 0 : beam_lds_bytes(V, beam_width);
   static ms::DeviceOnce attr_once;
   if (attr_once.need()) {
-    MS_HIP(hipFuncSetAttribute((const void*)beam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MS_HIP(hipFuncSetAttribute((const void*)beam_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.done();
   }
   BeamP p;
@@ -419,7 +465,8 @@ extern "C" int ms_ctc_beam_decode(const float* probs, const int32_t* lens, int32
   p.ws = (char*)workspace; p.L = L; p.T = T; p.N = N; p.V = V; p.W = beam_width; p.blank = blank;
   p.sep = separator < 0 ? -1 : separator; p.t_begin = t_begin; p.t_end = t_end; p.finish = finish;
   p.thr = prune_threshold;
-  hipLaunchKernelGGL(beam_kernel, dim3(N), dim3(256), lds, (hipStream_t)stream, p);
+  if (L.big) hipLaunchKernelGGL(beam_kernel<true>, dim3(N), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(beam_kernel<false>, dim3(N), dim3(256), lds, (hipStream_t)stream, p);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }

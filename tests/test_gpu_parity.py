@@ -988,7 +988,15 @@ def test_beam_golden_random():
 
 
 @pytest.mark.parametrize("Tn,N,V,W,thr,sep,temp", [(60, 6, 29, 8, 0.001, None, 6.0), (40, 4, 12, 20, 0.0, 3, 2.0),
-                                                    (80, 3, 6, 3, 0.05, 0, 1.0), (30, 5, 40, 16, 0.001, None, 3.0)])
+                                                    (80, 3, 6, 3, 0.05, 0, 1.0), (30, 5, 40, 16, 0.001, None, 3.0),
+                                                    # low temperature, no pruning: prefixes leave the beam and come back (their
+                                                    # child rows are restored from the workspace)
+                                                    (120, 4, 5, 4, 0.0, None, 0.7), (90, 3, 8, 6, 0.0, 2, 0.5),
+                                                    # widths whose candidate tables do not fit the LDS (the round-4
+                                                    # layout refused beam_width >= 84 at V = 29): 76 is the last LDS width, 100
+                                                    # and 128 run with the working arrays in the workspace
+                                                    (24, 3, 29, 76, 0.0, None, 1.5), (24, 3, 29, 100, 0.0, None, 1.5),
+                                                    (20, 2, 29, 128, 0.0005, 7, 1.0), (12, 2, 8, 256, 0.0, None, 0.8)])
 def test_beam_vs_oracle(Tn, N, V, W, thr, sep, temp):
     from myrtlespeech_amd.post_process.ctc_beam_decoder import CTCBeamDecoder
     rng = np.random.default_rng(Tn * 31 + V)
@@ -999,6 +1007,47 @@ def test_beam_vs_oracle(Tn, N, V, W, thr, sep, temp):
     lens[0] = Tn
     got = CTCBeamDecoder(V - 1, W, thr, separator_index=sep, word_weight=1.7)(T(x), T(lens))
     assert got == O.ctc_beam_decode(x, lens, V - 1, W, thr, separator_index=sep, word_weight=1.7)
+
+
+def test_beam_call_split_between_frames_equals_one_call():
+    """The state a call leaves in the workspace (beam, last frame's tables, the live beam's child rows, the trie) carries the
+    search across calls: every split of the frame range gives the single call's beams -- the path the host language model
+    uses one frame at a time (ctc_beam_decoder.py:222-228)."""
+    from myrtlespeech_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    Tn, N, V, W = 50, 5, 9, 5
+    z = rng.normal(size=(Tn, N, V)) * 0.8
+    x = np.exp(z - z.max(-1, keepdims=True))
+    x = (x / x.sum(-1, keepdims=True)).astype(np.float32)
+    lens = np.array([50, 50, 37, 20, 0], dtype=np.int32)
+    xd, ld = T(x).cuda(), T(lens).cuda()
+
+    def run(cuts):
+        ws = torch.zeros(lib.ms_ctc_beam_workspace_bytes(Tn, N, V, W), dtype=torch.uint8, device="cuda")
+        oi = torch.zeros((N, Tn), dtype=torch.int32, device="cuda")
+        ol = torch.zeros(N, dtype=torch.int32, device="cuda")
+        bl = torch.zeros(N, dtype=torch.int32, device="cuda")
+        bi = torch.zeros((N, W, Tn), dtype=torch.int32, device="cuda")
+        bp = torch.zeros((N, W), dtype=torch.int32, device="cuda")
+        edges = [0] + list(cuts) + [Tn]
+        for k in range(len(edges) - 1):
+            _lib.check(lib.ms_ctc_beam_decode(_lib.ptr(xd), _lib.ptr(ld), _lib.ptr(oi), _lib.ptr(ol), Tn, N, V, V - 1, W, 0.0, -1,
+                                              None, edges[k], edges[k + 1], None, 1 if k == len(edges) - 2 else 0, _lib.ptr(bl),
+                                              _lib.ptr(bi), _lib.ptr(bp), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "beam")
+        return cpu(oi), cpu(ol), cpu(bl), cpu(bi), cpu(bp)
+
+    whole = run([])
+    want = O.ctc_beam_decode(x, lens.astype(np.int64), V - 1, W, 0.0)
+    assert [list(whole[0][n, :whole[1][n]]) for n in range(N)] == want
+    for cuts in ([1], [25], [49], [7, 8, 9, 30], list(range(1, Tn)), [0, 0, 20, 20]):
+        got = run(cuts)
+        for a, b in zip(whole[:3], got[:3]):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(whole[4], got[4])
+        for n in range(N):
+            for w in range(int(whole[2][n])):
+                np.testing.assert_array_equal(whole[3][n, w, :whole[4][n, w]], got[3][n, w, :got[4][n, w]])
 
 
 def test_beam_one_output_per_batch_element_on_garbage():
