@@ -56,6 +56,7 @@ struct DecLayout {
   size_t total;
   int R, slots, maxn, bcap;
   size_t wcat_off[8], bcat_off[8];
+  size_t v2_E, v2_Etmp, v2_G, v2_hpl, v2_whh, v2_wih, v2_wpred, v2_bias, v2_plog, v2_A2;
 };
 
 DecLayout dec_layout(int T, int N, int V, int D, int H, int L, int J, int w, int max_symbols, int greedy) {
@@ -105,6 +106,20 @@ DecLayout dec_layout(int T, int N, int V, int D, int H, int L, int J, int w, int
   }
   W.wcat = take(wc * 6);      // float32 rows [4H][K] (4 B per weight) or three bf16 planes of them (6 B): sized for the planes
   W.bcat = take(bc * 4);
+  // ---- the round-5 beam path (beam2_*): see the comment above pred_gemm3_kernel
+  if (!greedy) {
+    const size_t rpad = (size_t)((R + 63) / 64 * 64);
+    W.v2_E = take((size_t)V1 * 4 * H * 4);
+    W.v2_Etmp = take((size_t)V1 * 4 * H * 4);
+    W.v2_G = take((size_t)W.slots * L * 4 * H * 4);
+    W.v2_hpl = take((size_t)L * 3 * rpad * H * 2);
+    W.v2_whh = take((size_t)L * 3 * 4 * H * H * 2);
+    W.v2_wih = take((size_t)(L > 1 ? L - 1 : 1) * 3 * 4 * H * H * 2);
+    W.v2_wpred = take((size_t)3 * J * H * 2);
+    W.v2_bias = take((size_t)L * 4 * H * 4);
+    W.v2_plog = take((size_t)((J + 31) / 32) * R * V1 * 4);
+    W.v2_A2 = take((size_t)(N + 3 * R) * 4);       // the next frame's live set (A_cnt, A_node, A_score, A_slot)
+  }
   W.total = o;
   return W;
 }
@@ -973,6 +988,668 @@ GreedyPoll* greedy_poll() {
   return state[dev] == 1 ? &polls[dev] : nullptr;
 }
 
+
+// =====================================================================================================================
+// The beam decode's predictor, round 5 (154 us per frame in 16 dependent launches).  The same
+// arithmetic -- every float32 product as an exact three-way bf16 split, float32 accumulation -- cut differently:
+//
+//   gates_0 = W_ih0 . emb[label] + W_hh0 . h0[parent] + b0      gates_l = W_ihl . h'_{l-1} + W_hhl . h_l[parent] + b_l
+//             `---- E[label] ---'  `--- G_0[parent] ---'                                    `--- G_l[parent] ---'
+//
+//   * E = W_ih0 . emb + b0 is a table of V + 1 rows, made once per decode;
+//   * G_l[slot] = W_hhl . h_l[slot] depends on a STATE only, not on what is appended to it: it is computed once per state,
+//     right after the state is made (pred_gemm3_kernel<.., false>, all layers in one launch), and kept beside it in the pool;
+//   * so a predictor step's chain is: round -> cell 0 of the picks (elementwise: E[label] + G_0[parent], in the round kernel
+//     itself) -> W_ihl . h'_{l-1} + G_l[parent] -> cell l (pred_gemm3_kernel<.., true>, K = H instead of In + H) -> joint;
+//   * pred_proj and the joint network are ONE kernel (beam2_joint_kernel): a workgroup owns 64 hypothesis rows x 32 joint
+//     units, contracts h_top against its W_pred rows, adds the encoder projection, applies tanh and leaves the 32-unit partial
+//     sums of the output layer; the round kernel adds the J / 32 partials in slice order and normalises;
+//   * the last round of a frame and the frame end are one kernel (beam2_frame_end_kernel).
+// A frame at max_symbols = 3, two layers: 10 launches (joint, round | layer 1, G, joint, round | layer 1, G, joint, frame end).
+// Shapes: H % 64 == 0, J % 32 == 0; anything else takes the round-4 sequence.  MS_RNNT_V2=0 (read per call) selects it too.
+
+// rows [rows][K] float32 -> three fragment-major bf16 planes; unit_major: gate row g H + u -> row (u / 8) 32 + g 8 + u % 8
+__global__ void pack_rows3_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes, int rows, int K, int H_units) {
+  const int src_row = blockIdx.x;
+  int row = src_row;
+  if (H_units > 0) {
+    const int gate_ = src_row / H_units, unit_ = src_row % H_units;
+    row = (unit_ >> 3) * 32 + gate_ * 8 + (unit_ & 7);
+  }
+  const size_t plane = (size_t)rows * K;
+  for (int k = threadIdx.x; k < K; k += blockDim.x)
+    store_split3(planes, plane, frag_off(row, k, K), w[(size_t)src_row * K + k]);
+}
+
+// out[unit-major row] = a[row] + b[row] (+ tab[v][row] for a table of nv rows)
+__global__ void unit_major_add_kernel(const float* __restrict__ tab, const float* __restrict__ a, const float* __restrict__ b,
+                                      float* __restrict__ out, int H, int nv) {
+  const int src = blockIdx.x * blockDim.x + threadIdx.x;
+  if (src >= 4 * H) return;
+  const int gate_ = src / H, unit_ = src % H;
+  const int row = (unit_ >> 3) * 32 + gate_ * 8 + (unit_ & 7);
+  const float bias = (a ? a[src] : 0.f) + (b ? b[src] : 0.f);
+  if (tab == nullptr) { out[row] = bias; return; }
+  for (int v = 0; v < nv; ++v) out[(size_t)v * 4 * H + row] = tab[(size_t)v * 4 * H + src] + bias;
+}
+
+struct Beam2P {
+  const int32_t* lens;
+  int32_t *A_cnt, *A_node, *A_slot;     // this frame's live set (the rounds replace it in place: one workgroup per utterance)
+  float* A_score;
+  int32_t *nA_cnt, *nA_node, *nA_slot;  // the next frame's, written by the frame end (its w workgroups per utterance all READ
+  float* nA_score;                      // this frame's set, so they must not write it)
+  int32_t *B_cnt, *B_node, *B_slot;
+  float* B_score;
+  int32_t *ext_label, *ext_src, *ext_dst;
+  int32_t *node_cnt, *node_parent, *node_label, *child;
+  float *st_h, *st_c, *pp, *G;
+  const float *E, *bias, *plog, *b_out;
+  unsigned short* hpl;          // [L][3][rpad * H] planes of the rows' new h of every layer
+  size_t hplane;                // rpad * H
+  int N, w, V, bcap, maxn, R, H, L, J, NS;
+};
+
+__device__ __forceinline__ void lstm_cell(const float pre[4], float c_old, float& h_new, float& c_new) {
+  const float gi = 1.f / (1.f + expf(-pre[0])), gf = 1.f / (1.f + expf(-pre[1]));
+  const float gg = tanhf(pre[2]), go = 1.f / (1.f + expf(-pre[3]));
+  c_new = gf * c_old + gi * gg;
+  h_new = go * tanhf(c_new);
+}
+
+// cell 0 of every request row (label k appended to the state in slot src; -1 = the zero state): E[k] + G_0[src].  One
+// workgroup per row; a thread's units' loads are all issued before the first is used (a unit at a time waited for an L2 round
+// trip per unit: 40 us inside the round kernel).
+__global__ __launch_bounds__(256) void beam2_cell0_kernel(Beam2P p) {
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int dst = p.ext_dst[r], src = p.ext_src[r], lab = p.ext_label[r];
+  if (dst < 0) return;
+  const int k = min(max(lab, 0), p.V);
+  const int H = p.H, L = p.L;
+  const float* e = p.E + (size_t)k * 4 * H;
+  const float* g = src >= 0 ? p.G + ((size_t)src * L + 0) * 4 * H : nullptr;
+  const float* cs = src >= 0 ? p.st_c + ((size_t)src * L + 0) * H : nullptr;
+  constexpr int UB = 4;                                      // units per thread and batch
+  for (int u0 = 0; u0 < H; u0 += 256 * UB) {
+    float ev[UB][4], gv[UB][4], cv[UB];
+#pragma unroll
+    for (int m = 0; m < UB; ++m) {
+      const int u = u0 + tid + 256 * m;
+      const int o = (u >> 3) * 32 + (u & 7);
+#pragma unroll
+      for (int gate = 0; gate < 4; ++gate) {
+        ev[m][gate] = u < H ? e[o + gate * 8] : 0.f;
+        gv[m][gate] = (u < H && g) ? g[o + gate * 8] : 0.f;
+      }
+      cv[m] = (u < H && cs) ? cs[u] : 0.f;
+    }
+#pragma unroll
+    for (int m = 0; m < UB; ++m) {
+      const int u = u0 + tid + 256 * m;
+      if (u >= H) continue;
+      float pre[4];
+#pragma unroll
+      for (int gate = 0; gate < 4; ++gate) pre[gate] = ev[m][gate] + gv[m][gate];
+      float h_new, c_new;
+      lstm_cell(pre, cv[m], h_new, c_new);
+      p.st_h[((size_t)dst * L + 0) * H + u] = h_new;
+      p.st_c[((size_t)dst * L + 0) * H + u] = c_new;
+      store_split3(p.hpl, p.hplane, frag_off(r, u, H), h_new);
+    }
+  }
+}
+
+// acc[64 rows x 32 weight rows] over K = H for one (weight-row group b, row block rb): eight waves = 2 row groups x 4 K
+// slices, three-way split products (pred_layer_fused_kernel's loop), partial sums met in LDS in slice order.
+// CELL: weight rows = W_ih of layer l (unit-major), x = the rows' new h of layer l - 1; pre = sum + bias + G_l[src] -> cell
+//       -> state of the destination slot, the rows' new h of layer l as planes.
+// !CELL: blockIdx.z = layer; weight rows = W_hh of that layer, x = the rows' new h of that layer; G_l[dst] = sum.
+template <bool CELL, int RG>
+__device__ __forceinline__ void pred_gemm3_body(const Beam2P& p, const unsigned short* __restrict__ wp_base, int l, int b, int rb,
+                                                float (*red)[32][33]) {
+  constexpr int KQ = 8 / RG;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int rg = wave % RG, kq = wave / RG;
+  const int H = p.H, L = p.L, K = H, R = p.R;
+  const int lx = CELL ? l - 1 : l;                                   // layer whose new h is the x operand
+  const size_t wplane = (size_t)4 * H * K;
+  const unsigned short* wp = wp_base + (CELL ? (size_t)(l - 1) : (size_t)l) * 3 * wplane;
+  const unsigned short* x = p.hpl + (size_t)lx * 3 * p.hplane;
+  const int m = rb * 32 * RG + rg * 32 + l31;                        // this lane's x row (planes are padded to 64 rows)
+  const int kslice = K / KQ, k0 = kq * kslice;
+  const unsigned short* xp = x + frag_off(m, k0 + half * 8, K);
+  const unsigned short* w0 = wp + frag_off(b * 32 + l31, k0 + half * 8, K);
+
+  f32x16r acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int PF = 4;
+  u32x4r xf[PF][3], wf[PF][3];
+  auto load = [&](int slot, int ks) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      xf[slot][pl] = *reinterpret_cast<const u32x4r*>(xp + (size_t)pl * p.hplane + (size_t)ks * 512);
+      wf[slot][pl] = *reinterpret_cast<const u32x4r*>(w0 + (size_t)pl * wplane + (size_t)ks * 512);
+    }
+  };
+  auto step = [&](int slot) {
+    const bf16x8r bh = __builtin_bit_cast(bf16x8r, wf[slot][0]), bm = __builtin_bit_cast(bf16x8r, wf[slot][1]);
+    const bf16x8r bl = __builtin_bit_cast(bf16x8r, wf[slot][2]);
+    const bf16x8r xh = __builtin_bit_cast(bf16x8r, xf[slot][0]), xm = __builtin_bit_cast(bf16x8r, xf[slot][1]);
+    const bf16x8r xl = __builtin_bit_cast(bf16x8r, xf[slot][2]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, acc, 0, 0, 0);   // smallest terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc, 0, 0, 0);
+  };
+  const int nks = kslice / 16;
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+    if (j < nks) load(j, j);
+  for (int ks = 0; ks < nks; ks += PF) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+      if (ks + j < nks) {
+        step(j);
+        if (ks + j + PF < nks) load(j, ks + j + PF);
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t >= 256 * RG) return;
+  const int rowl = t >> 3, u8 = t & 7, rgi = rowl >> 5, rr = rowl & 31;
+  const int r = rb * 32 * RG + rowl, u = b * 8 + u8;
+  if (r >= R) return;
+  const int src = p.ext_src[r], dst = p.ext_dst[r];
+  if (dst < 0) return;                                                // no request in this row
+  float sum[4];
+#pragma unroll
+  for (int gate = 0; gate < 4; ++gate) {
+    float v = red[rgi][rr][gate * 8 + u8];                            // slice 0 (wave index = kq RG + rg)
+#pragma unroll
+    for (int q = 1; q < KQ; ++q) v += red[q * RG + rgi][rr][gate * 8 + u8];
+    sum[gate] = v;
+  }
+  if (!CELL) {
+    float* g = p.G + ((size_t)dst * L + l) * 4 * H + b * 32 + u8;
+#pragma unroll
+    for (int gate = 0; gate < 4; ++gate) g[gate * 8] = sum[gate];
+    return;
+  }
+  const float* bias = p.bias + (size_t)l * 4 * H + b * 32 + u8;
+  const float* g = src >= 0 ? p.G + ((size_t)src * L + l) * 4 * H + b * 32 + u8 : nullptr;
+  float pre[4];
+#pragma unroll
+  for (int gate = 0; gate < 4; ++gate) pre[gate] = (sum[gate] + bias[gate * 8]) + (g ? g[gate * 8] : 0.f);
+  const float c_old = src >= 0 ? p.st_c[((size_t)src * L + l) * H + u] : 0.f;
+  float h_new, c_new;
+  lstm_cell(pre, c_old, h_new, c_new);
+  p.st_h[((size_t)dst * L + l) * H + u] = h_new;
+  p.st_c[((size_t)dst * L + l) * H + u] = c_new;
+  store_split3(p.hpl + (size_t)l * 3 * p.hplane, p.hplane, frag_off(r, u, H), h_new);
+}
+
+template <bool CELL, int RG>
+__global__ __launch_bounds__(512) void pred_gemm3_kernel(Beam2P p, const unsigned short* __restrict__ wp_base, int l_cell) {
+  __shared__ float red[8][32][33];
+  pred_gemm3_body<CELL, RG>(p, wp_base, CELL ? l_cell : (int)blockIdx.z, blockIdx.x, blockIdx.y, red);
+}
+
+// pred_proj + joint: grid (J / 32, cdiv(R, 32 RG)), 512 threads (RG row groups of 32 x 8 / RG K slices).  pp[slot][j] = W_pred[j] . h_top of a row whose state is new
+// (`gemm` != 0 and ext_dst[r] >= 0: committed to the pool), else the pool's; z = tanh(enc_p[t, i, j] + pp); the output
+// layer's partial sums over this workgroup's 32 joint units go to plog[slice][r][v].
+template <int RG>
+__device__ __forceinline__ void beam2_joint_body(const Beam2P& p, const unsigned short* __restrict__ wpred, const float* __restrict__ enc_p,
+                                                 const float* __restrict__ w_out, float* __restrict__ plog, int t, int gemm, int js, int rb,
+                                                 float (*red)[32][33], float (*zs)[33], float* wo) {
+  constexpr int KQ = 8 / RG, ROWS = 32 * RG;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int rg = wave % RG, kq = wave / RG;
+  const int H = p.H, J = p.J, V1 = p.V + 1, R = p.R, w = p.w, K = H;
+  for (int idx = threadIdx.x; idx < V1 * 32; idx += 512) {
+    const int v = idx >> 5, c = idx & 31;
+    wo[idx] = w_out[(size_t)v * J + js * 32 + c];
+  }
+  if (gemm) {
+    const size_t wplane = (size_t)J * K;
+    const unsigned short* x = p.hpl + (size_t)(p.L - 1) * 3 * p.hplane;
+    const int m = rb * ROWS + rg * 32 + l31;
+    const int kslice = K / KQ, k0 = kq * kslice;
+    const unsigned short* xp = x + frag_off(m, k0 + half * 8, K);
+    const unsigned short* w0 = wpred + frag_off(js * 32 + l31, k0 + half * 8, K);
+    f32x16r acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int PF = 4;
+    u32x4r xf[PF][3], wf[PF][3];
+    auto load = [&](int slot, int ks) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        xf[slot][pl] = *reinterpret_cast<const u32x4r*>(xp + (size_t)pl * p.hplane + (size_t)ks * 512);
+        wf[slot][pl] = *reinterpret_cast<const u32x4r*>(w0 + (size_t)pl * wplane + (size_t)ks * 512);
+      }
+    };
+    auto step = [&](int slot) {
+      const bf16x8r bh = __builtin_bit_cast(bf16x8r, wf[slot][0]), bm = __builtin_bit_cast(bf16x8r, wf[slot][1]);
+      const bf16x8r bl = __builtin_bit_cast(bf16x8r, wf[slot][2]);
+      const bf16x8r xh = __builtin_bit_cast(bf16x8r, xf[slot][0]), xm = __builtin_bit_cast(bf16x8r, xf[slot][1]);
+      const bf16x8r xl = __builtin_bit_cast(bf16x8r, xf[slot][2]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc, 0, 0, 0);
+    };
+    const int nks = kslice / 16;
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+      if (j < nks) load(j, j);
+    for (int ks = 0; ks < nks; ks += PF) {
+#pragma unroll
+      for (int j = 0; j < PF; ++j)
+        if (ks + j < nks) {
+          step(j);
+          if (ks + j + PF < nks) load(j, ks + j + PF);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
+  }
+  __syncthreads();
+  // z of this workgroup's 64 rows x 32 joint units
+  for (int idx = threadIdx.x; idx < ROWS * 32; idx += 512) {
+    const int rowl = idx >> 5, c = idx & 31, rgi = rowl >> 5, rr = rowl & 31;
+    const int r = rb * ROWS + rowl;
+    float z = 0.f;
+    if (r < R) {
+      const int i = r / w, j = r - i * w;
+      if (t < p.lens[i] && j < p.A_cnt[i]) {
+        const int slot = p.A_slot[r];
+        float* ppv = p.pp + (size_t)slot * J + js * 32 + c;
+        float pv;
+        if (gemm && p.ext_dst[r] >= 0) {
+          pv = red[rgi][rr][c];
+#pragma unroll
+          for (int q = 1; q < KQ; ++q) pv += red[q * RG + rgi][rr][c];
+          *ppv = pv;
+        } else {
+          pv = *ppv;
+        }
+        z = tanhf(enc_p[((size_t)t * p.N + i) * J + js * 32 + c] + pv);
+      }
+    }
+    zs[rowl][c] = z;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < ROWS * V1; idx += 512) {
+    const int rowl = idx / V1, v = idx - rowl * V1;
+    const int r = rb * ROWS + rowl;
+    if (r >= R) continue;
+    float a = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < 32; ++c) a = fmaf(wo[v * 32 + c], zs[rowl][c], a);
+    plog[((size_t)js * R + r) * V1 + v] = a;
+  }
+}
+
+template <int RG>
+__global__ __launch_bounds__(512) void beam2_joint_kernel(Beam2P p, const unsigned short* __restrict__ wpred, const float* __restrict__ enc_p,
+                                                          const float* __restrict__ w_out, float* __restrict__ plog, int t, int gemm) {
+  __shared__ float red[8][32][33];
+  __shared__ float zs[32 * RG][33];
+  extern __shared__ __attribute__((aligned(16))) float wo[];           // [V1][32] this slice's columns of W_out
+  beam2_joint_body<RG>(p, wpred, enc_p, w_out, plog, t, gemm, blockIdx.x, blockIdx.y, red, zs, wo);
+}
+
+// The joint of a predictor step and G of the step's new states in ONE launch: G is not on the step's chain (a state's G is first
+// read a round later), the joint is and uses a quarter of the CUs -- so the G workgroups (block ids behind the joint's) fill
+// the rest of the chip beside it instead of a launch of their own (19 us per step).  A second stream was measured for this: the
+// event hand-overs between two streams cost 7 .. 25 us of idle each on this chip (profiles/r05k_*), more than G itself.
+template <int RGJ, int RGG>
+__global__ __launch_bounds__(512) void beam2_joint_g_kernel(Beam2P p, const unsigned short* __restrict__ wpred, const float* __restrict__ enc_p,
+                                                            const float* __restrict__ w_out, float* __restrict__ plog, int t,
+                                                            const unsigned short* __restrict__ whh, int jx, int jy, int gx, int gy) {
+  __shared__ float red[8][32][33];
+  __shared__ float zs[32 * RGJ][33];
+  extern __shared__ __attribute__((aligned(16))) float wo[];
+  int id = blockIdx.x;
+  if (id < jx * jy) {
+    beam2_joint_body<RGJ>(p, wpred, enc_p, w_out, plog, t, 1, id % jx, id / jx, red, zs, wo);
+    return;
+  }
+  id -= jx * jy;
+  const int b = id % gx, rb = (id / gx) % gy, l = id / (gx * gy);
+  pred_gemm3_body<false, RGG>(p, whh, l, b, rb, red);
+}
+
+// cand[j * V1 + v] = log_softmax_v(b_out[v] + sum over the J / 32 slices, in slice order, of plog[slice][i w + j][v]) for the
+// rows j < rows of utterance i; `cand` in LDS, all 256 threads, ends with a barrier
+__device__ __forceinline__ void beam2_logp_rows(const Beam2P& p, float* cand, int i, int rows, int tid) {
+  const int V1 = p.V + 1, w = p.w, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < rows * V1; c += 256) {
+    const int j = c / V1, v = c - j * V1;
+    const float* src = p.plog + ((size_t)i * w + j) * V1 + v;
+    const size_t stride = (size_t)p.R * V1;
+    float a = 0.f;
+    // the slices' partial sums in batches of 16 independent loads (a load at a time waited for an L2 round trip per slice:
+    // 7 us of the round kernel), added in slice order
+    for (int s0 = 0; s0 < p.NS; s0 += 16) {
+      float part[16];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) part[m] = s0 + m < p.NS ? src[(size_t)(s0 + m) * stride] : 0.f;
+#pragma unroll
+      for (int m = 0; m < 16; ++m)
+        if (s0 + m < p.NS) a = (s0 + m == 0) ? part[m] : a + part[m];
+    }
+    cand[c] = a + (p.b_out ? p.b_out[v] : 0.f);
+  }
+  __syncthreads();
+  for (int j = wave; j < rows; j += 4) {
+    float m = -INFINITY;
+    for (int v = lane; v < V1; v += 64) m = fmaxf(m, cand[j * V1 + v]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float sum = 0.f;
+    for (int v = lane; v < V1; v += 64) sum += expf(cand[j * V1 + v] - m);
+    sum = wsum(sum);
+    const float lz = logf(sum) + m;
+    for (int v = lane; v < V1; v += 64) cand[j * V1 + v] -= lz;
+  }
+  __syncthreads();
+}
+
+// blank transitions of one round into the LDS copy of B (beam_round_kernel's merge); returns the new count through wi[0].
+// All 256 threads; b_* hold B (bc0 entries), old_* the live hypotheses (cnt), cand their log-probabilities.
+__device__ __forceinline__ void beam2_blank_merge(int cnt, int bc0, int bcap, int V1, int blank, const float* cand, const int* old_node,
+                                                  const int* old_slot, const float* old_score, int* b_node, int* b_slot,
+                                                  float* b_score, int* match_at, int* wi, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  if (tid < 32) match_at[tid] = -1;
+  __syncthreads();
+  for (int idx = tid; idx < cnt * bc0; idx += 256) {
+    const int j = idx / bc0, b = idx - j * bc0;
+    if (b_node[b] == old_node[j]) match_at[j] = b;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int j = lane;
+    bool dup = false;
+    if (j < cnt)
+      for (int k = 0; k < j; ++k) dup |= old_node[k] == old_node[j];
+    if (__any(dup)) {
+      if (lane == 0) {
+        int bc = bc0;
+        for (int jj = 0; jj < cnt; ++jj) {
+          const float s = old_score[jj] + cand[jj * V1 + blank];
+          int at = -1;
+          for (int b = 0; b < bc; ++b)
+            if (b_node[b] == old_node[jj]) { at = b; break; }
+          if (at >= 0) {
+            b_score[at] = logaddexp32(b_score[at], s);
+          } else if (bc < bcap) {
+            b_node[bc] = old_node[jj];
+            b_score[bc] = s;
+            b_slot[bc] = old_slot[jj];
+            ++bc;
+          }
+        }
+        wi[0] = bc;
+      }
+    } else {
+      const bool have = j < cnt;
+      const int at = have ? match_at[j] : 0;
+      const bool unmatched = have && at < 0;
+      const unsigned long long um = __ballot(unmatched);
+      const int pos = bc0 + __popcll(um & ((1ull << lane) - 1ull));
+      if (have) {
+        const float s = old_score[j] + cand[j * V1 + blank];
+        if (at >= 0) {
+          b_score[at] = logaddexp32(b_score[at], s);
+        } else if (pos < bcap) {
+          b_node[pos] = old_node[j];
+          b_score[pos] = s;
+          b_slot[pos] = old_slot[j];
+        }
+      }
+      if (lane == 0) wi[0] = min(bc0 + (int)__popcll(um), bcap);
+    }
+  }
+  __syncthreads();
+}
+
+// One emission round that is not the frame's last: beam_round_kernel with the log-probabilities made from the joint kernel's
+// partial sums.
+__global__ __launch_bounds__(256) void beam2_round_kernel(Beam2P p, int t, int region, int first) {
+  extern __shared__ __attribute__((aligned(16))) float cand[];  // [w * V1] log-probabilities, then candidate scores
+  __shared__ int wi[4];
+  __shared__ int pick_idx[32];
+  __shared__ float pick_val[32];
+  __shared__ int old_node[32], old_slot[32];
+  __shared__ float old_score[32];
+  __shared__ int b_node[128], b_slot[128];
+  __shared__ float b_score[128];
+  __shared__ int n_pick, next_node;
+  __shared__ int match_at[32];
+  const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w = p.w, V1 = p.V + 1, blank = p.V;
+  const int len_i = p.lens[i], cnt = p.A_cnt[i], bc0 = first ? 0 : p.B_cnt[i], nodes0 = p.node_cnt[i];
+  if (tid < w) {
+    old_node[tid] = p.A_node[i * w + tid];
+    old_slot[tid] = p.A_slot[i * w + tid];
+    old_score[tid] = p.A_score[i * w + tid];
+    p.ext_dst[i * w + tid] = -1;  // requests default to "none" (also for utterances that have ended)
+  }
+  if (tid < p.bcap) {
+    b_node[tid] = p.B_node[(size_t)i * p.bcap + tid];
+    b_score[tid] = p.B_score[(size_t)i * p.bcap + tid];
+    b_slot[tid] = p.B_slot[(size_t)i * p.bcap + tid];
+  }
+  if (t >= len_i) return;
+  if (tid == 0) { n_pick = 0; next_node = nodes0; }
+  beam2_logp_rows(p, cand, i, cnt, tid);
+  beam2_blank_merge(cnt, bc0, p.bcap, V1, blank, cand, old_node, old_slot, old_score, b_node, b_slot, b_score, match_at, wi, tid);
+  {
+    const int bc = wi[0];
+    if (tid == 0) p.B_cnt[i] = bc;
+    if (tid < bc) {
+      p.B_node[(size_t)i * p.bcap + tid] = b_node[tid];
+      p.B_score[(size_t)i * p.bcap + tid] = b_score[tid];
+      p.B_slot[(size_t)i * p.bcap + tid] = b_slot[tid];
+    }
+  }
+  __syncthreads();
+  // label extensions: the w best of cnt * V1 candidates (score desc, ties -> lowest flat index), blank and
+  // non-finite scores excluded
+  const int C = cnt * V1;
+  for (int c = tid; c < C; c += 256) {
+    const int j = c / V1, k = c - j * V1;
+    const float s = old_score[j] + cand[c];
+    cand[c] = (k == blank || !isfinite(s)) ? -INFINITY : s;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    int npk = 0;
+    for (int q = 0; q < w; ++q) {
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int c = lane; c < C; c += 64) {
+        const float v = cand[c];
+        if (v > bv) { bv = v; bi = c; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if (bi == 0x7fffffff || !(bv > -INFINITY)) break;      // wave-uniform: nothing finite is left
+      if (lane == 0) {
+        pick_idx[npk] = bi;
+        pick_val[npk] = bv;
+        cand[bi] = -INFINITY;
+      }
+      ++npk;
+    }
+    if (lane == 0) n_pick = npk;
+  }
+  __syncthreads();
+  const int np = n_pick;
+  if (tid < np) {
+    const int q = tid;
+    const int hi = pick_idx[q] / V1, k = pick_idx[q] - hi * V1;
+    const int parent = old_node[hi];
+    int32_t* ch = p.child + ((size_t)i * p.maxn + parent) * p.V + k;
+    int node = *ch;
+    if (node < 0) {
+      node = atomicAdd(&next_node, 1);
+      if (node < p.maxn) {
+        p.node_parent[(size_t)i * p.maxn + node] = parent;
+        p.node_label[(size_t)i * p.maxn + node] = k;
+        *ch = node;
+      } else {
+        node = parent;  // cannot happen: maxn bounds every possible insertion
+      }
+    }
+    const int slot = region * p.R + i * w + q;
+    p.A_node[i * w + q] = node;
+    p.A_score[i * w + q] = pick_val[q];
+    p.A_slot[i * w + q] = slot;
+    p.ext_label[i * w + q] = k;
+    p.ext_src[i * w + q] = old_slot[hi];
+    p.ext_dst[i * w + q] = slot;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    p.A_cnt[i] = np;
+    p.node_cnt[i] = min(next_node, p.maxn);
+  }
+}
+
+// The frame's last round (blank transitions only) and the frame end in one kernel, grid (w, N): every workgroup repeats the
+// (cheap, LDS) merge and selection and moves ONE survivor's state -- h, c, G of every layer and the projected predictor
+// output -- into frame-start region (t + 1) & 1.
+__global__ __launch_bounds__(256) void beam2_frame_end_kernel(Beam2P p, int t, int first) {
+  extern __shared__ __attribute__((aligned(16))) float cand[];
+  __shared__ int wi[4];
+  __shared__ int old_node[32], old_slot[32];
+  __shared__ float old_score[32];
+  __shared__ int b_node[128], b_slot[128];
+  __shared__ float b_score[128];
+  __shared__ int match_at[32];
+  __shared__ int sel_src[32], sel_node[32];
+  __shared__ float sel_score[32];
+  __shared__ int n_sel;
+  const int q = blockIdx.x, i = blockIdx.y, tid = threadIdx.x;
+  const int w = p.w, V1 = p.V + 1, blank = p.V;
+  const int len_i = p.lens[i], cnt = p.A_cnt[i], bc0 = first ? 0 : p.B_cnt[i];
+  if (tid < w) {
+    old_node[tid] = p.A_node[i * w + tid];
+    old_slot[tid] = p.A_slot[i * w + tid];
+    old_score[tid] = p.A_score[i * w + tid];
+  }
+  if (tid < p.bcap) {
+    b_node[tid] = p.B_node[(size_t)i * p.bcap + tid];
+    b_score[tid] = p.B_score[(size_t)i * p.bcap + tid];
+    b_slot[tid] = p.B_slot[(size_t)i * p.bcap + tid];
+  }
+  if (t >= len_i) {      // the utterance has ended: its final set moves along unchanged, so that it ends in the last frame's buffer
+    if (q == 0) {
+      if (tid == 0) p.nA_cnt[i] = cnt;
+      if (tid < w) {     // (a thread copies the entry it has just read itself)
+        p.nA_node[i * w + tid] = old_node[tid]; p.nA_slot[i * w + tid] = old_slot[tid]; p.nA_score[i * w + tid] = old_score[tid];
+      }
+    }
+    return;
+  }
+  beam2_logp_rows(p, cand, i, cnt, tid);
+  beam2_blank_merge(cnt, bc0, p.bcap, V1, blank, cand, old_node, old_slot, old_score, b_node, b_slot, b_score, match_at, wi, tid);
+  const int bc = wi[0];
+  // the beam_width best of B, one after the other (first maximum = earliest arrival among equals), by ONE wave
+  if (tid < 64) {
+    const int lane = tid;
+    const float s0 = lane < bc ? b_score[lane] : 0.f, s1 = lane + 64 < bc ? b_score[lane + 64] : 0.f;
+    bool t0 = !(lane < bc), t1 = !(lane + 64 < bc);          // "taken" also stands for "does not exist"
+    int ns = 0;
+    for (int x = 0; x < w && x < bc; ++x) {
+      bool have = false;
+      float bv = 0.f;
+      int bi = 0x7fffffff;
+      if (!t0) { have = true; bv = s0; bi = lane; }
+      if (!t1 && (!have || s1 > bv)) { have = true; bv = s1; bi = lane + 64; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const bool oh = __shfl_xor((int)have, o, 64) != 0;
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        const bool take = oh && (!have || ov > bv || (!(bv > ov) && oi < bi));
+        if (take) { have = true; bv = ov; bi = oi; }
+      }
+      if (!have) break;                                       // wave-uniform
+      if (bi == lane) t0 = true;
+      if (bi == lane + 64) t1 = true;
+      if (lane == 0) {
+        sel_src[ns] = b_slot[bi];
+        sel_node[ns] = b_node[bi];
+        sel_score[ns] = b_score[bi];
+      }
+      ++ns;
+    }
+    if (lane == 0) n_sel = ns;
+  }
+  __syncthreads();
+  const int ns = n_sel;
+  if (q == 0 && tid == 0) p.nA_cnt[i] = ns;
+  if (q >= ns) return;
+  const size_t src = (size_t)sel_src[q], dst = (size_t)((t + 1) & 1) * p.R + i * w + q;
+  const int LH = p.L * p.H, J = p.J;
+  if (src != dst) {
+    // h, c (L H each), G (4 L H), pp (J): ~50 KB at two layers of 1024.  Up to that size every load of the move is issued
+    // before the first store (13 float4 per thread); larger states go array by array.
+    const float4* sh4 = reinterpret_cast<const float4*>(p.st_h + src * LH);
+    const float4* sc4 = reinterpret_cast<const float4*>(p.st_c + src * LH);
+    const float4* sg4 = reinterpret_cast<const float4*>(p.G + src * 4 * LH);
+    const float4* sp4 = reinterpret_cast<const float4*>(p.pp + src * J);
+    float4* dh4 = reinterpret_cast<float4*>(p.st_h + dst * LH);
+    float4* dc4 = reinterpret_cast<float4*>(p.st_c + dst * LH);
+    float4* dg4 = reinterpret_cast<float4*>(p.G + dst * 4 * LH);
+    float4* dp4 = reinterpret_cast<float4*>(p.pp + dst * J);
+    const int nh = LH / 4, ng = LH, np4 = J / 4;
+    if (LH % 4 == 0 && J % 4 == 0 && nh <= 512 && np4 <= 256) {
+      float4 vh[2], vc[2], vg[8], vp;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        if (tid + 256 * m < nh) { vh[m] = sh4[tid + 256 * m]; vc[m] = sc4[tid + 256 * m]; }
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+        if (tid + 256 * m < ng) vg[m] = sg4[tid + 256 * m];
+      if (tid < np4) vp = sp4[tid];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        if (tid + 256 * m < nh) { dh4[tid + 256 * m] = vh[m]; dc4[tid + 256 * m] = vc[m]; }
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+        if (tid + 256 * m < ng) dg4[tid + 256 * m] = vg[m];
+      if (tid < np4) dp4[tid] = vp;
+    } else {
+      for (int k = tid; k < LH; k += 256) { p.st_h[dst * LH + k] = p.st_h[src * LH + k]; p.st_c[dst * LH + k] = p.st_c[src * LH + k]; }
+      for (int k = tid; k < 4 * LH; k += 256) p.G[dst * 4 * LH + k] = p.G[src * 4 * LH + k];
+      for (int k = tid; k < J; k += 256) p.pp[dst * J + k] = p.pp[src * J + k];
+    }
+  }
+  if (tid == 0) {
+    p.nA_node[i * w + q] = sel_node[q];
+    p.nA_score[i * w + q] = sel_score[q];
+    p.nA_slot[i * w + q] = (int)dst;
+  }
+}
+
 struct Net {
   const float* embedding;
   const float* w_pred;
@@ -1055,6 +1732,113 @@ int predictor_step(const Net& n, const DecLayout& W, char* ws, hipStream_t s) {
     MS_LAUNCH_CHECK();
   }
   return ms::linear_splitk_launch(htop, n.w_pred, nullptr, (float*)(ws + W.pp_tmp), R, H, n.J, KSPLIT, s);
+}
+
+// The round-5 beam decode (see pred_gemm3_kernel): the same hypothesis lists, trie and pool as the round-4 sequence below it.
+int beam2_decode(const BeamP& bp, const DecLayout& W, char* ws, const float* embedding, const float* const* w_ih,
+                 const float* const* w_hh, const float* const* b_ih, const float* const* b_hh, const float* w_pred,
+                 const float* w_out, const float* b_out, const float* enc_p, int32_t* out_idx, int32_t* out_len, float* out_score,
+                 int T, int N, int V, int D, int H, int L, int J, int w, int max_symbols, hipStream_t s) {
+  const int R = W.R, V1 = V + 1;
+  const size_t rpad = (size_t)((R + 63) / 64 * 64);
+  Beam2P q{};
+  q.lens = bp.lens;
+  int32_t* a2 = (int32_t*)(ws + W.v2_A2);
+  int32_t* Acnt[2] = {bp.A_cnt, a2};
+  int32_t* Anode[2] = {bp.A_node, a2 + N};
+  float* Ascore[2] = {bp.A_score, (float*)(a2 + N + R)};
+  int32_t* Aslot[2] = {bp.A_slot, a2 + N + 2 * R};
+  q.B_cnt = bp.B_cnt; q.B_node = bp.B_node; q.B_slot = bp.B_slot; q.B_score = bp.B_score;
+  q.ext_label = bp.ext_label; q.ext_src = bp.ext_src; q.ext_dst = bp.ext_dst;
+  q.node_cnt = bp.node_cnt; q.node_parent = bp.node_parent; q.node_label = bp.node_label; q.child = bp.child;
+  q.st_h = (float*)(ws + W.st_h); q.st_c = (float*)(ws + W.st_c); q.pp = (float*)(ws + W.pp); q.G = (float*)(ws + W.v2_G);
+  q.E = (const float*)(ws + W.v2_E); q.bias = (const float*)(ws + W.v2_bias); q.plog = (const float*)(ws + W.v2_plog); q.b_out = b_out;
+  q.hpl = (unsigned short*)(ws + W.v2_hpl); q.hplane = rpad * H;
+  q.N = N; q.w = w; q.V = V; q.bcap = bp.bcap; q.maxn = bp.maxn; q.R = R; q.H = H; q.L = L; q.J = J; q.NS = J / 32;
+  auto set_frame = [&](int t) {
+    const int c = t & 1, n = c ^ 1;
+    q.A_cnt = Acnt[c]; q.A_node = Anode[c]; q.A_score = Ascore[c]; q.A_slot = Aslot[c];
+    q.nA_cnt = Acnt[n]; q.nA_node = Anode[n]; q.nA_score = Ascore[n]; q.nA_slot = Aslot[n];
+  };
+  set_frame(0);
+  unsigned short* whh = (unsigned short*)(ws + W.v2_whh);
+  unsigned short* wih = (unsigned short*)(ws + W.v2_wih);
+  unsigned short* wpred = (unsigned short*)(ws + W.v2_wpred);
+  float* plog = (float*)(ws + W.v2_plog);
+  // ---- once per call: the operand planes, the embedding table, the biases
+  const size_t wplane3 = (size_t)3 * 4 * H * H;
+  for (int l = 0; l < L; ++l) {
+    hipLaunchKernelGGL(pack_rows3_kernel, dim3(4 * H), dim3(256), 0, s, w_hh[l], whh + (size_t)l * wplane3, 4 * H, H, H);
+    if (l > 0) {
+      hipLaunchKernelGGL(pack_rows3_kernel, dim3(4 * H), dim3(256), 0, s, w_ih[l], wih + (size_t)(l - 1) * wplane3, 4 * H, H, H);
+      hipLaunchKernelGGL(unit_major_add_kernel, dim3(ms::cdiv(4 * H, 256)), dim3(256), 0, s, (const float*)nullptr, b_ih[l], b_hh[l],
+                         (float*)(ws + W.v2_bias) + (size_t)l * 4 * H, H, 0);
+    }
+  }
+  hipLaunchKernelGGL(pack_rows3_kernel, dim3(J), dim3(256), 0, s, w_pred, wpred, J, H, 0);
+  MS_LAUNCH_CHECK();
+  int rc = ms::linear_launch(embedding, w_ih[0], nullptr, (float*)(ws + W.v2_Etmp), V1, D, 4 * H, MS_ACT_NONE, 0.f, 0.f, s);
+  if (rc != MS_OK) return rc;
+  hipLaunchKernelGGL(unit_major_add_kernel, dim3(ms::cdiv(4 * H, 256)), dim3(256), 0, s, (const float*)(ws + W.v2_Etmp), b_ih[0],
+                     b_hh[0], (float*)(ws + W.v2_E), H, V1);
+  MS_LAUNCH_CHECK();
+  // rows per workgroup: 32 (eight K slices) for the joint -- 64 workgroups instead of 32 at configs[3] --, 64 (four K slices) for
+  // the gate GEMMs (measured: 11.7 against 14.1 us per layer; MS_RNNT_RG = 1 / 2 forces one form for both)
+  static const int rg_env = getenv("MS_RNNT_RG") ? atoi(getenv("MS_RNNT_RG")) : 0;
+  const int rgg = rg_env == 1 && H % 128 == 0 ? 1 : 2;
+  const int rgj = rg_env == 2 || H % 128 != 0 ? 2 : 1;
+  const dim3 ggrid(H / 8, (R + 32 * rgg - 1) / (32 * rgg));
+  const dim3 jgrid(J / 32, (R + 32 * rgj - 1) / (32 * rgj));
+  const size_t cand_lds = (size_t)w * V1 * 4, wo_lds = (size_t)V1 * 32 * 4;
+  auto predictor_step2 = [&]() {       // cell 0 of the request rows, then cells 1 .. L - 1; G rides with the step's joint launch
+    hipLaunchKernelGGL(beam2_cell0_kernel, dim3(R), dim3(256), 0, s, q);
+    for (int l = 1; l < L; ++l) {
+      if (rgg == 1) hipLaunchKernelGGL((pred_gemm3_kernel<true, 1>), ggrid, dim3(512), 0, s, q, (const unsigned short*)wih, l);
+      else hipLaunchKernelGGL((pred_gemm3_kernel<true, 2>), ggrid, dim3(512), 0, s, q, (const unsigned short*)wih, l);
+    }
+  };
+  auto joint = [&](int t, bool after_step) {
+    const int nj = jgrid.x * jgrid.y, ng = ggrid.x * ggrid.y * L;
+    if (after_step) {
+      // the step's new states: their projected predictor output (joint) and their G (beside it)
+#define MS_JG(RJ, RGm) hipLaunchKernelGGL((beam2_joint_g_kernel<RJ, RGm>), dim3(nj + ng), dim3(512), wo_lds, s, q, (const unsigned short*)wpred, \
+                                          enc_p, w_out, plog, t, (const unsigned short*)whh, (int)jgrid.x, (int)jgrid.y, (int)ggrid.x, (int)ggrid.y)
+      if (rgj == 1 && rgg == 1) MS_JG(1, 1);
+      else if (rgj == 1) MS_JG(1, 2);
+      else if (rgg == 1) MS_JG(2, 1);
+      else MS_JG(2, 2);
+#undef MS_JG
+    } else if (rgj == 1) {
+      hipLaunchKernelGGL(beam2_joint_kernel<1>, jgrid, dim3(512), wo_lds, s, q, (const unsigned short*)wpred, enc_p, w_out, plog, t, 0);
+    } else {
+      hipLaunchKernelGGL(beam2_joint_kernel<2>, jgrid, dim3(512), wo_lds, s, q, (const unsigned short*)wpred, enc_p, w_out, plog, t, 0);
+    }
+  };
+  // ---- the root hypotheses' predictor state (blank on the zero state)
+  predictor_step2();
+  MS_LAUNCH_CHECK();
+  for (int t = 0; t < T; ++t) {
+    set_frame(t);
+    for (int v = 0; v < max_symbols; ++v) {
+      const int last = v == max_symbols - 1;
+      // the rows' states are new after a predictor step (and at the very start); a frame's first round works on the survivors
+      joint(t, v > 0 || t == 0);
+      if (last) {
+        hipLaunchKernelGGL(beam2_frame_end_kernel, dim3(w, N), dim3(256), cand_lds, s, q, t, v == 0 ? 1 : 0);
+      } else {
+        hipLaunchKernelGGL(beam2_round_kernel, dim3(N), dim3(256), cand_lds, s, q, t, 2 + v, v == 0 ? 1 : 0);
+        predictor_step2();
+      }
+      MS_LAUNCH_CHECK();
+    }
+  }
+  set_frame(T);           // the last frame end wrote buffer T & 1
+  BeamP fin = bp;
+  fin.A_cnt = q.A_cnt; fin.A_node = q.A_node; fin.A_score = q.A_score; fin.A_slot = q.A_slot;
+  hipLaunchKernelGGL(beam_finish_kernel, dim3(N), dim3(64), 0, s, fin, out_idx, out_len, out_score,
+                     T * (max_symbols > 1 ? max_symbols - 1 : 0) + 1);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
 }
 
 }  // namespace
@@ -1198,6 +1982,12 @@ extern "C" int ms_rnnt_decode(const float* enc_p, const int32_t* lens, const flo
   MS_HIP(hipMemsetAsync(p.child, 0xFF, (size_t)N * W.maxn * V * 4, s));
   hipLaunchKernelGGL(beam_init_kernel, dim3(ms::cdiv(N, 64)), dim3(64), 0, s, p);
   MS_LAUNCH_CHECK();
+  {
+    const char* e = getenv("MS_RNNT_V2");
+    if (!(e && e[0] == '0') && H % 64 == 0 && J % 32 == 0 && (size_t)w * V1 * 4 + (size_t)V1 * 32 * 4 <= 48 * 1024)
+      return beam2_decode(p, W, ws, embedding, w_ih, w_hh, b_ih, b_hh, w_pred, w_out, b_out, enc_p, out_idx, out_len, out_score, T,
+                          N, V, D, H, L, J, w, max_symbols, s);
+  }
   int rc = predictor_step(net, W, ws, s);
   if (rc != MS_OK) return rc;
   const float* pp_tmp = (const float*)(ws + W.pp_tmp);
