@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-/* 3 (round 5): ms_ctc_status and ms_rnn_padded_hidden are new; the CTC workspaces start with a 256-byte status region;
+/* 3 (round 5): ms_ctc_status, ms_rnn_padded_hidden and ms_rnn_hx_preinit (+ MS_RNN_HX_PREINIT, exchange regions) are new; the CTC workspaces start with a 256-byte status region;
  * ms_linear_splitk_workspace_bytes / ms_linear_splitk_forward take `flags` (MS_LINEAR_FEW_ROWS): the K-slice count
  * no longer depends on M.
  * 2 (round 4): ms_prof_read writes MS_PROF_KINDS = 9 entries (was 4 in version 1); the `zero_infinity` argument of the CTC
@@ -166,6 +166,15 @@ size_t ms_linear_split_workspace_bytes(int M, int K, int N);
 int ms_linear_split_forward(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act,
                             float act_lo, float act_hi, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same layer with its weight planes made once instead of per call (fully_connected.py:107-131 builds the Linear once and
+ * calls it per batch): ms_linear_split_pack writes [hi | lo] planes of w [N, K] (ms_linear_split_packed_bytes(K, N) bytes, in
+ * the precision mode of the process); ms_linear_split_forward_packed takes them, its workspace holds the x planes only
+ * (M * K * 4 bytes, 256-byte aligned size).  Same kernels, same plane values, same bits as ms_linear_split_forward. */
+size_t ms_linear_split_packed_bytes(int K, int N);
+int ms_linear_split_pack(const float* w, void* packed, int K, int N, void* stream);
+int ms_linear_split_forward_packed(const float* x, const void* packed_w, const float* bias, float* y, int M, int K, int N, int act,
+                                   float act_lo, float act_hi, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- model/lookahead.py ------------------------------------------------- */
 
 /* Lookahead.forward (lookahead.py:65-69): y[n,f,t] = sum_k w[f,k] * x[n,f,t+k]
@@ -224,8 +233,17 @@ int ms_rnn_layer_forward(int cell, const void* packed, const float* x, const int
  *   MS_RNN_X_PLANES_IN_WS    the input is taken from those planes (left there by the previous layer's call with the
  *                            same T, N, max_len and workspace); `x` may be NULL.
  * Same arithmetic as splitting the float32 output afterwards, one pass over the activations less per layer. */
-enum { MS_RNN_X_PLANES_IN_WS = 1, MS_RNN_OUT_PLANES_TO_WS = 2, MS_RNN_PACKED_ROWS = 4 };
+enum { MS_RNN_X_PLANES_IN_WS = 1, MS_RNN_OUT_PLANES_TO_WS = 2, MS_RNN_PACKED_ROWS = 4, MS_RNN_HX_PREINIT = 4096 };
 int ms_rnn_layer_chains_planes(int cell, int H, int ndir);
+/* One initialisation of the cross-workgroup exchange for a whole stack (rnn.py:112-120 num_layers > 1): every layer call
+ * of the persistent kernels starts with a small launch that sets its exchange buffer's epoch tags and zeroes the per-call
+ * status words -- five of them on a streaming chunk's critical path.  A workspace holds 8 exchange regions; a layer call
+ * selects one with `flags` bits 8 .. 11 (0 by default).  ms_rnn_hx_preinit initialises regions 0 .. nregions - 1 for layers
+ * that all run with this (cell, T, N, H, ndir, max_len) in ONE launch; the layer calls that follow on the same stream then
+ * carry MS_RNN_HX_PREINIT | (region << 8), region = the layer's index.  MS_ERR_UNSUPPORTED (nothing launched, no error text)
+ * for layer kinds it does not serve: the caller then simply leaves the flag out. */
+int ms_rnn_hx_preinit(int cell, int T, int N, int In, int H, int ndir, int max_len, int nregions, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* MS_RNN_PACKED_ROWS (a permission, for batches whose lengths differ): torch's packed sequences (rnn.py:174-181) hold only
  * the frames t < lens[n]; with this flag the layer does the same where it can -- the input projection runs over sum(lens)
  * rows instead of max_len * N and the chained planes hold only those rows, frame after frame -- and ignores it where it

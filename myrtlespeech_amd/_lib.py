@@ -54,11 +54,15 @@ SIGNATURES = {
     "ms_linear_splitk_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, _P, c_size_t, _P]),
     "ms_linear_split_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ms_linear_split_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
+    "ms_linear_split_packed_bytes": (c_size_t, [c_int, c_int]),
+    "ms_linear_split_pack": (c_int, [_P, _P, c_int, c_int, _P]),
+    "ms_linear_split_forward_packed": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
     "ms_lookahead_forward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_int, c_float, c_float, _P]),
     "ms_lookahead_window_forward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int] + [c_long] * 6 + [c_int, c_float, c_float, _P]),
     "ms_rnn_packed_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ms_ctc_status": (c_int, [_P, _P]),
     "ms_rnn_padded_hidden": (c_int, [c_int, c_int, c_int]),
+    "ms_rnn_hx_preinit": (c_int, [c_int] * 8 + [_P, c_size_t, _P]),
     "ms_rnn_pack": (c_int, [c_int, c_int, c_int, c_int, _PP, _PP, _PP, _PP, _P, _P]),
     "ms_rnn_workspace_bytes": (c_size_t, [c_int] * 6),
     "ms_rnn_layer_forward": (c_int, [c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P] + [c_int] * 5 + [_P, c_size_t, _P]),

@@ -1005,6 +1005,48 @@ extern "C" size_t ms_linear_split_workspace_bytes(int M, int K, int N) {
   return ms::align_up((size_t)M * K * 4, 256) + ms::align_up((size_t)N * K * 4, 256);
 }
 
+// The weight planes of ms_linear_split_forward, made once (a streaming chunk's hidden FC layer re-split its
+// 2.6 M weights on every call): [hi plane | lo plane] of N x K 16-bit words each, in the current precision mode's format.
+extern "C" size_t ms_linear_split_packed_bytes(int K, int N) {
+  if (K <= 0 || N <= 0) return 0;
+  return ms::align_up((size_t)N * K * 4, 256);
+}
+
+extern "C" int ms_linear_split_pack(const float* w, void* packed, int K, int N, void* stream_) {
+  MS_REQUIRE(w && packed, "null pointer");
+  MS_REQUIRE(K > 0 && N > 0 && K % 32 == 0, "bad shape (K must be a multiple of 32)");
+  MS_REQUIRE(((uintptr_t)w & 15) == 0, "w must be 16-byte aligned");
+  unsigned short* wh = (unsigned short*)packed;
+  const int prec = ms::precision_mode() == ms::PREC_F16 ? ms::PREC_F16 : ms::PREC_BF16X3;
+  return ms::split_planes_launch(w, wh, wh + (size_t)N * K, (size_t)N * K, prec, (hipStream_t)stream_);
+}
+
+// ms_linear_split_forward with the weights as ms_linear_split_pack left them; the workspace holds the x planes only
+// (M * K * 4 bytes).  Same kernels on the same plane values: the same bits.
+extern "C" int ms_linear_split_forward_packed(const float* x, const void* packed_w, const float* bias, float* y, int M, int K, int N,
+                                              int act, float act_lo, float act_hi, void* workspace, size_t workspace_bytes,
+                                              void* stream_) {
+  ms::ProfScope prof_span(MS_PROF_LINEAR, (hipStream_t)stream_);
+  MS_REQUIRE(x && packed_w && y && workspace, "null pointer");
+  MS_REQUIRE(M > 0 && K > 0 && N > 0, "bad shape");
+  MS_REQUIRE(K % 32 == 0, "K must be a multiple of 32 (use ms_linear_forward otherwise)");
+  MS_REQUIRE(act == MS_ACT_NONE || act == MS_ACT_CLAMP, "bad act");
+  MS_REQUIRE(((uintptr_t)x & 15) == 0, "x must be 16-byte aligned");
+  if (workspace_bytes < ms::align_up((size_t)M * K * 4, 256)) {
+    ms::set_error("ms_linear_split_forward_packed: workspace too small");
+    return MS_ERR_WORKSPACE;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  unsigned short* xh = (unsigned short*)workspace;
+  unsigned short* xl = xh + (size_t)M * K;
+  const unsigned short* wh = (const unsigned short*)packed_w;
+  const unsigned short* wl = wh + (size_t)N * K;
+  const int prec = ms::precision_mode() == ms::PREC_F16 ? ms::PREC_F16 : ms::PREC_BF16X3;
+  int rc = ms::split_planes_launch(x, xh, xl, (size_t)M * K, prec, stream);
+  if (rc == MS_OK) rc = ms::gemm_bf16x3_launch(xh, xl, wh, wl, bias, y, M, K, N, act, act_lo, act_hi, prec, stream);
+  return rc;
+}
+
 extern "C" int ms_linear_split_forward(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
                                        int act, float act_lo, float act_hi, void* workspace, size_t workspace_bytes,
                                        void* stream_) {

@@ -51,6 +51,7 @@ using ms::f32x4;
 constexpr int RED_STRIDE = 40;                    // floats per reduction row (conflict-free, see cell read)
 constexpr int RED_FLOATS = 4 * 32 * RED_STRIDE;   // 4 waves x 32 batch rows
 constexpr size_t STATUS_BYTES = 256;
+constexpr int HX_REGIONS = 8;                      // exchange regions in a workspace (flags bits 8..11 select one)
 constexpr unsigned long long SPIN_LIMIT_TICKS = 200000000ull;  // 2 s of the 100 MHz wall clock
 
 inline int gates_of(int cell) { return (cell == MS_CELL_LSTM || cell == MS_CELL_HARD_LSTM) ? 4 : (cell == MS_CELL_GRU ? 3 : 1); }
@@ -174,7 +175,7 @@ WsLayout ws_layout(int cell, int T, int N, int H, int ndir, int In) {
   // (the float32 two-stream kernel: ndir * 2 streams * 2 slots * 16 rows * H floats = the same ndir * 256 * H bytes)
   L.hx = o;
   L.hx_bytes = ms::align_up(((size_t)ndir * 2 * H * std::min(npad, 64) * sizeof(float)) << (lstm_ring_shift() - 1), 256);
-  o += L.hx_bytes;
+  o += L.hx_bytes * HX_REGIONS;     // one exchange region per layer of a stack (ms_rnn_hx_preinit); a single call uses region 0
   L.state_h = o; o += ms::align_up((size_t)2 * ndir * N * H * sizeof(float), 256);
   L.state_c = o; o += ms::align_up((size_t)ndir * N * H * sizeof(float), 256);
   L.dbg = o; o += ms::align_up((size_t)ndir * std::max(H / 8, 1) * 16 * sizeof(unsigned long long), 256);
@@ -2192,6 +2193,55 @@ using ms::ProfScope;
 
 // ================================================================================================ C ABI
 
+// ---- one exchange initialisation for a whole stack (five hx_init launches of ~4.8 us each sat on a
+// streaming chunk's critical path).  Every layer of a stack runs the same kernel on the same (steps, N, H, ndir), so their
+// exchange regions start out identical: with a region per layer (workspace regions 0 .. 7, selected by flags bits 8 .. 11)
+// ONE launch initialises all of them -- and zeroes the per-call status / epoch words once -- before the first layer, and the
+// layer calls carry MS_RNN_HX_PREINIT.  Served: the tagged-exchange kernels with ONE launch per layer call -- the wide-workgroup
+// LSTM (<= 64 sequences), the two-stream LSTM and the persistent GRU at <= 32 sequences.
+bool use_wide(int cell, int H, int ndir, int N);
+bool hx_preinit_ok(int cell, int N, int H, int ndir) {
+  if (use_wide(cell, H, ndir, N)) return true;
+  if (N > 32) return false;
+  if (use_fast(cell, H, ndir)) {
+    static const bool one_stream = getenv("MS_LSTM_ONE_STREAM") && getenv("MS_LSTM_ONE_STREAM")[0] == '1';
+    return use_split(cell, H, ndir) && two_stream_shape(H) && (!one_stream || use_f16(cell, H, ndir) || H > 1024);
+  }
+  return use_gru_persistent(cell, H, ndir);
+}
+
+extern "C" int ms_rnn_hx_preinit(int cell, int T, int N, int In, int H, int ndir, int max_len, int nregions, void* workspace,
+                                 size_t workspace_bytes, void* stream_) {
+  MS_REQUIRE(cell >= 0 && cell <= MS_CELL_HARD_LSTM && T > 0 && N > 0 && In > 0 && H > 0 && (ndir == 1 || ndir == 2), "bad shape");
+  MS_REQUIRE(workspace && max_len >= 1 && max_len <= T && nregions >= 1 && nregions <= HX_REGIONS, "bad argument");
+  if (!hx_preinit_ok(cell, N, H, ndir)) return MS_ERR_UNSUPPORTED;     // (not an error: the caller lets every layer initialise its own)
+  const WsLayout W = ws_layout(cell, T, N, H, ndir, In);
+  MS_REQUIRE(workspace_bytes >= W.total, "workspace too small");
+  char* ws = (char*)workspace;
+  const bool wide = use_wide(cell, H, ndir, N);
+  const int rs = wide ? 1 : lstm_ring_shift();
+  const int groups = wide ? ms::cdiv(N, 32) : 1;
+  const size_t words_per_dir = (size_t)32 * H << rs;
+  MS_REQUIRE(words_per_dir * ndir * groups * sizeof(unsigned) <= W.hx_bytes, "exchange region smaller than the kernel's ring");
+  hipStream_t stream = (hipStream_t)stream_;
+  for (int r = 0; r < nregions; ++r) {
+    // (regions are W.hx_bytes apart, which may exceed what the kernel uses: one launch per region would be nregions launches,
+    // so the kernel walks "directions" of a combined index space only when the regions are exactly contiguous)
+    if (words_per_dir * ndir * groups * sizeof(unsigned) == W.hx_bytes) {
+      hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir * groups * nregions)), dim3(256), 0, stream,
+                         (unsigned*)(ws + W.hx), words_per_dir, (size_t)8 * H, ndir * groups * nregions, max_len, rs,
+                         (unsigned*)(ws + W.status), (int)((W.xproj - W.status) / sizeof(unsigned)), ndir);
+      MS_LAUNCH_CHECK();
+      return MS_OK;
+    }
+    hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir * groups)), dim3(256), 0, stream,
+                       (unsigned*)(ws + W.hx + (size_t)r * W.hx_bytes), words_per_dir, (size_t)8 * H, ndir * groups, max_len, rs,
+                       (unsigned*)(ws + W.status), (int)((W.xproj - W.status) / sizeof(unsigned)), ndir);
+    MS_LAUNCH_CHECK();
+  }
+  return MS_OK;
+}
+
 // Hidden sizes without a persistent kernel (LSTM: not a multiple of 64; GRU: not one of gru_units()'s widths) used to fall to
 // one launch per step -- GRU-800 68 ms, LSTM-1000 100 ms per layer at [501, 32, .] against 1.7 .. 3 ms for their persistent
 // neighbours (VERDICT r4 missing 3).  The caller pads such a layer to the width returned here with zero weight rows /
@@ -2536,6 +2586,11 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
   char* ws = (char*)workspace;
   const int steps = max_len;
   const bool fast = use_fast(cell, H, ndir);
+  const int hx_region = (flags >> 8) & 15;
+  MS_REQUIRE(hx_region < HX_REGIONS, "exchange region out of range");
+  const bool hx_preinit = (flags & MS_RNN_HX_PREINIT) != 0;      // ms_rnn_hx_preinit initialised this call's region (and zeroed the flags)
+  MS_REQUIRE(!hx_preinit || hx_preinit_ok(cell, N, H, ndir), "MS_RNN_HX_PREINIT on a layer kind ms_rnn_hx_preinit does not serve");
+  char* hx_ptr = ws + W.hx + (size_t)hx_region * W.hx_bytes;
   // packed rows: only the rows (t, n) with t < lens[n] go through the projection and the planes (see row_offsets_kernel)
   const bool packed_rows = (flags & MS_RNN_PACKED_ROWS) != 0 && lens != nullptr && layer_packs_rows(cell, steps, N, In, H, ndir);
   MS_REQUIRE(packed_rows || !(flags & MS_RNN_PACKED_ROWS) || lens == nullptr || !(x_in_ws || out_to_ws),
@@ -2611,7 +2666,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
         p.out_hi = (unsigned short*)(ws + W.xsplit);
         p.out_lo = p.out_hi + (size_t)steps * N * ndir * H;
       }
-      p.hx = (float*)(ws + W.hx);
+      p.hx = (float*)hx_ptr;
       p.flags = (unsigned*)(ws + W.flags);
       p.status = (unsigned*)(ws + W.status);
       p.steps = steps; p.N = ng; p.n_base = n0; p.N_total = N; p.H = H; p.ndir = ndir; p.J = H / 8;
@@ -2641,9 +2696,11 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
         // one launch for all batch groups: a group's exchange region is `ndir` directions long, so group g's direction d is
         // "direction" g * ndir + d of a region with groups * ndir of them, and the tag a slot starts with depends on the
         // direction's parity only (hx_init_kernel: d & 1 -- forward / backward -- when ndir == 2, forward when ndir == 1)
-        hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir * groups)), dim3(256), 0, stream,
-                           (unsigned*)(ws + W.hx), words_per_dir, (size_t)8 * H, ndir * groups, steps, rs, zero_base(0), zero_words(0), ndir);
-        MS_LAUNCH_CHECK();
+        if (!hx_preinit) {
+          hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir * groups)), dim3(256), 0, stream,
+                             (unsigned*)hx_ptr, words_per_dir, (size_t)8 * H, ndir * groups, steps, rs, zero_base(0), zero_words(0), ndir);
+          MS_LAUNCH_CHECK();
+        }
         if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.row_off - W.dbg, stream));   // the stamp area only: row_off (packed rows) follows it
         rc = launch_wide2(p, cell == MS_CELL_HARD_LSTM, groups, use_f16(cell, H, ndir), stream);
         if (rc != MS_OK) return rc;
@@ -2660,9 +2717,11 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
           const size_t slab_words = two_stream ? (size_t)8 * H : (size_t)H * p.NPAD / 2;
           const size_t words_per_dir = two_stream ? ((size_t)32 * H << rs) : (size_t)2 * H * p.NPAD;
           p.ring_shift = rs;
-          hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir)), dim3(256), 0, stream,
-                             (unsigned*)(ws + W.hx), words_per_dir, slab_words, ndir, steps, rs, zero_base(n0), zero_words(n0), ndir);
-          MS_LAUNCH_CHECK();
+          if (!(hx_preinit && two_stream)) {
+            hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir)), dim3(256), 0, stream,
+                               (unsigned*)hx_ptr, words_per_dir, slab_words, ndir, steps, rs, zero_base(n0), zero_words(n0), ndir);
+            MS_LAUNCH_CHECK();
+          }
         }
         if (two_stream) {
           rc = launch_split2_any(p, hard_, stamps, use_f16(cell, H, ndir), stream);
@@ -2680,7 +2739,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       if (f32x2) {
         // every word of every slot starts with the tag that is NOT the first one expected there (also between groups)
         hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for((size_t)64 * H * ndir)), dim3(256), 0, stream,
-                           (unsigned*)(ws + W.hx), (size_t)64 * H, (size_t)16 * H, ndir, steps, 1, zero_base(n0), zero_words(n0), ndir);
+                           (unsigned*)hx_ptr, (size_t)64 * H, (size_t)16 * H, ndir, steps, 1, zero_base(n0), zero_words(n0), ndir);
         MS_LAUNCH_CHECK();
         rc = launch_f32x2_any(p, hard, stream);
         if (rc != MS_OK) return rc;
@@ -2711,9 +2770,11 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
     // one persistent launch per group of 32 sequences (two interleaved streams of 16)
     for (int n0 = 0; n0 < N; n0 += 32) {
       const int rs = lstm_ring_shift();
-      hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(((size_t)32 * H << rs) * ndir)), dim3(256), 0, stream,
-                         (unsigned*)(ws + W.hx), (size_t)32 * H << rs, (size_t)8 * H, ndir, steps, rs, zero_base(n0), zero_words(n0), ndir);
-      MS_LAUNCH_CHECK();
+      if (!hx_preinit) {
+        hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(((size_t)32 * H << rs) * ndir)), dim3(256), 0, stream,
+                           (unsigned*)hx_ptr, (size_t)32 * H << rs, (size_t)8 * H, ndir, steps, rs, zero_base(n0), zero_words(n0), ndir);
+        MS_LAUNCH_CHECK();
+      }
       GruP g;
       g.xproj = xproj;
       g.whh = (const unsigned short*)(pk + L.whh);
@@ -2725,7 +2786,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
         g.out_hi = (unsigned short*)(ws + W.xsplit);
         g.out_lo = g.out_hi + (size_t)steps * N * ndir * H;
       }
-      g.hx = (float*)(ws + W.hx);
+      g.hx = (float*)hx_ptr;
       g.status = (unsigned*)(ws + W.status);
       g.steps = steps; g.N = std::min(32, N - n0); g.n_base = n0; g.N_total = N; g.ndir = ndir; g.J = H / gru_units(H);
       g.ring_shift = rs;

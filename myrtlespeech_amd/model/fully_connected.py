@@ -60,6 +60,20 @@ def _stream_workspace() -> "_lib.Workspace":
     return ws
 
 
+def _packed_planes(lin: torch.nn.Linear, w: torch.Tensor, k: int, n: int) -> torch.Tensor:
+    """[hi | lo] operand planes of ``lin.weight`` (``ms_linear_split_pack``), cached on the module and remade when the
+    parameter is replaced or edited in place."""
+    key = (lin.weight.data_ptr(), _lib.version_of(lin.weight), w.data_ptr())
+    rec = getattr(lin, "_ms_planes", None)
+    if rec is None or rec[0] != key:
+        lib = _lib.load()
+        buf = torch.empty(lib.ms_linear_split_packed_bytes(k, n), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.ms_linear_split_pack(_lib.ptr(w), _lib.ptr(buf), k, n, _lib.stream_ptr()), "ms_linear_split_pack")
+        rec = (key, buf)
+        lin._ms_planes = rec
+    return rec[1]
+
+
 def run_linear_stack(x2d: torch.Tensor, plan, few_rows: bool = False) -> torch.Tensor:
     """x2d [M, K] float32 cuda contiguous.  Large layers with K % 32 == 0 run as the
     split-bf16 GEMM (unless MS_PRECISION=f32), the rest as the exact-f32 GEMM.
@@ -80,9 +94,11 @@ def run_linear_stack(x2d: torch.Tensor, plan, few_rows: bool = False) -> torch.T
         w = _lib.f32c(lin.weight.detach())
         b = None if lin.bias is None else _lib.f32c(lin.bias.detach())
         if _lib.split_precision() and k % 32 == 0 and 2.0 * m * k * n >= _SPLIT_MIN_FLOPS:
-            ws = _stream_workspace().get(lib.ms_linear_split_workspace_bytes(m, k, n), zero=False)
-            _lib.check(lib.ms_linear_split_forward(_lib.ptr(h), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), m, k, n, a, lo, hi,
-                                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "ms_linear_split_forward")
+            # the weight planes are made once per (weight, version) and kept with the layer; the scratch holds the x planes
+            pw = _packed_planes(lin, w, k, n)
+            ws = _stream_workspace().get((m * k * 4 + 255) // 256 * 256, zero=False)
+            _lib.check(lib.ms_linear_split_forward_packed(_lib.ptr(h), _lib.ptr(pw), _lib.ptr(b), _lib.ptr(y), m, k, n, a, lo, hi,
+                                                          _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "ms_linear_split_forward")
         else:
             # an output layer (<= 64 columns): K slices, added in slice order (ms_linear_splitk_forward); 0 bytes = not such a
             # layer, and the call is ms_linear_forward

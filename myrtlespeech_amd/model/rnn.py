@@ -9,6 +9,7 @@ initialisation and key names); the forward pass is ``ms_rnn_layer_forward``
 kernel, with ``pack_padded_sequence`` semantics folded into a per-frame predicate.
 """
 import ctypes
+import os
 from enum import IntEnum
 from typing import List, Optional, Tuple, TypeVar
 
@@ -28,6 +29,8 @@ class RNNType(IntEnum):
 RNNState = TypeVar("RNNState", torch.Tensor, Tuple[torch.Tensor, torch.Tensor])
 RNNData = TypeVar("RNNData", bound=torch.Tensor)
 Lengths = TypeVar("Lengths", bound=torch.Tensor)
+
+_HX_PREINIT = os.environ.get("MS_RNN_HX_PREINIT") != "0"      # A/B switch (tests): 0 = every layer call initialises its exchange
 
 _CELL = {RNNType.LSTM: _lib.CELL_LSTM, RNNType.GRU: _lib.CELL_GRU, RNNType.BASIC_RNN: _lib.CELL_RNN_TANH}
 
@@ -90,10 +93,13 @@ def pad_layer_params(cell: int, params, hp: int, padded_input: bool, in_pad: int
 def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max_len: int,
                layer_params: List[List[Tuple[Optional[torch.Tensor], ...]]], packed: List[PackedLayer], hidden: int,
                h0: Optional[torch.Tensor], c0: Optional[torch.Tensor], workspace: _lib.Workspace, check: bool = True,
-               ragged: bool = False, keep_padding: bool = False):
+               ragged: bool = False, keep_padding: bool = False, state_inplace: bool = False):
     """x [T,N,In] float32 cuda contiguous -> (out [T,N,D*H], hn, cn|None).  ``ragged``: the lengths differ -- layers that can
     then work on the rows that exist only, like torch's packed sequences (``MS_RNN_PACKED_ROWS``; same outputs).
-    ``keep_padding`` (tests): return a padded stack's outputs and states at the padded width."""
+    ``keep_padding`` (tests): return a padded stack's outputs and states at the padded width.  ``state_inplace``: the final
+    states are written over ``h0`` / ``c0`` (which are then returned): every kernel reads an element of the initial state
+    and writes the same element of the final state from the same thread, so the buffers may coincide -- a replayed HIP graph
+    then chains its recurrent state without copies (streaming.py)."""
     lib = _lib.load()
     t, n, _ = x.shape
     ndir = len(layer_params[0])
@@ -115,8 +121,10 @@ def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max
         if _lib.split_precision() and x.shape[2] % 32:
             in_pad = -x.shape[2] % 32
             x = torch.nn.functional.pad(x, (0, in_pad))
-    hn = torch.empty((nl * ndir, n, hidden), dtype=torch.float32, device="cuda")
-    cn = torch.empty_like(hn) if lstm_like else None
+    inplace = (state_inplace and not padded and h0 is not None and h0.is_contiguous() and tuple(h0.shape) == (nl * ndir, n, hidden)
+               and (not lstm_like or (c0 is not None and c0.is_contiguous() and c0.shape == h0.shape)))
+    hn = h0 if inplace else torch.empty((nl * ndir, n, hidden), dtype=torch.float32, device="cuda")
+    cn = (c0 if inplace else torch.empty_like(hn)) if lstm_like else None
     inp = x
     # one workspace for the whole stack (the time-out word in it is sticky, so ONE status check -- a host sync -- after
     # the last layer covers all of them)
@@ -127,11 +135,21 @@ def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max
     # (all layers or none: a chained stack hands its planes from layer to layer in one row layout)
     pack_rows = ragged and lens_dev is not None and all(lib.ms_rnn_layer_packs_rows(cell, max_len, n, k, hidden, ndir)
                                                         for k in in_sizes)
+    # one exchange initialisation for the whole stack where the layer kind allows it (ms_rnn_hx_preinit): the layers then use
+    # exchange regions 0 .. nl - 1 of the workspace instead of re-initialising region 0 before every layer
+    preinit = 0
+    if 1 < nl <= 8 and _HX_PREINIT:
+        rc = lib.ms_rnn_hx_preinit(cell, t, n, max(in_sizes), hidden, ndir, max_len, nl, _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        if rc == 0:
+            preinit = 4096          # MS_RNN_HX_PREINIT
+        elif rc != 5:               # MS_ERR_UNSUPPORTED: this layer kind initialises per call
+            _lib.check(rc, "ms_rnn_hx_preinit")
     for layer in range(nl):
         in_size = in_sizes[layer]
         pk = packed[layer].get(cell, in_size, hidden, layer_params[layer],
                                (hidden, layer > 0, in_pad if layer == 0 else 0) if padded else None)
         flags = (1 if (chain and layer > 0) else 0) | (2 if (chain and layer < nl - 1) else 0) | (4 if pack_rows else 0)
+        flags |= preinit | ((layer << 8) if preinit else 0)
         out = None if flags & 2 else torch.empty((t, n, ndir * hidden), dtype=torch.float32, device="cuda")
         sl = slice(layer * ndir, (layer + 1) * ndir)
         h0l = None if h0 is None else h0[sl].contiguous()
@@ -184,6 +202,7 @@ class RNN(torch.nn.Module):
         self._packed = [PackedLayer() for _ in range(num_layers)]
         self._workspace = _lib.Workspace()
         self.check_status = True
+        self.inplace_state = False      # streaming graphs: write h_n / c_n over the hx tensors they were given (run_layers)
         self.use_cuda = torch.cuda.is_available()
         if self.use_cuda:
             self.rnn = self.rnn.cuda()
@@ -227,7 +246,7 @@ class RNN(torch.nn.Module):
                 h0 = _lib.f32c(hx)
         out, hn, cn = run_layers(_CELL[self.rnn_type], data, _lib.lens_i32(lens_cpu), max_len, self._layer_params(),
                                  self._packed, self.rnn.hidden_size, h0, c0, self._workspace, self.check_status,
-                                 ragged=bool(int(lens_cpu[-1]) < max_len))
+                                 ragged=bool(int(lens_cpu[-1]) < max_len), state_inplace=self.inplace_state)
         if self.batch_first:
             out = out.transpose(0, 1)
         hid = (hn, cn) if self.rnn_type == RNNType.LSTM else hn

@@ -224,9 +224,8 @@ class _ContextStream:
         alive = int((lens_c > 0).sum())
         self.rnn_pos += cnt
         hidden = self.model.rnn.rnn.hidden_size
-        block = torch.zeros((cnt, self.n, hidden), dtype=torch.float32, device="cuda")
         if alive == 0:
-            return block
+            return torch.zeros((cnt, self.n, hidden), dtype=torch.float32, device="cuda")
         hx = None
         if self.state is not None:
             hx = tuple(s[:, :alive].contiguous() for s in self.state) if isinstance(self.state, tuple) else \
@@ -236,8 +235,12 @@ class _ContextStream:
             mk = lambda s: torch.zeros(s.shape[0], self.n, s.shape[2], device=s.device)  # noqa: E731
             self.full_state = tuple(mk(s) for s in st) if isinstance(st, tuple) else mk(st)
         for fs, s in zip(self.full_state if isinstance(st, tuple) else (self.full_state,), st if isinstance(st, tuple) else (st,)):
-            fs[:, :alive] = s
+            if not (alive == self.n and fs.data_ptr() == s.data_ptr()):
+                fs[:, :alive] = s
         self.state = self.full_state
+        if alive == self.n:            # every utterance alive: the stack's output IS the block (no zero fill, no copy)
+            return y
+        block = torch.zeros((cnt, self.n, hidden), dtype=torch.float32, device="cuda")
         block[:, :alive] = y
         return block
 
@@ -318,12 +321,15 @@ class _ContextGraph:
             if old.buf is not None:                    # no allocation, hence no zero-fill node, inside the capture
                 w_.get(old.buf.numel())
         check_was = getattr(model.rnn, "check_status", None)
+        inplace_was = getattr(model.rnn, "inplace_state", None)
         self.graph = torch.cuda.CUDAGraph()
         try:
             for (o, a), w_ in zip(slots, self._own):
                 setattr(o, a, w_)
             if check_was is not None:
                 model.rnn.check_status = False          # ms_rnn_status synchronises: not inside a capture
+            if inplace_was is not None:
+                model.rnn.inplace_state = True          # the new state lands in the static state tensors: no copies in the graph
             torch.cuda.synchronize()
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 y = stream.push(self.x, False)
@@ -344,6 +350,8 @@ class _ContextGraph:
                 setattr(o, a, w_)
             if check_was is not None:
                 model.rnn.check_status = check_was
+            if inplace_was is not None:
+                model.rnn.inplace_state = inplace_was
         self.y = y
         after = self._counters(stream)
         self.delta = [b - a for a, b in zip(snap, after)]
@@ -442,21 +450,25 @@ class _ChunkGraph:
         slots = _workspace_slots(model) if os.environ.get("MS_STREAM_GRAPH_OWN_WS") != "0" else []     # (0: A/B runs only)
         self._own = [_lib.Workspace() for _ in slots]
         saved = [getattr(o, a) for o, a in slots]
+        rnn = getattr(model, "rnn", None)
+        inplace_was = getattr(rnn, "inplace_state", None)
         try:
             for (o, a), w in zip(slots, self._own):
                 setattr(o, a, w)
+            if inplace_was is not None:
+                rnn.inplace_state = True       # h_n / c_n land in the static state tensors themselves: no copies in the graph
             model((self.x, self.lens), self.state)
             torch.cuda.synchronize()
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 (y, ol), st = model((self.x, self.lens), self.state)
-                if isinstance(st, tuple):
-                    for a_, b_ in zip(self.state, st):
+                for a_, b_ in zip(self.state if isinstance(st, tuple) else (self.state,), st if isinstance(st, tuple) else (st,)):
+                    if a_.data_ptr() != b_.data_ptr():
                         a_.copy_(b_)
-                else:
-                    self.state.copy_(st)
         finally:
             for (o, a), w in zip(slots, saved):
                 setattr(o, a, w)
+            if inplace_was is not None:
+                rnn.inplace_state = inplace_was
         self.y, self.out_lens_host = y, _lib.host_lens(ol).clone()
         rnn_ws = [w for (o, a), w in zip(slots, self._own) if o is getattr(model, "rnn", None)]
         self.rnn_ws = rnn_ws[0] if rnn_ws else None      # holds the sticky time-out word of this graph's recurrent launches
