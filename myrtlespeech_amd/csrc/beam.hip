@@ -90,10 +90,14 @@ struct BeamP {
   float thr;
 };
 
+// NT threads: 256.  ONE wave (NT = 64, MS_BEAM_THREADS=64: a lane takes four candidates at W = 8, V = 29, no cross-wave barrier)
+// was measured and is SLOWER -- 3.63 against 2.31 ms for 32 x 501 frames: a frame is ~70 exposed LDS round trips in seven
+// short phases (hipcc waits before every dependent use), and four candidates per lane lengthen every phase more than the
+// barriers cost.  The instantiation stays as the A/B switch.
 // BIG: beam_width * (alphabet + 1) too large for the LDS (~2 300 candidates; 84 prefixes at V = 29) -- the same code
 // with its working arrays in the workspace.  Slow (every phase goes through L2) but any width up to 256 decodes.
-template <bool BIG>
-__global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
+template <bool BIG, int NT>
+__global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, n = blockIdx.x;
   const int V = p.V, W = p.W, M = p.L.M, WV = W * V;
@@ -152,22 +156,22 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
       bm_last[b0 * W] = -1; bm_len[b0 * W] = 0; bm_nw[b0 * W] = 0; bm_cslot[b0 * W] = 0;
       sh[0] = 1; sh[2] = 1; sh[3] = 1;
     }
-    for (int v = tid; v < V; v += 256) {
+    for (int v = tid; v < V; v += NT) {
       childtab[v] = -1;
       lc_node[b0 * WV + v] = -1; lc_cslot[b0 * WV + v] = -1; lc_tidx[b0 * WV + v] = -1;
     }
   } else {
     if (tid == 0) { sh[0] = hdr[2]; sh[2] = hdr[0]; sh[3] = hdr[1]; }
     const int B_in = hdr[2];
-    for (int w = tid; w < W; w += 256)
+    for (int w = tid; w < W; w += NT)
       if (w < B_in) {
         const int nd = g_beam_node[w];
         bm_node[b0 * W + w] = nd; bm_pb[b0 * W + w] = g_beam_pb[w]; bm_pnb[b0 * W + w] = g_beam_pnb[w];
         bm_last[b0 * W + w] = node_sym[nd]; bm_len[b0 * W + w] = node_len[nd]; bm_nw[b0 * W + w] = node_nw[nd];
         bm_cslot[b0 * W + w] = node_cslot[nd];
       }
-    for (int i = tid; i < M; i += 256) { c_pb[(b0 ^ 1) * M + i] = tbl_pb[i]; c_pnb[(b0 ^ 1) * M + i] = tbl_pnb[i]; }
-    for (int i = tid; i < WV; i += 256) {
+    for (int i = tid; i < M; i += NT) { c_pb[(b0 ^ 1) * M + i] = tbl_pb[i]; c_pnb[(b0 ^ 1) * M + i] = tbl_pnb[i]; }
+    for (int i = tid; i < WV; i += NT) {
       lc_node[b0 * WV + i] = g_lc_node[i]; lc_cslot[b0 * WV + i] = g_lc_cslot[i]; lc_tidx[b0 * WV + i] = g_lc_tidx[i];
     }
   }
@@ -197,15 +201,15 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
     const int* lct = lc_tidx + cb * WV;
     const float* row = p.probs + ((size_t)t * p.N + n) * V;
     if (tid < V) prow[tid] = p_next;
-    for (int v = tid + 256; v < V; v += 256) prow[v] = row[v];
+    for (int v = tid + NT; v < V; v += NT) prow[v] = row[v];
     if (t + 1 < t_stop && tid < V) p_next = p.probs[((size_t)(t + 1) * p.N + n) * V + tid];
-    for (int w = tid; w < W; w += 256) par_present[w] = 0;
+    for (int w = tid; w < W; w += NT) par_present[w] = 0;
     if (tid == 0) sh[1] = 0;
     __syncthreads();
     const float p_blank = prow[p.blank];
 
     // ---- S1: extensions l + c
-    for (int i = tid; i < B * V; i += 256) {
+    for (int i = tid; i < B * V; i += NT) {
       const int w = i / V, c = i - w * V;
       const int slot = W + i;
       int flags = 0;
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
     __syncthreads();
 
     // ---- S2: the beam entries themselves
-    for (int w = tid; w < W; w += 256) {
+    for (int w = tid; w < W; w += NT) {
       int flags = 0;
       if (w < B) {
         const bool in_pb = !(p_blank <= p.thr);
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
 
     // ---- S3: sort key (+ word-count scaling) and compaction of A_next
     const int nslots = W + B * V;
-    for (int i = tid; i < nslots; i += 256) {
+    for (int i = tid; i < nslots; i += NT) {
       if (c_flags[i] & F_KEPT) {
         float score = c_s[i];
         if (p.sep >= 0) {
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
         if (have && pos < W) newbeam[pos] = k_idx[tid];
       }
     } else {
-      for (int j = tid; j < K; j += 256) {
+      for (int j = tid; j < K; j += NT) {
         const float sj = k_score[j];
         const int kj = k_key[j];
         int pos = 0;
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
     // ---- S5: an extension that enters the beam becomes a trie node (if it is not one yet) with a child-table slot (if it has
     // never been in the beam before); both are recorded in its parent's row, here and in the workspace copy of that row
     const int Bn = min(K, W);
-    for (int j = tid; j < Bn; j += 256) {
+    for (int j = tid; j < Bn; j += NT) {
       const int i = newbeam[j];
       int fresh = 0;
       if (i >= W) {
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
     __syncthreads();
 
     // ---- S6: A_prev <- best beam_width candidates; every new beam entry's child row
-    for (int idx = tid; idx < Bn * V; idx += 256) {
+    for (int idx = tid; idx < Bn * V; idx += NT) {
       const int j = idx / V, c = idx - j * V;
       const int i = newbeam[j];
       int child, cs, ti = -1;
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
           if (bmn[k] == child && (c_flags[k] & F_PRESENT)) ti = k;
       lc_node[nb * WV + idx] = child; lc_cslot[nb * WV + idx] = cs; lc_tidx[nb * WV + idx] = ti;
     }
-    for (int j = tid; j < Bn; j += 256) {
+    for (int j = tid; j < Bn; j += NT) {
       const int i = newbeam[j];
       int nd, last, ln, nw, cs;
       if (i < W) {
@@ -400,11 +404,11 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
   const int eb = t & 1;
   const int B = sh[0];
   if (tid == 0) { hdr[0] = sh[2]; hdr[1] = sh[3]; hdr[2] = B; }
-  for (int i = tid; i < M; i += 256) { tbl_pb[i] = c_pb[(eb ^ 1) * M + i]; tbl_pnb[i] = c_pnb[(eb ^ 1) * M + i]; }
-  for (int i = tid; i < WV; i += 256) {
+  for (int i = tid; i < M; i += NT) { tbl_pb[i] = c_pb[(eb ^ 1) * M + i]; tbl_pnb[i] = c_pnb[(eb ^ 1) * M + i]; }
+  for (int i = tid; i < WV; i += NT) {
     g_lc_node[i] = lc_node[eb * WV + i]; g_lc_cslot[i] = lc_cslot[eb * WV + i]; g_lc_tidx[i] = lc_tidx[eb * WV + i];
   }
-  for (int w = tid; w < W; w += 256)
+  for (int w = tid; w < W; w += NT)
     if (w < B) { g_beam_node[w] = bm_node[eb * W + w]; g_beam_pb[w] = bm_pb[eb * W + w]; g_beam_pnb[w] = bm_pnb[eb * W + w]; }
   if (p.finish && tid == 0) {
     int L = 0;
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamP p) {
   }
   if (p.beam_idx_out != nullptr) {
     if (tid == 0) p.beam_len_out[n] = B;
-    for (int w = tid; w < B; w += 256) {
+    for (int w = tid; w < B; w += NT) {
       int nd = bm_node[eb * W + w];
       const int L = node_len[nd];
       p.beam_plen_out[(size_t)n * W + w] = L;
@@ -456,7 +460,7 @@ extern "C" int ms_ctc_beam_decode(const float* probs, const int32_t* lens, int32
   const size_t lds = L.big ? 0 : beam_lds_bytes(V, beam_width);
   static ms::DeviceOnce attr_once;
   if (attr_once.need()) {
-    MS_HIP(hipFuncSetAttribute((const void*)beam_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MS_HIP(hipFuncSetAttribute((const void*)beam_kernel<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.done();
   }
   BeamP p;
@@ -465,8 +469,11 @@ extern "C" int ms_ctc_beam_decode(const float* probs, const int32_t* lens, int32
   p.ws = (char*)workspace; p.L = L; p.T = T; p.N = N; p.V = V; p.W = beam_width; p.blank = blank;
   p.sep = separator < 0 ? -1 : separator; p.t_begin = t_begin; p.t_end = t_end; p.finish = finish;
   p.thr = prune_threshold;
-  if (L.big) hipLaunchKernelGGL(beam_kernel<true>, dim3(N), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(beam_kernel<false>, dim3(N), dim3(256), lds, (hipStream_t)stream, p);
+  static const int nt_env = getenv("MS_BEAM_THREADS") ? atoi(getenv("MS_BEAM_THREADS")) : 0;      // A/B switch: 64 or 256
+  const bool one_wave = nt_env == 64;
+  if (L.big) hipLaunchKernelGGL((beam_kernel<true, 256>), dim3(N), dim3(256), 0, (hipStream_t)stream, p);
+  else if (one_wave && lds <= 64 * 1024) hipLaunchKernelGGL((beam_kernel<false, 64>), dim3(N), dim3(64), lds, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((beam_kernel<false, 256>), dim3(N), dim3(256), lds, (hipStream_t)stream, p);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }
