@@ -86,9 +86,23 @@ struct BeamP {
   int32_t* beam_plen_out;
   char* ws;
   BeamLayout L;
-  int T, N, V, W, blank, sep, t_begin, t_end, finish;
+  int T, N, V, W, blank, sep, t_begin, t_end, finish, stamps;
   float thr;
 };
+
+// beam index of `node` (-1: not in the beam): the beam's node ids in batches of eight independent LDS reads
+__device__ __forceinline__ int find_in_beam(const int* bmn, int B, int W, int node) {
+  int at = -1;
+  for (int k0 = 0; k0 < B; k0 += 8) {
+    int v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = bmn[min(k0 + m, W - 1)];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+      if (k0 + m < B && v[m] == node) at = k0 + m;
+  }
+  return at;
+}
 
 // NT threads: 256.  ONE wave (NT = 64, MS_BEAM_THREADS=64: a lane takes four candidates at W = 8, V = 29, no cross-wave barrier)
 // was measured and is SLOWER -- 3.63 against 2.31 ms for 32 x 501 frames: a frame is ~70 exposed LDS round trips in seven
@@ -96,6 +110,11 @@ struct BeamP {
 // barriers cost.  The instantiation stays as the A/B switch.
 // BIG: beam_width * (alphabet + 1) too large for the LDS (~2 300 candidates; 84 prefixes at V = 29) -- the same code
 // with its working arrays in the workspace.  Slow (every phase goes through L2) but any width up to 256 decodes.
+// MS_BEAM_STAMPS=1 (read per call): thread 0 of utterance 0 accumulates the 100 MHz wall clock per barrier-separated phase of
+// the frame loop into hdr[4 .. 4 + 8] (ticks summed over the call's frames; tools/beam_stamps.py prints them)
+#define MS_BEAM_STAMP_BEGIN() do { if (stamping) st_prev = wall_clock64(); } while (0)
+#define MS_BEAM_STAMP(k) do { if (stamping) { const unsigned long long now_ = wall_clock64(); st_acc[k] += (unsigned)(now_ - st_prev); st_prev = now_; } } while (0)
+
 template <bool BIG, int NT>
 __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -147,6 +166,9 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
   int* node_cslot = reinterpret_cast<int*>(u + p.L.node_cslot);
   int* childtab = reinterpret_cast<int*>(u + p.L.childtab);
 
+  const bool stamping = p.stamps != 0 && tid == 0 && n == 0;
+  unsigned long long st_prev = 0;
+  unsigned st_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int b0 = p.t_begin & 1;      // buffer of the beam / child rows a frame reads = the frame's parity
   if (p.t_begin == 0) {
     // Pb[-1][()] = 1, Pnb[-1][()] = 0, A_prev = [()]   (ctc_beam_decoder.py:182-192)
@@ -185,6 +207,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
   if (p.t_begin < t_stop && tid < V) p_next = p.probs[((size_t)p.t_begin * p.N + n) * V + tid];
   int t = p.t_begin;
   for (; t < t_stop; ++t) {
+    MS_BEAM_STAMP_BEGIN();
     const int B = sh[0];
     if (B == 0) break;  // an empty beam stays empty (ctc_beam_decoder.py:258)
     const int cp = t & 1, pp = cp ^ 1;          // tables: this frame's / the previous frame's
@@ -206,58 +229,76 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
     for (int w = tid; w < W; w += NT) par_present[w] = 0;
     if (tid == 0) sh[1] = 0;
     __syncthreads();
+    MS_BEAM_STAMP(0);
     const float p_blank = prow[p.blank];
 
-    // ---- S1: extensions l + c
+    // (S2's words that do not depend on S1 are requested here, ahead of S1 and its barrier)
+    const int s2_w = tid;                                   // W <= NT is not assumed: the S2 loop below re-reads for w >= NT
+    float s2_pb = 0.f, s2_pnb = 0.f, s2_plast = 0.f;
+    int s2_last = 0, s2_len = 0;
+    if (s2_w < B) {
+      s2_pb = bmpb[s2_w]; s2_pnb = bmpnb[s2_w]; s2_last = bml[s2_w]; s2_len = bmlen[s2_w];
+      s2_plast = prow[max(s2_last, 0)];
+    }
+
+    // ---- S1: extensions l + c.  Every LDS word a candidate may need is requested before the first is looked at (the phase is
+    // a chain of LDS round trips on one wave per SIMD: with the loads behind the branches that need them hipcc waited five
+    // times where two suffice); the addresses are valid for every candidate, the values are used under the same conditions.
     for (int i = tid; i < B * V; i += NT) {
       const int w = i / V, c = i - w * V;
       const int slot = W + i;
+      const float pc = prow[c];
+      const int child = lcn[i];
+      const int ti = lct[i];
+      const int len_w = bmlen[w], last_w = bml[w];
+      const float pb_w = bmpb[w], pnb_w = bmpnb[w];
+      const int w2 = find_in_beam(bmn, B, W, child);       // -1 for child == -1 (node ids are >= 0)
+      const int tis = ti >= 0 ? ti : 0;
+      const float pb_t = c_pb[pp * M + tis], pnb_t = c_pnb[pp * M + tis];
       int flags = 0;
-      if (c != p.blank) {
-        const float pc = prow[c];
-        if (!(pc <= p.thr)) {  // `if ctc[t][c] <= prune_threshold: continue`
-          const int child = lcn[i];
-          int w2 = -1;
-          if (child >= 0)
-            for (int k = 0; k < B; ++k)
-              if (bmn[k] == child) w2 = k;
-          const bool repeat = bmlen[w] > 0 && c == bml[w];
-          float a = repeat ? pc * bmpb[w] : pc * (bmpb[w] + bmpnb[w]);
-          if (!repeat && p.lm_factor != nullptr && c == p.sep) a = a * p.lm_factor[(size_t)n * W + w];
-          if (w2 >= 0) {  // l_plus in A_prev: only Pnb[t][l_plus] += a
-            par_val[w2] = a; par_rank[w2] = i * 4; par_present[w2] = 1;
-          } else {
-            float pb_c = 0.f, pnb_c = 0.f;
-            const int ti = lct[i];         // l_plus was a candidate of the previous frame: its Pb / Pnb (ctc_beam_decoder.py:232-241)
-            if (ti >= 0) { pb_c = c_pb[pp * M + ti]; pnb_c = c_pnb[pp * M + ti]; }
-            const float bterm = pc * pnb_c;
-            const float pnb_new = a + bterm;
-            const float pb_new = p_blank * (pb_c + pnb_c);
-            const float s = pb_new + pnb_new;
-            c_pb[cp * M + slot] = pb_new; c_pnb[cp * M + slot] = pnb_new; c_s[slot] = s; c_key[slot] = i * 4 + 2;
-            flags = F_PRESENT | (s > 0.f ? F_KEPT : 0);
-          }
+      if (c != p.blank && !(pc <= p.thr)) {  // `if ctc[t][c] <= prune_threshold: continue`
+        const bool repeat = len_w > 0 && c == last_w;
+        float a = repeat ? pc * pb_w : pc * (pb_w + pnb_w);
+        if (!repeat && p.lm_factor != nullptr && c == p.sep) a = a * p.lm_factor[(size_t)n * W + w];
+        if (w2 >= 0) {  // l_plus in A_prev: only Pnb[t][l_plus] += a
+          par_val[w2] = a; par_rank[w2] = i * 4; par_present[w2] = 1;
+        } else {
+          // l_plus was a candidate of the previous frame: its Pb / Pnb (ctc_beam_decoder.py:232-241)
+          const float pb_c = ti >= 0 ? pb_t : 0.f, pnb_c = ti >= 0 ? pnb_t : 0.f;
+          const float bterm = pc * pnb_c;
+          const float pnb_new = a + bterm;
+          const float pb_new = p_blank * (pb_c + pnb_c);
+          const float s = pb_new + pnb_new;
+          c_pb[cp * M + slot] = pb_new; c_pnb[cp * M + slot] = pnb_new; c_s[slot] = s; c_key[slot] = i * 4 + 2;
+          flags = F_PRESENT | (s > 0.f ? F_KEPT : 0);
         }
       }
       c_flags[slot] = flags;
     }
     __syncthreads();
+    MS_BEAM_STAMP(1);
 
     // ---- S2: the beam entries themselves
     for (int w = tid; w < W; w += NT) {
       int flags = 0;
       if (w < B) {
+        const bool first = w == s2_w;
+        const float pb_w = first ? s2_pb : bmpb[w], pnb_w = first ? s2_pnb : bmpnb[w];
+        const int last = first ? s2_last : bml[w], len_w = first ? s2_len : bmlen[w];
+        const float p_last = first ? s2_plast : prow[max(last, 0)];
+        const int parp = par_present[w];
+        const float parv = par_val[w];
+        const int parr = par_rank[w];
         const bool in_pb = !(p_blank <= p.thr);
-        const float pb_new = in_pb ? p_blank * (bmpb[w] + bmpnb[w]) : 0.f;
-        const int last = bml[w];
-        const bool own = bmlen[w] > 0 && !(prow[last] <= p.thr);
-        const float ownv = own ? prow[last] * bmpnb[w] : 0.f;
-        const bool par = par_present[w] != 0;
+        const float pb_new = in_pb ? p_blank * (pb_w + pnb_w) : 0.f;
+        const bool own = len_w > 0 && !(p_last <= p.thr);
+        const float ownv = own ? p_last * pnb_w : 0.f;
+        const bool par = parp != 0;
         const bool in_pnb = own || par;
         float pnb_new = 0.f;
-        if (own && par) pnb_new = ownv + par_val[w];
+        if (own && par) pnb_new = ownv + parv;
         else if (own) pnb_new = ownv;
-        else if (par) pnb_new = par_val[w];
+        else if (par) pnb_new = parv;
         float s = 0.f;
         int key = 0;
         if (in_pb) {
@@ -267,7 +308,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
           s = pnb_new;
           int r = 0x3fffffff;
           if (own) r = min(r, (w * V + last) * 4 + 1);
-          if (par) r = min(r, par_rank[w]);
+          if (par) r = min(r, parr);
           key = 0x40000000 | r;  // keys only in Pnb[t] follow every key of Pb[t] (Counter.__add__)
         }
         c_pb[cp * M + w] = pb_new; c_pnb[cp * M + w] = pnb_new; c_s[w] = s; c_key[w] = key;
@@ -276,59 +317,72 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
       c_flags[w] = flags;
     }
     __syncthreads();
+    MS_BEAM_STAMP(2);
 
-    // ---- S3: sort key (+ word-count scaling) and compaction of A_next
+    // ---- S3: sort key (+ word-count scaling) and compaction of A_next: a wave's kept candidates take consecutive places
+    // behind ONE LDS atomic per wave (their order among the kept does not matter: S4 ranks by (score, key))
     const int nslots = W + B * V;
-    for (int i = tid; i < nslots; i += NT) {
-      if (c_flags[i] & F_KEPT) {
-        float score = c_s[i];
-        if (p.sep >= 0) {
-          int nw;
-          if (i < W) nw = bmnw[i];
-          else {
-            const int w = (i - W) / V, c = (i - W) - w * V;
-            nw = bmnw[w] + ((c == p.sep && bml[w] != p.sep) ? 1 : 0);
-          }
-          score = score * p.word_factor[nw];
+    for (int i0 = 0; i0 < nslots; i0 += NT) {
+      const int i = i0 + tid;
+      const bool in = i < nslots;
+      const int fl = in ? c_flags[i] : 0;
+      float score = in ? c_s[i] : 0.f;
+      const int key = in ? c_key[i] : 0;
+      if (in) c_s[i] = 0.f;                           // (S4's rank counters live here: all-zero bits)
+      const bool kept = (fl & F_KEPT) != 0;
+      if (kept && p.sep >= 0) {
+        int nw;
+        if (i < W) nw = bmnw[i];
+        else {
+          const int w = (i - W) / V, c = (i - W) - w * V;
+          nw = bmnw[w] + ((c == p.sep && bml[w] != p.sep) ? 1 : 0);
         }
-        const int j = atomicAdd(&sh[1], 1);
-        k_idx[j] = i; k_score[j] = score; k_key[j] = c_key[i];
+        score = score * p.word_factor[nw];
+      }
+      const unsigned long long km = __ballot(kept);
+      int base = 0;
+      if ((tid & 63) == 0 && km != 0ull) base = atomicAdd(&sh[1], (int)__popcll(km));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (kept) {
+        const int j = base + (int)__popcll(km & ((1ull << (tid & 63)) - 1ull));
+        k_idx[j] = i; k_score[j] = score; k_key[j] = key;
       }
     }
     __syncthreads();
+    MS_BEAM_STAMP(3);
     const int K = sh[1];
 
-    // ---- S4: stable descending order, keep beam_width.  Rank of candidate j = candidates that sort before it; the pairs are
-    // read in sequence
-    if (K <= 64) {
-      // the usual case (22 kept candidates on average at V = 29, W = 8): one wave, candidate j in lane j, the others'
-      // pairs broadcast from registers (v_readlane) -- no LDS traffic in the loop
-      if (tid < 64) {
-        const bool have = tid < K;
-        const float sj = have ? k_score[tid] : 0.f;
-        const int kj = have ? k_key[tid] : 0;
+    // ---- S4: stable descending order, keep beam_width.  Rank of candidate j = candidates that sort before it.  Every wave
+    // counts over its share of the candidates (wave q: m = q, q + NT / 64, ...), the partial counts meet in LDS counters (c_s is
+    // free after S3, which left zeros in it): with one wave ranking its lanes' candidates against all K through v_readlane the
+    // phase was 3 400 of the frame's 12 000 cycles
+    {
+      int* pos_acc = reinterpret_cast<int*>(c_s);
+      constexpr int NW = NT / 64;
+      const int lane = tid & 63, q = tid >> 6;
+      for (int j0 = 0; j0 < K; j0 += 64) {
+        const int j = j0 + lane;
+        const bool have = j < K;
+        const float sj = have ? k_score[j] : 0.f;
+        const int kj = have ? k_key[j] : 0;
         int pos = 0;
-        for (int m = 0; m < K; ++m) {
-          const float sm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sj), m));   // m is wave-uniform: v_readlane
-          const int km = __builtin_amdgcn_readlane(kj, m);
+#pragma unroll 4
+        for (int m = q; m < K; m += NW) {
+          const float sm = k_score[m];
+          const int km = k_key[m];
           pos += (sm > sj || (sm == sj && km < kj)) ? 1 : 0;
         }
-        if (have && pos < W) newbeam[pos] = k_idx[tid];
+        if (have && pos) atomicAdd(&pos_acc[j], pos);
       }
-    } else {
+      __syncthreads();
+    MS_BEAM_STAMP(4);
       for (int j = tid; j < K; j += NT) {
-        const float sj = k_score[j];
-        const int kj = k_key[j];
-        int pos = 0;
-#pragma unroll 8
-        for (int m = 0; m < K; ++m) {
-          const float sm = k_score[m];
-          pos += (sm > sj || (sm == sj && k_key[m] < kj)) ? 1 : 0;
-        }
+        const int pos = pos_acc[j];
         if (pos < W) newbeam[pos] = k_idx[j];
       }
     }
     __syncthreads();
+    MS_BEAM_STAMP(5);
 
     // ---- S5: an extension that enters the beam becomes a trie node (if it is not one yet) with a child-table slot (if it has
     // never been in the beam before); both are recorded in its parent's row, here and in the workspace copy of that row
@@ -356,30 +410,34 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
       ent_fresh[j] = fresh;
     }
     __syncthreads();
+    MS_BEAM_STAMP(6);
 
     // ---- S6: A_prev <- best beam_width candidates; every new beam entry's child row
     for (int idx = tid; idx < Bn * V; idx += NT) {
       const int j = idx / V, c = idx - j * V;
       const int i = newbeam[j];
+      const bool stay = i < W;
+      // (both cases' words are requested together; the addresses are valid either way)
+      const int e = stay ? i * V + c : 0;
+      const int child_s = lcn[e], cs_s = lcc[e], fl_s = c_flags[W + e];
+      const int mycs = lcc[stay ? 0 : i - W];
+      const int fresh = ent_fresh[j];
       int child, cs, ti = -1;
-      if (i < W) {                     // a beam entry that stays: its row moves along; a child that was a candidate of this
-        const int e = i * V + c;       // frame is found at its slot in this frame's tables
-        child = lcn[e]; cs = lcc[e];
-        if (c_flags[W + e] & F_PRESENT) ti = W + e;
-      } else {
-        const int mycs = lcc[i - W];
-        if (ent_fresh[j]) {            // never in the beam before: no children yet
-          child = -1; cs = -1;
-          childtab[(size_t)mycs * V + c] = -1;
-        } else {                       // it was in the beam once, left and comes back: its row from the workspace
-          child = childtab[(size_t)mycs * V + c];
-          cs = child >= 0 ? node_cslot[child] : -1;
-        }
+      if (stay) {                      // a beam entry that stays: its row moves along; a child that was a candidate of this
+        child = child_s; cs = cs_s;    // frame is found at its slot in this frame's tables
+        if (fl_s & F_PRESENT) ti = W + e;
+      } else if (fresh) {              // never in the beam before: no children yet
+        child = -1; cs = -1;
+        childtab[(size_t)mycs * V + c] = -1;
+      } else {                         // it was in the beam once, left and comes back: its row from the workspace
+        child = childtab[(size_t)mycs * V + c];
+        cs = child >= 0 ? node_cslot[child] : -1;
       }
       // a child that is itself in the (old) beam is a candidate of this frame under its own beam slot
-      if (ti < 0 && child >= 0)
-        for (int k = 0; k < B; ++k)
-          if (bmn[k] == child && (c_flags[k] & F_PRESENT)) ti = k;
+      if (ti < 0 && child >= 0) {
+        const int k = find_in_beam(bmn, B, W, child);
+        if (k >= 0 && (c_flags[k] & F_PRESENT)) ti = k;
+      }
       lc_node[nb * WV + idx] = child; lc_cslot[nb * WV + idx] = cs; lc_tidx[nb * WV + idx] = ti;
     }
     for (int j = tid; j < Bn; j += NT) {
@@ -398,12 +456,15 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
     }
     if (tid == 0) sh[0] = Bn;
     __syncthreads();
+    MS_BEAM_STAMP(7);
   }
 
   // ---- persist state, emit results (the beam and its rows sit in the buffers of the frame the loop stopped at)
   const int eb = t & 1;
   const int B = sh[0];
   if (tid == 0) { hdr[0] = sh[2]; hdr[1] = sh[3]; hdr[2] = B; }
+  if (stamping)
+    for (int k = 0; k < 9; ++k) hdr[4 + k] = (int)st_acc[k];
   for (int i = tid; i < M; i += NT) { tbl_pb[i] = c_pb[(eb ^ 1) * M + i]; tbl_pnb[i] = c_pnb[(eb ^ 1) * M + i]; }
   for (int i = tid; i < WV; i += NT) {
     g_lc_node[i] = lc_node[eb * WV + i]; g_lc_cslot[i] = lc_cslot[eb * WV + i]; g_lc_tidx[i] = lc_tidx[eb * WV + i];
@@ -469,6 +530,10 @@ extern "C" int ms_ctc_beam_decode(const float* probs, const int32_t* lens, int32
   p.ws = (char*)workspace; p.L = L; p.T = T; p.N = N; p.V = V; p.W = beam_width; p.blank = blank;
   p.sep = separator < 0 ? -1 : separator; p.t_begin = t_begin; p.t_end = t_end; p.finish = finish;
   p.thr = prune_threshold;
+  {
+    const char* e = getenv("MS_BEAM_STAMPS");
+    p.stamps = (e && e[0] == '1') ? 1 : 0;
+  }
   static const int nt_env = getenv("MS_BEAM_THREADS") ? atoi(getenv("MS_BEAM_THREADS")) : 0;      // A/B switch: 64 or 256
   const bool one_wave = nt_env == 64;
   if (L.big) hipLaunchKernelGGL((beam_kernel<true, 256>), dim3(N), dim3(256), 0, (hipStream_t)stream, p);

@@ -270,11 +270,18 @@ def leg_ctc_beam(ctx):
     b_us = ctx["barrier_step_us"]
     phases = 7
     floor = 501 * phases * b_us * 1e-3
+    # the instruction-chain floor: since round 5 a frame reads nothing from global memory (the live beam's
+    # child rows are in LDS); what it is made of is waits for LDS data -- hipcc's gfx950 code of the frame loop has 95
+    # `s_waitcnt lgkmcnt` (tools: hipcc -S), a wave passes ~55 of them per frame, each >= the 50-cycle ds_read latency
+    chain = 501 * (55 * 50 / (CLOCK_GHZ * 1e3) + phases * b_us) * 1e-3
     out = {"workload": "CTC beam decode, softmax(randn(501,32,29)*12), beam 8, prune 1e-3, no LM (BASELINE.md 3)",
            "ms": round(ms, 3), "ms_min": round(ms_min, 3), "utterances_per_s": round(32 / ms * 1e3, 1),
            "floor_ms": round(floor, 4), "frac_of_floor": round(floor / ms, 3),
-           "floor": f"501 frames x {phases} barrier-separated phases per frame (csrc/beam.hip) x {b_us:.3f} us; the trie / "
-                    "child-table look-ups between them are dependent global loads and are NOT in the floor"}
+           "chain_floor_ms": round(chain, 4), "frac_of_chain_floor": round(chain / ms, 3),
+           "chain_floor": "501 frames x (~55 exposed LDS round trips x 50 cycles at 2.4 GHz + 7 barrier phases): one workgroup per "
+                          "utterance, one wave per SIMD, every phase a chain of dependent LDS reads (a frame measures 4.6 us = 11 000 cycles)",
+           "floor": f"501 frames x {phases} barrier-separated phases per frame (csrc/beam.hip) x {b_us:.3f} us; the dependent LDS "
+                    "reads between them are not in this floor (see chain_floor)"}
     if ctx.get("cpu"):
         from oracle import ds_oracle as O
         t0 = time.perf_counter()
@@ -340,8 +347,13 @@ def leg_rnnt(ctx):
         pass
     frames = int(lens.sum())
     rows = G.N * G.W
-    gemm_us = [2.0 * rows * (k + G.P) * 4 * G.P / (F32_MFMA_TF * 1e6) for k in (G.D, G.P)]
-    per_frame_us = (G.MS - 1) * sum(gemm_us)
+    # floor of the round-5 sequence (csrc/rnnt_decode.hip, beam2_*): per predictor step the three-plane operand planes of
+    # W_hh0, W_ih1, W_hh1 (4H x H x 6 B each) and W_pred (J x H x 6 B) are streamed once; a frame is 10 dependent launches
+    # (joint, round, cell 0, layer 1 | joint + G, round, cell 0, layer 1 | joint + G, frame end) at the chip's dependent-launch
+    # boundary (MI355X_MICROARCH.md price list, "boundary": 1.45 us)
+    plane_bytes = (3 * 4 * G.P * G.P + G.J * G.P) * 6
+    launches = 3 * G.MS + 2 * (G.MS - 1) - 1 + 2 * (G.MS - 1) * (G.L - 2)      # 10 at MS = 3, L = 2
+    per_frame_us = (G.MS - 1) * plane_bytes / (HBM_GBS * 1e3) + launches * 1.45
     floor = G.T * per_frame_us * 1e-3
     audio_s = G.N * 10.0
     out = {"workload": "cfg[3] RNN-T (own spec, parity unpinned): batch 16 x 501 frames, 2xLSTM-1024 predictor, joint 512, beam 8, "
@@ -349,11 +361,12 @@ def leg_rnnt(ctx):
            "encoder_ms": round(ms_enc, 3), "beam8_decode_ms": round(ms_b, 2), "beam8_decode_ms_min": round(ms_b_min, 2),
            "greedy_decode_ms": round(ms_g, 2), "ms": round(ms_enc + ms_b, 2),
            "audio_sec_per_s": round(audio_s / (ms_enc + ms_b) * 1e3, 1), "us_per_frame": round(ms_b / G.T * 1e3, 1),
+           "launches_per_frame": launches,
            "transcripts_equal_oracle_fixture": gold,
            "floor_ms": round(floor, 2), "frac_of_floor": round(floor / ms_b, 3),
-           "floor": f"decode only: 501 frames x {G.MS - 1} predictor steps x the two layers' gate GEMMs at the exact-f32 MFMA peak "
-                    f"({rows} rows: {gemm_us[0]:.1f} + {gemm_us[1]:.1f} us at 157.3 TFLOP/s); joint, top-k and the ~12 launch "
-                    "boundaries per frame are not in the floor"}
+           "floor": f"decode only: 501 frames x ({G.MS - 1} predictor steps x {plane_bytes / 1e6:.0f} MB of three-plane operand planes "
+                    f"(W_hh0, W_ih1, W_hh1, W_pred) at 8 TB/s + {launches} dependent launches x 1.45 us); the kernels' own latency "
+                    "chains (2 .. 4 dependent L2 round trips each) are not in the floor"}
     if ctx.get("cpu"):
         from oracle import rnnt_oracle as RO
         psd = {k: v.detach().cpu().numpy() for k, v in pred.state_dict().items()}
