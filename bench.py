@@ -52,7 +52,7 @@ LSTM_STEP_FLOP = 2 * BATCH_PER_GPU * HIDDEN * 4 * HIDDEN            # 268.4 MFLO
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 / fp16 MFMA
 MFMA_F32_PEAK_TF = 157.3    # float32-input MFMA
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc_bench.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r05_pmc_bench.json")
 
 
 def precision_mode():
@@ -79,7 +79,7 @@ KERNEL_SOURCES = {"lstm": ("rnn.hip", "common.h"), "gemm_nt_bf16x3": ("gemm_spli
 
 
 def source_sha16(names=None):
-    """Digests of the kernel source files the timed binary was built from ({file: sha16}); profiles/r04_pmc_bench.json
+    """Digests of the kernel source files the timed binary was built from ({file: sha16}); profiles/r05_pmc_bench.json
     records the digests its counters were taken on, so a stale counter file is detected instead of being quoted."""
     csrc = os.path.join(ROOT, "myrtlespeech_amd", "csrc")
     out = {}
@@ -96,13 +96,13 @@ def pmc_record(kernel_key):
         with open(PMC_PROFILE) as f:
             prof = json.load(f)
     except Exception:
-        return None, "profiles/r04_pmc_bench.json not found"
+        return None, "profiles/r05_pmc_bench.json not found"
     if prof.get("precision") != precision_mode():
         return None, f"counters were taken in {prof.get('precision')} mode"
     files = next((v for k, v in KERNEL_SOURCES.items() if kernel_key.startswith(k)), None)
     now = source_sha16(files)
     if any(prof.get("source_sha16", {}).get(f) != d for f, d in now.items()):
-        return None, f"{', '.join(now)} changed since the counter passes (profiles/r04_pmc_bench.json is stale for this kernel)"
+        return None, f"{', '.join(now)} changed since the counter passes (profiles/r05_pmc_bench.json is stale for this kernel)"
     rec = prof.get("kernels", {}).get(kernel_key)
     return (rec, None) if rec else (None, f"no counters for {kernel_key}")
 
@@ -738,7 +738,7 @@ def main(argv=None, runtime=None, json_fd=None):
             roof["mfma_frac"] = round(rec["mfma_flop"] / (rec_ms * 1e-3) / 1e12 / mfma_peak, 4)
             roof["mfma_busy_frac_pmc"] = rec.get("mfma_busy_frac")
             roof["l2_hit_rate_pmc"] = rec.get("l2_hit_rate")
-            roof["pmc_source"] = "profiles/r04_pmc_bench.json (rocprofv3 --pmc passes over this bench, same kernel sources)"
+            roof["pmc_source"] = "profiles/r05_pmc_bench.json (rocprofv3 --pmc passes over this bench, same kernel sources)"
         else:
             roof["traffic"] = None
             roof["pmc_note"] = why

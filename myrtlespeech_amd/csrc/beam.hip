@@ -166,6 +166,9 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
   int* node_cslot = reinterpret_cast<int*>(u + p.L.node_cslot);
   int* childtab = reinterpret_cast<int*>(u + p.L.childtab);
 
+  // a thread's first (usually only) candidate / row entry is (tid / V, tid % V) in every frame: the integer division -- ~40
+  // instructions each in S1 and S6 -- is done once
+  const int w_first = tid / V, c_first = tid - w_first * V;
   const bool stamping = p.stamps != 0 && tid == 0 && n == 0;
   unsigned long long st_prev = 0;
   unsigned st_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
     // a chain of LDS round trips on one wave per SIMD: with the loads behind the branches that need them hipcc waited five
     // times where two suffice); the addresses are valid for every candidate, the values are used under the same conditions.
     for (int i = tid; i < B * V; i += NT) {
-      const int w = i / V, c = i - w * V;
+      const int w = i == tid ? w_first : i / V, c = i == tid ? c_first : i - (i / V) * V;
       const int slot = W + i;
       const float pc = prow[c];
       const int child = lcn[i];
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
 
     // ---- S6: A_prev <- best beam_width candidates; every new beam entry's child row
     for (int idx = tid; idx < Bn * V; idx += NT) {
-      const int j = idx / V, c = idx - j * V;
+      const int j = idx == tid ? w_first : idx / V, c = idx == tid ? c_first : idx - (idx / V) * V;
       const int i = newbeam[j];
       const bool stay = i < W;
       // (both cases' words are requested together; the addresses are valid either way)

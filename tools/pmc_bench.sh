@@ -2,8 +2,8 @@
 # Counter passes over bench.py itself (HEAD's chained 5-layer stack, the binary the bench times), on the GPU box:
 #     bash tools/pmc_bench.sh [tag] [precision]
 # Each pass is its own rocprofv3 run (PMC only -- no tracing flags), bounded by `timeout`; the program after `--` is
-# python3 itself.  Writes gpurun_out/pmc_bench_<tag>.json (copy it to profiles/r03_pmc_bench.json) and a text summary.
-TAG=${1:-r03}
+# python3 itself.  Writes gpurun_out/pmc_bench_<tag>.json (copy it to profiles/r05_pmc_bench.json) and a text summary.
+TAG=${1:-r05}
 PREC=${2:-bf16x3}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmc_bench_$TAG
@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 pass() {
   local name=$1; shift
   echo "[pmc_bench] pass $name: $*"
-  timeout -k 10 240 rocprofv3 --pmc "$@" -d $OUT/$name -o $name --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-child --no-frontend --no-ragged --no-legs --in-flight 1 > $OUT.$name.log 2>&1 || { echo "[pmc_bench] pass $name failed or timed out"; tail -5 $OUT.$name.log; return 1; }
+  timeout -k 10 240 rocprofv3 --pmc "$@" -d $OUT/$name -o $name --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-child --no-frontend --no-ragged --no-legs --reps 0 --detail-path /dev/null --in-flight 1 > $OUT.$name.log 2>&1 || { echo "[pmc_bench] pass $name failed or timed out"; tail -5 $OUT.$name.log; return 1; }
 }
 mkdir -p $OUT
 pass p1 FETCH_SIZE || exit 1
