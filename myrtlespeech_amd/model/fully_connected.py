@@ -44,11 +44,35 @@ _split_ws = OrderedDict()
 _SPLIT_WS_STREAMS = 4    # scratch buffers kept: the most recently used streams (a pipeline uses two)
 
 
+_graph_ws = None      # set while a HIP graph is being sized / captured (graph_scratch): that graph's own scratch
+
+
+class graph_scratch:
+    """``with graph_scratch(ws):`` -- the linear layers' operand-plane scratch comes from ``ws`` (a Workspace the capturing
+    graph owns and keeps alive) instead of the per-stream LRU: a graph records POINTERS, and an LRU entry may be evicted and
+    freed while a graph that recorded it is still replayed."""
+
+    def __init__(self, ws: "_lib.Workspace"):
+        self.ws = ws
+
+    def __enter__(self):
+        global _graph_ws
+        self.prev, _graph_ws = _graph_ws, self.ws
+        return self.ws
+
+    def __exit__(self, *exc):
+        global _graph_ws
+        _graph_ws = self.prev
+        return False
+
+
 def _stream_workspace() -> "_lib.Workspace":
     """Least-recently-used cache keyed on the stream handle: a stream that has been destroyed (its handle may be re-issued
     later) or is no longer used loses its buffer once ``_SPLIT_WS_STREAMS`` other streams have come by.  Dropping an entry is
     safe while its stream still runs: the caching allocator hands a block allocated on stream S only to later allocations
     on S, i.e. behind the kernels that read it."""
+    if _graph_ws is not None:
+        return _graph_ws
     key = torch.cuda.current_stream().cuda_stream
     ws = _split_ws.get(key)
     if ws is None:

@@ -323,6 +323,13 @@ class _ContextGraph:
         check_was = getattr(model.rnn, "check_status", None)
         inplace_was = getattr(model.rnn, "inplace_state", None)
         self.graph = torch.cuda.CUDAGraph()
+        from myrtlespeech_amd.model import fully_connected as _fc
+        self._fc_ws = _lib.Workspace()          # the linear layers' plane scratch of THIS graph (not the per-stream LRU)
+        old_fc = _fc._stream_workspace()
+        if old_fc.buf is not None:
+            self._fc_ws.get(old_fc.buf.numel(), zero=False)      # sized by the eager pushes before this one: no allocation inside the capture
+        scratch = _fc.graph_scratch(self._fc_ws)
+        scratch.__enter__()
         try:
             for (o, a), w_ in zip(slots, self._own):
                 setattr(o, a, w_)
@@ -352,6 +359,7 @@ class _ContextGraph:
                 model.rnn.check_status = check_was
             if inplace_was is not None:
                 model.rnn.inplace_state = inplace_was
+            scratch.__exit__(None, None, None)
         self.y = y
         after = self._counters(stream)
         self.delta = [b - a for a, b in zip(snap, after)]
@@ -452,6 +460,10 @@ class _ChunkGraph:
         saved = [getattr(o, a) for o, a in slots]
         rnn = getattr(model, "rnn", None)
         inplace_was = getattr(rnn, "inplace_state", None)
+        from myrtlespeech_amd.model import fully_connected as _fc
+        self._fc_ws = _lib.Workspace()          # the linear layers' plane scratch of THIS graph (not the per-stream LRU)
+        scratch = _fc.graph_scratch(self._fc_ws)
+        scratch.__enter__()
         try:
             for (o, a), w in zip(slots, self._own):
                 setattr(o, a, w)
@@ -469,6 +481,7 @@ class _ChunkGraph:
                 setattr(o, a, w)
             if inplace_was is not None:
                 rnn.inplace_state = inplace_was
+            scratch.__exit__(None, None, None)
         self.y, self.out_lens_host = y, _lib.host_lens(ol).clone()
         rnn_ws = [w for (o, a), w in zip(slots, self._own) if o is getattr(model, "rnn", None)]
         self.rnn_ws = rnn_ws[0] if rnn_ws else None      # holds the sticky time-out word of this graph's recurrent launches
@@ -516,6 +529,10 @@ class GraphedForward:
             saved = [getattr(o, a) for o, a in slots]
             checked = [m_ for m_ in model.modules() if getattr(m_, "check_status", False) is True]
             self.graph = torch.cuda.CUDAGraph()
+            from myrtlespeech_amd.model import fully_connected as _fc
+            self._fc_ws = _lib.Workspace()      # the linear layers' plane scratch of THIS graph (not the per-stream LRU)
+            scratch = _fc.graph_scratch(self._fc_ws)
+            scratch.__enter__()
             try:
                 for (o, a), w_ in zip(slots, self._own):
                     setattr(o, a, w_)
@@ -530,6 +547,7 @@ class GraphedForward:
                     setattr(o, a, w_)
                 for m_ in checked:
                     m_.check_status = True
+                scratch.__exit__(None, None, None)
             self.status_ws = [w_ for (o, a), w_ in zip(slots, self._own) if o in checked]
 
         def run(self, x, hx):
