@@ -233,7 +233,9 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
     if (tid == 0) sh[1] = 0;
     __syncthreads();
     MS_BEAM_STAMP(0);
-    const float p_blank = prow[p.blank];
+    // (the blank's probability is the same word for every lane: taken into an SGPR, so that `p_blank <= thr` is a scalar
+    // compare and not a lane mask evaluated under one loop's EXEC and read under another's -- tools/isa_lanemask_audit.py)
+    const float p_blank = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(prow[p.blank])));
 
     // (S2's words that do not depend on S1 are requested here, ahead of S1 and its barrier)
     const int s2_w = tid;                                   // W <= NT is not assumed: the S2 loop below re-reads for w >= NT

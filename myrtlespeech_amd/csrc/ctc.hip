@@ -355,7 +355,9 @@ template <int VB>
 __device__ __forceinline__ bool alpha_wave_normalise(const float* __restrict__ logits, float* __restrict__ lpn, int n, int Tn,
                                                      int N, int V, int log_probs_in, int tid) {
   constexpr float LOG2E = 1.4426950408889634f;
-  bool bad = false;   // a frame's normaliser is NaN or infinite
+  // a frame's normaliser is NaN or infinite.  An int in a VGPR, not a bool: a loop-carried bool lives in an SGPR lane mask that
+  // hipcc merges per iteration -- the shape tools/isa_lanemask_audit.py watches for; per-lane integer OR needs no mask at all
+  int bad = 0;
   for (int t = tid; t < Tn; t += CTC_THREADS) {
     const float* row = logits + ((size_t)t * N + n) * V;
     float* out = lpn + (size_t)t * V;
@@ -371,16 +373,16 @@ __device__ __forceinline__ bool alpha_wave_normalise(const float* __restrict__ l
 #pragma unroll
       for (int v = 0; v < VB; ++v) sum += expf(r[v] - m);
       lz = logf(sum) + m;
-      bad |= !(fabsf(lz) < INFINITY);
+      bad |= (fabsf(lz) < INFINITY) ? 0 : 1;
     } else {
 #pragma unroll
-      for (int v = 0; v < VB; ++v) bad |= (v < V) && (r[v] != r[v]);
+      for (int v = 0; v < VB; ++v) bad |= (r[v] != r[v]) ? 1 : 0;      // (columns >= V hold -inf, not NaN: no `v < V` needed)
     }
 #pragma unroll
     for (int v = 0; v < VB; ++v)
       if (v < V) out[v] = fminf(fmaxf((r[v] - lz) * LOG2E, CTC_NEG), -CTC_NEG);
   }
-  return bad;
+  return bad != 0;
 }
 
 // mode: bit 0 = the reversed recursion (beta), bit 1 = the workspace already holds this call's normalised log-probabilities
@@ -401,7 +403,8 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
                                                                      unsigned* __restrict__ status = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
-  bool bad_row = false;   // a frame whose normaliser is not finite (a NaN / +inf logit, a row of -inf): the loss is NaN (torch)
+  int bad_row = 0;        // a frame whose normaliser is not finite (a NaN / +inf logit, a row of -inf): the loss is NaN (torch); an int
+                          // in a VGPR rather than a loop-carried bool (alpha_wave_normalise)
   MbEntry* mb = reinterpret_cast<MbEntry*>(smem);   // [3][T] {alpha(top), alpha(top - 1)} of waves 0..2, per frame
   float* fin = smem + (size_t)6 * T;                // [2] the last two states' values, [2] = a wave gave up waiting
   const int Tn = min(max(in_lens[n], 0), T);
@@ -418,8 +421,8 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
   float* lps = wide_v ? lps_ws + (size_t)n * T * S_max : nullptr;
 
   if (mode & 2) {
-  } else if (V <= 32) bad_row = alpha_wave_normalise<32>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
-  else if (V <= 64) bad_row = alpha_wave_normalise<64>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
+  } else if (V <= 32) bad_row = (int)alpha_wave_normalise<32>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
+  else if (V <= 64) bad_row = (int)alpha_wave_normalise<64>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
   else {
     // wide alphabets (word pieces): a WAVE per frame, lanes across the symbols (coalesced row reads, wave reductions), a
     // lane's share of the row in registers with every load of the row in flight at once -- a thread per frame, or one load
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
         lz = logf(sum) + m;
-        bad_row |= !(fabsf(lz) < INFINITY);
+        bad_row |= (fabsf(lz) < INFINITY) ? 0 : 1;
       }
       if (ROWS) {                                   // every symbol's value: only the gradient kernel reads these
 #pragma unroll

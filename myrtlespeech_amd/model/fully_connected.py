@@ -57,7 +57,9 @@ class graph_scratch:
 
     def __enter__(self):
         global _graph_ws
-        self.prev, _graph_ws = _graph_ws, self.ws
+        self.prev = _graph_ws
+        if os.environ.get("MS_GRAPH_SCRATCH") != "0":      # (0: A/B runs -- the graphs record the per-stream LRU scratch as before)
+            _graph_ws = self.ws
         return self.ws
 
     def __exit__(self, *exc):

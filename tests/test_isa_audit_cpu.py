@@ -98,6 +98,31 @@ def test_audit_does_not_report_new_live_ranges_or_the_per_lane_merge(tmp_path):
     assert audit.audit(str(merge)) == []
 
 
+# a block of an INNER loop laid out before that loop's header label reads a mask the OUTER loop made: nesting, not a sibling
+NESTED = """
+nested_like_beam_kernel:
+.LBB0_28:                               ; =>This Loop Header: Depth=1
+	v_cmp_nge_f32_e64 s[24:25], s46, v23
+	s_branch .LBB0_91
+.LBB0_89:                               ;   in Loop: Header=BB0_91 Depth=2
+	v_cndmask_b32_e64 v79, 0, v79, s[24:25]
+.LBB0_91:                               ;   Parent Loop BB0_28 Depth=1
+                                        ; =>  This Inner Loop Header: Depth=2
+	v_add_u32_e32 v23, 0x400, v23
+	s_cbranch_execnz .LBB0_89
+"""
+
+
+def test_audit_knows_the_nesting_of_blocks_laid_out_before_their_loop_header(tmp_path):
+    f = tmp_path / "nested.s"
+    f.write_text(NESTED)
+    assert audit.audit(str(f)) == []
+    # the same read from a loop that is NOT inside the defining loop is still reported
+    f.write_text(NESTED.replace(";   Parent Loop BB0_28 Depth=1\n                                        ; =>  This Inner Loop Header: Depth=2",
+                                "; =>This Loop Header: Depth=1").replace("Header=BB0_91 Depth=2", "Header=BB0_91 Depth=1"))
+    assert len(audit.audit(str(f))) == 1
+
+
 def test_no_kernel_of_the_library_has_the_signature(tmp_path):
     import glob
     hips = sorted(glob.glob(os.path.join(audit.CSRC, "*.hip")))

@@ -106,8 +106,8 @@ def test_bench_refuses_a_stale_counter_profile(tmp_path, monkeypatch):
     assert bench.pmc_record("lstm_persistent_split2_kernel")[0] is None
     monkeypatch.delenv("MS_PRECISION")
     # the committed profile describes the committed sources
-    monkeypatch.setattr(bench, "PMC_PROFILE", os.path.join(ROOT, "profiles", "r04_pmc_bench.json"))
-    assert bench.pmc_record("lstm_persistent_wide2_kernel@1group")[1] is None, "profiles/r04_pmc_bench.json is stale: re-run tools/pmc_bench.sh"
+    monkeypatch.setattr(bench, "PMC_PROFILE", os.path.join(ROOT, "profiles", "r05_pmc_bench.json"))
+    assert bench.pmc_record("lstm_persistent_wide2_kernel@1group")[1] is None, "profiles/r05_pmc_bench.json is stale: re-run tools/pmc_bench.sh"
     assert bench.pmc_record("gemm_nt_bf16x3_kernel4@K2048")[1] is None
 
 

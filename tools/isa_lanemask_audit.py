@@ -78,12 +78,37 @@ def audit(path):
     pending_parents = []
     with open(path) as f:
         lines = f.readlines()
+    # first pass: every loop's parent, per kernel -- a block of an inner loop may be laid out BEFORE that loop's header label
+    # (hipcc puts latches and side blocks first), and the nesting must be known when such a block reads a mask of the outer loop
+    all_parents = {}
+    k_name, p_label, p_parents = None, None, []
+    for raw in lines:
+        line = raw.rstrip("\n")
+        km = re.match(r"^([A-Za-z_][\w$.]*):", line)
+        if km:
+            k_name, p_label, p_parents = km.group(1), None, []
+            all_parents[k_name] = {}
+            continue
+        st = line.strip()
+        m = LABEL.match(st)
+        if m:
+            p_label = m.group(1).lstrip(".L") if m.group(1).startswith(".L") else None
+            p_parents = []
+        elif not st.startswith(";"):
+            continue
+        pp = PARENT.search(line)
+        if pp:
+            p_parents.append(pp.group(1))
+        if HEADER.search(line) and p_label and k_name is not None:
+            il = IN_LOOP.search(line)
+            all_parents[k_name][p_label] = p_parents[-1] if p_parents else None
     for ln, raw in enumerate(lines, 1):
         line = raw.rstrip("\n")
         stripped = line.strip()
         km = re.match(r"^([A-Za-z_][\w$.]*):", line)
         if km:
-            kernel, cur_loop, parents, masks = km.group(1), None, {}, {}
+            kernel, cur_loop, masks = km.group(1), None, {}
+            parents = dict(all_parents.get(kernel, {}))
             continue
         m = LABEL.match(stripped)
         if m:
