@@ -801,15 +801,19 @@ def main(argv=None, runtime=None, json_fd=None):
                        "headline_mode": ("two_batches_per_forward" if (pipelined and headline is paired) else
                                          "two_batches_in_flight" if pipelined else "one_batch_in_flight"),
                        "headline_latency_ms_per_batch": round(latency_ms if pipelined else one["span"], 3),
-                       "one_batch_ms_per_step": round(one_ms, 3),
-                       "one_batch_value": round(world * BATCH_PER_GPU * CLIP_SECONDS * args.steps / one_elapsed, 1),
+                       # the one-batch leg is the FIRST thing timed after W warm-up steps and its first region runs 4 .. 12 % slower
+                       # than the four that follow (allocator / clock settling): the side figure is the median region, the first
+                       # region is kept beside it; `value` (the headline) stays its first region, as the contract says
+                       "one_batch_ms_per_step": spread["one_batch_ms_per_step"]["median"],
+                       "one_batch_first_region_ms_per_step": round(one_ms, 3),
+                       "one_batch_value": round(world * BATCH_PER_GPU * CLIP_SECONDS / (spread["one_batch_ms_per_step"]["median"] * 1e-3), 1),
                        "f32_value": (f32 or {}).get("value"), "f32_ms_per_step": (f32 or {}).get("ms_per_step"),
                        "f32_one_batch_ms_per_step": ((f32 or {}).get("one_batch_in_flight") or {}).get("ms_per_step"),
                        "ragged_value": (ragged or {}).get("value"), "ragged_ms_per_step": (ragged or {}).get("ms_per_step"),
                        "ms_per_step_min": spread["headline_ms_per_step"]["min"],
                        "ms_per_step_median": spread["headline_ms_per_step"]["median"],
                        "ms_per_step_max": spread["headline_ms_per_step"]["max"],
-                       "one_batch_ms_per_step_median": spread["one_batch_ms_per_step"]["median"]},
+                       "one_batch_ms_per_step_min": spread["one_batch_ms_per_step"]["min"]},
             "timing": spread,
             "stages": {"one_batch": {k: round(one["per_step"][k], 3) for k in ("conv", "layout", "projection", "recurrence", "linear", "greedy")},
                        "headline": ({k: round((pair if headline is paired else two)["per_step"][k], 3)
@@ -885,7 +889,7 @@ def main(argv=None, runtime=None, json_fd=None):
                 cb = rec.get("cpu_baseline")
                 if cb:
                     legs[name]["cpu"] = compact(cb, ("value", "unit", "cores"))
-            legs["encoder_greedy"] = {"ms": round(ms_per_step, 3), "value": round(value, 1), "one_batch_ms": round(one_ms, 3),
+            legs["encoder_greedy"] = {"ms": round(ms_per_step, 3), "value": round(value, 1), "one_batch_ms": spread["one_batch_ms_per_step"]["median"],
                                       "f32_ms": (f32 or {}).get("ms_per_step"), "roofline_frac": roof["frac"],
                                       "cpu": compact(out.get("cpu_baseline", {}), ("value", "unit", "cores"))}
             out["legs"] = legs
