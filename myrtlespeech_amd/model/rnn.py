@@ -79,12 +79,13 @@ def pad_layer_params(cell: int, params, hp: int, padded_input: bool, in_pad: int
     out = []
     for w_ih, w_hh, b_ih, b_hh in params:
         h = w_hh.shape[1]
-        wi = _lib.f32c(w_ih.detach()).view(gates, h, -1)
+        f32 = lambda t_: t_.detach().float().contiguous()      # noqa: E731 -- (on whatever device the parameter lives: the CPU tests use this)
+        wi = f32(w_ih).view(gates, h, -1)
         if padded_input:
             wi = torch.nn.functional.pad(wi.view(gates, h, ndir, h), (0, hp - h)).reshape(gates, h, ndir * hp)
         wi = torch.nn.functional.pad(wi, (0, in_pad, 0, hp - h)).reshape(gates * hp, -1).contiguous()   # (+ in_pad zero columns)
-        wh = torch.nn.functional.pad(_lib.f32c(w_hh.detach()).view(gates, h, h), (0, hp - h, 0, hp - h)).reshape(gates * hp, hp).contiguous()
-        bs = [None if b is None else torch.nn.functional.pad(_lib.f32c(b.detach()).view(gates, h), (0, hp - h)).reshape(-1).contiguous()
+        wh = torch.nn.functional.pad(f32(w_hh).view(gates, h, h), (0, hp - h, 0, hp - h)).reshape(gates * hp, hp).contiguous()
+        bs = [None if b is None else torch.nn.functional.pad(f32(b).view(gates, h), (0, hp - h)).reshape(-1).contiguous()
               for b in (b_ih, b_hh)]
         out.append((wi, wh, bs[0], bs[1]))
     return out

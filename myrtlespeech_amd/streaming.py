@@ -276,6 +276,15 @@ class _ContextStream:
         return out.transpose(0, 1)
 
 
+def _pipeline_running() -> bool:
+    """A ``pipeline.BatchesInFlight`` call is in progress in this process.  The library serialises persistent recurrent launches
+    of different streams by chaining them with events at ENQUEUE time (``PersistentTurn``, csrc/rnn.hip) -- which a captured
+    graph skips (nothing runs at capture time, and the replay stream is not the capture stream).  A graph holding persistent
+    launches replayed beside another stream's persistent launch could lose co-residency and run into the 2 s time-out
+    (ADVICE r4), so while a pipeline is running no NEW graph is started: those calls take the eager path (same bits)."""
+    return _lib.issue_point is not None
+
+
 def _workspace_slots(model):
     """(owner, attribute name) of every grow-only scratch buffer a forward pass of ``model`` uses."""
     slots = []
@@ -563,7 +572,7 @@ class GraphedForward:
         _lib.require_gpu()
         lens_h = _lib.host_lens(lens)
         same = lens_h.numel() > 0 and bool((lens_h == lens_h[0]).all())
-        if not same or self.graph_error is not None:
+        if not same or self.graph_error is not None or _pipeline_running():
             return self.model((x, lens), hx)
         sig = tuple((p_.data_ptr(), _lib.version_of(p_)) for p_ in self.model.parameters())
         if sig != self._sig:
@@ -639,7 +648,7 @@ class ChunkedDeepSpeech2:
             raise RuntimeError("call begin(lens) first")
         st = self._stream
         with torch.no_grad():
-            if self.use_graph and st.graph_ok and self.graph_error is None:
+            if self.use_graph and st.graph_ok and self.graph_error is None and not (_pipeline_running() and st.graph is None):
                 y = self._push_graph(st, chunk, final)
                 if y is not None:
                     return y
@@ -740,7 +749,7 @@ class ChunkedDeepSpeech2:
             xc = x[:alive, :, :, t0:t0 + self.chunk_frames]
             lc = (lens_cpu[:alive] - t0).clamp(max=xc.shape[-1])
             steady = (self.use_graph and self.graph_error is None and state is not None and xc.shape[-1] == self.chunk_frames
-                      and int(lc.min()) == self.chunk_frames)
+                      and int(lc.min()) == self.chunk_frames and not _pipeline_running())
             y = ol_host = None
             cg_used = False
             if steady:

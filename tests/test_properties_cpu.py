@@ -167,3 +167,42 @@ def test_oracle_beam_with_full_width_is_the_exact_map_prefix(T_, V, seed):
     best = max(scores.values())
     got = tuple(O.ctc_beam_decode(x, np.array([T_]), blank, 10_000, 0.0)[0])
     assert scores[got] >= best * (1 - 1e-5)
+
+
+def test_zero_padded_recurrent_weights_keep_the_padded_units_at_zero_and_the_real_units_unchanged():
+    """``model.rnn.pad_layer_params`` (any hidden_size on the persistent kernels) on the CPU, through stock
+    torch cells: a two-layer bidirectional LSTM / GRU run at a padded width with the padded weights gives the unpadded stack's
+    outputs and states in its first H units and exact zeros in the rest -- also with a padded first-layer input."""
+    import torch
+    from myrtlespeech_amd import _lib
+    from myrtlespeech_amd.model.rnn import pad_layer_params
+
+    for cls, cell, h, hp, in_pad in ((torch.nn.LSTM, _lib.CELL_LSTM, 5, 8, 0), (torch.nn.GRU, _lib.CELL_GRU, 6, 16, 3),
+                                     (torch.nn.LSTM, _lib.CELL_LSTM, 3, 4, 2)):
+        torch.manual_seed(h)
+        In, T_, N = 7, 9, 4
+        ref = cls(In, h, num_layers=2, bidirectional=True)
+        big = cls(In + in_pad, hp, num_layers=2, bidirectional=True)
+        with torch.no_grad():
+            for layer in range(2):
+                params = [tuple(getattr(ref, f"{n}_l{layer}{sfx}") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+                          for sfx in ("", "_reverse")]
+                padded = pad_layer_params(cell, params, hp, layer > 0, in_pad if layer == 0 else 0)
+                for sfx, tensors in zip(("", "_reverse"), padded):
+                    for n, v in zip(("weight_ih", "weight_hh", "bias_ih", "bias_hh"), tensors):
+                        dst = getattr(big, f"{n}_l{layer}{sfx}")
+                        assert dst.shape == v.shape, (n, layer, dst.shape, v.shape)
+                        dst.copy_(v)
+            x = torch.randn(T_, N, In)
+            h0 = torch.randn(4, N, h) * 0.3
+            grow = (0, hp - h)
+            hx = (h0, h0 * 0.5) if cls is torch.nn.LSTM else h0
+            hx_p = tuple(torch.nn.functional.pad(s_, grow) for s_ in hx) if isinstance(hx, tuple) else torch.nn.functional.pad(hx, grow)
+            want, want_h = ref(x, hx)
+            got, got_h = big(torch.nn.functional.pad(x, (0, in_pad)), hx_p)
+        got = got.view(T_, N, 2, hp)
+        assert float(got[..., h:].abs().max()) == 0.0
+        assert torch.allclose(got[..., :h].reshape(T_, N, 2 * h), want, atol=1e-6)
+        for g_, w_ in zip(got_h if isinstance(got_h, tuple) else (got_h,), want_h if isinstance(want_h, tuple) else (want_h,)):
+            assert float(g_[..., h:].abs().max()) == 0.0
+            assert torch.allclose(g_[..., :h], w_, atol=1e-6)
