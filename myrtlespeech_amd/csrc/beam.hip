@@ -36,7 +36,7 @@ constexpr size_t BEAM_LDS_LIMIT = 150 * 1024;
 // bytes of the per-utterance working arrays (LDS; the workspace's scratch region when they do not fit)
 size_t beam_lds_bytes(int V, int W) {
   const size_t M = (size_t)W * (V + 1), WV = (size_t)W * V;
-  return ((size_t)V + 10 * M + 6 * WV + 19 * (size_t)W + 8) * 4;
+  return ((size_t)V + 10 * M + 6 * WV + 17 * (size_t)W + 2 * (size_t)((W + 7) / 8 * 8) + 8) * 4;      // (bm_node: padded to eights)
 }
 
 struct BeamLayout {
@@ -90,16 +90,18 @@ struct BeamP {
   float thr;
 };
 
-// beam index of `node` (-1: not in the beam): the beam's node ids in batches of eight independent LDS reads
-__device__ __forceinline__ int find_in_beam(const int* bmn, int B, int W, int node) {
+// beam index of `node` (-1: not in the beam): the beam's node ids in batches of eight independent LDS reads.  The array is
+// padded to a multiple of eight entries and every entry that is not a beam member holds -2 (never a node id, never the "no
+// child" -1), so the scan needs neither a bound per element nor the beam's size
+__device__ __forceinline__ int find_in_beam(const int* bmn, int W8, int node) {
   int at = -1;
-  for (int k0 = 0; k0 < B; k0 += 8) {
+  for (int k0 = 0; k0 < W8; k0 += 8) {
     int v[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = bmn[min(k0 + m, W - 1)];
+    for (int m = 0; m < 8; ++m) v[m] = bmn[k0 + m];
 #pragma unroll
     for (int m = 0; m < 8; ++m)
-      if (k0 + m < B && v[m] == node) at = k0 + m;
+      if (v[m] == node) at = k0 + m;
   }
   return at;
 }
@@ -135,8 +137,9 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
   int* lc_node = k_key + M;                                   // [2][W][V] child rows of the live beam: node id (-1: none yet)
   int* lc_cslot = lc_node + 2 * WV;                           //           the child's child-table slot (-1: never in the beam)
   int* lc_tidx = lc_cslot + 2 * WV;                           //           its slot in the previous frame's tables (-1: absent)
-  int* bm_node = lc_tidx + 2 * WV;                            // [2][W] each: the beam, this frame's and the next one's
-  int* bm_last = bm_node + 2 * W;
+  const int W8 = (W + 7) / 8 * 8;
+  int* bm_node = lc_tidx + 2 * WV;                            // [2][W8]: the beam's nodes, this frame's and the next one's (-2 = no entry)
+  int* bm_last = bm_node + 2 * W8;                            // [2][W] each
   int* bm_len = bm_last + 2 * W;
   int* bm_nw = bm_len + 2 * W;
   int* bm_cslot = bm_nw + 2 * W;
@@ -172,12 +175,14 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
   const bool stamping = p.stamps != 0 && tid == 0 && n == 0;
   unsigned long long st_prev = 0;
   unsigned st_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k = tid; k < 2 * W8; k += NT) bm_node[k] = -2;     // (members are written below, behind a barrier)
+  __syncthreads();
   const int b0 = p.t_begin & 1;      // buffer of the beam / child rows a frame reads = the frame's parity
   if (p.t_begin == 0) {
     // Pb[-1][()] = 1, Pnb[-1][()] = 0, A_prev = [()]   (ctc_beam_decoder.py:182-192)
     if (tid == 0) {
       node_parent[0] = -1; node_sym[0] = -1; node_len[0] = 0; node_nw[0] = 0; node_cslot[0] = 0;
-      bm_node[b0 * W] = 0; bm_pb[b0 * W] = 1.0f; bm_pnb[b0 * W] = 0.0f;
+      bm_node[b0 * W8] = 0; bm_pb[b0 * W] = 1.0f; bm_pnb[b0 * W] = 0.0f;
       bm_last[b0 * W] = -1; bm_len[b0 * W] = 0; bm_nw[b0 * W] = 0; bm_cslot[b0 * W] = 0;
       sh[0] = 1; sh[2] = 1; sh[3] = 1;
     }
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
     for (int w = tid; w < W; w += NT)
       if (w < B_in) {
         const int nd = g_beam_node[w];
-        bm_node[b0 * W + w] = nd; bm_pb[b0 * W + w] = g_beam_pb[w]; bm_pnb[b0 * W + w] = g_beam_pnb[w];
+        bm_node[b0 * W8 + w] = nd; bm_pb[b0 * W + w] = g_beam_pb[w]; bm_pnb[b0 * W + w] = g_beam_pnb[w];
         bm_last[b0 * W + w] = node_sym[nd]; bm_len[b0 * W + w] = node_len[nd]; bm_nw[b0 * W + w] = node_nw[nd];
         bm_cslot[b0 * W + w] = node_cslot[nd];
       }
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
     if (B == 0) break;  // an empty beam stays empty (ctc_beam_decoder.py:258)
     const int cp = t & 1, pp = cp ^ 1;          // tables: this frame's / the previous frame's
     const int cb = cp, nb = pp;                 // beam + child rows: read / built for the next frame
-    const int* bmn = bm_node + cb * W;
+    const int* bmn = bm_node + cb * W8;
     const int* bml = bm_last + cb * W;
     const int* bmlen = bm_len + cb * W;
     const int* bmnw = bm_nw + cb * W;
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
       const int ti = lct[i];
       const int len_w = bmlen[w], last_w = bml[w];
       const float pb_w = bmpb[w], pnb_w = bmpnb[w];
-      const int w2 = find_in_beam(bmn, B, W, child);       // -1 for child == -1 (node ids are >= 0)
+      const int w2 = find_in_beam(bmn, W8, child);         // -1 for child == -1 (node ids are >= 0, non-members hold -2)
       const int tis = ti >= 0 ? ti : 0;
       const float pb_t = c_pb[pp * M + tis], pnb_t = c_pnb[pp * M + tis];
       int flags = 0;
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
       }
       // a child that is itself in the (old) beam is a candidate of this frame under its own beam slot
       if (ti < 0 && child >= 0) {
-        const int k = find_in_beam(bmn, B, W, child);
+        const int k = find_in_beam(bmn, W8, child);
         if (k >= 0 && (c_flags[k] & F_PRESENT)) ti = k;
       }
       lc_node[nb * WV + idx] = child; lc_cslot[nb * WV + idx] = cs; lc_tidx[nb * WV + idx] = ti;
@@ -456,9 +461,10 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
         last = c; ln = bmlen[w] + 1;
         nw = bmnw[w] + ((c == p.sep && bml[w] != p.sep) ? 1 : 0);
       }
-      bm_node[nb * W + j] = nd; bm_last[nb * W + j] = last; bm_len[nb * W + j] = ln; bm_nw[nb * W + j] = nw;
+      bm_node[nb * W8 + j] = nd; bm_last[nb * W + j] = last; bm_len[nb * W + j] = ln; bm_nw[nb * W + j] = nw;
       bm_cslot[nb * W + j] = cs; bm_pb[nb * W + j] = c_pb[cp * M + i]; bm_pnb[nb * W + j] = c_pnb[cp * M + i];
     }
+    for (int j = Bn + tid; j < W8; j += NT) bm_node[nb * W8 + j] = -2;
     if (tid == 0) sh[0] = Bn;
     __syncthreads();
     MS_BEAM_STAMP(7);
@@ -475,11 +481,11 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
     g_lc_node[i] = lc_node[eb * WV + i]; g_lc_cslot[i] = lc_cslot[eb * WV + i]; g_lc_tidx[i] = lc_tidx[eb * WV + i];
   }
   for (int w = tid; w < W; w += NT)
-    if (w < B) { g_beam_node[w] = bm_node[eb * W + w]; g_beam_pb[w] = bm_pb[eb * W + w]; g_beam_pnb[w] = bm_pnb[eb * W + w]; }
+    if (w < B) { g_beam_node[w] = bm_node[eb * W8 + w]; g_beam_pb[w] = bm_pb[eb * W + w]; g_beam_pnb[w] = bm_pnb[eb * W + w]; }
   if (p.finish && tid == 0) {
     int L = 0;
     if (B > 0) {
-      int nd = bm_node[eb * W];
+      int nd = bm_node[eb * W8];
       L = node_len[nd];
       for (int i = L - 1; i >= 0; --i) { p.out_idx[(size_t)n * p.T + i] = node_sym[nd]; nd = node_parent[nd]; }
     }
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
   if (p.beam_idx_out != nullptr) {
     if (tid == 0) p.beam_len_out[n] = B;
     for (int w = tid; w < B; w += NT) {
-      int nd = bm_node[eb * W + w];
+      int nd = bm_node[eb * W8 + w];
       const int L = node_len[nd];
       p.beam_plen_out[(size_t)n * W + w] = L;
       for (int i = L - 1; i >= 0; --i) { p.beam_idx_out[((size_t)n * W + w) * p.T + i] = node_sym[nd]; nd = node_parent[nd]; }
