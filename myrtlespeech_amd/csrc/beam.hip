@@ -90,6 +90,11 @@ struct BeamP {
   float thr;
 };
 
+// MS_PIN(x): an empty asm that "modifies" x -- the load that produced x is issued where it is written.  hipcc otherwise sinks an
+// LDS load behind the branch that uses its value, which turns a phase's independent loads into a chain of round trips on a
+// workgroup that has one wave per SIMD (S4a: 0.79 -> 0.55 us per frame with nothing else changed)
+#define MS_PIN(x) asm volatile("" : "+v"(x))
+
 // beam index of `node` (-1: not in the beam): the beam's node ids in batches of eight independent LDS reads.  The array is
 // padded to a multiple of eight entries and every entry that is not a beam member holds -2 (never a node id, never the "no
 // child" -1), so the scan needs neither a bound per element nor the beam's size
@@ -100,8 +105,9 @@ __device__ __forceinline__ int find_in_beam(const int* bmn, int W8, int node) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = bmn[k0 + m];
 #pragma unroll
-    for (int m = 0; m < 8; ++m)
-      if (v[m] == node) at = k0 + m;
+    for (int m = 0; m < 8; ++m) MS_PIN(v[m]);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) at = v[m] == node ? k0 + m : at;
   }
   return at;
 }
@@ -257,14 +263,17 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
     for (int i = tid; i < B * V; i += NT) {
       const int w = i == tid ? w_first : i / V, c = i == tid ? c_first : i - (i / V) * V;
       const int slot = W + i;
-      const float pc = prow[c];
-      const int child = lcn[i];
-      const int ti = lct[i];
-      const int len_w = bmlen[w], last_w = bml[w];
-      const float pb_w = bmpb[w], pnb_w = bmpnb[w];
+      float pc = prow[c];
+      int child = lcn[i];
+      int ti = lct[i];
+      int len_w = bmlen[w], last_w = bml[w];
+      MS_PIN(pc); MS_PIN(child); MS_PIN(ti); MS_PIN(len_w); MS_PIN(last_w);
+      float pb_w = bmpb[w], pnb_w = bmpnb[w];
+      MS_PIN(pb_w); MS_PIN(pnb_w);
       const int w2 = find_in_beam(bmn, W8, child);         // -1 for child == -1 (node ids are >= 0, non-members hold -2)
       const int tis = ti >= 0 ? ti : 0;
-      const float pb_t = c_pb[pp * M + tis], pnb_t = c_pnb[pp * M + tis];
+      float pb_t = c_pb[pp * M + tis], pnb_t = c_pnb[pp * M + tis];
+      MS_PIN(pb_t); MS_PIN(pnb_t);
       int flags = 0;
       if (c != p.blank && !(pc <= p.thr)) {  // `if ctc[t][c] <= prune_threshold: continue`
         const bool repeat = len_w > 0 && c == last_w;
@@ -296,9 +305,10 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
         const float pb_w = first ? s2_pb : bmpb[w], pnb_w = first ? s2_pnb : bmpnb[w];
         const int last = first ? s2_last : bml[w], len_w = first ? s2_len : bmlen[w];
         const float p_last = first ? s2_plast : prow[max(last, 0)];
-        const int parp = par_present[w];
-        const float parv = par_val[w];
-        const int parr = par_rank[w];
+        int parp = par_present[w];
+        float parv = par_val[w];
+        int parr = par_rank[w];
+        MS_PIN(parp); MS_PIN(parv); MS_PIN(parr);
         const bool in_pb = !(p_blank <= p.thr);
         const float pb_new = in_pb ? p_blank * (pb_w + pnb_w) : 0.f;
         const bool own = len_w > 0 && !(p_last <= p.thr);
@@ -335,9 +345,10 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
     for (int i0 = 0; i0 < nslots; i0 += NT) {
       const int i = i0 + tid;
       const bool in = i < nslots;
-      const int fl = in ? c_flags[i] : 0;
+      int fl = in ? c_flags[i] : 0;
       float score = in ? c_s[i] : 0.f;
-      const int key = in ? c_key[i] : 0;
+      int key = in ? c_key[i] : 0;
+      MS_PIN(fl); MS_PIN(score); MS_PIN(key);
       if (in) c_s[i] = 0.f;                           // (S4's rank counters live here: all-zero bits)
       const bool kept = (fl & F_KEPT) != 0;
       if (kept && p.sep >= 0) {
@@ -376,11 +387,25 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
         const float sj = have ? k_score[j] : 0.f;
         const int kj = have ? k_key[j] : 0;
         int pos = 0;
-#pragma unroll 4
-        for (int m = q; m < K; m += NW) {
-          const float sm = k_score[m];
-          const int km = k_key[m];
-          pos += (sm > sj || (sm == sj && km < kj)) ? 1 : 0;
+        // four (score, key) pairs per batch, every word of the batch requested before the first comparison: left to itself
+        // hipcc loads a key only behind the branch on its score (two dependent LDS round trips per candidate: the phase was
+        // 0.79 us for ~6 candidates per wave); the empty asm pins the loads where they are written
+        for (int m0 = q; m0 < K; m0 += 4 * NW) {
+          float sm[4];
+          int km[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int m = min(m0 + u * NW, K - 1);
+            sm[u] = k_score[m];
+            km[u] = k_key[m];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(sm[u]), "+v"(km[u]));
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int before = (int)(sm[u] > sj) | ((int)(sm[u] == sj) & (int)(km[u] < kj));
+            pos += (m0 + u * NW < K) ? before : 0;
+          }
         }
         if (have && pos) atomicAdd(&pos_acc[j], pos);
       }
@@ -429,9 +454,10 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
       const bool stay = i < W;
       // (both cases' words are requested together; the addresses are valid either way)
       const int e = stay ? i * V + c : 0;
-      const int child_s = lcn[e], cs_s = lcc[e], fl_s = c_flags[W + e];
-      const int mycs = lcc[stay ? 0 : i - W];
-      const int fresh = ent_fresh[j];
+      int child_s = lcn[e], cs_s = lcc[e], fl_s = c_flags[W + e];
+      int mycs = lcc[stay ? 0 : i - W];
+      int fresh = ent_fresh[j];
+      MS_PIN(child_s); MS_PIN(cs_s); MS_PIN(fl_s); MS_PIN(mycs); MS_PIN(fresh);
       int child, cs, ti = -1;
       if (stay) {                      // a beam entry that stays: its row moves along; a child that was a candidate of this
         child = child_s; cs = cs_s;    // frame is found at its slot in this frame's tables
