@@ -55,6 +55,8 @@ class _CTCLossFunction(torch.autograd.Function):
                                             m["blank"], m["zero_infinity"] | (0 if lp is None else 2), _lib.ptr(ws), nbytes,
                                             _lib.stream_ptr()),
                    "ms_ctc_loss_backward")
+        if m.get("check_status"):     # the alpha / beta pipeline of the backward has the same bounded mailbox spin as the forward
+            _lib.check(lib.ms_ctc_status(_lib.ptr(ws), _lib.stream_ptr()), "ms_ctc_loss_backward")
         if lp is not None:
             outer, axis, inner = m["axis_view"]
             _lib.check(lib.ms_log_softmax_axis_backward(_lib.ptr(lp), _lib.ptr(grad), _lib.ptr(grad), outer, axis, inner,
@@ -167,6 +169,7 @@ class CTCLoss(torch.nn.Module):
 
         if torch.is_grad_enabled() and x.requires_grad:
             meta = dict(red=red, s_max=s_max, blank=blank, zero_infinity=zero_inf, xl_dev=xl_dev, off_dev=off_dev,
-                        yl_dev=yl_dev, y_dev=y_dev, workspace=self._bwd_workspace, log_probs=log_probs, axis_view=axis_view)
+                        yl_dev=yl_dev, y_dev=y_dev, workspace=self._bwd_workspace, log_probs=log_probs, axis_view=axis_view,
+                        check_status=self.check_status)
             return _CTCLossFunction.apply(x_in, run_forward, meta)
         return run_forward(x)
