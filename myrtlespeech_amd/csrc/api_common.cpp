@@ -4,6 +4,7 @@
 #include <mutex>
 #include <vector>
 
+#include <algorithm>
 #include "common.h"
 
 namespace ms {
@@ -26,11 +27,46 @@ int precision_mode() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("MS_PRECISION");
-    v = PREC_BF16X3;
+    v = PREC_F16X3;
     if (e && strcmp(e, "f32") == 0) v = PREC_F32;
     if (e && strcmp(e, "fp16") == 0) v = PREC_F16;
+    if (e && strcmp(e, "bf16x3") == 0) v = PREC_BF16X3;
   }
   return v;
+}
+
+namespace {
+__global__ void absmax_bits_kernel(const float* __restrict__ w, size_t n, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned b = __float_as_uint(w[i]) & 0x7FFFFFFFu;
+    if (b < 0x7F800000u) m = max(m, b);          // finite values only (|x| as bits is monotone)
+  }
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+__global__ void scale_word_kernel(float* __restrict__ word, int half_planes) {
+  const unsigned bits = __float_as_uint(word[0]);
+  int s = 0;
+  if (half_planes && bits != 0) {
+    const int e = (int)((bits >> 23) & 255) - 127;      // floor(log2(max |w|)) (a subnormal maximum counts as 2^-127)
+    s = min(max(12 - e, -100), 100);
+  }
+  word[0] = ldexpf(1.0f, s);
+  word[1] = ldexpf(1.0f, -s);
+}
+}  // namespace
+
+int weight_scale_launch(const float* w, size_t n, float* scale_word, int prec, hipStream_t stream) {
+  MS_HIP(hipMemsetAsync(scale_word, 0, 2 * sizeof(float), stream));
+  const bool half_planes = prec == PREC_F16X3 || prec == PREC_F16;
+  if (half_planes && n > 0) {
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3(blocks), dim3(256), 0, stream, w, n, (unsigned*)scale_word);
+  }
+  hipLaunchKernelGGL(scale_word_kernel, dim3(1), dim3(1), 0, stream, scale_word, half_planes ? 1 : 0);
+  MS_LAUNCH_CHECK();
+  return MS_OK;
 }
 
 namespace {

@@ -14,23 +14,28 @@ int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const
 
 namespace {
 
+// (HM: fp16 hi / lo planes -- the default f16x3 mode -- else bf16 pairs)
+template <bool HM>
 __device__ __forceinline__ void split_store(float x, unsigned short* hi, unsigned short* lo, size_t at) {
-  const __bf16 h = (__bf16)x;
-  hi[at] = __builtin_bit_cast(unsigned short, h);
-  lo[at] = __builtin_bit_cast(unsigned short, (__bf16)(x - (float)h));
+  unsigned h, l;
+  ms::plane_split<HM>(x, h, l);
+  hi[at] = (unsigned short)h;
+  lo[at] = (unsigned short)l;
 }
 
 // weight [Cout, Cin*KT] f32 -> planes [Cout, Kp] (zero padded columns)
+template <bool HM>
 __global__ void conv1d_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ hi,
                                    unsigned short* __restrict__ lo, int K, int Kp) {
   const int row = blockIdx.x;
   for (int k = threadIdx.x; k < Kp; k += blockDim.x)
-    split_store(k < K ? w[(size_t)row * K + k] : 0.f, hi, lo, (size_t)row * Kp + k);
+    split_store<HM>(k < K ? w[(size_t)row * K + k] : 0.f, hi, lo, (size_t)row * Kp + k);
 }
 
 // patches: row (n, t_out), column ci*KT + k  <-  x[n, ci, t_out*ST + k*DT - pad_l] if that frame exists and is < lens[n].
 // A workgroup builds a 32-row x 64-column tile through LDS: the gather runs with lanes along t_out (consecutive lanes read
 // consecutive frames of one channel: coalesced), the scatter with 8 lanes per row (one 16-byte store per plane each).
+template <bool HM>
 __global__ __launch_bounds__(256) void conv1d_im2col_kernel(const float* __restrict__ x, const int32_t* __restrict__ lens,
                                                             unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
                                                             int Cin, int Tin, int Tout, int KT, int ST, int DT, int pad_l,
@@ -52,9 +57,10 @@ __global__ __launch_bounds__(256) void conv1d_im2col_kernel(const float* __restr
         const int t = t_out * ST + k * DT - pad_l;
         if (t >= 0 && t < len) v = xn[(size_t)ci * Tin + t];
       }
-      const __bf16 hb = (__bf16)v;
-      th[tr][cl] = __builtin_bit_cast(unsigned short, hb);
-      tl[tr][cl] = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)hb));
+      unsigned hb, lb;
+      ms::plane_split<HM>(v, hb, lb);
+      th[tr][cl] = (unsigned short)hb;
+      tl[tr][cl] = (unsigned short)lb;
     }
   }
   __syncthreads();
@@ -87,6 +93,8 @@ __global__ void ntc_to_nct_kernel(const float* __restrict__ y, float* __restrict
 }
 
 inline int padded_k(int Cin, int KT) { return ms::cdiv(Cin * KT, 32) * 32; }
+// two planes always (MS_PRECISION=fp16 has no one-plane form of this path): fp16 pairs in f16x3 mode, bf16 pairs otherwise
+inline bool half_planes() { return ms::precision_mode() == ms::PREC_F16X3; }
 
 }  // namespace
 
@@ -100,8 +108,8 @@ extern "C" int ms_maskconv1d_gemm_pack(const float* w, void* packed, int Cout, i
   MS_REQUIRE(Cout > 0 && Cin > 0 && KT > 0, "bad shape");
   const int Kp = padded_k(Cin, KT);
   unsigned short* hi = (unsigned short*)packed;
-  hipLaunchKernelGGL(conv1d_pack_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, w, hi, hi + (size_t)Cout * Kp,
-                     Cin * KT, Kp);
+  hipLaunchKernelGGL(half_planes() ? conv1d_pack_kernel<true> : conv1d_pack_kernel<false>, dim3(Cout), dim3(256), 0,
+                     (hipStream_t)stream, w, hi, hi + (size_t)Cout * Kp, Cin * KT, Kp);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }
@@ -131,10 +139,11 @@ extern "C" int ms_maskconv1d_gemm_forward(const float* x, const int32_t* lens, c
   float* yt = (float*)((char*)workspace + ms::align_up(rows * Kp * 2 * sizeof(unsigned short), 256));
   const unsigned short* wh = (const unsigned short*)packed;
   const unsigned short* wl = wh + (size_t)Cout * Kp;
-  hipLaunchKernelGGL(conv1d_im2col_kernel, dim3(ms::cdiv(Kp, 64), ms::cdiv(Tout, 32), N), dim3(256), 0, stream, x, lens, ph,
-                     pl, Cin, Tin, Tout, KT, ST, DT, pad_l, K, Kp);
+  hipLaunchKernelGGL(half_planes() ? conv1d_im2col_kernel<true> : conv1d_im2col_kernel<false>, dim3(ms::cdiv(Kp, 64)
+                     , ms::cdiv(Tout, 32), N), dim3(256), 0, stream, x, lens, ph, pl, Cin, Tin, Tout, KT, ST, DT, pad_l, K, Kp);
   MS_LAUNCH_CHECK();
-  int rc = ms::gemm_bf16x3_launch(ph, pl, wh, wl, bias, yt, (int)rows, Kp, Cout, act, act_lo, act_hi, ms::PREC_BF16X3, stream);
+  int rc = ms::gemm_bf16x3_launch(ph, pl, wh, wl, bias, yt, (int)rows, Kp, Cout, act, act_lo, act_hi,
+                                  half_planes() ? ms::PREC_F16X3 : ms::PREC_BF16X3, stream);
   if (rc != MS_OK) return rc;
   hipLaunchKernelGGL(ntc_to_nct_kernel, dim3(ms::cdiv(Tout, 32), ms::cdiv(Cout, 32), N), dim3(32, 8), 0, stream, yt, y, Tout,
                      Cout);

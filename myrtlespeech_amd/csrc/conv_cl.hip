@@ -43,11 +43,18 @@ struct ClP {
 
 __device__ __forceinline__ unsigned bf16b(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ unsigned f16b(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x); }
+// hi / lo bits of x in plane format `prec` (ms::PREC_BF16X3 | PREC_F16 | PREC_F16X3; PREC_F16: lo = 0): layout kernels only
+__device__ __forceinline__ void split_by_prec(float x, int prec, unsigned& hi, unsigned& lo) {
+  if (prec == ms::PREC_F16) { hi = f16b(x); lo = 0u; }
+  else if (prec == ms::PREC_F16X3) ms::plane_split<true>(x, hi, lo);
+  else ms::plane_split<false>(x, hi, lo);
+}
 
 // packed[plane][kf][kt][kg][cout_pad][8] <- w[cout][cin][kf][kt]
 __global__ void conv_cl_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int Cout, int Cin,
-                                    int KF, int KT, int cout_pad, int f16) {
+                                    int KF, int KT, int cout_pad, int prec, const float* __restrict__ scale_word) {
   const int KG = Cin / 8;
+  const float wscale = scale_word[0];
   const size_t plane = (size_t)KF * KT * KG * cout_pad * 8;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x) {
     const int e = i & 7;
@@ -56,15 +63,11 @@ __global__ void conv_cl_pack_kernel(const float* __restrict__ w, unsigned short*
     const int kt = (i / ((size_t)8 * cout_pad * KG)) % KT;
     const int kf = i / ((size_t)8 * cout_pad * KG * KT);
     float x = 0.f;
-    if (co < Cout) x = w[(((size_t)co * Cin + kg * 8 + e) * KF + kf) * KT + kt];
-    if (f16) {
-      packed[i] = (unsigned short)f16b(x);
-      packed[plane + i] = 0;
-    } else {
-      const unsigned h = bf16b(x);
-      packed[i] = (unsigned short)h;
-      packed[plane + i] = (unsigned short)bf16b(x - __uint_as_float(h << 16));
-    }
+    if (co < Cout) x = w[(((size_t)co * Cin + kg * 8 + e) * KF + kf) * KT + kt] * wscale;
+    unsigned h, l;
+    split_by_prec(x, prec, h, l);
+    packed[i] = (unsigned short)h;
+    packed[plane + i] = (unsigned short)l;
   }
 }
 
@@ -73,12 +76,14 @@ __global__ void conv_cl_pack_kernel(const float* __restrict__ w, unsigned short*
 // WF: waves along the feature axis.  WF = 1: the four waves own four consecutive 32-frame blocks (128 frames x CL_F rows
 // per workgroup).  WF = 4: they own the SAME 32 frames of four consecutive row groups (32 frames x 4 CL_F rows) -- for short
 // inputs (a 320 ms streaming chunk is 16 output frames) a 128-frame tile would be seven-eighths padding.
-template <bool F16, bool WIN = false, int WF = 1>
+template <int P, bool WIN = false, int WF = 1>
 __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned short* __restrict__ xh,
                                                              const unsigned short* __restrict__ xl,
                                                              const int32_t* __restrict__ lens,
                                                              const unsigned short* __restrict__ wp,
-                                                             const float* __restrict__ bias, float* __restrict__ y, ClP p) {
+                                                             const float* __restrict__ bias, float* __restrict__ y, ClP p,
+                                                             const float* __restrict__ scale_word) {
+  constexpr bool F16 = ms::prec_one_plane(P), HM = P == ms::PREC_F16X3;
   constexpr int WT = 4 / WF;        // waves along time
   constexpr int TT = 32 * WT;       // output frames per workgroup
   constexpr int RF = CL_F * WF;     // output feature rows per workgroup
@@ -172,9 +177,9 @@ __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned shor
               acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), acc[f], 0, 0, 0);
             } else {
               const u32x4 bl = *reinterpret_cast<const u32x4*>(Pl + poff);
-              acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc[f], 0, 0, 0);
-              acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc[f], 0, 0, 0);
-              acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc[f], 0, 0, 0);
+              acc[f] = ms::mfma_32x32x16<HM>(ah, bh, acc[f]);
+              acc[f] = ms::mfma_32x32x16<HM>(al, bh, acc[f]);
+              acc[f] = ms::mfma_32x32x16<HM>(ah, bl, acc[f]);
             }
           }
         }
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned shor
   }
 
   const int t = t0 + wt * 32 + l31;
+  const float winv = scale_word[1];
   if (t < p.Tout) {
 #pragma unroll
     for (int f = 0; f < CL_F; ++f) {
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned shor
       for (int r = 0; r < 16; ++r) {
         const int co = tile * 32 + ms::mfma32_row(r, lane);
         if (co < p.Cout) {
-          float v = acc[f][r] + (bias ? bias[co] : 0.f);
+          float v = acc[f][r] * winv + (bias ? bias[co] : 0.f);   // (winv: the packed weights' 2^-s, exact)
           if (p.act == MS_ACT_CLAMP) v = fminf(fmaxf(v, p.lo), p.hi);
           y[(((size_t)n * p.Cout + co) * p.Fout + fo) * p.Tout + t] = v;
         }
@@ -215,13 +221,15 @@ __global__ __launch_bounds__(256, 2) void maskconv_cl_kernel(const unsigned shor
 constexpr int SH_RB = 12;     // output feature rows per workgroup, at most
 constexpr int SH_KT = 11;     // time taps held in registers per kernel row (DS2: 11)
 
-template <bool F16>
+template <int P>
 __global__ __launch_bounds__(256, 1) void maskconv_cl_short_kernel(const unsigned short* __restrict__ xh,
                                                                    const unsigned short* __restrict__ xl,
                                                                    const int32_t* __restrict__ lens,
                                                                    const unsigned short* __restrict__ wp,
                                                                    const float* __restrict__ bias, float* __restrict__ y, ClP p,
-                                                                   int RB, int RIN) {
+                                                                   int RB, int RIN, const float* __restrict__ scale_word) {
+  constexpr bool F16 = ms::prec_one_plane(P), HM = P == ms::PREC_F16X3;
+  const float winv = scale_word[1];
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
@@ -287,9 +295,9 @@ __global__ __launch_bounds__(256, 1) void maskconv_cl_short_kernel(const unsigne
               acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fh[set][kt]), __builtin_bit_cast(f16x8, bh), acc[i], 0, 0, 0);
             } else {
               const u32x4 bl = *reinterpret_cast<const u32x4*>(Pl + rbase + kt * 64);
-              acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fh[set][kt]), __builtin_bit_cast(bf16x8, bh), acc[i], 0, 0, 0);
-              acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fl[set][kt]), __builtin_bit_cast(bf16x8, bh), acc[i], 0, 0, 0);
-              acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fh[set][kt]), __builtin_bit_cast(bf16x8, bl), acc[i], 0, 0, 0);
+              acc[i] = ms::mfma_16x16x32<HM>(fh[set][kt], bh, acc[i]);
+              acc[i] = ms::mfma_16x16x32<HM>(fl[set][kt], bh, acc[i]);
+              acc[i] = ms::mfma_16x16x32<HM>(fh[set][kt], bl, acc[i]);
             }
           }
       }
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void maskconv_cl_short_kernel(const unsigne
       for (int r = 0; r < 4; ++r) {
         const int co = cb * 16 + 4 * q + r;
         if (co < p.Cout) {
-          float o = v[r] + (bias ? bias[co] : 0.f);
+          float o = v[r] * winv + (bias ? bias[co] : 0.f);
           if (p.act == MS_ACT_CLAMP) o = fminf(fmaxf(o, p.lo), p.hi);
           y[(((size_t)n * p.Cout + co) * p.Fout + fo) * p.Tout + c16] = o;
         }
@@ -352,7 +360,7 @@ int conv_cl_short_plan(const ClP& p, bool f16, int* RB, int* RIN, size_t* lds) {
 
 // f32 NCHW [N][C][F][T] -> channels-last bf16 hi / lo planes [N][F][T][C]  (C % 8 == 0)
 __global__ void nchw_to_cl_split_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi,
-                                        unsigned short* __restrict__ lo, int C, int F, int T, int f16) {
+                                        unsigned short* __restrict__ lo, int C, int F, int T, int prec) {
   __shared__ float tile[32][33];
   const int n = blockIdx.z / F, f = blockIdx.z % F;
   const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -367,20 +375,17 @@ __global__ void nchw_to_cl_split_kernel(const float* __restrict__ x, unsigned sh
     if (t < T && c < C) {
       const float v = tile[tx][i];
       const size_t o = (((size_t)n * F + f) * T + t) * C + c;
-      if (f16) {
-        hi[o] = (unsigned short)f16b(v);
-      } else {
-        const unsigned h = bf16b(v);
-        hi[o] = (unsigned short)h;
-        lo[o] = (unsigned short)bf16b(v - __uint_as_float(h << 16));
-      }
+      unsigned h, l;
+      split_by_prec(v, prec, h, l);
+      hi[o] = (unsigned short)h;
+      if (prec != ms::PREC_F16) lo[o] = (unsigned short)l;
     }
   }
 }
 
 // single-channel input x [N][Fin][T] f32 -> bf16 hi / lo planes [N][T][FP], element j = feature j - pad (zeros outside)
 __global__ void ft_to_tf_split_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi,
-                                      unsigned short* __restrict__ lo, int Fin, int T, int FP, int pad, int f16) {
+                                      unsigned short* __restrict__ lo, int Fin, int T, int FP, int pad, int prec) {
   __shared__ float tile[32][33];
   const int n = blockIdx.z;
   const int t0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
@@ -395,21 +400,19 @@ __global__ void ft_to_tf_split_kernel(const float* __restrict__ x, unsigned shor
     if (t < T && j < FP) {
       const float v = tile[tx][i];
       const size_t o = ((size_t)n * T + t) * FP + j;
-      if (f16) {
-        hi[o] = (unsigned short)f16b(v);
-      } else {
-        const unsigned h = bf16b(v);
-        hi[o] = (unsigned short)h;
-        lo[o] = (unsigned short)bf16b(v - __uint_as_float(h << 16));
-      }
+      unsigned h, l;
+      split_by_prec(v, prec, h, l);
+      hi[o] = (unsigned short)h;
+      if (prec != ms::PREC_F16) lo[o] = (unsigned short)l;
     }
   }
 }
 
 // packed[plane][kt][kg][cout_pad][8] <- w[cout][0][kf = 8 kg + e][kt]  (zero for kf >= KF)
 __global__ void conv_fwin_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int Cout, int KF,
-                                      int KT, int KG, int cout_pad, int f16) {
+                                      int KT, int KG, int cout_pad, int prec, const float* __restrict__ scale_word) {
   const size_t plane = (size_t)KT * KG * cout_pad * 8;
+  const float wscale = scale_word[0];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x) {
     const int e = i & 7;
     const int co = (i >> 3) % cout_pad;
@@ -417,15 +420,11 @@ __global__ void conv_fwin_pack_kernel(const float* __restrict__ w, unsigned shor
     const int kt = i / ((size_t)8 * cout_pad * KG);
     const int kf = kg * 8 + e;
     float x = 0.f;
-    if (co < Cout && kf < KF) x = w[((size_t)co * KF + kf) * KT + kt];
-    if (f16) {
-      packed[i] = (unsigned short)f16b(x);
-      packed[plane + i] = 0;
-    } else {
-      const unsigned h = bf16b(x);
-      packed[i] = (unsigned short)h;
-      packed[plane + i] = (unsigned short)bf16b(x - __uint_as_float(h << 16));
-    }
+    if (co < Cout && kf < KF) x = w[((size_t)co * KF + kf) * KT + kt] * wscale;
+    unsigned h, l;
+    split_by_prec(x, prec, h, l);
+    packed[i] = (unsigned short)h;
+    packed[plane + i] = (unsigned short)l;
   }
 }
 
@@ -445,26 +444,26 @@ int conv_cl_plan(ClP& p, size_t* lds) {
 
 template <bool WIN>
 int conv_cl_launch(const ClP& p, int wf, size_t lds, const unsigned short* xh, const unsigned short* xl, const int32_t* lens,
-                   const void* packed_w, const float* bias, float* y, hipStream_t stream) {
+                   const void* packed_w, const float* bias, float* y, hipStream_t stream, const float* scale_word) {
   static ms::DeviceOnce attr_once;
   if (attr_once.need()) {
-    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<false, WIN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<true, WIN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<false, WIN, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<true, WIN, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define MS_CL_ATTR(PP)                                                                                                                     \
+    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<PP, WIN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));   \
+    MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_kernel<PP, WIN, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MS_CL_ATTR(ms::PREC_BF16X3) MS_CL_ATTR(ms::PREC_F16) MS_CL_ATTR(ms::PREC_F16X3)
+#undef MS_CL_ATTR
     attr_once.done();
   }
-  const bool f16 = ms::precision_mode() == ms::PREC_F16;
+  const int prec = ms::split_mode();
   const int tt = 128 / wf, rf = CL_F * wf;
   dim3 grid(ms::cdiv(p.Tout, tt), ms::cdiv(p.Fout, rf), p.N * p.co_tiles);
   const unsigned short* wq = (const unsigned short*)packed_w;
-  if (wf == 4) {
-    if (f16) hipLaunchKernelGGL((maskconv_cl_kernel<true, WIN, 4>), grid, dim3(256), lds, stream, xh, xl, lens, wq, bias, y, p);
-    else hipLaunchKernelGGL((maskconv_cl_kernel<false, WIN, 4>), grid, dim3(256), lds, stream, xh, xl, lens, wq, bias, y, p);
-  } else {
-    if (f16) hipLaunchKernelGGL((maskconv_cl_kernel<true, WIN, 1>), grid, dim3(256), lds, stream, xh, xl, lens, wq, bias, y, p);
-    else hipLaunchKernelGGL((maskconv_cl_kernel<false, WIN, 1>), grid, dim3(256), lds, stream, xh, xl, lens, wq, bias, y, p);
-  }
+#define MS_CL_LAUNCH(WF_)                                                                                                             \
+  if (prec == ms::PREC_F16) hipLaunchKernelGGL((maskconv_cl_kernel<ms::PREC_F16, WIN, WF_>), grid, dim3(256), lds, stream, xh, xl, lens, wq, bias, y, p, scale_word); \
+  else if (prec == ms::PREC_F16X3) hipLaunchKernelGGL((maskconv_cl_kernel<ms::PREC_F16X3, WIN, WF_>), grid, dim3(256), lds, stream, xh, xl, lens, wq, bias, y, p, scale_word); \
+  else hipLaunchKernelGGL((maskconv_cl_kernel<ms::PREC_BF16X3, WIN, WF_>), grid, dim3(256), lds, stream, xh, xl, lens, wq, bias, y, p, scale_word);
+  if (wf == 4) { MS_CL_LAUNCH(4) } else { MS_CL_LAUNCH(1) }
+#undef MS_CL_LAUNCH
   MS_LAUNCH_CHECK();
   return MS_OK;
 }
@@ -477,9 +476,13 @@ inline int fwin_fp(int KF, int SF, int Fout) { return ms::cdiv((Fout - 1) * SF +
 // ---- single-channel convolutions (DS2 conv1: 1 -> 32 channels, 41 x 11 taps) as the same split-bf16 implicit GEMM: the
 // KF feature rows under an output row play the role of the input channels (padded to a multiple of 16), the time taps
 // stay taps.  Input planes are [N][Tin][FP] (feature-contiguous, zero feature padding materialised).
+// (the two planes, then the weights' scale word {2^s, 2^-s}: common.h "per-tensor power-of-two scale")
+static size_t fwin_plane_bytes(int Cout, int KF, int KT) {
+  return ms::align_up((size_t)2 * KT * (fwin_kfp(KF) / 8) * (ms::cdiv(Cout, 32) * 32) * 8 * sizeof(unsigned short), 256);
+}
 extern "C" size_t ms_maskconv_fwin_packed_bytes(int Cout, int KF, int KT) {
   if (Cout <= 0 || KF <= 0 || KT <= 0) return 0;
-  return (size_t)2 * KT * (fwin_kfp(KF) / 8) * (ms::cdiv(Cout, 32) * 32) * 8 * sizeof(unsigned short);
+  return fwin_plane_bytes(Cout, KF, KT) + 256;
 }
 
 extern "C" int ms_maskconv_fwin_pack(const float* w, void* packed, int Cout, int KF, int KT, void* stream) {
@@ -488,8 +491,11 @@ extern "C" int ms_maskconv_fwin_pack(const float* w, void* packed, int Cout, int
   const int cout_pad = ms::cdiv(Cout, 32) * 32, KG = fwin_kfp(KF) / 8;
   const size_t plane = (size_t)KT * KG * cout_pad * 8;
   const int blocks = (int)std::min<size_t>((plane + 255) / 256, 2048);
+  float* scale_word = (float*)((char*)packed + fwin_plane_bytes(Cout, KF, KT));
+  const int rc = ms::weight_scale_launch(w, (size_t)Cout * KF * KT, scale_word, ms::split_mode(), (hipStream_t)stream);
+  if (rc != MS_OK) return rc;
   hipLaunchKernelGGL(conv_fwin_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)packed, Cout,
-                     KF, KT, KG, cout_pad, ms::precision_mode() == ms::PREC_F16 ? 1 : 0);
+                     KF, KT, KG, cout_pad, ms::split_mode(), scale_word);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }
@@ -528,16 +534,21 @@ extern "C" int ms_maskconv_fwin_forward(const float* x, const int32_t* lens, con
   }
   unsigned short* xh = (unsigned short*)workspace;
   unsigned short* xl = xh + (size_t)N * Tin * p.FP;
-  const bool f16 = ms::precision_mode() == ms::PREC_F16;
+  const int prec = ms::split_mode();
+  const bool f16 = prec == ms::PREC_F16;
   hipLaunchKernelGGL(ft_to_tf_split_kernel, dim3(ms::cdiv(Tin, 32), ms::cdiv(p.FP, 32), N), dim3(32, 8), 0, stream, x, xh, xl,
-                     Fin, Tin, p.FP, pad_f_l, f16 ? 1 : 0);
+                     Fin, Tin, p.FP, pad_f_l, prec);
   MS_LAUNCH_CHECK();
-  return conv_cl_launch<true>(p, wf, lds, xh, xl, lens, packed_w, bias, y, stream);
+  return conv_cl_launch<true>(p, wf, lds, xh, xl, lens, packed_w, bias, y, stream,
+                              (const float*)((const char*)packed_w + fwin_plane_bytes(Cout, KF, KT)));
 }
 
+static size_t cl_plane_bytes(int Cout, int Cin, int KF, int KT) {
+  return ms::align_up((size_t)2 * KF * KT * (Cin / 8) * (ms::cdiv(Cout, 32) * 32) * 8 * sizeof(unsigned short), 256);
+}
 extern "C" size_t ms_maskconv_cl_packed_bytes(int Cout, int Cin, int KF, int KT) {
   if (Cout <= 0 || Cin <= 0 || Cin % 16 || KF <= 0 || KT <= 0) return 0;
-  return (size_t)2 * KF * KT * (Cin / 8) * (ms::cdiv(Cout, 32) * 32) * 8 * sizeof(unsigned short);
+  return cl_plane_bytes(Cout, Cin, KF, KT) + 256;      // + the weights' scale word
 }
 
 extern "C" int ms_maskconv_cl_pack(const float* w, void* packed, int Cout, int Cin, int KF, int KT, void* stream) {
@@ -546,8 +557,11 @@ extern "C" int ms_maskconv_cl_pack(const float* w, void* packed, int Cout, int C
   const int cout_pad = ms::cdiv(Cout, 32) * 32;
   const size_t plane = (size_t)KF * KT * (Cin / 8) * cout_pad * 8;
   const int blocks = (int)std::min<size_t>((plane + 255) / 256, 2048);
+  float* scale_word = (float*)((char*)packed + cl_plane_bytes(Cout, Cin, KF, KT));
+  const int rc = ms::weight_scale_launch(w, (size_t)Cout * Cin * KF * KT, scale_word, ms::split_mode(), (hipStream_t)stream);
+  if (rc != MS_OK) return rc;
   hipLaunchKernelGGL(conv_cl_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)packed, Cout,
-                     Cin, KF, KT, cout_pad, ms::precision_mode() == ms::PREC_F16 ? 1 : 0);
+                     Cin, KF, KT, cout_pad, ms::split_mode(), scale_word);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }
@@ -583,12 +597,14 @@ extern "C" int ms_maskconv_cl_forward(const float* x, const int32_t* lens, const
     ms::set_error("ms_maskconv_cl_forward: shape outside the LDS / grid budget");
     return MS_ERR_UNSUPPORTED;
   }
+  const float* scale_word = (const float*)((const char*)packed_w + cl_plane_bytes(Cout, Cin, KF, KT));
   unsigned short* xh = (unsigned short*)workspace;
   unsigned short* xl = xh + (size_t)N * Cin * Fin * Tin;
   MS_REQUIRE(N * Fin <= 65535, "N*Fin exceeds grid limits");
-  const bool f16 = ms::precision_mode() == ms::PREC_F16;
+  const int prec = ms::split_mode();
+  const bool f16 = prec == ms::PREC_F16;
   hipLaunchKernelGGL(nchw_to_cl_split_kernel, dim3(ms::cdiv(Tin, 32), ms::cdiv(Cin, 32), N * Fin), dim3(32, 8), 0, stream, x,
-                     xh, xl, Cin, Fin, Tin, f16 ? 1 : 0);
+                     xh, xl, Cin, Fin, Tin, prec);
   MS_LAUNCH_CHECK();
   {
     int RB = 0, RIN = 0;
@@ -596,19 +612,21 @@ extern "C" int ms_maskconv_cl_forward(const float* x, const int32_t* lens, const
     if (conv_cl_short_plan(p, f16, &RB, &RIN, &slds)) {
       static ms::DeviceOnce attr_once;
       if (attr_once.need()) {
-        MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_short_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_short_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_short_kernel<ms::PREC_BF16X3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_short_kernel<ms::PREC_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MS_HIP(hipFuncSetAttribute((const void*)maskconv_cl_short_kernel<ms::PREC_F16X3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_once.done();
       }
       ClP ps = p;
       ps.PW = Tout + KT - 1;
       const dim3 grid(ms::cdiv(Fout, RB), ms::cdiv(Cout, 16), N);
       const unsigned short* wq = (const unsigned short*)packed_w;
-      if (f16) hipLaunchKernelGGL(maskconv_cl_short_kernel<true>, grid, dim3(256), slds, stream, xh, xl, lens, wq, bias, y, ps, RB, RIN);
-      else hipLaunchKernelGGL(maskconv_cl_short_kernel<false>, grid, dim3(256), slds, stream, xh, xl, lens, wq, bias, y, ps, RB, RIN);
+      auto kern = prec == ms::PREC_F16 ? maskconv_cl_short_kernel<ms::PREC_F16>
+                  : prec == ms::PREC_F16X3 ? maskconv_cl_short_kernel<ms::PREC_F16X3> : maskconv_cl_short_kernel<ms::PREC_BF16X3>;
+      hipLaunchKernelGGL(kern, grid, dim3(256), slds, stream, xh, xl, lens, wq, bias, y, ps, RB, RIN, scale_word);
       MS_LAUNCH_CHECK();
       return MS_OK;
     }
   }
-  return conv_cl_launch<false>(p, wf, lds, xh, xl, lens, packed_w, bias, y, stream);
+  return conv_cl_launch<false>(p, wf, lds, xh, xl, lens, packed_w, bias, y, stream, scale_word);
 }

@@ -36,6 +36,7 @@ __global__ void to_f16_plane_kernel(const float* __restrict__ x, unsigned short*
   }
 }
 
+template <bool HM>
 __global__ void split_planes_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi,
                                     unsigned short* __restrict__ lo, size_t n4) {
   // n4 = number of 4-element groups
@@ -43,10 +44,7 @@ __global__ void split_planes_kernel(const float* __restrict__ x, unsigned short*
     const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
     unsigned h[4], l[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      h[e] = bf16_hi_bits(v[e]);
-      l[e] = bf16_hi_bits(v[e] - __uint_as_float(h[e] << 16));
-    }
+    for (int e = 0; e < 4; ++e) plane_split<HM>(v[e], h[e], l[e]);
     u32x2 ho = {h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
     u32x2 lo2 = {l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
     reinterpret_cast<u32x2*>(hi)[i] = ho;
@@ -66,6 +64,7 @@ __device__ __forceinline__ u32x4 ld_granule(const unsigned short* __restrict__ p
   return *reinterpret_cast<const u32x4*>(p + (size_t)min(row, rows - 1) * K + k);
 }
 
+template <bool HM>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel(const unsigned short* __restrict__ Ah,
                                                                 const unsigned short* __restrict__ Al,
                                                                 const unsigned short* __restrict__ Wh,
@@ -135,26 +134,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel(const unsigned s
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int g = 2 * s + half;
-      bf16x8 ah[2], al[2], bh[4], bl[4];
+      u32x4 ah[2], al[2], bh[4], bl[4];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int off = g * A_PLANE + (wave * 64 + i * 32 + l31) * 16;
-        ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sAh + off));
-        al[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sAl + off));
+        ah[i] = *reinterpret_cast<const u32x4*>(sAh + off);
+        al[i] = *reinterpret_cast<const u32x4*>(sAl + off);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int off = g * B_PLANE + (j * 32 + l31) * 16;
-        bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sBh + off));
-        bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sBl + off));
+        bh[j] = *reinterpret_cast<const u32x4*>(sBh + off);
+        bl[j] = *reinterpret_cast<const u32x4*>(sBl + off);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_32x32x16<HM>(ah[i], bh[j], acc[i][j]);
+          acc[i][j] = mfma_32x32x16<HM>(al[i], bh[j], acc[i][j]);
+          acc[i][j] = mfma_32x32x16<HM>(ah[i], bl[j], acc[i][j]);
         }
     }
     __syncthreads();
@@ -195,13 +194,14 @@ constexpr int T6_TILE = 4 * T6_PLANE;             // one operand plane (hi or lo
 constexpr int T6_STAGE = 4 * T6_TILE;             // x hi, x lo, W hi, W lo
 constexpr int T6_LDS = 2 * T6_STAGE;
 
-template <bool F16 = false>
+template <int P = PREC_BF16X3>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_tile64_kernel(const unsigned short* __restrict__ Ah,
                                                                        const unsigned short* __restrict__ Al,
                                                                        const unsigned short* __restrict__ Wh,
                                                                        const unsigned short* __restrict__ Wl,
                                                                        const float* __restrict__ bias, float* __restrict__ Y,
                                                                        int M, int K, int N, int act, float lo, float hi) {
+  constexpr bool F16 = prec_one_plane(P), HM = P == PREC_F16X3;
   __shared__ __attribute__((aligned(16))) char lds[T6_LDS];
   const int nbn = (N + T6 - 1) / T6, nbm = (M + T6 - 1) / T6;
   const int nwg = nbn * nbm;
@@ -254,13 +254,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_tile64_kernel(const uns
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
         continue;
       }
-      const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + offa));
-      const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + T6_TILE + offa));
-      const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + 2 * T6_TILE + offb));
-      const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + 3 * T6_TILE + offb));
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      const u32x4 ah = *reinterpret_cast<const u32x4*>(st + offa);
+      const u32x4 al = *reinterpret_cast<const u32x4*>(st + T6_TILE + offa);
+      const u32x4 bh = *reinterpret_cast<const u32x4*>(st + 2 * T6_TILE + offb);
+      const u32x4 bl = *reinterpret_cast<const u32x4*>(st + 3 * T6_TILE + offb);
+      acc = mfma_32x32x16<HM>(ah, bh, acc);
+      acc = mfma_32x32x16<HM>(al, bh, acc);
+      acc = mfma_32x32x16<HM>(ah, bl, acc);
     }
   };
   load_block(0, ring[0]);
@@ -304,13 +304,14 @@ constexpr int S2_TILE = 4 * S2_PLANE;           // one operand plane-set (hi or 
 constexpr int S2_BUF = 4 * S2_TILE;             // A_hi, A_lo, B_hi, B_lo
 constexpr int SPLIT2_LDS = 2 * S2_BUF;
 
-template <bool F16>
+template <int P>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel2(const unsigned short* __restrict__ Ah,
                                                                  const unsigned short* __restrict__ Al,
                                                                  const unsigned short* __restrict__ Wh,
                                                                  const unsigned short* __restrict__ Wl,
                                                                  const float* __restrict__ bias, float* __restrict__ Y,
                                                                  int M, int K, int N, int act, float lo, float hi) {
+  constexpr bool F16 = prec_one_plane(P), HM = P == PREC_F16X3;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int nbn = (N + S2_N - 1) / S2_N, nbm = (M + S2_M - 1) / S2_M;
   const int nwg = nbn * nbm;
@@ -403,17 +404,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel2(const unsigned 
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_32x32x16<HM>(ah[i], bh[j], acc[i][j]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_32x32x16<HM>(al[i], bh[j], acc[i][j]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_32x32x16<HM>(ah[i], bl[j], acc[i][j]);
     }
   };
   {
@@ -497,11 +498,12 @@ __device__ __forceinline__ void lds_dma_16(__amdgpu_buffer_rsrc_t rsrc, char* ds
 // waves of 64 x 64 (round 4): twice the workgroups of the 256 x 256 form for outputs that would otherwise leave CUs idle
 // (a streaming chunk's projection is 1 024 x 8 192: 128 tiles of 256 x 256 on 256 CUs), every output still the same
 // k-ordered sum (bit-identical), 8 fragment reads per 12 MFMAs instead of 12 per 24.
-template <bool F16, int WN, int PER_STEP_ = 3, bool SPACED = false, int NJ = 4>
+template <int P, int WN, int PER_STEP_ = 3, bool SPACED = false, int NJ = 4>
 __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah, const unsigned short* __restrict__ Al,
                                            const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
                                            const float* __restrict__ bias, float* __restrict__ Y, int M, int K, int N, int act,
                                            float lo, float hi, const int* __restrict__ m_eff = nullptr) {
+  constexpr bool F16 = prec_one_plane(P), HM = P == PREC_F16X3;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int TN = 32 * NJ * WN;
   static_assert(NJ == 4 || (NJ == 2 && WN == 2), "the narrow form is the 8-wave kernel");
@@ -627,20 +629,17 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][4 + j]),
-                                                              __builtin_bit_cast(bf16x8, fa[set][i]), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_32x32x16<HM>(fa[set][4 + j], fa[set][i], acc[i][j]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][4 + j]),
-                                                              __builtin_bit_cast(bf16x8, fa[set][2 + i]), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_32x32x16<HM>(fa[set][4 + j], fa[set][2 + i], acc[i][j]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][8 + j]),
-                                                              __builtin_bit_cast(bf16x8, fa[set][i]), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_32x32x16<HM>(fa[set][8 + j], fa[set][i], acc[i][j]);
     }
   };
 
@@ -682,18 +681,18 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
         if (F16) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wb[wr][0]), __builtin_bit_cast(f16x8, xa[xr][i]), acc[i][j], 0, 0, 0);
         } else {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[wr][0]), __builtin_bit_cast(bf16x8, xa[xr][i]), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_32x32x16<HM>(wb[wr][0], xa[xr][i], acc[i][j]);
         }
       }
       if (!F16) {
         issue(1);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[wr][0]), __builtin_bit_cast(bf16x8, xa[xr][2 + i]), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_32x32x16<HM>(wb[wr][0], xa[xr][2 + i], acc[i][j]);
         issue(2);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[wr][1]), __builtin_bit_cast(bf16x8, xa[xr][i]), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_32x32x16<HM>(wb[wr][1], xa[xr][i], acc[i][j]);
       }
     };
     rd_x(0, 0, 0);
@@ -812,7 +811,7 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
   }
 }
 
-template <bool F16>
+template <int P>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4(const unsigned short* __restrict__ Ah,
                                                                  const unsigned short* __restrict__ Al,
                                                                  const unsigned short* __restrict__ Wh,
@@ -820,11 +819,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4(const unsigned 
                                                                  const float* __restrict__ bias, float* __restrict__ Y,
                                                                  int M, int K, int N, int act, float lo, float hi,
                                                                  const int* __restrict__ m_eff) {
-  gemm4_body<F16, 2>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff);
+  gemm4_body<P, 2>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff);
 }
 
 // 256 x 128 tiles on eight waves (NJ = 2): outputs whose 256 x 256 tiles would leave CUs without a workgroup
-template <bool F16>
+template <int P>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4h(const unsigned short* __restrict__ Ah,
                                                                   const unsigned short* __restrict__ Al,
                                                                   const unsigned short* __restrict__ Wh,
@@ -832,16 +831,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4h(const unsigned
                                                                   const float* __restrict__ bias, float* __restrict__ Y,
                                                                   int M, int K, int N, int act, float lo, float hi,
                                                                   const int* __restrict__ m_eff) {
-  gemm4_body<F16, 2, 3, false, 2>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff);
+  gemm4_body<P, 2, 3, false, 2>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff);
 }
 
 // the 4-wave form, capped at 208 VGPRs (the two-stream LSTM kernel allocates 304 of a SIMD's 512): experiment only
-template <bool F16, int PER_STEP = 3, bool SPACED = false>
+template <int P, int PER_STEP = 3, bool SPACED = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel4n(
     const unsigned short* __restrict__ Ah, const unsigned short* __restrict__ Al, const unsigned short* __restrict__ Wh,
     const unsigned short* __restrict__ Wl, const float* __restrict__ bias, float* __restrict__ Y, int M, int K, int N, int act,
     float lo, float hi, const int* __restrict__ m_eff) {
-  gemm4_body<F16, 1, PER_STEP, SPACED>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff);
+  gemm4_body<P, 1, PER_STEP, SPACED>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff);
 }
 
 // tuning switch (tools/gemm_probe.py A/B runs in one process): 0 = default choice (kernel4, LDS-DMA), 2 = kernel2 (register staging), 7 = kernel4 with 256 x 128 tiles / 4 waves
@@ -853,10 +852,18 @@ int split_planes_launch(const float* x, unsigned short* hi, unsigned short* lo, 
   const int blocks = (int)std::min<size_t>((n4 + 255) / 256, 4096);
   if (prec == PREC_F16)
     hipLaunchKernelGGL(to_f16_plane_kernel, dim3(blocks), dim3(256), 0, stream, x, hi, n4);
+  else if (prec == PREC_F16X3)
+    hipLaunchKernelGGL(split_planes_kernel<true>, dim3(blocks), dim3(256), 0, stream, x, hi, lo, n4);
   else
-    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, stream, x, hi, lo, n4);
+    hipLaunchKernelGGL(split_planes_kernel<false>, dim3(blocks), dim3(256), 0, stream, x, hi, lo, n4);
   MS_LAUNCH_CHECK();
   return MS_OK;
+}
+
+// the split mode of this process for callers that have no layer-specific choice to make (linear layers, convolutions)
+int split_mode() {
+  const int m = precision_mode();
+  return m == PREC_F32 ? PREC_F16X3 : m;
 }
 
 // requires K % 32 == 0 and 16-byte aligned planes
@@ -880,25 +887,31 @@ int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const
   return gemm_bf16x3_launch_rows(ah, al, wh, wl, bias, y, M, K, N, act, lo, hi, prec, stream, nullptr);
 }
 
-// m_eff: optional device word holding the number of rows that exist (<= M); only where gemm_rows_from_device_ok(M, K, N)
+// one of a kernel template's three plane-format instances (`prec`: PREC_BF16X3 | PREC_F16 | PREC_F16X3)
+#define MS_BY_PREC(K) (prec == PREC_F16 ? K<PREC_F16> : prec == PREC_F16X3 ? K<PREC_F16X3> : K<PREC_BF16X3>)
+
+// m_eff: optional device word holding the number of rows that exist (<= M); only where gemm_rows_from_device_ok(M, K, N).
+// The names say bf16x3 for history's sake: `prec` selects the plane format (bf16 hi + lo, fp16 hi + lo, one fp16 plane).
 int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
                             const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
                             float hi, int prec, hipStream_t stream, const int* m_eff) {
   static ms::DeviceOnce attr_once;
   if (attr_once.need()) {
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT2_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT2_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4h<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
-    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4h<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS));
+#define MS_ATTR3(K, bytes)                                                                                         \
+    MS_HIP(hipFuncSetAttribute((const void*)K<PREC_BF16X3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));   \
+    MS_HIP(hipFuncSetAttribute((const void*)K<PREC_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));      \
+    MS_HIP(hipFuncSetAttribute((const void*)K<PREC_F16X3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    MS_ATTR3(gemm_nt_bf16x3_kernel2, SPLIT2_LDS)
+    MS_ATTR3(gemm_nt_bf16x3_kernel4, G4_LDS)
+    MS_ATTR3(gemm_nt_bf16x3_kernel4n, G4_LDS)
+    MS_ATTR3(gemm_nt_bf16x3_kernel4h, G4_LDS)
+#undef MS_ATTR3
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<PREC_BF16X3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<PREC_BF16X3, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<PREC_BF16X3, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
+    MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<PREC_BF16X3, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     attr_once.done();
   }
   static const bool small_tile = getenv("MS_GEMM_TILE128") && getenv("MS_GEMM_TILE128")[0] == '1';
@@ -919,12 +932,8 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
            (long)cdiv(M, T6) * cdiv(N, T6) <= 2L * num_cus();
   };
   auto launch_tile64 = [&]() {
-    if (f16)
-      hipLaunchKernelGGL(gemm_nt_bf16x3_tile64_kernel<true>, dim3(cdiv(M, T6) * cdiv(N, T6)), dim3(256), 0, stream, ah, al, wh, wl, bias, y,
-                         M, K, N, act, lo, hi);
-    else
-      hipLaunchKernelGGL(gemm_nt_bf16x3_tile64_kernel<false>, dim3(cdiv(M, T6) * cdiv(N, T6)), dim3(256), 0, stream, ah, al, wh, wl, bias, y,
-                         M, K, N, act, lo, hi);
+    hipLaunchKernelGGL(MS_BY_PREC(gemm_nt_bf16x3_tile64_kernel), dim3(cdiv(M, T6) * cdiv(N, T6)), dim3(256), 0, stream, ah, al, wh, wl,
+                       bias, y, M, K, N, act, lo, hi);
   };
   if (tile64() && (long)cdiv(M, S2_M) * cdiv(N, 128) * 4 <= (long)num_cus()) {
     launch_tile64();
@@ -933,17 +942,14 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
   }
   if (!half_off && !small_tile && starved && m_eff == nullptr && (long)M * N >= 1024L * 1024 &&
       g_gemm_variant.load(std::memory_order_relaxed) == 0 && (size_t)std::max(M, N) * K * 2 < ((size_t)1 << 31)) {
-    auto k4h = f16 ? gemm_nt_bf16x3_kernel4h<true> : gemm_nt_bf16x3_kernel4h<false>;
-    hipLaunchKernelGGL(k4h, dim3(cdiv(M, S2_M) * cdiv(N, 128)), dim3(512), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi,
-                       m_eff);
+    hipLaunchKernelGGL(MS_BY_PREC(gemm_nt_bf16x3_kernel4h), dim3(cdiv(M, S2_M) * cdiv(N, 128)), dim3(512), G4_LDS, stream, ah, al, wh, wl,
+                       bias, y, M, K, N, act, lo, hi, m_eff);
     MS_LAUNCH_CHECK();
     return MS_OK;
   }
   if (f16 || (!small_tile && !starved && (long)M * N >= 4L * 1024 * 1024)) {
     const int nwg2 = cdiv(M, S2_M) * cdiv(N, S2_N);
-    auto kern = f16 ? gemm_nt_bf16x3_kernel2<true> : gemm_nt_bf16x3_kernel2<false>;
     const int variant = g_gemm_variant.load(std::memory_order_relaxed);
-    // the DMA kernel addresses its planes with 32-bit byte offsets
     // the LDS-DMA kernel (default) addresses its planes with 32-bit byte offsets; MS_GEMM_REGSTAGE=1 / variant 2 keep kernel2
     static const bool regstage = getenv("MS_GEMM_REGSTAGE") && getenv("MS_GEMM_REGSTAGE")[0] == '1';
     if (variant != 2 && !regstage && (size_t)std::max(M, N) * K * 2 < ((size_t)1 << 31)) {
@@ -951,20 +957,20 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
         // how a wave issues the next block's 12 DMA pieces (bf16x3; experiments of tools/cotenant_variants.py): 7 = 3 per step
         // over four steps, 8 = 2 per step over six, 9 = 6 per step over two, 10 / 11 = as 7 / 8 with a step's pieces spaced
         // between its three MFMA groups
-        auto k41 = f16 ? gemm_nt_bf16x3_kernel4n<true> : gemm_nt_bf16x3_kernel4n<false>;
-        if (!f16) {
-          if (variant == 8) k41 = gemm_nt_bf16x3_kernel4n<false, 2>;
-          if (variant == 9) k41 = gemm_nt_bf16x3_kernel4n<false, 6>;
-          if (variant == 10) k41 = gemm_nt_bf16x3_kernel4n<false, 3, true>;
-          if (variant == 11) k41 = gemm_nt_bf16x3_kernel4n<false, 2, true>;
+        auto k41 = MS_BY_PREC(gemm_nt_bf16x3_kernel4n);
+        if (prec == PREC_BF16X3) {
+          if (variant == 8) k41 = gemm_nt_bf16x3_kernel4n<PREC_BF16X3, 2>;
+          if (variant == 9) k41 = gemm_nt_bf16x3_kernel4n<PREC_BF16X3, 6>;
+          if (variant == 10) k41 = gemm_nt_bf16x3_kernel4n<PREC_BF16X3, 3, true>;
+          if (variant == 11) k41 = gemm_nt_bf16x3_kernel4n<PREC_BF16X3, 2, true>;
         }
         hipLaunchKernelGGL(k41, dim3(cdiv(M, S2_M) * cdiv(N, 128)), dim3(256), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N,
                            act, lo, hi, m_eff);
         MS_LAUNCH_CHECK();
         return MS_OK;
       }
-      auto k4 = f16 ? gemm_nt_bf16x3_kernel4<true> : gemm_nt_bf16x3_kernel4<false>;
-      hipLaunchKernelGGL(k4, dim3(nwg2), dim3(512), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi, m_eff);
+      hipLaunchKernelGGL(MS_BY_PREC(gemm_nt_bf16x3_kernel4), dim3(nwg2), dim3(512), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act,
+                         lo, hi, m_eff);
       MS_LAUNCH_CHECK();
       return MS_OK;
     }
@@ -972,7 +978,8 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
       set_error("gemm_bf16x3_launch_rows: this shape does not run on the kernels that take the row count from the device");
       return MS_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(kern, dim3(nwg2), dim3(512), SPLIT2_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);
+    hipLaunchKernelGGL(MS_BY_PREC(gemm_nt_bf16x3_kernel2), dim3(nwg2), dim3(512), SPLIT2_LDS, stream, ah, al, wh, wl, bias, y, M, K, N,
+                       act, lo, hi);
     MS_LAUNCH_CHECK();
     return MS_OK;
   }
@@ -988,10 +995,14 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
     return MS_OK;
   }
   const int nwg = cdiv(M, SB_M) * cdiv(N, SB_N);
-  hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, dim3(nwg), dim3(256), SPLIT_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);
+  if (prec == PREC_F16X3)
+    hipLaunchKernelGGL(gemm_nt_bf16x3_kernel<true>, dim3(nwg), dim3(256), SPLIT_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);
+  else
+    hipLaunchKernelGGL(gemm_nt_bf16x3_kernel<false>, dim3(nwg), dim3(256), SPLIT_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }
+#undef MS_BY_PREC
 
 }  // namespace ms
 
@@ -1017,7 +1028,7 @@ extern "C" int ms_linear_split_pack(const float* w, void* packed, int K, int N, 
   MS_REQUIRE(K > 0 && N > 0 && K % 32 == 0, "bad shape (K must be a multiple of 32)");
   MS_REQUIRE(((uintptr_t)w & 15) == 0, "w must be 16-byte aligned");
   unsigned short* wh = (unsigned short*)packed;
-  const int prec = ms::precision_mode() == ms::PREC_F16 ? ms::PREC_F16 : ms::PREC_BF16X3;
+  const int prec = ms::split_mode();
   return ms::split_planes_launch(w, wh, wh + (size_t)N * K, (size_t)N * K, prec, (hipStream_t)stream_);
 }
 
@@ -1041,7 +1052,7 @@ extern "C" int ms_linear_split_forward_packed(const float* x, const void* packed
   unsigned short* xl = xh + (size_t)M * K;
   const unsigned short* wh = (const unsigned short*)packed_w;
   const unsigned short* wl = wh + (size_t)N * K;
-  const int prec = ms::precision_mode() == ms::PREC_F16 ? ms::PREC_F16 : ms::PREC_BF16X3;
+  const int prec = ms::split_mode();
   int rc = ms::split_planes_launch(x, xh, xl, (size_t)M * K, prec, stream);
   if (rc == MS_OK) rc = ms::gemm_bf16x3_launch(xh, xl, wh, wl, bias, y, M, K, N, act, act_lo, act_hi, prec, stream);
   return rc;
@@ -1065,7 +1076,7 @@ extern "C" int ms_linear_split_forward(const float* x, const float* w, const flo
   unsigned short* xl = xh + (size_t)M * K;
   unsigned short* wh = (unsigned short*)((char*)workspace + ms::align_up((size_t)M * K * 4, 256));
   unsigned short* wl = wh + (size_t)N * K;
-  const int prec = ms::precision_mode() == ms::PREC_F16 ? ms::PREC_F16 : ms::PREC_BF16X3;
+  const int prec = ms::split_mode();
   int rc = ms::split_planes_launch(x, xh, xl, (size_t)M * K, prec, stream);
   if (rc == MS_OK) rc = ms::split_planes_launch(w, wh, wl, (size_t)N * K, prec, stream);
   if (rc == MS_OK) rc = ms::gemm_bf16x3_launch(xh, xl, wh, wl, bias, y, M, K, N, act, act_lo, act_hi, prec, stream);

@@ -80,7 +80,7 @@ bool use_fast(int cell, int H, int ndir) {
   if (!(cell == MS_CELL_LSTM || cell == MS_CELL_HARD_LSTM)) return false;
   const int cus = ms::num_cus();
   if (H > 1024) {
-    if (!wide_lstm_h(H) || cell != MS_CELL_LSTM || ms::precision_mode() != ms::PREC_BF16X3) return false;
+    if (!wide_lstm_h(H) || cell != MS_CELL_LSTM || !(ms::precision_mode() == ms::PREC_BF16X3 || ms::precision_mode() == ms::PREC_F16X3)) return false;
     return cus > 0 && (H / 8) <= cus * std::min(1, persistent_blocks_per_cu(false));
   }
   if (H % 32 != 0) return false;
@@ -104,6 +104,11 @@ bool use_f32x2(int cell, int H, int ndir) {
 bool use_f16(int cell, int H, int ndir) {
   return ms::precision_mode() == ms::PREC_F16 && use_split(cell, H, ndir) && two_stream_shape(H);
 }
+// Plane format of a layer's split operands: one fp16 plane where MS_PRECISION=fp16 has a kernel for the shape; otherwise the
+// two-plane format of the mode -- fp16 pairs in the default f16x3 mode, bf16 pairs in bf16x3 mode (and, as before round 6, for
+// the layers MS_PRECISION=fp16 has no one-plane kernel for).
+int two_plane_mode() { return ms::precision_mode() == ms::PREC_F16X3 ? ms::PREC_F16X3 : ms::PREC_BF16X3; }
+int layer_prec(int cell, int H, int ndir) { return use_f16(cell, H, ndir) ? ms::PREC_F16 : two_plane_mode(); }
 // the input projection runs as the bf16x3 GEMM whenever the operands are split (every cell, also the streamed-weights
 // path) and In allows 16-byte granules
 bool use_split_gemm(int cell, int H, int ndir, int In) {
@@ -197,9 +202,10 @@ __global__ void pack_rows_fast_kernel(const float* __restrict__ w, float* __rest
 }
 
 // same row order, written as bf16 hi / lo planes (plane stride = rows_total * In elements)
-template <bool F16>
+template <int P>
 __global__ void pack_rows_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ hi,
                                        unsigned short* __restrict__ lo, int H, int In) {
+  constexpr bool F16 = ms::prec_one_plane(P), HM = P == ms::PREC_F16X3;
   const int row = blockIdx.x;
   const int j = row / 32, g = (row % 32) / 8, u = row % 8;
   const float* src = w + (size_t)(g * H + 8 * j + u) * In;
@@ -208,9 +214,10 @@ __global__ void pack_rows_split_kernel(const float* __restrict__ w, unsigned sho
     if (F16) {
       hi[(size_t)row * In + k] = __builtin_bit_cast(unsigned short, (_Float16)x);
     } else {
-      const __bf16 h = (__bf16)x;
-      hi[(size_t)row * In + k] = __builtin_bit_cast(unsigned short, h);
-      lo[(size_t)row * In + k] = __builtin_bit_cast(unsigned short, (__bf16)(x - (float)h));
+      unsigned hb, lb;
+      ms::plane_split<HM>(x, hb, lb);
+      hi[(size_t)row * In + k] = (unsigned short)hb;
+      lo[(size_t)row * In + k] = (unsigned short)lb;
     }
   }
 }
@@ -238,8 +245,9 @@ __global__ void pack_whh_fast_kernel(const float* __restrict__ w, float* __restr
 }
 
 // whh_s[j][plane][kg][r = g*8+u][e] (bf16) = hi / lo part of w_hh[g*H + 8j + u][8kg + e]
-template <bool F16>
+template <int P>
 __global__ void pack_whh_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int H) {
+  constexpr bool F16 = ms::prec_one_plane(P), HM = P == ms::PREC_F16X3;
   const size_t total = (size_t)4 * H * H;  // elements per plane
   const int KG = H / 8;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -254,10 +262,10 @@ __global__ void pack_whh_split_kernel(const float* __restrict__ w, unsigned shor
       dst[base] = __builtin_bit_cast(unsigned short, (_Float16)x);
       dst[base + (size_t)KG * 256] = 0;
     } else {
-      const __bf16 hi = (__bf16)x;
-      const __bf16 lo = (__bf16)(x - (float)hi);
-      dst[base] = __builtin_bit_cast(unsigned short, hi);
-      dst[base + (size_t)KG * 256] = __builtin_bit_cast(unsigned short, lo);
+      unsigned hb, lb;
+      ms::plane_split<HM>(x, hb, lb);
+      dst[base] = (unsigned short)hb;
+      dst[base + (size_t)KG * 256] = (unsigned short)lb;
     }
   }
 }
@@ -792,7 +800,8 @@ __global__ __launch_bounds__(256) void row_offsets_kernel(const int32_t* __restr
   }
 }
 
-// x f32 [steps][N][In] -> bf16 hi / lo planes of the rows that exist, packed (split_planes_kernel's arithmetic)
+// x f32 [steps][N][In] -> hi / lo planes of the rows that exist, packed (split_planes_kernel's arithmetic)
+template <bool HM>
 __global__ __launch_bounds__(256) void split_planes_packed_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi,
                                                                   unsigned short* __restrict__ lo,
                                                                   const int32_t* __restrict__ lens,
@@ -806,10 +815,7 @@ __global__ __launch_bounds__(256) void split_planes_packed_kernel(const float* _
     const float f[4] = {v.x, v.y, v.z, v.w};
     unsigned h[4], l[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      h[e] = bf16_bits(f[e]);
-      l[e] = bf16_bits(f[e] - bf16_val(h[e]));
-    }
+    for (int e = 0; e < 4; ++e) ms::plane_split<HM>(f[e], h[e], l[e]);
     *reinterpret_cast<uint2*>(hi + dst + 4 * k) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
     *reinterpret_cast<uint2*>(lo + dst + 4 * k) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
   }
@@ -877,17 +883,19 @@ __device__ __forceinline__ unsigned row_shl(unsigned v) {
 }
 typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 
-// F16: the hi plane carries tagged fp16 values and the lo plane is not used.
-template <bool F16 = false>
+// P = PREC_F16: the hi plane carries tagged fp16 values and the lo plane is not used.  PREC_F16X3: both planes fp16 (the
+// tagged hi's lost bit is recovered by lo, lo's own costs 2^-11 of lo = ~2^-22 of h).  h is a cell output: |h| <= 1.
+template <int P = ms::PREC_BF16X3>
 __device__ __forceinline__ void publish_split(float hval, unsigned tag, __amdgpu_buffer_rsrc_t rsrc, int off_hi, int off_lo,
                                               int lane, bool row_exists = true) {
+  constexpr bool F16 = ms::prec_one_plane(P), HM = P == ms::PREC_F16X3;
   unsigned hi, lo;
   if (F16) {
     hi = ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)hval) & 0xFFFEu) | tag;
     lo = 0u;
   } else {
-    hi = (bf16_bits(hval) & 0xFFFEu) | tag;
-    lo = (bf16_bits(hval - bf16_val(hi)) & 0xFFFEu) | tag;
+    hi = (ms::plane_bits<HM>(hval) & 0xFFFEu) | tag;
+    lo = (ms::plane_bits<HM>(hval - ms::plane_val<HM>(hi)) & 0xFFFEu) | tag;
   }
   const unsigned v = hi | (lo << 16);
   unsigned g[8];
@@ -907,8 +915,9 @@ __device__ __forceinline__ void publish_split(float hval, unsigned tag, __amdgpu
 
 // NCH > 0: the wave's K-quarter is NCH chunks of 4 k-steps (K = 64 each), all held in registers;
 // NCH == 0: any H % 64 == 0, one k-step at a time.
-template <int NB, int NCH, bool HARD, bool STAMP = false>
+template <int NB, int NCH, bool HARD, bool STAMP = false, bool HM = false>
 __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) {
+  constexpr int P = HM ? ms::PREC_F16X3 : ms::PREC_BF16X3;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = p.H, N = p.N, KG = H / 8;
   const char* Wbytes = reinterpret_cast<const char*>(smem);  // [hi|lo][KG][32][8 bf16]
@@ -941,7 +950,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) 
     c[b] = (valid && p.c0) ? p.c0[sidx] : 0.f;
     len_n[b] = valid ? (p.lens ? p.lens[p.n_base + n] : p.steps) : 0;
     const int off = epoch_par0(d, p.steps) * KG * p.NPAD * 16 + (j * p.NPAD + n) * 16;  // slot read by the first step
-    publish_split(h[b], epoch_tag0(d, p.steps), hx_rsrc, off, plane_bytes + off, lane);
+    publish_split<P>(h[b], epoch_tag0(d, p.steps), hx_rsrc, off, plane_bytes + off, lane);
   }
   __syncthreads();  // weights are in LDS
 
@@ -995,9 +1004,9 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) 
     auto mfma3 = [&](const u32x4& ah, const u32x4& al, int kg, f32x16& accb) {
       const u32x4 bh = *reinterpret_cast<const u32x4*>(Wbytes + (kg * 32 + l31) * 16);
       const u32x4 bl = *reinterpret_cast<const u32x4*>(Wbytes + KG * 512 + (kg * 32 + l31) * 16);
-      accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), accb, 0, 0, 0);
-      accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), accb, 0, 0, 0);
-      accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), accb, 0, 0, 0);
+      accb = ms::mfma_32x32x16<HM>(ah, bh, accb);
+      accb = ms::mfma_32x32x16<HM>(al, bh, accb);
+      accb = ms::mfma_32x32x16<HM>(ah, bl, accb);
     };
     auto give_up = [&]() -> bool {  // called while waiting; true = stop waiting for the rest of the launch
       if ((++spins & 63u) != 0) { __builtin_amdgcn_s_sleep(1); return false; }
@@ -1011,9 +1020,9 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) 
 
     if (NCH > 0) {
       auto mfma3r = [&](const u32x4& xh, const u32x4& xl, const u32x4& bh, const u32x4& bl, f32x16& accb) {
-        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xh), __builtin_bit_cast(bf16x8, bh), accb, 0, 0, 0);
-        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xl), __builtin_bit_cast(bf16x8, bh), accb, 0, 0, 0);
-        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xh), __builtin_bit_cast(bf16x8, bl), accb, 0, 0, 0);
+        accb = ms::mfma_32x32x16<HM>(xh, bh, accb);
+        accb = ms::mfma_32x32x16<HM>(xl, bh, accb);
+        accb = ms::mfma_32x32x16<HM>(xh, bl, accb);
       };
       u32x4 ah[NCH > 0 ? NCH : 1][4][NB], al[NCH > 0 ? NCH : 1][4][NB];
       auto issue = [&](int cidx, u32x4(&xh)[4][NB], u32x4(&xl)[4][NB]) {
@@ -1113,7 +1122,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) 
       h[b] = active ? hnew : h[b];
       hout[b] = active ? hnew : 0.f;
       const int off = (par ^ 1) * KG * p.NPAD * 16 + (j * p.NPAD + b * 32 + nl) * 16;
-      publish_split(h[b], wtag, hx_rsrc, off, plane_bytes + off, lane);
+      publish_split<P>(h[b], wtag, hx_rsrc, off, plane_bytes + off, lane);
     }
     if (STAMP) { const unsigned long long now = wall_clock64(); st_sum[2] += now - st_prev; st_prev = now; }
 #pragma unroll
@@ -1149,8 +1158,9 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split_kernel(LstmP p) 
 // H in {256, 512, 768, 1024}, N <= 32 per launch.  hx layout per direction: [stream][plane hi|lo][parity][k/8][16][8 bf16].
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int KS, bool HARD, bool STAMP = false, bool F16 = false>
+template <int KS, bool HARD, bool STAMP = false, int P = ms::PREC_BF16X3>
 __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p) {
+  constexpr bool F16 = ms::prec_one_plane(P), HM = P == ms::PREC_F16X3;
   constexpr int H = 128 * KS, KG = H / 8;  // KS k-steps (K = 32) per wave; H in {256, 512, 768, 1024, 1280, 1536, 2048}
   constexpr int RED2 = 4 * 16 * RED_STRIDE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1199,7 +1209,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
       c[sg] = (valid && p.c0) ? p.c0[sidx] : 0.f;
       len_n[sg] = valid ? (p.lens ? p.lens[p.n_base + n] : p.steps) : 0;
       const int off = sg * STREAM + epoch_par0(d, p.steps, rs) * KG * 256 + j * 256 + nl * 16;  // slot read by the first step
-      publish_split<F16>(h[sg], epoch_tag0(d, p.steps, rs), hx_rsrc, off, PLANE + off, lane);
+      publish_split<P>(h[sg], epoch_tag0(d, p.steps, rs), hx_rsrc, off, PLANE + off, lane);
     }
   }
   __syncthreads();
@@ -1281,18 +1291,14 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
           acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, __builtin_bit_cast(f16x8v, wh0[ks]), acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, __builtin_bit_cast(f16x8v, wh1[ks]), acc1, 0, 0, 0);
         } else {
-          const bf16x8 bh0 = __builtin_bit_cast(bf16x8, wh0[ks]);
-          const bf16x8 bh1 = __builtin_bit_cast(bf16x8, wh1[ks]);
-          const bf16x8 bl0 = __builtin_bit_cast(bf16x8, wl0[ks]);
-          const bf16x8 bl1 = __builtin_bit_cast(bf16x8, wl1[ks]);
-          const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]);
-          const bf16x8 xl = __builtin_bit_cast(bf16x8, al[ks]);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh0, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh1, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh0, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh1, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl0, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl1, acc1, 0, 0, 0);
+          const u32x4 bh0 = wh0[ks], bh1 = wh1[ks], bl0 = wl0[ks], bl1 = wl1[ks];
+          const u32x4 xh = ah[ks], xl = al[ks];
+          acc0 = ms::mfma_16x16x32<HM>(xh, bh0, acc0);
+          acc1 = ms::mfma_16x16x32<HM>(xh, bh1, acc1);
+          acc0 = ms::mfma_16x16x32<HM>(xl, bh0, acc0);
+          acc1 = ms::mfma_16x16x32<HM>(xl, bh1, acc1);
+          acc0 = ms::mfma_16x16x32<HM>(xh, bl0, acc0);
+          acc1 = ms::mfma_16x16x32<HM>(xh, bl1, acc1);
         }
       }
       if (STAMP) st_sum[1] += spins;   // slot 1: failed tag checks (repeated requests) of this stream-step, not a time
@@ -1329,7 +1335,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
         c[sg] = active ? cnew : c[sg];
         h[sg] = active ? hnew : h[sg];
         const int off = sg * STREAM + ec.wpar * KG * 256 + j * 256 + nl * 16;
-        publish_split<F16>(h[sg], wtag, hx_rsrc, off, PLANE + off, lane);
+        publish_split<P>(h[sg], wtag, hx_rsrc, off, PLANE + off, lane);
         if (n < N) {
           const size_t oidx = ((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit;
           const float ov = active ? hnew : 0.f;
@@ -1337,9 +1343,10 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
             if (F16) {
               p.out_hi[oidx] = __builtin_bit_cast(unsigned short, (_Float16)ov);
             } else {
-              const unsigned hb = bf16_bits(ov);
+              unsigned hb, lb;
+              ms::plane_split<HM>(ov, hb, lb);
               p.out_hi[oidx] = (unsigned short)hb;
-              p.out_lo[oidx] = (unsigned short)bf16_bits(ov - bf16_val(hb));
+              p.out_lo[oidx] = (unsigned short)lb;
             }
           } else {
             p.out[oidx] = ov;
@@ -1386,8 +1393,9 @@ constexpr int WIDE_RED2 = 8 * 16 * WIDE_RED_STRIDE;        // 8 waves x 16 rows,
 // stream-step on the cell and the publish before they request their own operands, waves 4-7 go straight from the barrier
 // to the next request and share the SIMDs' matrix pipes with them.
 // F16 (MS_PRECISION=fp16): one fp16 plane of W_hh and of h (the lo planes are neither loaded nor published), one MFMA pass.
-template <int KS, bool CELL, bool HARD, bool STAMP = false, bool PACKED = false, bool F16 = false>
+template <int KS, bool CELL, bool HARD, bool STAMP = false, bool PACKED = false, int P = ms::PREC_BF16X3>
 __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int k0, const int32_t* __restrict__ row_off) {
+  constexpr bool F16 = ms::prec_one_plane(P), HM = P == ms::PREC_F16X3;
   constexpr int H = 1024, KG = H / 8;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1447,7 +1455,7 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
       c[sg] = (valid && p.c0) ? p.c0[sidx] : 0.f;
       len_n[sg] = valid ? (p.lens ? p.lens[n_base + n] : p.steps) : 0;
       const int off = sg * STREAM + epoch_par0(d, p.steps, rs) * KG * 256 + jb * 256 + nl * 16;  // slot read by the first step
-      publish_split<F16>(h[sg], epoch_tag0(d, p.steps, rs), hx_rsrc, off, PLANE + off, lane, valid);
+      publish_split<P>(h[sg], epoch_tag0(d, p.steps, rs), hx_rsrc, off, PLANE + off, lane, valid);
     }
   }
   __syncthreads();
@@ -1515,20 +1523,16 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
           }
           return;
         }
-        const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[ks]);
-        const bf16x8 xl = __builtin_bit_cast(bf16x8, al[F16 ? 0 : ks]);
+        const u32x4 xh = ah[ks], xl = al[F16 ? 0 : ks];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          const bf16x8 bh0 = __builtin_bit_cast(bf16x8, wh[b][0][ks]);
-          const bf16x8 bh1 = __builtin_bit_cast(bf16x8, wh[b][1][ks]);
-          const bf16x8 bl0 = __builtin_bit_cast(bf16x8, wl[b][0][F16 ? 0 : ks]);
-          const bf16x8 bl1 = __builtin_bit_cast(bf16x8, wl[b][1][F16 ? 0 : ks]);
-          acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh0, acc[b][0], 0, 0, 0);
-          acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh1, acc[b][1], 0, 0, 0);
-          acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh0, acc[b][0], 0, 0, 0);
-          acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh1, acc[b][1], 0, 0, 0);
-          acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl0, acc[b][0], 0, 0, 0);
-          acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl1, acc[b][1], 0, 0, 0);
+          const u32x4 bh0 = wh[b][0][ks], bh1 = wh[b][1][ks], bl0 = wl[b][0][F16 ? 0 : ks], bl1 = wl[b][1][F16 ? 0 : ks];
+          acc[b][0] = ms::mfma_16x16x32<HM>(xh, bh0, acc[b][0]);
+          acc[b][1] = ms::mfma_16x16x32<HM>(xh, bh1, acc[b][1]);
+          acc[b][0] = ms::mfma_16x16x32<HM>(xl, bh0, acc[b][0]);
+          acc[b][1] = ms::mfma_16x16x32<HM>(xl, bh1, acc[b][1]);
+          acc[b][0] = ms::mfma_16x16x32<HM>(xh, bl0, acc[b][0]);
+          acc[b][1] = ms::mfma_16x16x32<HM>(xh, bl1, acc[b][1]);
         }
       };
       for (;;) {
@@ -1593,7 +1597,7 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
         c[sg] = active ? cnew : c[sg];
         h[sg] = active ? hnew : h[sg];
         const int off = sg * STREAM + ec.wpar * KG * 256 + jb * 256 + nl * 16;
-        publish_split<F16>(h[sg], wtag, hx_rsrc, off, PLANE + off, lane, n < N);
+        publish_split<P>(h[sg], wtag, hx_rsrc, off, PLANE + off, lane, n < N);
         if (n < N) {
           const size_t oidx = ((size_t)t * p.N_total + n_base + n) * (p.ndir * H) + d * H + unit;
           const float ov = active ? hnew : 0.f;
@@ -1605,9 +1609,10 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
             if (F16) {
               p.out_hi[pidx] = __builtin_bit_cast(unsigned short, (_Float16)ov);
             } else {
-              const unsigned hb = bf16_bits(ov);
+              unsigned hb, lb;
+              ms::plane_split<HM>(ov, hb, lb);
               p.out_hi[pidx] = (unsigned short)hb;
-              p.out_lo[pidx] = (unsigned short)bf16_bits(ov - bf16_val(hb));
+              p.out_lo[pidx] = (unsigned short)lb;
             }
           } else {
             p.out[oidx] = ov;
@@ -1633,13 +1638,13 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
   }
 }
 
-template <bool HARD, int KSC, bool STAMP = false, bool PACKED = false, bool F16 = false>
+template <bool HARD, int KSC, bool STAMP = false, bool PACKED = false, int P = ms::PREC_BF16X3>
 __global__ __launch_bounds__(512, 2) void lstm_persistent_wide2_kernel(LstmP p, const int32_t* __restrict__ row_off) {
   static_assert(KSC >= 1 && KSC <= 7, "both wave sets need at least one k-step");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wave < 4) wide2_wave<KSC, true, HARD, STAMP, PACKED, F16>(p, smem, wave * KSC, row_off);
-  else wide2_wave<8 - KSC, false, HARD, STAMP, false, F16>(p, smem, 4 * KSC + (wave - 4) * (8 - KSC), row_off);
+  if (wave < 4) wide2_wave<KSC, true, HARD, STAMP, PACKED, P>(p, smem, wave * KSC, row_off);
+  else wide2_wave<8 - KSC, false, HARD, STAMP, false, P>(p, smem, 4 * KSC + (wave - 4) * (8 - KSC), row_off);
 }
 
 
@@ -1866,14 +1871,15 @@ struct GruP {
   unsigned short* out_lo;
 };
 
+template <bool HM>
 __device__ __forceinline__ void publish_elem(float hval, unsigned tag, __amdgpu_buffer_rsrc_t rsrc, int off_hi, int off_lo) {
-  const unsigned hi = (bf16_bits(hval) & 0xFFFEu) | tag;
-  const unsigned lo = (bf16_bits(hval - bf16_val(hi)) & 0xFFFEu) | tag;
+  const unsigned hi = (ms::plane_bits<HM>(hval) & 0xFFFEu) | tag;
+  const unsigned lo = (ms::plane_bits<HM>(hval - ms::plane_val<HM>(hi)) & 0xFFFEu) | tag;
   __builtin_amdgcn_raw_buffer_store_b16((unsigned short)hi, rsrc, off_hi, 0, /*aux: sc1*/ 16);
   __builtin_amdgcn_raw_buffer_store_b16((unsigned short)lo, rsrc, off_lo, 0, /*aux: sc1*/ 16);
 }
 
-template <int KS, int U>
+template <int KS, int U, bool HM = false>
 __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
   constexpr int H = 128 * KS, KG = H / 8, CH = KS % 5 == 0 ? 5 : KS % 4 == 0 ? 4 : 3, NCH = KS / CH;
   static_assert(KS % CH == 0 && 3 * U <= 32 && 16 * U <= 256 && H % U == 0, "unsupported GRU tiling");
@@ -1925,7 +1931,7 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
       h[sg] = (valid && p.h0) ? p.h0[sidx] : 0.f;
       len_n[sg] = valid ? (p.lens ? p.lens[p.n_base + n] : p.steps) : 0;
       const int off = sg * STREAM + epoch_par0(d, p.steps, rs) * KG * 256 + elem_off;  // slot read by the first step
-      publish_elem(h[sg], epoch_tag0(d, p.steps, rs), hx_rsrc, off, PLANE + off);
+      publish_elem<HM>(h[sg], epoch_tag0(d, p.steps, rs), hx_rsrc, off, PLANE + off);
     }
   }
   __syncthreads();
@@ -1989,18 +1995,14 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
           const int ks = c * CH + i;
-          const bf16x8 bh0 = __builtin_bit_cast(bf16x8, wh0[ks]);
-          const bf16x8 bh1 = __builtin_bit_cast(bf16x8, wh1[ks]);
-          const bf16x8 bl0 = __builtin_bit_cast(bf16x8, wl0[ks]);
-          const bf16x8 bl1 = __builtin_bit_cast(bf16x8, wl1[ks]);
-          const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[buf][i]);
-          const bf16x8 xl = __builtin_bit_cast(bf16x8, al[buf][i]);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh0, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh1, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh0, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh1, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl0, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl1, acc1, 0, 0, 0);
+          const u32x4 bh0 = wh0[ks], bh1 = wh1[ks], bl0 = wl0[ks], bl1 = wl1[ks];
+          const u32x4 xh = ah[buf][i], xl = al[buf][i];
+          acc0 = ms::mfma_16x16x32<HM>(xh, bh0, acc0);
+          acc1 = ms::mfma_16x16x32<HM>(xh, bh1, acc1);
+          acc0 = ms::mfma_16x16x32<HM>(xl, bh0, acc0);
+          acc1 = ms::mfma_16x16x32<HM>(xl, bh1, acc1);
+          acc0 = ms::mfma_16x16x32<HM>(xh, bl0, acc0);
+          acc1 = ms::mfma_16x16x32<HM>(xh, bl1, acc1);
         }
       }
 
@@ -2028,14 +2030,15 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
         const bool active = t < len_n[sg];
         h[sg] = active ? hnew : h[sg];
         const int off = sg * STREAM + ec.wpar * KG * 256 + elem_off;
-        publish_elem(h[sg], wtag, hx_rsrc, off, PLANE + off);
+        publish_elem<HM>(h[sg], wtag, hx_rsrc, off, PLANE + off);
         if (n < N) {
           const size_t oidx = ((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit;
           const float ov = active ? hnew : 0.f;
           if (p.out_hi) {   // exactly split_planes_kernel's arithmetic
-            const unsigned hb = bf16_bits(ov);
+            unsigned hb, lb;
+            ms::plane_split<HM>(ov, hb, lb);
             p.out_hi[oidx] = (unsigned short)hb;
-            p.out_lo[oidx] = (unsigned short)bf16_bits(ov - bf16_val(hb));
+            p.out_lo[oidx] = (unsigned short)lb;
           } else {
             p.out[oidx] = ov;
           }
@@ -2053,6 +2056,7 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
 }
 
 // [d][j][plane][kg][32 rows][8]: row r < 3U is gate r / U of unit U*j + r % U, rows 3U..31 are zero
+template <bool HM>
 __global__ void pack_whh_gru_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int H, int U) {
   const int KG = H / 8, J = H / U;
   const size_t total = (size_t)J * KG * 256;  // elements per plane
@@ -2064,10 +2068,10 @@ __global__ void pack_whh_gru_kernel(const float* __restrict__ w, unsigned short*
     float x = 0.f;
     if (r < 3 * U) x = w[(size_t)((r / U) * H + U * j + r % U) * H + 8 * kg + e];
     const size_t base = (size_t)j * 2 * KG * 256 + ((size_t)kg * 32 + r) * 8 + e;
-    const __bf16 hi = (__bf16)x;
-    const __bf16 lo = (__bf16)(x - (float)hi);
-    dst[base] = __builtin_bit_cast(unsigned short, hi);
-    dst[base + (size_t)KG * 256] = __builtin_bit_cast(unsigned short, lo);
+    unsigned hb, lb;
+    ms::plane_split<HM>(x, hb, lb);
+    dst[base] = (unsigned short)hb;
+    dst[base + (size_t)KG * 256] = (unsigned short)lb;
   }
 }
 
@@ -2125,7 +2129,10 @@ int persistent_blocks_per_cu(bool gru) {
           {(const void*)lstm_persistent_split2_kernel<8, false>, red},
           {(const void*)lstm_persistent_split2_kernel<16, false>, red},
           {(const void*)lstm_persistent_split2_kernel<8, true>, red},
-          {(const void*)lstm_persistent_split2_kernel<8, false, false, true>, red},
+          {(const void*)lstm_persistent_split2_kernel<8, false, false, ms::PREC_F16>, red},
+          {(const void*)lstm_persistent_split2_kernel<8, false, false, ms::PREC_F16X3>, red},
+          {(const void*)lstm_persistent_split2_kernel<16, false, false, ms::PREC_F16X3>, red},
+          {(const void*)lstm_persistent_split_kernel<1, 4, false, false, true>, big},
           {(const void*)lstm_persistent_f32x2_kernel<16, false>, red},
           {(const void*)lstm_persistent_f32x2_kernel<16, true>, red}};
       nb = min_blocks_per_cu(ks, (int)(sizeof(ks) / sizeof(ks[0])));
@@ -2297,24 +2304,20 @@ extern "C" int ms_rnn_pack(int cell, int In, int H, int ndir, const float* const
       if (use_split_gemm(cell, H, ndir, In)) {
         unsigned short* hi0 = (unsigned short*)(base + L.wih);
         unsigned short* lo0 = hi0 + (size_t)ndir * GH * In;
-        if (use_f16(cell, H, ndir))
-          hipLaunchKernelGGL(pack_rows_split_kernel<true>, dim3(4 * H), dim3(128), 0, stream, w_ih[d],
-                             hi0 + (size_t)d * GH * In, lo0 + (size_t)d * GH * In, H, In);
-        else
-          hipLaunchKernelGGL(pack_rows_split_kernel<false>, dim3(4 * H), dim3(128), 0, stream, w_ih[d],
-                             hi0 + (size_t)d * GH * In, lo0 + (size_t)d * GH * In, H, In);
+        const int prec = layer_prec(cell, H, ndir);
+        auto kern = prec == ms::PREC_F16 ? pack_rows_split_kernel<ms::PREC_F16>
+                    : prec == ms::PREC_F16X3 ? pack_rows_split_kernel<ms::PREC_F16X3> : pack_rows_split_kernel<ms::PREC_BF16X3>;
+        hipLaunchKernelGGL(kern, dim3(4 * H), dim3(128), 0, stream, w_ih[d], hi0 + (size_t)d * GH * In, lo0 + (size_t)d * GH * In, H, In);
       } else {
         hipLaunchKernelGGL(pack_rows_fast_kernel, dim3(4 * H), dim3(128), 0, stream, w_ih[d], wih_d, H, In);
       }
       hipLaunchKernelGGL(pack_bias_fast_kernel, dim3(ms::cdiv(4 * H, 256)), dim3(256), 0, stream, bi, bh, bx_d, H);
-      if (use_split(cell, H, ndir))
-        if (use_f16(cell, H, ndir))
-          hipLaunchKernelGGL(pack_whh_split_kernel<true>, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d],
-                             (unsigned short*)whh_d, H);
-        else
-          hipLaunchKernelGGL(pack_whh_split_kernel<false>, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d],
-                             (unsigned short*)whh_d, H);
-      else if (use_f32x2(cell, H, ndir))
+      if (use_split(cell, H, ndir)) {
+        const int prec = layer_prec(cell, H, ndir);
+        auto kern = prec == ms::PREC_F16 ? pack_whh_split_kernel<ms::PREC_F16>
+                    : prec == ms::PREC_F16X3 ? pack_whh_split_kernel<ms::PREC_F16X3> : pack_whh_split_kernel<ms::PREC_BF16X3>;
+        hipLaunchKernelGGL(kern, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d], (unsigned short*)whh_d, H);
+      } else if (use_f32x2(cell, H, ndir))
         hipLaunchKernelGGL(pack_whh_f32x2_kernel, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d], whh_d, H);
       else
         hipLaunchKernelGGL(pack_whh_fast_kernel, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d], whh_d, H);
@@ -2326,7 +2329,7 @@ extern "C" int ms_rnn_pack(int cell, int In, int H, int ndir, const float* const
         unsigned short* hi0 = (unsigned short*)(base + L.wih);
         unsigned short* lo0 = hi0 + (size_t)ndir * GH * In;
         int rc = ms::split_planes_launch(w_ih[d], hi0 + (size_t)d * GH * In, lo0 + (size_t)d * GH * In, GH * In,
-                                         ms::PREC_BF16X3, stream);
+                                         two_plane_mode(), stream);
         if (rc != MS_OK) return rc;
       } else {
         hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH * In)), dim3(256), 0, stream, w_ih[d], wih_d, GH * In);
@@ -2335,8 +2338,8 @@ extern "C" int ms_rnn_pack(int cell, int In, int H, int ndir, const float* const
       if (use_gru_persistent(cell, H, ndir)) {
         const int U = gru_units(H);
         unsigned short* dst = (unsigned short*)(base + L.whh) + (size_t)d * (H / U) * 64 * H;
-        hipLaunchKernelGGL(pack_whh_gru_kernel, dim3(blocks_for((size_t)(H / U) * (H / 8) * 256)), dim3(256), 0, stream,
-                           w_hh[d], dst, H, U);
+        auto kern = two_plane_mode() == ms::PREC_F16X3 ? pack_whh_gru_kernel<true> : pack_whh_gru_kernel<false>;
+        hipLaunchKernelGGL(kern, dim3(blocks_for((size_t)(H / U) * (H / 8) * 256)), dim3(256), 0, stream, w_hh[d], dst, H, U);
       } else {
         hipLaunchKernelGGL(copy_or_zero_kernel, dim3(blocks_for(GH * H)), dim3(256), 0, stream, w_hh[d], whh_d, GH * H);
       }
@@ -2366,21 +2369,26 @@ static int launch_persistent(const LstmP& p, hipStream_t stream) {
   return MS_OK;
 }
 
-template <int NB, int NCH, bool HARD, bool STAMP = false>
-static int launch_split(const LstmP& p, hipStream_t stream) {
+template <int NB, int NCH, bool HARD, bool STAMP = false, bool HM = false>
+static int launch_split_hm(const LstmP& p, hipStream_t stream) {
   const size_t lds = ((size_t)p.H * 32 + RED_FLOATS) * sizeof(float);
   static ms::DeviceOnce attr_once;
   if (attr_once.need()) {
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_split_kernel<NB, NCH, HARD, STAMP>,
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_split_kernel<NB, NCH, HARD, STAMP, HM>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.done();
   }
-  hipLaunchKernelGGL((lstm_persistent_split_kernel<NB, NCH, HARD, STAMP>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((lstm_persistent_split_kernel<NB, NCH, HARD, STAMP, HM>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }
+template <int NB, int NCH, bool HARD, bool STAMP = false>
+static int launch_split(const LstmP& p, hipStream_t stream) {
+  return two_plane_mode() == ms::PREC_F16X3 ? launch_split_hm<NB, NCH, HARD, STAMP, true>(p, stream)
+                                            : launch_split_hm<NB, NCH, HARD, STAMP, false>(p, stream);
+}
 
-template <int KS, bool HARD, bool STAMP = false, bool F16 = false>
+template <int KS, bool HARD, bool STAMP = false, int P = ms::PREC_BF16X3>
 static int launch_split2(const LstmP& p, hipStream_t stream) {
   const size_t lds = (size_t)RED_FLOATS * sizeof(float);
   if (p.ndir * p.J > ms::num_cus()) {
@@ -2388,54 +2396,55 @@ static int launch_split2(const LstmP& p, hipStream_t stream) {
     for (int d = 0; d < p.ndir; ++d) {
       LstmP q = p;
       q.d_base = d;
-      hipLaunchKernelGGL((lstm_persistent_split2_kernel<KS, HARD, STAMP, F16>), dim3(p.J), dim3(256), lds, stream, q);
+      hipLaunchKernelGGL((lstm_persistent_split2_kernel<KS, HARD, STAMP, P>), dim3(p.J), dim3(256), lds, stream, q);
       MS_LAUNCH_CHECK();
     }
     return MS_OK;
   }
-  hipLaunchKernelGGL((lstm_persistent_split2_kernel<KS, HARD, STAMP, F16>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((lstm_persistent_split2_kernel<KS, HARD, STAMP, P>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }
 
 // wide workgroups (16 units, 8 waves), `groups` batch groups of <= 32 rows side by side in one launch
-static int launch_wide2(const LstmP& p, bool hard, int groups, bool f16, hipStream_t stream) {
+template <int P>
+static int launch_wide2_p(const LstmP& p, bool hard, int groups, hipStream_t stream) {
   const size_t lds = (size_t)2 * WIDE_RED2 * sizeof(float);
   static ms::DeviceOnce attr_once;
   if (attr_once.need()) {
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 3, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 4, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 2, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, false, false, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 3, false, false, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 4, false, false, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (P == ms::PREC_F16) {
+      MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 2, false, false, ms::PREC_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else {
+      MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 4, false, false, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, true, false, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, false, true, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<true, 3, false, true, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     attr_once.done();
   }
   const dim3 grid(groups * p.ndir * (p.J / 2));
-  if (f16) {   // MS_PRECISION=fp16: one fp16 plane of h (32 KB pulled per workgroup and stream-step) and one MFMA pass
+  if constexpr (P == ms::PREC_F16) {   // MS_PRECISION=fp16: one fp16 plane of h (32 KB pulled per workgroup and stream-step) and one MFMA pass
     // cell waves take MS_LSTM_WIDE_KSC_F16 of the 8 k-steps of a pair each (default 3, as in the bf16x3 form)
     static const int kf = getenv("MS_LSTM_WIDE_KSC_F16") ? atoi(getenv("MS_LSTM_WIDE_KSC_F16")) : 3;
-    if (hard) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 3, false, false, true>), grid, dim3(512), lds, stream, p, p.row_off);
-    else if (kf == 4) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 4, false, false, true>), grid, dim3(512), lds, stream, p, p.row_off);
-    else if (kf == 2) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 2, false, false, true>), grid, dim3(512), lds, stream, p, p.row_off);
-    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, false, false, true>), grid, dim3(512), lds, stream, p, p.row_off);
+    if (hard) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 3, false, false, P>), grid, dim3(512), lds, stream, p, p.row_off);
+    else if (kf == 4) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 4, false, false, P>), grid, dim3(512), lds, stream, p, p.row_off);
+    else if (kf == 2) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 2, false, false, P>), grid, dim3(512), lds, stream, p, p.row_off);
+    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, false, false, P>), grid, dim3(512), lds, stream, p, p.row_off);
     MS_LAUNCH_CHECK();
     return MS_OK;
-  }
+  } else {
   static const bool stamps = getenv("MS_LSTM_STAMPS") && getenv("MS_LSTM_STAMPS")[0] == '1';
   if (p.row_off != nullptr) {   // packed rows (ragged batch): xproj and the planes hold only the rows that exist
-    if (hard) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 3, false, true>), grid, dim3(512), lds, stream, p, p.row_off);
-    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, false, true>), grid, dim3(512), lds, stream, p, p.row_off);
+    if (hard) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 3, false, true, P>), grid, dim3(512), lds, stream, p, p.row_off);
+    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, false, true, P>), grid, dim3(512), lds, stream, p, p.row_off);
     MS_LAUNCH_CHECK();
     return MS_OK;
   }
   if (stamps && !hard) {   // diagnostic build (tools/wide_stamps.py): the shipped arithmetic with wall-clock stamps around its phases
-    hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, true>), grid, dim3(512), lds, stream, p, p.row_off);
+    hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, true, false, P>), grid, dim3(512), lds, stream, p, p.row_off);
     MS_LAUNCH_CHECK();
     return MS_OK;
   }
@@ -2443,14 +2452,20 @@ static int launch_wide2(const LstmP& p, bool hard, int groups, bool f16, hipStre
   // 3.1 for 2 / 6, which spills (profiles/r03z_*); MS_LSTM_WIDE_KSC=4 keeps the equal split for A/B runs
   static const int ksc = getenv("MS_LSTM_WIDE_KSC") ? atoi(getenv("MS_LSTM_WIDE_KSC")) : 3;
   if (hard) {
-    if (ksc == 4) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 4>), grid, dim3(512), lds, stream, p, p.row_off);
-    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 3>), grid, dim3(512), lds, stream, p, p.row_off);
+    if (ksc == 4) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 4, false, false, P>), grid, dim3(512), lds, stream, p, p.row_off);
+    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<true, 3, false, false, P>), grid, dim3(512), lds, stream, p, p.row_off);
   } else {
-    if (ksc == 4) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 4>), grid, dim3(512), lds, stream, p, p.row_off);
-    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3>), grid, dim3(512), lds, stream, p, p.row_off);
+    if (ksc == 4) hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 4, false, false, P>), grid, dim3(512), lds, stream, p, p.row_off);
+    else hipLaunchKernelGGL((lstm_persistent_wide2_kernel<false, 3, false, false, P>), grid, dim3(512), lds, stream, p, p.row_off);
   }
   MS_LAUNCH_CHECK();
   return MS_OK;
+  }
+}
+static int launch_wide2(const LstmP& p, bool hard, int groups, int prec, hipStream_t stream) {
+  if (prec == ms::PREC_F16) return launch_wide2_p<ms::PREC_F16>(p, hard, groups, stream);
+  if (prec == ms::PREC_F16X3) return launch_wide2_p<ms::PREC_F16X3>(p, hard, groups, stream);
+  return launch_wide2_p<ms::PREC_BF16X3>(p, hard, groups, stream);
 }
 
 // The wide-workgroup kernel serves H = 1024 bf16x3 layers of up to 64 sequences: one batch group of <= 32 rows on 128
@@ -2472,8 +2487,8 @@ bool use_wide(int cell, int H, int ndir, int N) {
   if (v == 0) {
     int nb = 0;
     const size_t lds = (size_t)2 * WIDE_RED2 * sizeof(float);
-    const bool fits = hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)lstm_persistent_wide2_kernel<false, 3>, 512, lds) == hipSuccess &&
+    const bool fits = hipFuncSetAttribute((const void*)lstm_persistent_wide2_kernel<false, 3, false, false, ms::PREC_F16X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)lstm_persistent_wide2_kernel<false, 3, false, false, ms::PREC_F16X3>, 512, lds) == hipSuccess &&
                       nb >= 1;
     v = fits ? 1 : 2;
     ok[dev & 63].store(v, std::memory_order_relaxed);
@@ -2499,26 +2514,29 @@ static int launch_f32x2_any(const LstmP& p, bool hard, hipStream_t stream) {
   }
 }
 
-static int launch_split2_any(const LstmP& p, bool hard, bool stamps, bool f16, hipStream_t stream) {
-  if (f16) {
-    switch (p.H) {
-      case 256: return hard ? launch_split2<2, true, false, true>(p, stream) : launch_split2<2, false, false, true>(p, stream);
-      case 512: return hard ? launch_split2<4, true, false, true>(p, stream) : launch_split2<4, false, false, true>(p, stream);
-      case 768: return hard ? launch_split2<6, true, false, true>(p, stream) : launch_split2<6, false, false, true>(p, stream);
-      default: return hard ? launch_split2<8, true, false, true>(p, stream) : launch_split2<8, false, false, true>(p, stream);
-    }
-  }
+template <int P>
+static int launch_split2_prec(const LstmP& p, bool hard, bool stamps, hipStream_t stream) {
   switch (p.H) {
-    case 256: return hard ? launch_split2<2, true>(p, stream) : launch_split2<2, false>(p, stream);
-    case 512: return hard ? launch_split2<4, true>(p, stream) : launch_split2<4, false>(p, stream);
-    case 768: return hard ? launch_split2<6, true>(p, stream) : launch_split2<6, false>(p, stream);
-    case 1280: return launch_split2<10, false>(p, stream);      // (use_fast admits the wide shapes for the plain LSTM cell only)
-    case 1536: return launch_split2<12, false>(p, stream);
-    case 2048: return launch_split2<16, false>(p, stream);
-    default:
-      if (stamps && !hard) return launch_split2<8, false, true>(p, stream);
-      return hard ? launch_split2<8, true>(p, stream) : launch_split2<8, false>(p, stream);
+    case 256: return hard ? launch_split2<2, true, false, P>(p, stream) : launch_split2<2, false, false, P>(p, stream);
+    case 512: return hard ? launch_split2<4, true, false, P>(p, stream) : launch_split2<4, false, false, P>(p, stream);
+    case 768: return hard ? launch_split2<6, true, false, P>(p, stream) : launch_split2<6, false, false, P>(p, stream);
+    default: break;
   }
+  if constexpr (P != ms::PREC_F16) {
+    switch (p.H) {
+      case 1280: return launch_split2<10, false, false, P>(p, stream);      // (use_fast admits the wide shapes for the plain LSTM cell only)
+      case 1536: return launch_split2<12, false, false, P>(p, stream);
+      case 2048: return launch_split2<16, false, false, P>(p, stream);
+      default: break;
+    }
+    if (stamps && !hard) return launch_split2<8, false, true, P>(p, stream);
+  }
+  return hard ? launch_split2<8, true, false, P>(p, stream) : launch_split2<8, false, false, P>(p, stream);
+}
+static int launch_split2_any(const LstmP& p, bool hard, bool stamps, int prec, hipStream_t stream) {
+  if (prec == ms::PREC_F16) return launch_split2_prec<ms::PREC_F16>(p, hard, stamps, stream);
+  if (prec == ms::PREC_F16X3) return launch_split2_prec<ms::PREC_F16X3>(p, hard, stamps, stream);
+  return launch_split2_prec<ms::PREC_BF16X3>(p, hard, stamps, stream);
 }
 
 // Does a layer of this kind hand its output to the next layer as GEMM operand planes inside the shared workspace
@@ -2622,11 +2640,12 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       unsigned short* xl = xh + (size_t)steps * N * In;
       const unsigned short* wh = (const unsigned short*)(pk + L.wih);
       const unsigned short* wl = wh + (size_t)ndir * GH * In;
-      const int prec = use_f16(cell, H, ndir) ? ms::PREC_F16 : ms::PREC_BF16X3;
+      const int prec = layer_prec(cell, H, ndir);
       if (x_in_ws) {
         rc = MS_OK;
       } else if (packed_rows) {
-        hipLaunchKernelGGL(split_planes_packed_kernel, dim3(steps * N), dim3(256), 0, stream, x, xh, xl, lens, row_off, N, In);
+        auto kern = prec == ms::PREC_F16X3 ? split_planes_packed_kernel<true> : split_planes_packed_kernel<false>;
+        hipLaunchKernelGGL(kern, dim3(steps * N), dim3(256), 0, stream, x, xh, xl, lens, row_off, N, In);
         rc = hipGetLastError() == hipSuccess ? MS_OK : MS_ERR_HIP;
       } else {
         rc = ms::split_planes_launch(x, xh, xl, (size_t)steps * N * In, prec, stream);
@@ -2702,7 +2721,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
           MS_LAUNCH_CHECK();
         }
         if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.row_off - W.dbg, stream));   // the stamp area only: row_off (packed rows) follows it
-        rc = launch_wide2(p, cell == MS_CELL_HARD_LSTM, groups, use_f16(cell, H, ndir), stream);
+        rc = launch_wide2(p, cell == MS_CELL_HARD_LSTM, groups, layer_prec(cell, H, ndir), stream);
         if (rc != MS_OK) return rc;
         break;
       }
@@ -2724,7 +2743,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
           }
         }
         if (two_stream) {
-          rc = launch_split2_any(p, hard_, stamps, use_f16(cell, H, ndir), stream);
+          rc = launch_split2_any(p, hard_, stamps, layer_prec(cell, H, ndir), stream);
         } else if (p.NPAD == 32 && H == 1024) {
           if (stamps && !hard_) rc = launch_split<1, 4, false, true>(p, stream);
           else rc = hard_ ? launch_split<1, 4, true>(p, stream) : launch_split<1, 4, false>(p, stream);
@@ -2797,7 +2816,10 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       const size_t lds = (size_t)RED_FLOATS * sizeof(float);
       switch (H) {
 #define MS_GRU_CASE(HH, KS_, U_) \
-        case HH: hipLaunchKernelGGL((gru_persistent_kernel<KS_, U_>), dim3(ndir * g.J), dim3(256), lds, stream, g); break;
+        case HH:                                                                                                         \
+          if (two_plane_mode() == ms::PREC_F16X3) hipLaunchKernelGGL((gru_persistent_kernel<KS_, U_, true>), dim3(ndir * g.J), dim3(256), lds, stream, g); \
+          else hipLaunchKernelGGL((gru_persistent_kernel<KS_, U_, false>), dim3(ndir * g.J), dim3(256), lds, stream, g);  \
+          break;
         MS_GRU_CASE(2560, 20, 10) MS_GRU_CASE(1280, 10, 10) MS_GRU_CASE(2048, 16, 8) MS_GRU_CASE(1536, 12, 8)
         MS_GRU_CASE(1024, 8, 8) MS_GRU_CASE(768, 6, 8) MS_GRU_CASE(512, 4, 8)
 #undef MS_GRU_CASE

@@ -33,3 +33,23 @@ def unragged(flat, lens):
 
 def golden_names(prefix):
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith(prefix) and f.endswith(".npz"))
+
+
+def apply_trained_gains(module, gains, fc_prefixes=("fully_connected",)):
+    """The weight scaling of the trained-scale fixtures (tests/golden/gen_golden.py::apply_trained_gains), on one of this
+    package's modules or on a plain {key: numpy array} state dict: rnn.weight_ih_* x gains['weight_ih'], rnn.weight_hh_* x
+    gains['weight_hh'], fully-connected weights x gains['fully_connected']; biases and convolutions untouched."""
+    items = module.items() if isinstance(module, dict) else module.state_dict().items()
+    for k, v in items:
+        if "weight_ih" in k:
+            g = gains["weight_ih"]
+        elif "weight_hh" in k:
+            g = gains["weight_hh"]
+        elif k.startswith(fc_prefixes) and k.endswith("weight"):
+            g = gains["fully_connected"]
+        else:
+            continue
+        if isinstance(v, np.ndarray):
+            v *= np.float32(g)
+        else:
+            v.mul_(g)
