@@ -57,21 +57,29 @@ PMC_PROFILE = os.path.join(ROOT, "profiles", "r05_pmc_bench.json")
 
 def precision_mode():
     m = os.environ.get("MS_PRECISION")
-    return m if m in ("f32", "fp16") else "bf16x3"
+    return m if m in ("f32", "fp16", "bf16x3") else "f16x3"
+
+
+def split2(mode=None):
+    """True in the two-plane split modes (three MFMA passes): f16x3 (default) and bf16x3."""
+    return (mode or precision_mode()) in ("f16x3", "bf16x3")
 
 
 def precision_label():
     """Arithmetic of the step, kept under 120 characters (the driver's record cuts strings there).  Default mode: every f32
     operand of the large contractions -- LSTM recurrence, input-projection GEMMs, conv1 (feature-window form), conv2
-    (channels-last) and the hidden FC layer -- is split into bf16 hi + lo and multiplied as hi*hi + lo*hi + hi*lo with f32
-    accumulation (model/cnn.py, model/fully_connected.py route by size); the output layer (29 columns), CTC and the
-    decoders are exact f32.  MS_PRECISION=f32 selects float32 MFMA everywhere."""
+    (channels-last) and the hidden FC layer -- is split into fp16 hi + lo (22 mantissa bits; bf16 pairs, 16 bits, with
+    MS_PRECISION=bf16x3: the default of rounds 1-5, which misses the 1e-3 gate on trained-scale weights) and multiplied as
+    hi*hi + lo*hi + hi*lo with f32 accumulation (model/cnn.py, model/fully_connected.py route by size); the output layer
+    (29 columns), CTC and the decoders are exact f32.  MS_PRECISION=f32 selects float32 MFMA everywhere."""
     mode = precision_mode()
     if mode == "f32":
         return "f32 (float32 MFMA everywhere; recurrent h crosses workgroups with its mantissa LSB as epoch tag)"
     if mode == "fp16":
         return "fp16 (one fp16 MFMA pass, f32 accumulate: LSTM, projections, conv2, FC1; optional mode outside the 1e-3 gate)"
-    return "bf16x3 (f32 split in bf16 hi+lo, 3 MFMA passes, f32 acc: LSTM, projections, conv1/2, FC1; FC2/CTC/decode f32)"
+    if mode == "bf16x3":
+        return "bf16x3 (f32 split in bf16 hi+lo, 3 MFMA passes, f32 acc: LSTM, projections, conv1/2, FC1; FC2/CTC/decode f32)"
+    return "f16x3 (f32 split in fp16 hi+lo, 3 fp16 MFMA passes, f32 acc: LSTM, projections, conv1/2, FC1; FC2/CTC/decode f32)"
 
 
 KERNEL_SOURCES = {"lstm": ("rnn.hip", "common.h"), "gemm_nt_bf16x3": ("gemm_split.hip", "common.h"),
@@ -354,8 +362,8 @@ def main(argv=None, runtime=None, json_fd=None):
                          "TwoBatchesInFlight (two streams, the next batch's projection GEMMs run beside this batch's "
                          "persistent recurrence; bit-identical results, per-batch latency of two batches); 1 = one batch "
                          "at a time.  The one-batch leg is always timed too (kernel durations / rooflines come from it)")
-    ap.add_argument("--precision", choices=["bf16x3", "f32", "fp16"], default=None,
-                    help="operand mode of the recurrence / projection kernels (default: MS_PRECISION or bf16x3); "
+    ap.add_argument("--precision", choices=["f16x3", "bf16x3", "f32", "fp16"], default=None,
+                    help="operand mode of the recurrence / projection kernels (default: MS_PRECISION or f16x3); "
                          "f32 = float32 MFMA everywhere")
     ap.add_argument("--gather-logits", action="store_true",
                     help="batched-decode path: all-gather every shard's logits (RCCL over xGMI) and decode the whole "
@@ -393,10 +401,10 @@ def main(argv=None, runtime=None, json_fd=None):
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     f32 = stream_fp16 = None
-    if world == 1 and "RANK" not in os.environ and precision_mode() == "bf16x3" and not args.no_f32_child:
+    if world == 1 and "RANK" not in os.environ and precision_mode() == "f16x3" and not args.no_f32_child:
         f32 = f32_child(args)          # before the first GPU call of this process
     gather1 = None
-    if world == 1 and "RANK" not in os.environ and precision_mode() == "bf16x3" and not args.no_legs:
+    if world == 1 and "RANK" not in os.environ and precision_mode() == "f16x3" and not args.no_legs:
         stream_fp16 = fp16_stream_child()
         gather1 = gather_one_rank_child(args)
 
@@ -683,7 +691,7 @@ def main(argv=None, runtime=None, json_fd=None):
         # ---- dominant kernel: the persistent recurrence (one launch = one layer, both directions, 501 steps)
         launch_bytes = T_OUT * 2 * LSTM_STEP_BYTES
         achieved = launch_bytes / (rec_ms * 1e-3) / 1e9 if rec_ms > 0 else 0.0
-        wide = mode == "bf16x3" and os.environ.get("MS_LSTM_WIDE") != "0"
+        wide = split2(mode) and os.environ.get("MS_LSTM_WIDE") != "0"
         kname = {"f32": "lstm_persistent_kernel" if os.environ.get("MS_LSTM_F32_ONE_STREAM") == "1"
                  else "lstm_persistent_f32x2_kernel"}.get(mode, "lstm_persistent_wide2_kernel" if wide else "lstm_persistent_split2_kernel")
         pmc_key = kname + ("@1group" if wide else "")
@@ -744,7 +752,7 @@ def main(argv=None, runtime=None, json_fd=None):
             roof["pmc_note"] = why
         # ---- second kernel: the input-projection GEMM at K = 2048 (layers 1..4): 3 bf16 MFMA passes in bf16x3 mode
         M, K, N = T_OUT * BATCH_PER_GPU, 2 * HIDDEN, 2 * 4 * HIDDEN
-        passes = {"bf16x3": 3, "fp16": 1, "f32": 1}[mode]
+        passes = {"f16x3": 3, "bf16x3": 3, "fp16": 1, "f32": 1}[mode]
         gname = "gemm_nt_f32_kernel" if mode == "f32" else "gemm_nt_bf16x3_kernel4"
         gemm = {"kernel": gname, "shape": f"M {M} x N {N} x K {K}", "kernel_note": "layers 2-5 of the stack", "bound": "mfma"}
         g_ms = gemm_k2048_ms

@@ -1110,3 +1110,187 @@ def gen_ds2_cfg2_trained_scale_summary():
 
 if __name__ == "__main__" and "cfg2trained" in sys.argv[1:]:
     gen_ds2_cfg2_trained_scale_summary()
+
+
+def _logit_stats(y, ol, blank=28):
+    valid = (torch.arange(y.shape[0])[:, None] < ol[None, :])
+    yv = y[valid]
+    dec = CTCGreedyDecoder(blank)(y, ol)
+    top2 = torch.topk(yv, 2, dim=1).values
+    return dict(logit_abs_mean=float(yv.abs().mean()), logit_abs_max=float(yv.abs().max()),
+                greedy_distinct_symbols=len({s for u in dec for s in u}),
+                top2_margin_median=float((top2[:, 0] - top2[:, 1]).median()),
+                top2_margin_min=float((top2[:, 0] - top2[:, 1]).min())), dec, valid
+
+
+# DS1: the three Linear layers in front of the BiLSTM compound into its input (a common gain of 3 saturates 87 % of its
+# gates: a nearly binary network), the two behind it set the logit scale -- separate gains
+DS1_TRAINED_GAINS = dict(weight_ih=12.0, weight_hh=2.0, fc_pre=2.0, fc_post=6.0)
+
+
+def apply_ds1_trained_gains(m, gains=DS1_TRAINED_GAINS):
+    """fc1 / fc2 / fc3 weights x gains['fc_pre'], fc4 / out weights x gains['fc_post'], the BiLSTM's (torch or Hard) weight_ih /
+    weight_hh x gains['weight_ih'] / gains['weight_hh']; biases untouched.  tests/util.py::apply_ds1_trained_gains is the twin."""
+    for k, v in m.state_dict().items():
+        if "weight_ih" in k:
+            v.mul_(gains["weight_ih"])
+        elif "weight_hh" in k:
+            v.mul_(gains["weight_hh"])
+        elif k.startswith(("fc1", "fc2", "fc3")) and k.endswith("weight"):
+            v.mul_(gains["fc_pre"])
+        elif k.startswith(("fc4", "out")) and k.endswith("weight"):
+            v.mul_(gains["fc_post"])
+
+
+def gen_ds1_cfg1_trained_scale_summary(gains=DS1_TRAINED_GAINS, save_it=True):
+    """BASELINE configs[0] (DS1 at the shipped width, gen_ds1_cfg1_summary's seeds and inputs) with trained-scale weights:
+    the five Linear layers x gains['fully_connected'] (they compound through the Hardtanh(0, 20) stack), the BiLSTM's
+    weight_ih / weight_hh as in config 2; both the torch-LSTM and the HardLSTM flavour; the float64 twin's logits beside
+    the float32 ones."""
+    for hard in (False, True):
+        def build():
+            torch.manual_seed(11 + hard)
+            m = DeepSpeech1(input_features=26, input_channels=19, n_hidden=1024, out_features=29, drop_prob=0.25,
+                            relu_clip=20.0, forget_gate_bias=1.0, hard_lstm=hard).eval()
+            apply_ds1_trained_gains(m, gains)
+            return m
+        m = build()
+        g = torch.Generator().manual_seed(99 + hard)
+        x1 = torch.randn(1, 19, 26, 201, generator=g)
+        x3 = torch.randn(3, 19, 26, 120, generator=g)
+        l3 = torch.tensor([120, 120, 120] if hard else [120, 77, 31], dtype=torch.int64)
+        (y1, o1), h1 = m((x1.clone(), torch.tensor([201])))
+        (y3, o3), h3 = m((x3.clone(), l3))
+        m64 = build().double()
+        (y1d, _), _ = m64((x1.double(), torch.tensor([201])))
+        (y3d, _), _ = m64((x3.double(), l3))
+        st1, d1_, v1 = _logit_stats(y1, o1)
+        st3, d3_, v3 = _logit_stats(y3, o3)
+        st1["ref_f32_vs_f64_max_abs"] = float((y1d - y1.double()).abs().max())
+        st3["ref_f32_vs_f64_max_abs"] = float((y3d - y3.double()).abs()[v3].max())
+        # share of the BiLSTM's gate pre-activations beyond |4| (torch-LSTM flavour: its input is fc3's output)
+        if not hard:
+            h = x1.view(1, 19 * 26, 201).permute(0, 2, 1)
+            for fc in (m.fc1, m.fc2, m.fc3):
+                h = fc(h)
+            st1["gate_share_beyond_4"] = lstm_gate_shares(m.bi_lstm.rnn, h.transpose(0, 1).contiguous(), torch.tensor([201]))[0]
+        print(f"DS1 hard={hard} clip: {json.dumps(st1)}\n   batch of 3: {json.dumps(st3)}")
+        if not save_it:
+            continue
+        f1, d1 = ragged(d1_)
+        f3, d3 = ragged(d3_)
+        chk = {k: float(v.double().abs().sum()) for k, v in m.state_dict().items()}
+        arrays = {"in/l3": npy(l3), "out/y1_sub": npy(y1[::5]), "out/y1d_sub": npy(y1d[::5]), "out/y3_sub": npy(y3[::4]),
+                  "out/y3d_sub": npy(y3d[::4]), "out/o3": npy(o3),
+                  "out/hn1_sub": npy(h1[0][:, :, ::32]), "out/cn3_sub": npy(h3[1][:, :, ::32]),
+                  "out/am1": npy(y1.argmax(-1).to(torch.int8)), "out/am3": npy(y3.argmax(-1).to(torch.int8)),
+                  "out/g1_flat": f1, "out/g1_lens": d1, "out/g3_flat": f3, "out/g3_lens": d3}
+        save("ds1_cfg1_hard_trained_summary" if hard else "ds1_cfg1_trained_summary",
+             dict(weight_abs_sums=chk, gains=gains, stats_clip=st1, stats_batch3=st3, seed_weights=11 + hard,
+                  seed_input=99 + hard, hard_lstm=hard), arrays)
+
+
+if __name__ == "__main__" and "ds1trained" in sys.argv[1:]:
+    gen_ds1_cfg1_trained_scale_summary(save_it="probe" not in sys.argv[1:])
+
+
+SHIPPED_TRAINED_GAINS = dict(weight_ih=8.0, weight_hh=2.0, fully_connected=6.0)
+
+
+def gen_ds2_shipped_trained_scale_summary(gains=SHIPPED_TRAINED_GAINS, save_it=True):
+    """The SHIPPED architecture (3 x GRU-2560 unidirectional + lookahead 80 + FC; gen_ds2_shipped_summary's seeds, input and
+    lengths) with trained-scale weights; the float64 twin's logits beside the float32 ones.  (GRU gates: r, z, n; the share of
+    pre-activations beyond |4| is not computed for the GRU -- the logit statistics and the twin distance are.)"""
+    def build():
+        torch.manual_seed(7)
+        cnn = torch.nn.Sequential(
+            MaskConv2d(1, 32, [41, 11], [2, 2], PaddingMode.SAME), act_wrap(0.0, 20.0),
+            MaskConv2d(32, 32, [21, 11], [2, 1], PaddingMode.SAME), act_wrap(0.0, 20.0),
+        )
+        rnn = RNN(RNNType.GRU, 640, 2560, num_layers=3, bidirectional=False)
+        la = torch.nn.Sequential(Lookahead(2560, 80), SeqLenWrapper(torch.nn.Identity(), torch.nn.Identity()))
+        fc = FullyConnected(2560, 29, 1, 1024, torch.nn.Hardtanh(0.0, 20.0))
+        m = DeepSpeech2(cnn, rnn, la, fc).eval()
+        apply_trained_gains(m, gains)
+        return m
+    m = build()
+    g = torch.Generator().manual_seed(4321)
+    N, T = 8, 401
+    x = torch.randn(N, 1, 80, T, generator=g)
+    lens = torch.sort(torch.randint(150, T + 1, (N,), generator=g), descending=True).values
+    lens[0] = T
+    (y, ol), hid = m((x.clone(), lens))
+    (yd, _), _ = build().double()((x.double(), lens))
+    st, dec, valid = _logit_stats(y, ol)
+    st["ref_f32_vs_f64_max_abs"] = float((yd - y.double()).abs()[valid].max())
+    print("shipped (trained scale):", json.dumps(st))
+    if not save_it:
+        return
+    flat, dl = ragged(dec)
+    chk = {k: float(v.double().abs().sum()) for k, v in m.state_dict().items()}
+    arrays = {"in/lens": npy(lens), "in/x_abs_sum": np.array(float(x.double().abs().sum())),
+              "out/lens": npy(ol), "out/y_sub": npy(y[::10, ::2, :]), "out/yd_sub": npy(yd[::10, ::2, :]),
+              "out/argmax": npy(y.argmax(-1).to(torch.int8)),
+              "out/hn_sub": npy(hid[:, :, ::64]), "out/greedy_flat": flat, "out/greedy_lens": dl}
+    save("ds2_shipped_trained_summary", dict(weight_abs_sums=chk, gains=gains, stats=st, seed_weights=7, seed_input=4321,
+                                             N=N, T=T), arrays)
+
+
+if __name__ == "__main__" and "shippedtrained" in sys.argv[1:]:
+    gen_ds2_shipped_trained_scale_summary(save_it="probe" not in sys.argv[1:])
+
+
+def gen_streaming_n64_trained_scale(gains=TRAINED_GAINS, save_it=True):
+    """BASELINE configs[4] (gen_streaming_n64: the config-2 network on 32-frame chunks, state threaded, 64 ragged utterances)
+    with config 2's trained-scale gains; the float64 twin run chunk by chunk the same way."""
+    def run(m, x, lens, N, T, chunk, dt):
+        outs, out_lens = [], torch.zeros(N, dtype=torch.int64)
+        hid, t0 = None, 0
+        final_h, final_c = torch.zeros(10, N, 1024, dtype=dt), torch.zeros(10, N, 1024, dtype=dt)
+        while t0 < T:
+            alive = int((lens > t0).sum())
+            if alive == 0:
+                break
+            xc = x[:alive, :, :, t0:t0 + chunk].clone()
+            lc = (lens[:alive] - t0).clamp(max=xc.shape[-1])
+            hx = None if hid is None else (hid[0][:, :alive].contiguous(), hid[1][:, :alive].contiguous())
+            (y, ol), hid = m((xc, lc), hx)
+            final_h[:, :alive] = hid[0]
+            final_c[:, :alive] = hid[1]
+            full = torch.zeros(y.shape[0], N, y.shape[2], dtype=dt)
+            full[:, :alive] = y
+            outs.append(full)
+            out_lens[:alive] += ol
+            t0 += chunk
+        return torch.cat(outs, 0), out_lens, final_h, final_c
+    m = build_cfg2_reference(0)
+    apply_trained_gains(m, gains)
+    g = torch.Generator().manual_seed(556)
+    N, T, chunk = 64, 192, 32
+    x = torch.randn(N, 1, 80, T, generator=g)
+    lens = torch.sort(torch.randint(20, T + 1, (N,), generator=g), descending=True).values
+    lens[0] = T
+    y, out_lens, fh, fc_ = run(m, x, lens, N, T, chunk, torch.float32)
+    m64 = build_cfg2_reference(0)
+    apply_trained_gains(m64, gains)
+    yd, _, _, _ = run(m64.double(), x.double(), lens, N, T, chunk, torch.float64)
+    # a chunk's block holds 16 output frames; utterance n's valid frames of block b are its first min(16, ol_n - 16 b)
+    blocks = y.shape[0] // 16
+    fr = torch.arange(16)[None, :, None] + 16 * torch.arange(blocks)[:, None, None]
+    valid = (fr < out_lens[None, None, :]).reshape(-1, N)
+    st = dict(logit_abs_mean=float(y[valid].abs().mean()), logit_abs_max=float(y[valid].abs().max()),
+              ref_f32_vs_f64_max_abs=float((yd - y.double()).abs()[valid].max()),
+              distinct_argmax_symbols=int(y[valid].argmax(-1).unique().numel()))
+    print("cfg5 N=64 (trained scale):", json.dumps(st))
+    if not save_it:
+        return
+    chk = {k: float(v.double().abs().sum()) for k, v in m.state_dict().items()}
+    arrays = {"in/lens": npy(lens), "out/y_sub": npy(y[::3, ::3, ::2]), "out/yd_sub": npy(yd[::3, ::3, ::2]), "out/lens": npy(out_lens),
+              "out/argmax": npy(y.argmax(-1).to(torch.int8)),
+              "out/hn_sub": npy(fh[:, ::3, ::64]), "out/cn_sub": npy(fc_[:, ::3, ::64])}
+    save("cfg5_stream_n64_trained_summary", dict(weight_abs_sums=chk, gains=gains, stats=st, seed_input=556, N=N, T=T, chunk_frames=chunk,
+                                                 y_abs_mean=float(y.abs().mean())), arrays)
+
+
+if __name__ == "__main__" and "stream64trained" in sys.argv[1:]:
+    gen_streaming_n64_trained_scale(save_it="probe" not in sys.argv[1:])

@@ -36,9 +36,17 @@ def _child(call: str, **env):
 
 
 # ----------------------------------------------------------------------------- configs[4]: streaming, batch 64
-def test_cfg5_streaming_batch64_bf16x3_vs_reference():
+def test_cfg5_streaming_batch64_default_mode_vs_reference():
     err = cfg_checks.stream64(atol=1e-3, check_argmax=True)
     assert err < 1e-4   # measured ~3e-7; the gate above is the north-star's 1e-3
+
+
+def test_cfg5_streaming_batch64_trained_scale_vs_reference():
+    """configs[4] on TRAINED-SCALE weights (tests/golden/cfg5_stream_n64_trained_summary.npz: config 2's gains, logits of mean
+    2.8 / max 15, 28 arg-max symbols; the reference run chunk by chunk with hx threaded): logits and final states within 1e-3
+    absolute, every frame's arg max equal.  The reference's own float32 rounding is 4.1e-4 from its float64 twin here."""
+    err = cfg_checks.stream64(atol=1e-3, check_argmax=True, name="cfg5_stream_n64_trained_summary")
+    print(f"cfg5 trained-scale max |logit err| {err:.3e}")
 
 
 def test_cfg5_streaming_batch64_fp16_mfma_in_subprocess():
@@ -233,6 +241,43 @@ def test_two_batches_in_flight_full_size_f32_mode_in_subprocess():
     bit-identical to the sequential run."""
     out = _child("pipeline_full_equal(4)", MS_PRECISION="f32")
     assert "two batches in flight == sequential run, 4 full-size batches, mode f32" in out
+
+
+# ----------------------------------------------------------------------------- configs[1] where a trained model lives (VERDICT r5 item 1)
+def test_cfg2_trained_scale_default_mode_vs_reference():
+    """Full-size config 2 with TRAINED-SCALE weights (tests/golden/ds2_cfg2_trained_summary.npz, made by the reference:
+    weight_ih x 16, weight_hh x 2, FC x 6 -- logits of mean 2.8 / max 17, 37 % of the LSTM gate pre-activations beyond |4|,
+    28 greedy symbols) in the DEFAULT arithmetic (f16x3): logits within the north-star's 1e-3 ABSOLUTE of the reference's
+    float32 outputs, (h_n, c_n) likewise, every frame's arg max and every greedy transcript bit-exact, CTCLoss within 1e-4,
+    the reference CTCBeamDecoder's transcripts on the encoder's own posteriors bit-exact.  The reference's own float32
+    rounding is 5.1e-4 away from its float64 twin on this fixture, so the gate is about as tight as a gate against a
+    float32 reference can be; measured 8.8e-4 (5.8e-4 against the float64 twin)."""
+    rec = cfg_checks.cfg2_trained(atol=1e-3, strict_transcripts=True)
+    assert rec["logit_err_vs_ref_f64"] < 1e-3
+
+
+def test_cfg2_trained_scale_f32_mode_in_subprocess():
+    """The same in ``MS_PRECISION=f32`` (float32 MFMA everywhere): measured 6.3e-4."""
+    out = _child("cfg2_trained(atol=1e-3, strict_transcripts=True)", MS_PRECISION="f32")
+    print([l for l in out.splitlines() if "cfg2 trained-scale" in l][-1])
+
+
+def test_cfg2_trained_scale_bf16x3_and_fp16_are_outside_the_gate_and_say_so():
+    """The finding that moved the default (rounds 1-5 shipped bf16x3): on trained-scale weights bf16 hi + lo operands are
+    7.7e-3 from the reference with 7 arg-max flips (margins up to 2.8e-3) and 4 of 32 greedy transcripts changed; one fp16
+    plane is 0.48 away.  Both modes remain selectable and are NOT parity modes: the test pins the order of magnitude of
+    their error so that a record quoting them cannot be mistaken for the gated arithmetic."""
+    import ast
+    for mode, lo, hi in (("bf16x3", 1e-3, 5e-2), ("fp16", 5e-2, 2.0)):
+        out = _child("cfg2_trained(atol=1e9, strict_transcripts=False)", MS_PRECISION=mode)
+        rec = ast.literal_eval([l for l in out.splitlines() if "cfg2 trained-scale" in l][-1].split("cfg2 trained-scale:", 1)[1].strip())
+        assert rec["mode"] == mode and lo < rec["logit_err_vs_ref_f32"] < hi, rec
+        print(mode, "logit err", rec["logit_err_vs_ref_f32"], "arg-max flips", rec["argmax_flips"], "transcripts differing",
+              rec["greedy_transcripts_differing"])
+
+
+def test_throughput_modes_and_shards_equal_one_batch_on_the_trained_scale_fixture():
+    cfg_checks.trained_modes_equal()
 
 
 # ----------------------------------------------------------------------------- configs[2]: the RCCL exchange step

@@ -477,7 +477,8 @@ def test_ds1_tiny_golden(name):
     np.testing.assert_allclose(cpu(hid[1]), g["out/cn"], **TOL)
 
 
-@pytest.mark.parametrize("name", ["ds1_cfg1_summary", "ds1_cfg1_hard_summary"])
+@pytest.mark.parametrize("name", ["ds1_cfg1_summary", "ds1_cfg1_hard_summary", "ds1_cfg1_trained_summary",
+                                  "ds1_cfg1_hard_trained_summary"])
 def test_ds1_shipped_width_vs_reference_summary(name):
     """BASELINE.json configs[0]: DS1 at the shipped width (n_hidden 1024, input [1, 19, 26, 201]) and a ragged batch of
     3, torch-LSTM and HardLSTM flavours; weights and inputs regenerated from the generator's seeds (checksums pinned),
@@ -489,6 +490,10 @@ def test_ds1_shipped_width_vs_reference_summary(name):
     torch.manual_seed(g.cfg["seed_weights"])
     m = DeepSpeech1(input_features=26, input_channels=19, n_hidden=1024, out_features=29, drop_prob=0.25,
                     relu_clip=20.0, forget_gate_bias=1.0, hard_lstm=hard).eval()
+    if "gains" in g.cfg:     # the *_trained_* twins: logits of mean ~3 / max ~14, ~45 % of the BiLSTM's gates beyond |4|
+        from util import apply_ds1_trained_gains
+        with torch.no_grad():
+            apply_ds1_trained_gains(m, g.cfg["gains"])
     for k, v in m.state_dict().items():
         assert abs(float(v.double().abs().sum()) - g.cfg["weight_abs_sums"][k]) <= 1e-6 * max(1.0, g.cfg["weight_abs_sums"][k]), k
     gen = torch.Generator().manual_seed(g.cfg["seed_input"])
@@ -505,7 +510,11 @@ def test_ds1_shipped_width_vs_reference_summary(name):
     dec = CTCGreedyDecoder(28)
     assert dec(y1, o1) == unragged(g["out/g1_flat"], g["out/g1_lens"])
     assert dec(y3, o3) == unragged(g["out/g3_flat"], g["out/g3_lens"])
-    print(f"{name}: max |logit err| {float(np.abs(cpu(y1[::5]) - g['out/y1_sub']).max()):.3e}")
+    if g.has("out/am1"):
+        assert np.array_equal(cpu(y1.argmax(-1))[:, 0], g["out/am1"][:, 0].astype(np.int64))
+    print(f"{name}: max |logit err| {float(np.abs(cpu(y1[::5]) - g['out/y1_sub']).max()):.3e}"
+          + (f" (vs the float64 twin {float(np.abs(cpu(y1[::5]) - g['out/y1d_sub']).max()):.3e}; the reference itself "
+             f"{g.cfg['stats_clip']['ref_f32_vs_f64_max_abs']:.3e})" if g.has("out/y1d_sub") else ""))
 
 
 # ----------------------------------------------------------------------------- CTC loss / greedy
@@ -743,13 +752,14 @@ def test_ds2_cfg2_full_size_vs_reference_summary():
     """BASELINE.json configs[1] at full size (32 x 1001 frames, 5xBiLSTM-1024): weights and
     inputs are regenerated from the seeds the golden generator used (weight checksums
     pinned), logits compared on the stored sub-grid within the north-star's 1e-3, greedy
-    transcripts bit-exact (default bf16x3 mode; the f32 twin runs in a child: test_gpu_configs.py)."""
+    transcripts bit-exact (default f16x3 mode; the f32 twin runs in a child: test_gpu_configs.py)."""
     import cfg_checks
     err = cfg_checks.cfg2_full(atol=1e-3)
     assert err < 1e-5   # measured 2.5e-7
 
 
-def test_ds2_shipped_architecture_full_width_vs_reference_summary():
+@pytest.mark.parametrize("name", ["ds2_shipped_summary", "ds2_shipped_trained_summary"])
+def test_ds2_shipped_architecture_full_width_vs_reference_summary(name):
     """The reference's SHIPPED config shape (2 x conv2d, 3 x GRU-2560 unidirectional, lookahead 80, FC 1 x 1024) at full
     width: weights and inputs regenerated from the golden generator's seeds (checksums pinned), logits on the stored
     sub-grid and the final hidden state within 1e-3 of the reference, greedy transcripts bit-exact.  Exercises the
@@ -761,7 +771,7 @@ def test_ds2_shipped_architecture_full_width_vs_reference_summary():
     from myrtlespeech_amd.model.rnn import RNN, RNNType
     from myrtlespeech_amd.model.seq_len_wrapper import SeqLenWrapper
     from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
-    g = Golden("ds2_shipped_summary")
+    g = Golden(name)
 
     def act():
         return SeqLenWrapper(torch.nn.Hardtanh(0.0, 20.0), torch.nn.Identity())
@@ -772,6 +782,10 @@ def test_ds2_shipped_architecture_full_width_vs_reference_summary():
     la = torch.nn.Sequential(Lookahead(2560, 80), SeqLenWrapper(torch.nn.Identity(), torch.nn.Identity()))
     fc = FullyConnected(2560, 29, 1, 1024, torch.nn.Hardtanh(0.0, 20.0))
     model = DeepSpeech2(cnn, rnn, la, fc).eval()
+    if "gains" in g.cfg:     # the trained-scale twin: GRU weight_ih x 8, weight_hh x 2, FC x 6 -> logits of mean 2.4, max 13
+        from util import apply_trained_gains
+        with torch.no_grad():
+            apply_trained_gains(model, g.cfg["gains"])
     for k, v in model.state_dict().items():
         assert abs(float(v.double().abs().sum()) - g.cfg["weight_abs_sums"][k]) <= 1e-6 * max(1.0, g.cfg["weight_abs_sums"][k]), k
     gen = torch.Generator().manual_seed(g.cfg["seed_input"])
@@ -787,7 +801,14 @@ def test_ds2_shipped_architecture_full_width_vs_reference_summary():
     np.testing.assert_allclose(cpu(hn[:, :, ::64]), g["out/hn_sub"], rtol=0, atol=1e-3)
     assert CTCGreedyDecoder(28)(y, ol) == unragged(g["out/greedy_flat"], g["out/greedy_lens"])
     err = float(np.abs(cpu(y[::10, ::2, :]) - g["out/y_sub"]).max())
-    print(f"shipped-architecture max |logit err| on the sub-grid: {err:.3e} (mean |logit| {float(g['out/y_abs_mean']):.3e})")
+    if g.has("out/argmax"):
+        am, ref = cpu(y.argmax(-1)), g["out/argmax"].astype(np.int64)
+        for n_ in range(N):
+            assert np.array_equal(am[:int(g["out/lens"][n_]), n_], ref[:int(g["out/lens"][n_]), n_]), n_
+        print(f"{name}: max |logit err| {err:.3e} (vs the float64 twin {float(np.abs(cpu(y[::10, ::2, :]) - g['out/yd_sub']).max()):.3e}; "
+              f"the reference itself {g.cfg['stats']['ref_f32_vs_f64_max_abs']:.3e}; mean |logit| {g.cfg['stats']['logit_abs_mean']:.2f})")
+    else:
+        print(f"shipped-architecture max |logit err| on the sub-grid: {err:.3e} (mean |logit| {float(g['out/y_abs_mean']):.3e})")
 
 
 # ----------------------------------------------------------------------------- streaming with carried context (a16)
@@ -909,7 +930,7 @@ def test_streaming_with_carried_context_shipped_architecture_vs_full_utterance_r
     from myrtlespeech_amd.model.seq_len_wrapper import SeqLenWrapper
     from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
     from myrtlespeech_amd.streaming import ChunkedDeepSpeech2
-    g = Golden("ds2_shipped_summary")
+    g = Golden(name)
 
     def act():
         return SeqLenWrapper(torch.nn.Hardtanh(0.0, 20.0), torch.nn.Identity())

@@ -350,3 +350,49 @@ def test_beam_oracle_config_size_vs_reference():
     want = unragged(g["out/plain_flat"], g["out/plain_lens"])
     got = O.ctc_beam_decode(x[:, 2:3], lens[2:3], 28, c["beam_width"], c["prune"])
     assert got == want[2:3]
+
+
+def test_oracles_vs_the_trained_scale_config2_fixture():
+    """Both CPU oracles (the numpy restatement and the stock-torch re-assembly that is bench.py's cpu_baseline) on two
+    utterances of the TRAINED-SCALE config-2 fixture (tests/golden/ds2_cfg2_trained_summary.npz, the reference with
+    weight_ih x 16 / weight_hh x 2 / FC x 6: saturated gates, logits of O(1 .. 10)): logits on the stored sub-grid within
+    1e-3 absolute (the reference's own float32 rounding is 5e-4 there), every frame's arg max and the greedy transcripts of
+    those utterances equal, the CTC loss of the fixture's targets within 1e-4, the prefix beam search on the ORACLE's own
+    posteriors of utterance 0 equal to the reference's transcript.  Weights are regenerated from seed 0 (checksums pinned)."""
+    import bench
+    from oracle import torch_cpu as TC
+    from util import apply_trained_gains
+    g = Golden("ds2_cfg2_trained_summary")
+    model = bench.build_model()
+    with torch.no_grad():
+        apply_trained_gains(model, g.cfg["gains"])
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    for k, v in sd.items():
+        want = g.cfg["weight_abs_sums"][k]
+        assert abs(float(np.abs(v.astype(np.float64)).sum()) - want) <= 1e-6 * max(1.0, want), k
+    gen = torch.Generator().manual_seed(g.cfg["seed_input"])
+    x = torch.randn(g.cfg["N"], 1, 80, g.cfg["T"], generator=gen)
+    lens = torch.sort(torch.randint(501, 1002, (g.cfg["N"],), generator=gen), descending=True).values
+    lens[0] = g.cfg["T"]
+    cfg = dict(convs=[dict(kind="conv2d", idx=0, stride=(2, 2), same=True, act=(0.0, 20.0)),
+                      dict(kind="conv2d", idx=2, stride=(2, 1), same=True, act=(0.0, 20.0))],
+               rnn=dict(kind=O.LSTM, hidden=1024, layers=5, bidirectional=True), lookahead=None,
+               fc=dict(n_hidden=1, act=(0.0, 20.0)))
+    sel = [0, 4]                                           # columns 0 and 1 of the stored [::25, ::4] sub-grid
+    want_dec = unragged(g["out/greedy_flat"], g["out/greedy_lens"])
+    for name, fwd in (("numpy", lambda: O.deep_speech_2_forward(x[sel].numpy(), lens[sel].numpy(), cfg, sd)[:2]),
+                      ("torch_cpu", lambda: TC.deep_speech_2_forward(x[sel].numpy(), lens[sel].numpy(), cfg, sd))):
+        y, ol = fwd()
+        np.testing.assert_array_equal(ol, g["out/lens"][sel])
+        np.testing.assert_allclose(y[::25], g["out/y_sub"][:, :2], rtol=0, atol=1e-3, err_msg=name)
+        for j, n in enumerate(sel):
+            assert np.array_equal(y[:ol[j], j].argmax(-1), g["out/argmax"][:ol[j], n].astype(np.int64)), name
+        assert O.ctc_greedy_decode(y, ol, 28) == [want_dec[n] for n in sel], name
+        loss = O.ctc_loss(y, ol, g["ctc/y"][sel], g["ctc/y_lens"][sel], blank=28, reduction="none")
+        np.testing.assert_allclose(loss, g["ctc/none"][sel], rtol=1e-4, err_msg=name)
+    # the reference beam search on the encoder's own posteriors: utterance 0 over its first 140 frames (beam/* entry 0)
+    e = np.exp(y[:, 0] - y[:, 0].max(-1, keepdims=True))
+    probs = (e / e.sum(-1, keepdims=True)).astype(np.float32)[:, None, :]
+    assert int(g["beam/utts"][0]) == 0
+    got = O.ctc_beam_decode(probs, np.array([int(g["beam/lens"][0])]), 28, 8, prune_threshold=0.001)
+    assert got == unragged(g["beam/flat"], g["beam/out_lens"])[:1]

@@ -53,3 +53,17 @@ def apply_trained_gains(module, gains, fc_prefixes=("fully_connected",)):
             v *= np.float32(g)
         else:
             v.mul_(g)
+
+
+def apply_ds1_trained_gains(module, gains):
+    """tests/golden/gen_golden.py::apply_ds1_trained_gains: fc1-3 weights x fc_pre, fc4 / out weights x fc_post, BiLSTM
+    weight_ih / weight_hh x their gains."""
+    for k, v in module.state_dict().items():
+        if "weight_ih" in k:
+            v.mul_(gains["weight_ih"])
+        elif "weight_hh" in k:
+            v.mul_(gains["weight_hh"])
+        elif k.startswith(("fc1", "fc2", "fc3")) and k.endswith("weight"):
+            v.mul_(gains["fc_pre"])
+        elif k.startswith(("fc4", "out")) and k.endswith("weight"):
+            v.mul_(gains["fc_post"])

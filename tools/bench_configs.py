@@ -411,7 +411,7 @@ def leg_stream(ctx, chunks=16):
     ms = 0.5 * (samples[len(samples) // 2 - 1] + samples[len(samples) // 2])
     per_chunk, per_chunk_wall = ms / chunks, wall / chunks
     mode = bench.precision_mode()
-    bpe = {"bf16x3": 4, "fp16": 2, "f32": 4}[mode]            # bytes per weight element as the kernels read it
+    bpe = {"f16x3": 4, "bf16x3": 4, "fp16": 2, "f32": 4}[mode]            # bytes per weight element as the kernels read it
     step_us = ctx.get("lstm_step_us_n64") or lstm_step_us(64)
     w_ih = [2 * 4096 * 640] + [2 * 4096 * 2048] * 4
     w_hh = 2 * 4096 * 1024
