@@ -930,7 +930,7 @@ def test_streaming_with_carried_context_shipped_architecture_vs_full_utterance_r
     from myrtlespeech_amd.model.seq_len_wrapper import SeqLenWrapper
     from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
     from myrtlespeech_amd.streaming import ChunkedDeepSpeech2
-    g = Golden(name)
+    g = Golden("ds2_shipped_summary")
 
     def act():
         return SeqLenWrapper(torch.nn.Hardtanh(0.0, 20.0), torch.nn.Identity())
