@@ -52,7 +52,7 @@ LSTM_STEP_FLOP = 2 * BATCH_PER_GPU * HIDDEN * 4 * HIDDEN            # 268.4 MFLO
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 / fp16 MFMA
 MFMA_F32_PEAK_TF = 157.3    # float32-input MFMA
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r05_pmc_bench.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r06_pmc_bench.json")
 
 
 def precision_mode():
@@ -87,7 +87,7 @@ KERNEL_SOURCES = {"lstm": ("rnn.hip", "common.h"), "gemm_nt_bf16x3": ("gemm_spli
 
 
 def source_sha16(names=None):
-    """Digests of the kernel source files the timed binary was built from ({file: sha16}); profiles/r05_pmc_bench.json
+    """Digests of the kernel source files the timed binary was built from ({file: sha16}); profiles/r06_pmc_bench.json
     records the digests its counters were taken on, so a stale counter file is detected instead of being quoted."""
     csrc = os.path.join(ROOT, "myrtlespeech_amd", "csrc")
     out = {}
@@ -104,13 +104,13 @@ def pmc_record(kernel_key):
         with open(PMC_PROFILE) as f:
             prof = json.load(f)
     except Exception:
-        return None, "profiles/r05_pmc_bench.json not found"
+        return None, "profiles/r06_pmc_bench.json not found"
     if prof.get("precision") != precision_mode():
         return None, f"counters were taken in {prof.get('precision')} mode"
     files = next((v for k, v in KERNEL_SOURCES.items() if kernel_key.startswith(k)), None)
     now = source_sha16(files)
     if any(prof.get("source_sha16", {}).get(f) != d for f, d in now.items()):
-        return None, f"{', '.join(now)} changed since the counter passes (profiles/r05_pmc_bench.json is stale for this kernel)"
+        return None, f"{', '.join(now)} changed since the counter passes (profiles/r06_pmc_bench.json is stale for this kernel)"
     rec = prof.get("kernels", {}).get(kernel_key)
     return (rec, None) if rec else (None, f"no counters for {kernel_key}")
 
@@ -626,11 +626,24 @@ def main(argv=None, runtime=None, json_fd=None):
         return {"min": round(v[0], 3), "median": round(v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2]), 3),
                 "max": round(v[-1], 3)}
 
-    spread["one_batch_ms_per_step"] = stats(one_elapsed / args.steps * 1e3,
-                                            [timed(lens_full, args.steps, False)["elapsed"] / args.steps * 1e3 for _ in range(reps)])
+    def more_regions(runner):
+        """`reps` further K-step regions of a leg; a failure in one of them degrades the spread to the regions that ran (the
+        first region -- `value` -- is already in hand) instead of losing the whole line."""
+        out = []
+        for _ in range(reps):
+            try:
+                out.append(timed(lens_full, args.steps, runner)["elapsed"] / args.steps * 1e3)
+            except Exception as e:  # noqa: BLE001
+                spread["error"] = f"{type(e).__name__}: {e}"[:200]
+                rt.synchronize()
+                break
+        return out
+
+    # both legs carry both statistics under parallel keys: the first region's mean (`value` / ms_per_step for the headline,
+    # config.one_batch_first_region_ms_per_step for the one-batch leg) and min / median / max over all regions
+    spread["one_batch_ms_per_step"] = stats(one_elapsed / args.steps * 1e3, more_regions(False))
     if pipelined:
-        spread["headline_ms_per_step"] = stats(elapsed / args.steps * 1e3,
-                                               [timed(lens_full, args.steps, headline)["elapsed"] / args.steps * 1e3 for _ in range(reps)])
+        spread["headline_ms_per_step"] = stats(elapsed / args.steps * 1e3, more_regions(headline))
     else:
         spread["headline_ms_per_step"] = spread["one_batch_ms_per_step"]
 
@@ -746,7 +759,7 @@ def main(argv=None, runtime=None, json_fd=None):
             roof["mfma_frac"] = round(rec["mfma_flop"] / (rec_ms * 1e-3) / 1e12 / mfma_peak, 4)
             roof["mfma_busy_frac_pmc"] = rec.get("mfma_busy_frac")
             roof["l2_hit_rate_pmc"] = rec.get("l2_hit_rate")
-            roof["pmc_source"] = "profiles/r05_pmc_bench.json (rocprofv3 --pmc passes over this bench, same kernel sources)"
+            roof["pmc_source"] = "profiles/r06_pmc_bench.json (rocprofv3 --pmc passes over this bench, same kernel sources)"
         else:
             roof["traffic"] = None
             roof["pmc_note"] = why
@@ -821,7 +834,10 @@ def main(argv=None, runtime=None, json_fd=None):
                        "ms_per_step_min": spread["headline_ms_per_step"]["min"],
                        "ms_per_step_median": spread["headline_ms_per_step"]["median"],
                        "ms_per_step_max": spread["headline_ms_per_step"]["max"],
-                       "one_batch_ms_per_step_min": spread["one_batch_ms_per_step"]["min"]},
+                       "one_batch_ms_per_step_min": spread["one_batch_ms_per_step"]["min"],
+                       # the second kernel's figures as scalars too (the nested `projection_gemm` object may be cut from the line)
+                       "projection_gemm_launch_ms": gemm.get("launch_ms"), "projection_gemm_frac": gemm.get("frac"),
+                       "recurrence_launch_ms": roof.get("launch_ms")},
             "timing": spread,
             "stages": {"one_batch": {k: round(one["per_step"][k], 3) for k in ("conv", "layout", "projection", "recurrence", "linear", "greedy")},
                        "headline": ({k: round((pair if headline is paired else two)["per_step"][k], 3)
@@ -901,6 +917,11 @@ def main(argv=None, runtime=None, json_fd=None):
                                       "f32_ms": (f32 or {}).get("ms_per_step"), "roofline_frac": roof["frac"],
                                       "cpu": compact(out.get("cpu_baseline", {}), ("value", "unit", "cores"))}
             out["legs"] = legs
+            # the box calibration as FLAT config scalars (the driver's record keeps scalars of `config`): a reader of
+            # BENCH_rNN.json can tell a slow box (these move with it) from a regression of the kernels (these do not)
+            cal = detail.get("calibration") or {}
+            for k_, v_ in cal.items():
+                out["config"]["calib_" + k_] = v_
         # the full record: a side file + stderr; stdout gets ONE line of numbers under LINE_LIMIT bytes
         full = json.dumps(out, indent=1, default=str)
         try:

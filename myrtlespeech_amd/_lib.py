@@ -143,9 +143,30 @@ def stream_ptr():
 
 
 def ptr(t):
-    """Device pointer of a tensor (None -> NULL)."""
+    """DEVICE pointer of a tensor (None -> NULL) for a C-ABI argument.  Every pointer of include/ms_hotpath.h is a device
+    pointer unless its name ends in ``_host`` and every kernel assumes dense storage, so anything else is refused HERE with an
+    exception: a host tensor's ``data_ptr()`` handed to a kernel is a GPU page fault that takes the whole process down (round
+    5: a test passed CPU tensors to ``run_layers``; the runtime aborted inside ``ms_rnn_status``), and a strided view would be
+    read as if it were dense."""
     if t is None:
         return c_void_p(0)
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"_lib.ptr: expected a torch.Tensor or None, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise ValueError(f"_lib.ptr: a {t.device.type} tensor (shape {tuple(t.shape)}) cannot be a device-pointer argument; "
+                         "move it to the GPU first (host buffers go through _lib.host_ptr)")
+    if not t.is_contiguous():
+        raise ValueError(f"_lib.ptr: tensor of shape {tuple(t.shape)} and strides {tuple(t.stride())} is not contiguous; the "
+                         "kernels read dense storage (call .contiguous())")
+    return c_void_p(t.data_ptr())
+
+
+def host_ptr(t):
+    """HOST pointer of a CPU tensor (None -> NULL): only for arguments whose name ends in ``_host`` in include/ms_hotpath.h."""
+    if t is None:
+        return c_void_p(0)
+    if not isinstance(t, torch.Tensor) or t.is_cuda or not t.is_contiguous():
+        raise ValueError("_lib.host_ptr: expected a contiguous CPU tensor")
     return c_void_p(t.data_ptr())
 
 

@@ -102,6 +102,12 @@ __device__ __forceinline__ unsigned plane_bits(float x) {
   if constexpr (HM) return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f));
   else return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x);
 }
+// (for values known to lie in the fp16 range -- a cell's h in [-1, 1]: no clamp on the recurrence's critical path)
+template <bool HM>
+__device__ __forceinline__ unsigned plane_bits_bounded(float x) {
+  if constexpr (HM) return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x);
+  else return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x);
+}
 template <bool HM>
 __device__ __forceinline__ float plane_val(unsigned bits) {
   if constexpr (HM) return (float)__builtin_bit_cast(_Float16, (unsigned short)bits);
@@ -112,6 +118,11 @@ template <bool HM>
 __device__ __forceinline__ void plane_split(float x, unsigned& hi, unsigned& lo) {
   hi = plane_bits<HM>(x);
   lo = plane_bits<HM>(x - plane_val<HM>(hi));
+}
+template <bool HM>
+__device__ __forceinline__ void plane_split_bounded(float x, unsigned& hi, unsigned& lo) {
+  hi = plane_bits_bounded<HM>(x);
+  lo = plane_bits_bounded<HM>(x - plane_val<HM>(hi));
 }
 template <bool HM>
 __device__ __forceinline__ f32x16 mfma_32x32x16(u32x4_ a, u32x4_ b, f32x16 c) {

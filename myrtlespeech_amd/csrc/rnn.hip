@@ -894,8 +894,8 @@ __device__ __forceinline__ void publish_split(float hval, unsigned tag, __amdgpu
     hi = ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)hval) & 0xFFFEu) | tag;
     lo = 0u;
   } else {
-    hi = (ms::plane_bits<HM>(hval) & 0xFFFEu) | tag;
-    lo = (ms::plane_bits<HM>(hval - ms::plane_val<HM>(hi)) & 0xFFFEu) | tag;
+    hi = (ms::plane_bits_bounded<HM>(hval) & 0xFFFEu) | tag;
+    lo = (ms::plane_bits_bounded<HM>(hval - ms::plane_val<HM>(hi)) & 0xFFFEu) | tag;
   }
   const unsigned v = hi | (lo << 16);
   unsigned g[8];
@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
               p.out_hi[oidx] = __builtin_bit_cast(unsigned short, (_Float16)ov);
             } else {
               unsigned hb, lb;
-              ms::plane_split<HM>(ov, hb, lb);
+              ms::plane_split_bounded<HM>(ov, hb, lb);
               p.out_hi[oidx] = (unsigned short)hb;
               p.out_lo[oidx] = (unsigned short)lb;
             }
@@ -1610,7 +1610,7 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
               p.out_hi[pidx] = __builtin_bit_cast(unsigned short, (_Float16)ov);
             } else {
               unsigned hb, lb;
-              ms::plane_split<HM>(ov, hb, lb);
+              ms::plane_split_bounded<HM>(ov, hb, lb);
               p.out_hi[pidx] = (unsigned short)hb;
               p.out_lo[pidx] = (unsigned short)lb;
             }
@@ -1873,8 +1873,8 @@ struct GruP {
 
 template <bool HM>
 __device__ __forceinline__ void publish_elem(float hval, unsigned tag, __amdgpu_buffer_rsrc_t rsrc, int off_hi, int off_lo) {
-  const unsigned hi = (ms::plane_bits<HM>(hval) & 0xFFFEu) | tag;
-  const unsigned lo = (ms::plane_bits<HM>(hval - ms::plane_val<HM>(hi)) & 0xFFFEu) | tag;
+  const unsigned hi = (ms::plane_bits_bounded<HM>(hval) & 0xFFFEu) | tag;
+  const unsigned lo = (ms::plane_bits_bounded<HM>(hval - ms::plane_val<HM>(hi)) & 0xFFFEu) | tag;
   __builtin_amdgcn_raw_buffer_store_b16((unsigned short)hi, rsrc, off_hi, 0, /*aux: sc1*/ 16);
   __builtin_amdgcn_raw_buffer_store_b16((unsigned short)lo, rsrc, off_lo, 0, /*aux: sc1*/ 16);
 }
@@ -2036,7 +2036,7 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
           const float ov = active ? hnew : 0.f;
           if (p.out_hi) {   // exactly split_planes_kernel's arithmetic
             unsigned hb, lb;
-            ms::plane_split<HM>(ov, hb, lb);
+            ms::plane_split_bounded<HM>(ov, hb, lb);
             p.out_hi[oidx] = (unsigned short)hb;
             p.out_lo[oidx] = (unsigned short)lb;
           } else {

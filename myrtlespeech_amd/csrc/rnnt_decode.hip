@@ -1984,7 +1984,12 @@ extern "C" int ms_rnnt_decode(const float* enc_p, const int32_t* lens, const flo
   MS_LAUNCH_CHECK();
   {
     const char* e = getenv("MS_RNNT_V2");
-    if (!(e && e[0] == '0') && H % 64 == 0 && J % 32 == 0 && (size_t)w * V1 * 4 + (size_t)V1 * 32 * 4 <= 48 * 1024)
+    // LDS of the re-cut sequence's two largest kernels, each against the 64 KB a launch gets without an attribute: the joint
+    // (static red[8][32][33] + zs[64][33] = 42 240 B, dynamic W_out slice V1 x 32 floats) and the round kernel (candidates
+    // w x V1 floats beside ~3 KB of static arrays).  Larger vocabularies take the round-4 sequence below.
+    constexpr size_t JOINT_STATIC_LDS = (8 * 32 * 33 + 64 * 33) * sizeof(float);
+    if (!(e && e[0] == '0') && H % 64 == 0 && J % 32 == 0 && JOINT_STATIC_LDS + (size_t)V1 * 32 * 4 <= 64 * 1024 &&
+        (size_t)w * V1 * 4 <= 48 * 1024)
       return beam2_decode(p, W, ws, embedding, w_ih, w_hh, b_ih, b_hh, w_pred, w_out, b_out, enc_p, out_idx, out_len, out_score, T,
                           N, V, D, H, L, J, w, max_symbols, s);
   }

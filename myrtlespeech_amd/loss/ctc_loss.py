@@ -79,6 +79,10 @@ class CTCLoss(torch.nn.Module):
         # like RNN.check_status: after every forward ask ms_ctc_status (a 4-byte read-back and a stream synchronisation)
         # whether a wave of the alpha pipeline timed out, and raise instead of handing back a NaN loss.  A caller that must
         # not synchronise sets it to False and calls ``status()`` when it reads the loss.
+        # COST in a training loop: one 4-byte device-to-host copy and a stream synchronisation per forward and
+        # another per backward -- the host cannot run ahead of the device across the loss.  A loop that reads ``loss.item()``
+        # every step synchronises there anyway; one that does not should set ``check_status = False`` and call ``status()``
+        # wherever it does read the loss (the time-out word is sticky: nothing is lost by asking later).
         self.check_status = True
 
     def status(self) -> None:

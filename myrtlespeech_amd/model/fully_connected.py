@@ -7,6 +7,7 @@ are parameter containers -- the forward pass runs each Linear (+ its clamp) as o
 MFMA GEMM with a fused epilogue (``ms_linear_forward``).
 """
 import os
+import threading
 from collections import OrderedDict
 from typing import List, Optional, Tuple, Union
 
@@ -44,7 +45,10 @@ _split_ws = OrderedDict()
 _SPLIT_WS_STREAMS = 4    # scratch buffers kept: the most recently used streams (a pipeline uses two)
 
 
-_graph_ws = None      # set while a HIP graph is being sized / captured (graph_scratch): that graph's own scratch
+# set while a HIP graph is being sized / captured (graph_scratch): that graph's own scratch.  Per THREAD: a capture on one host
+# thread must not redirect the scratch of linear layers another thread issues on another stream (a cross-stream
+# race on the operand planes)
+_graph_tls = threading.local()
 
 
 class graph_scratch:
@@ -56,15 +60,13 @@ class graph_scratch:
         self.ws = ws
 
     def __enter__(self):
-        global _graph_ws
-        self.prev = _graph_ws
+        self.prev = getattr(_graph_tls, "ws", None)
         if os.environ.get("MS_GRAPH_SCRATCH") != "0":      # (0: A/B runs -- the graphs record the per-stream LRU scratch as before)
-            _graph_ws = self.ws
+            _graph_tls.ws = self.ws
         return self.ws
 
     def __exit__(self, *exc):
-        global _graph_ws
-        _graph_ws = self.prev
+        _graph_tls.ws = self.prev
         return False
 
 
@@ -73,8 +75,9 @@ def _stream_workspace() -> "_lib.Workspace":
     later) or is no longer used loses its buffer once ``_SPLIT_WS_STREAMS`` other streams have come by.  Dropping an entry is
     safe while its stream still runs: the caching allocator hands a block allocated on stream S only to later allocations
     on S, i.e. behind the kernels that read it."""
-    if _graph_ws is not None:
-        return _graph_ws
+    graph_ws = getattr(_graph_tls, "ws", None)
+    if graph_ws is not None:
+        return graph_ws
     key = torch.cuda.current_stream().cuda_stream
     ws = _split_ws.get(key)
     if ws is None:

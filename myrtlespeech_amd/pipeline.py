@@ -113,7 +113,11 @@ class BatchesInFlight:
         self.streams = tuple(torch.cuda.Stream() for _ in range(depth))
         self.post = post
         self.pre = pre      # called with the batch index on the batch's stream before its forward is issued (e.g. to record an event)
-        self._stacks = [m for mod in self.models for m in mod.modules() if hasattr(m, "check_status") and hasattr(m, "_workspace")]
+        # the recurrent stacks (their workspaces carry ms_rnn_status's sticky word) -- by TYPE: a wrapped model that contains its
+        # loss would otherwise hand the CTC workspace to ms_rnn_status (CTCLoss has check_status and _workspace too)
+        from myrtlespeech_amd.model.hard_lstm import HardLSTM
+        from myrtlespeech_amd.model.rnn import RNN
+        self._stacks = [m for mod in self.models for m in mod.modules() if isinstance(m, (RNN, HardLSTM))]
         self._n_caller_stacks = len(self._stacks) // depth
 
     def __call__(self, batches: Sequence) -> List:

@@ -574,7 +574,12 @@ class GraphedForward:
         same = lens_h.numel() > 0 and bool((lens_h == lens_h[0]).all())
         if not same or self.graph_error is not None or _pipeline_running():
             return self.model((x, lens), hx)
-        sig = tuple((p_.data_ptr(), _lib.version_of(p_)) for p_ in self.model.parameters())
+        # what a captured graph froze besides the shapes: the parameters (pointer + version) and every module's call-site
+        # switches that select kernels (DeepSpeech1.few_rows, RNN.inplace_state / check_status: ADVICE r5 -- flipping
+        # few_rows after a capture kept replaying the old choice)
+        sig = (tuple((p_.data_ptr(), _lib.version_of(p_)) for p_ in self.model.parameters()),
+               tuple((n_, getattr(m_, a_)) for n_, m_ in self.model.named_modules() for a_ in ("few_rows", "inplace_state")
+                     if hasattr(m_, a_)))
         if sig != self._sig:
             self._graphs.clear()
             self._sig = sig

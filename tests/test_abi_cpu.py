@@ -135,6 +135,26 @@ def test_no_cpu_fallback():
         CTCGreedyDecoder(0)(torch.zeros(3, 1, 2), torch.tensor([3]))
 
 
+def test_device_pointer_arguments_refuse_host_and_strided_tensors():
+    """``_lib.ptr`` turned any tensor's ``data_ptr()`` into a kernel argument -- a CPU tensor reached a
+    kernel as a device pointer (GPU page fault, process abort).  It now raises instead; ``host_ptr`` is the explicit door for
+    the ``_host`` arguments."""
+    from myrtlespeech_amd import _lib
+    assert _lib.ptr(None).value in (None, 0)
+    with pytest.raises(ValueError, match="cannot be a device-pointer argument"):
+        _lib.ptr(torch.zeros(1))
+    with pytest.raises(TypeError):
+        _lib.ptr(np.zeros(1))
+    assert _lib.host_ptr(torch.zeros(4)).value
+    with pytest.raises(ValueError):
+        _lib.host_ptr(torch.zeros(4, 4)[:, 1])
+    if torch.cuda.is_available():
+        with pytest.raises(ValueError, match="not contiguous"):
+            _lib.ptr(torch.zeros(4, 4, device="cuda")[:, 1])
+        with pytest.raises(ValueError):
+            _lib.host_ptr(torch.zeros(4, device="cuda"))
+
+
 def test_levenshtein():
     from myrtlespeech_amd.post_process.utils import levenshtein
     from oracle.ds_oracle import levenshtein as ref

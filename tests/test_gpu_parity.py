@@ -147,7 +147,7 @@ def test_streamed_weights_step_kernel_vs_oracle(kind, H, N, T_, bidir, In):
 
 
 @pytest.mark.parametrize("kind,H,Hp", [("LSTM", 200, 256), ("LSTM", 1000, 1024), ("GRU", 800, 1024), ("GRU", 200, 512)])
-def test_any_hidden_size_runs_on_a_persistent_kernel(kind, H, Hp):
+def test_any_hidden_size_runs_on_a_persistent_kernel(kind, H, Hp, tmp_path):
     """hidden sizes without a persistent kernel (LSTM not a multiple of 64, GRU not one of the persistent
     widths) are padded with zero weights to the next width that has one.  The padded units stay EXACTLY zero (checked on the
     raw padded run), the padded run equals the per-step kernels within float32 rounding (they add the same products in another
@@ -194,7 +194,8 @@ def test_any_hidden_size_runs_on_a_persistent_kernel(kind, H, Hp):
     assert rcn is None or float(rcn[..., H:].abs().max()) == 0.0
     assert torch.equal(raw.view(T_, N, 2, Hp)[..., :H].reshape(T_, N, 2 * H), out)
     # against the per-step kernels (MS_RNN_PAD_HIDDEN=0 is read once per process: a child)
-    np.savez("/tmp/pad_in_%d.npz" % H, x=x, lens=lens, h0=h0)
+    f_in, f_out = str(tmp_path / "pad_in.npz"), str(tmp_path / "pad_out.npy")      # (per test case: parametrisations share H)
+    np.savez(f_in, x=x, lens=lens, h0=h0)
     code = (
         "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
         "from myrtlespeech_amd.model.rnn import RNN, RNNType\n"
@@ -203,10 +204,10 @@ def test_any_hidden_size_runs_on_a_persistent_kernel(kind, H, Hp):
         "hx = (hx, hx * 0.5) if %r == 'LSTM' else hx\n"
         "(o, _), _ = m((torch.tensor(d['x']).cuda(), torch.tensor(d['lens'])), hx); np.save(sys.argv[2], o.cpu().numpy())\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), H, kind, In, H, kind)
-    child = subprocess.run([sys.executable, "-c", code, "/tmp/pad_in_%d.npz" % H, "/tmp/pad_out_%d.npy" % H],
+    child = subprocess.run([sys.executable, "-c", code, f_in, f_out],
                            env=dict(os.environ, MS_RNN_PAD_HIDDEN="0"), capture_output=True, text=True, timeout=600)
     assert child.returncode == 0, child.stderr[-2000:]
-    np.testing.assert_allclose(cpu(out), np.load("/tmp/pad_out_%d.npy" % H), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(cpu(out), np.load(f_out), rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("cin,cout,k,s,d,T_", [(80, 512, 11, 2, 1, 1001), (512, 256, 11, 1, 1, 501), (96, 64, 5, 3, 2, 700),
@@ -1394,7 +1395,10 @@ def test_rnnt_greedy_event_driven_decode_vs_oracle(ms, blank_bias, seed):
 
 
 @pytest.mark.parametrize("V,w,ms,N,steps,seed", [(4, 8, 3, 4, 24, 0), (11, 1, 2, 2, 12, 1), (6, 5, 4, 3, 10, 2),
-                                                 (28, 8, 3, 2, 8, 3), (3, 16, 2, 2, 16, 4)])
+                                                 (28, 8, 3, 2, 8, 3), (3, 16, 2, 2, 16, 4),
+                                                 # vocabularies around the re-cut sequence's LDS gate (V + 1 <= 182): the last
+                                                 # one it serves, the first one that takes the round-4 sequence, and a BPE-sized one
+                                                 (181, 4, 2, 2, 8, 5), (182, 4, 2, 2, 8, 6), (255, 4, 2, 2, 6, 7)])
 def test_rnnt_device_decode_sweep(V, w, ms, N, steps, seed):
     """Small vocabularies force same-prefix merges of blank transitions (the trie / logaddexp path); ragged lengths
     including an empty utterance; every width / round count against the oracle, greedy as well."""

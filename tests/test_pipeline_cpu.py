@@ -84,7 +84,7 @@ def test_bench_refuses_a_stale_counter_profile(tmp_path, monkeypatch):
     import bench
     digests = bench.source_sha16()
     assert set(digests) >= {"rnn.hip", "gemm_split.hip", "common.h"}
-    prof = {"precision": "bf16x3", "source_sha16": dict(digests),
+    prof = {"precision": "f16x3", "source_sha16": dict(digests),
             "kernels": {"lstm_persistent_split2_kernel": {"hbm_bytes": 1, "mfma_flop": 2.0},
                         "gemm_nt_bf16x3_kernel4@K2048": {"hbm_bytes": 3, "mfma_flop": 4.0}}}
     path = tmp_path / "pmc.json"
@@ -106,8 +106,8 @@ def test_bench_refuses_a_stale_counter_profile(tmp_path, monkeypatch):
     assert bench.pmc_record("lstm_persistent_split2_kernel")[0] is None
     monkeypatch.delenv("MS_PRECISION")
     # the committed profile describes the committed sources
-    monkeypatch.setattr(bench, "PMC_PROFILE", os.path.join(ROOT, "profiles", "r05_pmc_bench.json"))
-    assert bench.pmc_record("lstm_persistent_wide2_kernel@1group")[1] is None, "profiles/r05_pmc_bench.json is stale: re-run tools/pmc_bench.sh"
+    monkeypatch.setattr(bench, "PMC_PROFILE", os.path.join(ROOT, "profiles", "r06_pmc_bench.json"))
+    assert bench.pmc_record("lstm_persistent_wide2_kernel@1group")[1] is None, "profiles/r06_pmc_bench.json is stale: re-run tools/pmc_bench.sh"
     assert bench.pmc_record("gemm_nt_bf16x3_kernel4@K2048")[1] is None
 
 

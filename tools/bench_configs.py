@@ -536,10 +536,49 @@ LEGS = {"ds1": ("cfg1_ds1", leg_ds1), "ctc": ("ctc_loss", leg_ctc_loss), "ctcgra
         "frontend": ("frontend", leg_frontend)}
 
 
+def shader_clock_under_projection_ghz():
+    """The shader clock the chip sustains under the projection GEMM (16 032 x 8 192 x 2 048, the process's split mode), sampled
+    by one wave on a stream of its own (ms_clock_probe: {100 MHz wall ticks, shader cycles} every 20 us; tools/clock_probe.py):
+    the mean over 0.5 .. 4.5 ms of ~6 ms of back-to-back launches.  A box calibration figure: the GEMM is clock-capped, so a
+    slow box shows here (and in lstm_step_us_*) while a regression of the kernels does not."""
+    lib = _lib.load()
+    M, K, NN = 501 * 32, 2048, 8192
+    xa = torch.randn(M, K, device="cuda")
+    w = torch.randn(NN, K, device="cuda") * 0.02
+    y = torch.empty(M, NN, device="cuda")
+    ws = torch.empty(lib.ms_linear_split_workspace_bytes(M, K, NN), dtype=torch.uint8, device="cuda")
+    samples, spacing = 300, 20
+    buf = torch.zeros(2 * samples, dtype=torch.int64, device="cuda")
+    side, probe = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(2):
+        torch.cuda.synchronize()
+        go = torch.cuda.Event()
+        go.record()
+        with torch.cuda.stream(probe):
+            probe.wait_event(go)
+            _lib.check(lib.ms_clock_probe(_lib.ptr(buf), samples, spacing, _lib.stream_ptr()), "ms_clock_probe")
+        with torch.cuda.stream(side):
+            side.wait_event(go)
+            for _ in range(5):
+                _lib.check(lib.ms_linear_split_forward(_lib.ptr(xa), _lib.ptr(w), None, _lib.ptr(y), M, K, NN, 0, 0.0, 0.0, _lib.ptr(ws),
+                                                       ws.numel(), _lib.stream_ptr()), "ms_linear_split_forward")
+        torch.cuda.synchronize()
+    b = buf.cpu().view(samples, 2).double()
+    dt = b[1:, 0] - b[:-1, 0]
+    clk = (b[1:, 1] - b[:-1, 1]) / dt * 0.1
+    t_ms = (b[1:, 0] - b[0, 0]) / 1e5
+    busy = clk[(t_ms > 0.5) & (t_ms < 4.5)]
+    return float(busy.mean()) if busy.numel() else float("nan")
+
+
 def context(cpu=True, which=None):
     """The per-process calibration figures the floors are built from."""
     ctx = {"cpu": cpu, "cores": host_threads() if cpu else 0}
     ctx["barrier_step_us"] = barrier_step_us()
+    try:
+        ctx["shader_clock_under_gemm_ghz_us_"] = shader_clock_under_projection_ghz()     # ("_us_": kept by run_legs' calibration filter)
+    except Exception:  # noqa: BLE001 -- a calibration figure, never a reason to lose the legs
+        pass
     which = which or set(LEGS)
     if "ds1" in which:
         ctx["lstm_step_us_n1"] = lstm_step_us(1, 201)
@@ -555,7 +594,7 @@ def run_legs(which, cpu=True):
         ctx = context(cpu, set(which))
     except Exception as e:  # noqa: BLE001
         return {"error": f"calibration failed: {type(e).__name__}: {e}"[:300]}
-    out["calibration"] = {k: round(v, 4) for k, v in ctx.items() if k.endswith("_us") or "_us_" in k}
+    out["calibration"] = {k.replace("_ghz_us_", "_ghz"): round(v, 4) for k, v in ctx.items() if k.endswith("_us") or "_us_" in k}
     for key in which:
         name, fn = LEGS[key]
         try:
