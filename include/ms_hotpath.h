@@ -42,14 +42,18 @@
 extern "C" {
 #endif
 
-/* 3 (round 5): ms_ctc_status, ms_rnn_padded_hidden and ms_rnn_hx_preinit (+ MS_RNN_HX_PREINIT, exchange regions) are new; the CTC workspaces start with a 256-byte status region;
+/* 4 (round 6): MS_PRECISION's default is "f16x3" (fp16 hi + lo operand planes, three fp16 MFMAs; "bf16x3" selects the bf16
+ * pairs of versions 1-3): packed weights made by an older library are in another plane format; ms_maskconv_cl_packed_bytes /
+ * ms_maskconv_fwin_packed_bytes grew by 256 bytes (the weights' power-of-two scale word); MS_RNN_TIMING_SKIP_PROJECTION,
+ * ms_rnn_stack_overlap_ok and ms_rnn_stack_forward are new; ms_rnn_workspace_bytes grew (four projection buffers for K-halves layers).
+ * 3 (round 5): ms_ctc_status, ms_rnn_padded_hidden and ms_rnn_hx_preinit (+ MS_RNN_HX_PREINIT, exchange regions) are new; the CTC workspaces start with a 256-byte status region;
  * ms_linear_splitk_workspace_bytes / ms_linear_splitk_forward take `flags` (MS_LINEAR_FEW_ROWS): the K-slice count
  * no longer depends on M.
  * 2 (round 4): ms_prof_read writes MS_PROF_KINDS = 9 entries (was 4 in version 1); the `zero_infinity` argument of the CTC
  * entry points is a bit field {1 = zero_infinity, MS_CTC_LOG_PROBS_IN} and values above 3 are rejected;
  * ms_ctc_loss_backward takes the same bit field; ms_log_softmax_axis_backward is new.  The Python binding refuses a
  * library whose ms_abi_version() differs (myrtlespeech_amd/_lib.py). */
-#define MS_ABI_VERSION 3
+#define MS_ABI_VERSION 4
 
 enum {
   MS_OK = 0,
@@ -233,7 +237,10 @@ int ms_rnn_layer_forward(int cell, const void* packed, const float* x, const int
  *   MS_RNN_X_PLANES_IN_WS    the input is taken from those planes (left there by the previous layer's call with the
  *                            same T, N, max_len and workspace); `x` may be NULL.
  * Same arithmetic as splitting the float32 output afterwards, one pass over the activations less per layer. */
-enum { MS_RNN_X_PLANES_IN_WS = 1, MS_RNN_OUT_PLANES_TO_WS = 2, MS_RNN_PACKED_ROWS = 4, MS_RNN_HX_PREINIT = 4096 };
+enum { MS_RNN_X_PLANES_IN_WS = 1, MS_RNN_OUT_PLANES_TO_WS = 2, MS_RNN_PACKED_ROWS = 4, MS_RNN_HX_PREINIT = 4096,
+       /* TIMING EXPERIMENTS ONLY (tools/overlap_emulation.py): the call launches its recurrence on whatever the workspace's
+        * projection region holds and skips the input-projection GEMM; the outputs are meaningless. */
+       MS_RNN_TIMING_SKIP_PROJECTION = 8192 };
 int ms_rnn_layer_chains_planes(int cell, int H, int ndir);
 /* One initialisation of the cross-workgroup exchange for a whole stack (rnn.py:112-120 num_layers > 1): every layer call
  * of the persistent kernels starts with a small launch that sets its exchange buffer's epoch tags and zeroes the per-call
@@ -264,6 +271,19 @@ int ms_rnn_layer_forward_ex(int cell, const void* packed, const float* x, const 
  * at most half of the CUs per batch group of 32 rows (H = 1024, split-bf16 operands, up to 64 sequences): the two-in-flight
  * pipeline then runs the OTHER batch's projection as the regular GEMM on the free CUs instead of the co-tenant form. */
 int ms_rnn_layer_is_wide(int cell, int H, int ndir, int N);
+/* A whole stack in one call with layer l+1's input projection computed BESIDE layer l's recurrence (rnn.py:112-120 with
+ * num_layers > 1, bidirectional; deep_speech_2.py:159): a bidirectional stack of wide-workgroup LSTM layers (H = 1024, up to 32
+ * sequences) leaves half of the CUs idle during every recurrence; here a layer's recurrence runs as `segments` launches over
+ * consecutive time segments and, after each, a second (library-owned) stream computes the next layer's two K-half projections
+ * of the rows that segment produced.  Same kernels on the same operands as nl calls of ms_rnn_layer_forward_ex with the planes
+ * chained -- the same bits -- for rows that all exist (not MS_RNN_PACKED_ROWS).  packed_host: HOST array of the nl layers'
+ * packed weights (device pointers, layer 0 first; layer 0 packed for In, the others for ndir * H); h0 / c0 / hn / cn:
+ * [nl * ndir, N, H]; out: [T, N, ndir * H] float32 of the last layer.  ms_rnn_stack_overlap_ok says whether a stack qualifies
+ * (MS_RNN_OVERLAP=0: never).  Not for use inside a stream capture or beside another stream's persistent launches. */
+int ms_rnn_stack_overlap_ok(int cell, int T, int N, int In, int H, int ndir, int nl);
+int ms_rnn_stack_forward(int cell, const void* const* packed_host, const float* x, const int32_t* lens, int max_len,
+                         const float* h0, const float* c0, float* out, float* hn, float* cn, int T, int N, int In, int H, int ndir,
+                         int nl, int segments, void* workspace, size_t workspace_bytes, void* stream);
 
 int ms_rnn_status(const void* workspace, void* stream);
 

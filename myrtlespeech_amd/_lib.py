@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MS_HOTPATH_LIB") or os.path.join(_HERE, "libms_hotpat
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ms_hotpath.h")
 
 MS_OK = 0
-ABI_VERSION = 3    # include/ms_hotpath.h MS_ABI_VERSION this binding was written against (checked in load())
+ABI_VERSION = 4    # include/ms_hotpath.h MS_ABI_VERSION this binding was written against (checked in load())
 ERR_NAMES = {1: "MS_ERR_INVALID", 2: "MS_ERR_HIP", 3: "MS_ERR_WORKSPACE", 4: "MS_ERR_TIMEOUT", 5: "MS_ERR_UNSUPPORTED"}
 
 CELL_LSTM, CELL_GRU, CELL_RNN_TANH, CELL_HARD_LSTM = 0, 1, 2, 3
@@ -69,6 +69,8 @@ SIGNATURES = {
     "ms_rnn_layer_forward_ex": (c_int, [c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P] + [c_int] * 6 + [_P, c_size_t, _P]),
     "ms_rnn_layer_chains_planes": (c_int, [c_int, c_int, c_int]),
     "ms_rnn_layer_is_wide": (c_int, [c_int] * 4),
+    "ms_rnn_stack_overlap_ok": (c_int, [c_int] * 7),
+    "ms_rnn_stack_forward": (c_int, [c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P] + [c_int] * 7 + [_P, c_size_t, _P]),
     "ms_rnn_status": (c_int, [_P, _P]),
     "ms_rnn_debug_offset": (c_size_t, [c_int] * 6),
     "ms_rnn_layer_packs_rows": (c_int, [c_int] * 6),

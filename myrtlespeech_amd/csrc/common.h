@@ -87,6 +87,8 @@ int split_mode();   // the two-plane (or one-plane fp16) format of this process:
 // every weight within 2^-16 of the largest one in the normal range (22 mantissa bits), the products stay far inside float32
 // (|x| <= 65504, K <= 2^20), and the kernel multiplies its accumulator by 2^-s -- exact -- in the epilogue.  The word
 // {2^s, 2^-s} lives in device memory beside the packed planes (no host round trip at pack time); bf16 planes get {1, 1}.
+// a contraction run whole, or as the first / second of two launches cut along K (gemm_split.hip: gemm4_body)
+enum { GEMM_K_WHOLE = 0, GEMM_K_FIRST = 1, GEMM_K_SECOND = 2 };
 int weight_scale_launch(const float* w, size_t n, float* scale_word, int prec, hipStream_t stream);
 
 // the two-plane split modes' plane format: the kernels take it as a template parameter `P` (one of the PREC_* above)

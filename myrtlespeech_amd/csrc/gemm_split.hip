@@ -60,8 +60,10 @@ constexpr int SPLIT_LDS = 2 * A_TILE + 2 * B_TILE;
 
 // Rows past the matrix edge are clamped to the last row (their products are never stored), so
 // the loads need no predicate; K % 32 == 0 is a launch precondition.
-__device__ __forceinline__ u32x4 ld_granule(const unsigned short* __restrict__ p, int rows, int K, int row, int k) {
-  return *reinterpret_cast<const u32x4*>(p + (size_t)min(row, rows - 1) * K + k);
+// (ld: elements between consecutive rows, >= K: an operand may be a column block of a wider matrix -- the forward / backward
+// half of a bidirectional layer's output planes and of the next layer's W_ih, rnn.hip "K-halves")
+__device__ __forceinline__ u32x4 ld_granule(const unsigned short* __restrict__ p, int rows, int ld, int row, int k) {
+  return *reinterpret_cast<const u32x4*>(p + (size_t)min(row, rows - 1) * ld + k);
 }
 
 template <bool HM>
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel(const unsigned s
                                                                 const unsigned short* __restrict__ Wh,
                                                                 const unsigned short* __restrict__ Wl,
                                                                 const float* __restrict__ bias, float* __restrict__ Y,
-                                                                int M, int K, int N, int act, float lo, float hi) {
+                                                                int M, int K, int N, int act, float lo, float hi, int lda, int ldw) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* sAh = lds;
   char* sAl = lds + A_TILE;
@@ -103,13 +105,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel(const unsigned s
   auto load_regs = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      rah[i] = ld_granule(Ah, M, K, m0 + r_in + 64 * i, k0 + kg * 8);
-      ral[i] = ld_granule(Al, M, K, m0 + r_in + 64 * i, k0 + kg * 8);
+      rah[i] = ld_granule(Ah, M, lda, m0 + r_in + 64 * i, k0 + kg * 8);
+      ral[i] = ld_granule(Al, M, lda, m0 + r_in + 64 * i, k0 + kg * 8);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      rbh[i] = ld_granule(Wh, N, K, n0 + r_in + 64 * i, k0 + kg * 8);
-      rbl[i] = ld_granule(Wl, N, K, n0 + r_in + 64 * i, k0 + kg * 8);
+      rbh[i] = ld_granule(Wh, N, ldw, n0 + r_in + 64 * i, k0 + kg * 8);
+      rbl[i] = ld_granule(Wl, N, ldw, n0 + r_in + 64 * i, k0 + kg * 8);
     }
   };
   auto store_regs = [&]() {
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_tile64_kernel(const uns
                                                                        const unsigned short* __restrict__ Wh,
                                                                        const unsigned short* __restrict__ Wl,
                                                                        const float* __restrict__ bias, float* __restrict__ Y,
-                                                                       int M, int K, int N, int act, float lo, float hi) {
+                                                                       int M, int K, int N, int act, float lo, float hi, int lda, int ldw) {
   constexpr bool F16 = prec_one_plane(P), HM = P == PREC_F16X3;
   __shared__ __attribute__((aligned(16))) char lds[T6_LDS];
   const int nbn = (N + T6 - 1) / T6, nbm = (M + T6 - 1) / T6;
@@ -221,10 +223,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_tile64_kernel(const uns
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  const unsigned short* pa_h = Ah + (size_t)min(m0 + r_in, M - 1) * K + kg * 8;
-  const unsigned short* pa_l = Al + (size_t)min(m0 + r_in, M - 1) * K + kg * 8;
-  const unsigned short* pb_h = Wh + (size_t)min(n0 + r_in, N - 1) * K + kg * 8;
-  const unsigned short* pb_l = Wl + (size_t)min(n0 + r_in, N - 1) * K + kg * 8;
+  const unsigned short* pa_h = Ah + (size_t)min(m0 + r_in, M - 1) * lda + kg * 8;
+  const unsigned short* pa_l = Al + (size_t)min(m0 + r_in, M - 1) * lda + kg * 8;
+  const unsigned short* pb_h = Wh + (size_t)min(n0 + r_in, N - 1) * ldw + kg * 8;
+  const unsigned short* pb_l = Wl + (size_t)min(n0 + r_in, N - 1) * ldw + kg * 8;
   const int nk = K / SB_K;
   u32x4 ring[4][4];                             // [block % 4][x hi, x lo, W hi, W lo]
   auto load_block = [&](int kb, u32x4 (&r)[4]) {
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel2(const unsigned 
                                                                  const unsigned short* __restrict__ Wh,
                                                                  const unsigned short* __restrict__ Wl,
                                                                  const float* __restrict__ bias, float* __restrict__ Y,
-                                                                 int M, int K, int N, int act, float lo, float hi) {
+                                                                 int M, int K, int N, int act, float lo, float hi, int lda, int ldw) {
   constexpr bool F16 = prec_one_plane(P), HM = P == PREC_F16X3;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int nbn = (N + S2_N - 1) / S2_N, nbm = (M + S2_M - 1) / S2_M;
@@ -347,11 +349,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel2(const unsigned 
   auto load_regs = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      rah[i] = ld_granule(Ah, M, K, m0 + r_in + 128 * i, k0 + kg * 8);
-      rbh[i] = ld_granule(Wh, N, K, n0 + r_in + 128 * i, k0 + kg * 8);
+      rah[i] = ld_granule(Ah, M, lda, m0 + r_in + 128 * i, k0 + kg * 8);
+      rbh[i] = ld_granule(Wh, N, ldw, n0 + r_in + 128 * i, k0 + kg * 8);
       if (!F16) {
-        ral[i] = ld_granule(Al, M, K, m0 + r_in + 128 * i, k0 + kg * 8);
-        rbl[i] = ld_granule(Wl, N, K, n0 + r_in + 128 * i, k0 + kg * 8);
+        ral[i] = ld_granule(Al, M, lda, m0 + r_in + 128 * i, k0 + kg * 8);
+        rbl[i] = ld_granule(Wl, N, ldw, n0 + r_in + 128 * i, k0 + kg * 8);
       }
     }
   };
@@ -502,7 +504,11 @@ template <int P, int WN, int PER_STEP_ = 3, bool SPACED = false, int NJ = 4>
 __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah, const unsigned short* __restrict__ Al,
                                            const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
                                            const float* __restrict__ bias, float* __restrict__ Y, int M, int K, int N, int act,
-                                           float lo, float hi, const int* __restrict__ m_eff = nullptr) {
+                                           float lo, float hi, const int* __restrict__ m_eff, int lda, int ldw, int kmode) {
+  // kmode (GEMM_K_*): a contraction cut in two along K and run as two launches -- the first (K_FIRST) writes its accumulators as
+  // they are (no bias, no activation), the second (K_SECOND) starts from them and finishes with the epilogue -- gives every
+  // output element the k-ordered chain of the single launch, i.e. its bits: the accumulators travel through memory as exact
+  // float32 copies (rnn.hip, ms_rnn_stack_forward: the two halves become available at different times).
   constexpr bool F16 = prec_one_plane(P), HM = P == PREC_F16X3;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int TN = 32 * NJ * WN;
@@ -555,7 +561,7 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
   }
   auto plane_rsrc = [&](int pl) {
     const unsigned short* src = pl == 0 ? Ah : pl == 1 ? Al : pl == 2 ? Wh : Wl;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(src), 0, (unsigned)((size_t)(pl < 2 ? M : N) * K * 2), 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(src), 0, (unsigned)((size_t)(pl < 2 ? M : N) * (pl < 2 ? lda : ldw) * 2), 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t rsrc_a = plane_rsrc(PA), rsrc_b = plane_rsrc(PB);
   int voff[NP];                                              // byte offset of this lane's granule at k0 = 0
@@ -565,7 +571,7 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
     for (int p = 0; p < NP; ++p) {
       const int pl = p < NPA ? PA : PB;
       const int rows = pl < 2 ? M : N, row = (pl < 2 ? m0 : n0) + (p < NPA ? RA + p * 16 : RB + (p - NPA) * 16) + (lane >> 2);
-      voff[p] = min(row, rows - 1) * (K * 2) + kgs * 16;
+      voff[p] = min(row, rows - 1) * ((pl < 2 ? lda : ldw) * 2) + kgs * 16;
     }
   }
   // LDS stages.  bf16x3: two stages of four planes (x hi, x lo, W hi, W lo).  fp16 on the 8-wave forms (round 4): the lo planes
@@ -592,6 +598,23 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (kmode == GEMM_K_SECOND) {   // the first half's accumulators, in the epilogue's own element mapping (N % 4 == 0: launcher)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + wm * 64 + i * 32 + l31;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wn * (32 * NJ) + j * 32 + 8 * g + 4 * half;
+          if (n + 3 < N) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(Y + (size_t)m * N + n);
+            acc[i][j][4 * g] = v[0]; acc[i][j][4 * g + 1] = v[1]; acc[i][j][4 * g + 2] = v[2]; acc[i][j][4 * g + 3] = v[3];
+          }
+        }
+    }
+  }
 
   // fragment addresses: row (lane & 31) of a 32-row group, granule kg = 2 h + half at position kg ^ ((row >> 2) & 3)
   const int sw = (l31 >> 2) & 3;
@@ -789,11 +812,11 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
         const int n = n0 + wn * (32 * NJ) + j * 32 + 8 * g + 4 * half;
         f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
         if (n_vec && n + 3 < N) {
-          if (bias != nullptr) {
+          if (bias != nullptr && kmode != GEMM_K_FIRST) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
             v += bv;
           }
-          if (act == MS_ACT_CLAMP) {
+          if (act == MS_ACT_CLAMP && kmode != GEMM_K_FIRST) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], lo), hi);
           }
@@ -818,8 +841,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4(const unsigned 
                                                                  const unsigned short* __restrict__ Wl,
                                                                  const float* __restrict__ bias, float* __restrict__ Y,
                                                                  int M, int K, int N, int act, float lo, float hi,
-                                                                 const int* __restrict__ m_eff) {
-  gemm4_body<P, 2>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff);
+                                                                 const int* __restrict__ m_eff, int lda, int ldw, int kmode) {
+  gemm4_body<P, 2>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff, lda, ldw, kmode);
 }
 
 // 256 x 128 tiles on eight waves (NJ = 2): outputs whose 256 x 256 tiles would leave CUs without a workgroup
@@ -830,8 +853,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4h(const unsigned
                                                                   const unsigned short* __restrict__ Wl,
                                                                   const float* __restrict__ bias, float* __restrict__ Y,
                                                                   int M, int K, int N, int act, float lo, float hi,
-                                                                  const int* __restrict__ m_eff) {
-  gemm4_body<P, 2, 3, false, 2>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff);
+                                                                  const int* __restrict__ m_eff, int lda, int ldw, int kmode) {
+  gemm4_body<P, 2, 3, false, 2>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff, lda, ldw, kmode);
 }
 
 // the 4-wave form, capped at 208 VGPRs (the two-stream LSTM kernel allocates 304 of a SIMD's 512): experiment only
@@ -839,8 +862,8 @@ template <int P, int PER_STEP = 3, bool SPACED = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel4n(
     const unsigned short* __restrict__ Ah, const unsigned short* __restrict__ Al, const unsigned short* __restrict__ Wh,
     const unsigned short* __restrict__ Wl, const float* __restrict__ bias, float* __restrict__ Y, int M, int K, int N, int act,
-    float lo, float hi, const int* __restrict__ m_eff) {
-  gemm4_body<P, 1, PER_STEP, SPACED>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff);
+    float lo, float hi, const int* __restrict__ m_eff, int lda, int ldw, int kmode) {
+  gemm4_body<P, 1, PER_STEP, SPACED>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff, lda, ldw, kmode);
 }
 
 // tuning switch (tools/gemm_probe.py A/B runs in one process): 0 = default choice (kernel4, LDS-DMA), 2 = kernel2 (register staging), 7 = kernel4 with 256 x 128 tiles / 4 waves
@@ -880,6 +903,9 @@ bool gemm_rows_from_device_ok(int M, int K, int N) {
 int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
                             const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
                             float hi, int prec, hipStream_t stream, const int* m_eff);
+int gemm_bf16x3_launch_ld(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
+                          const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
+                          float hi, int prec, hipStream_t stream, const int* m_eff, int lda, int ldw, int kmode);
 
 int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
                        const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
@@ -890,11 +916,36 @@ int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const
 // one of a kernel template's three plane-format instances (`prec`: PREC_BF16X3 | PREC_F16 | PREC_F16X3)
 #define MS_BY_PREC(K) (prec == PREC_F16 ? K<PREC_F16> : prec == PREC_F16X3 ? K<PREC_F16X3> : K<PREC_BF16X3>)
 
-// m_eff: optional device word holding the number of rows that exist (<= M); only where gemm_rows_from_device_ok(M, K, N).
-// The names say bf16x3 for history's sake: `prec` selects the plane format (bf16 hi + lo, fp16 hi + lo, one fp16 plane).
 int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
                             const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
                             float hi, int prec, hipStream_t stream, const int* m_eff) {
+  return gemm_bf16x3_launch_ld(ah, al, wh, wl, bias, y, M, K, N, act, lo, hi, prec, stream, m_eff, K, K, GEMM_K_WHOLE);
+}
+
+// m_eff: optional device word holding the number of rows that exist (<= M); only where gemm_rows_from_device_ok(M, K, N).
+// lda / ldw: elements between consecutive rows of the x / W planes (>= K, multiples of 8; K itself for dense operands).
+// The names say bf16x3 for history's sake: `prec` selects the plane format (bf16 hi + lo, fp16 hi + lo, one fp16 plane).
+// kmode: GEMM_K_WHOLE, or one of the two launches of a contraction cut along K (gemm4_body) -- only on the LDS-DMA kernels:
+// gemm_k_halves_ok(M, N) says whether this output runs on them.
+bool gemm_k_halves_ok(int M, int N) {
+  static const bool small_tile = getenv("MS_GEMM_TILE128") && getenv("MS_GEMM_TILE128")[0] == '1';
+  static const bool regstage = getenv("MS_GEMM_REGSTAGE") && getenv("MS_GEMM_REGSTAGE")[0] == '1';
+  static const bool half_off = getenv("MS_GEMM_HALF_TILE") && getenv("MS_GEMM_HALF_TILE")[0] == '0';
+  if (small_tile || regstage || half_off || N % 4 != 0 || g_gemm_variant.load(std::memory_order_relaxed) != 0) return false;
+  const long tiles256 = (long)cdiv(M, S2_M) * cdiv(N, S2_N);
+  const bool starved = tiles256 * 4 < (long)num_cus() * 3 && (long)cdiv(M, SB_M) * cdiv(N, SB_N) > tiles256;
+  const bool t64 = (long)cdiv(M, T6) * cdiv(N, T6) <= 2L * num_cus() && (long)cdiv(M, S2_M) * cdiv(N, 128) * 4 <= (long)num_cus();
+  if (t64) return false;
+  return starved ? (long)M * N >= 1024L * 1024 : (long)M * N >= 4L * 1024 * 1024;
+}
+
+int gemm_bf16x3_launch_ld(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
+                          const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
+                          float hi, int prec, hipStream_t stream, const int* m_eff, int lda, int ldw, int kmode) {
+  if (kmode != GEMM_K_WHOLE && !gemm_k_halves_ok(M, N)) {
+    set_error("gemm_bf16x3_launch_ld: a contraction cut along K needs an output that runs on the LDS-DMA kernels");
+    return MS_ERR_UNSUPPORTED;
+  }
   static ms::DeviceOnce attr_once;
   if (attr_once.need()) {
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_LDS));
@@ -933,7 +984,7 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
   };
   auto launch_tile64 = [&]() {
     hipLaunchKernelGGL(MS_BY_PREC(gemm_nt_bf16x3_tile64_kernel), dim3(cdiv(M, T6) * cdiv(N, T6)), dim3(256), 0, stream, ah, al, wh, wl,
-                       bias, y, M, K, N, act, lo, hi);
+                       bias, y, M, K, N, act, lo, hi, lda, ldw);
   };
   if (tile64() && (long)cdiv(M, S2_M) * cdiv(N, 128) * 4 <= (long)num_cus()) {
     launch_tile64();
@@ -941,9 +992,9 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
     return MS_OK;
   }
   if (!half_off && !small_tile && starved && m_eff == nullptr && (long)M * N >= 1024L * 1024 &&
-      g_gemm_variant.load(std::memory_order_relaxed) == 0 && (size_t)std::max(M, N) * K * 2 < ((size_t)1 << 31)) {
+      g_gemm_variant.load(std::memory_order_relaxed) == 0 && std::max((size_t)M * lda, (size_t)N * ldw) * 2 < ((size_t)1 << 31)) {
     hipLaunchKernelGGL(MS_BY_PREC(gemm_nt_bf16x3_kernel4h), dim3(cdiv(M, S2_M) * cdiv(N, 128)), dim3(512), G4_LDS, stream, ah, al, wh, wl,
-                       bias, y, M, K, N, act, lo, hi, m_eff);
+                       bias, y, M, K, N, act, lo, hi, m_eff, lda, ldw, kmode);
     MS_LAUNCH_CHECK();
     return MS_OK;
   }
@@ -952,7 +1003,7 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
     const int variant = g_gemm_variant.load(std::memory_order_relaxed);
     // the LDS-DMA kernel (default) addresses its planes with 32-bit byte offsets; MS_GEMM_REGSTAGE=1 / variant 2 keep kernel2
     static const bool regstage = getenv("MS_GEMM_REGSTAGE") && getenv("MS_GEMM_REGSTAGE")[0] == '1';
-    if (variant != 2 && !regstage && (size_t)std::max(M, N) * K * 2 < ((size_t)1 << 31)) {
+    if (variant != 2 && !regstage && std::max((size_t)M * lda, (size_t)N * ldw) * 2 < ((size_t)1 << 31)) {
       if (variant >= 7 && variant <= 11) {   // 256 x 128 tiles, 4 waves: co-resident with the persistent LSTM (tools/overlap_probe.py)
         // how a wave issues the next block's 12 DMA pieces (bf16x3; experiments of tools/cotenant_variants.py): 7 = 3 per step
         // over four steps, 8 = 2 per step over six, 9 = 6 per step over two, 10 / 11 = as 7 / 8 with a step's pieces spaced
@@ -965,12 +1016,12 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
           if (variant == 11) k41 = gemm_nt_bf16x3_kernel4n<PREC_BF16X3, 2, true>;
         }
         hipLaunchKernelGGL(k41, dim3(cdiv(M, S2_M) * cdiv(N, 128)), dim3(256), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N,
-                           act, lo, hi, m_eff);
+                           act, lo, hi, m_eff, lda, ldw, kmode);
         MS_LAUNCH_CHECK();
         return MS_OK;
       }
       hipLaunchKernelGGL(MS_BY_PREC(gemm_nt_bf16x3_kernel4), dim3(nwg2), dim3(512), G4_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act,
-                         lo, hi, m_eff);
+                         lo, hi, m_eff, lda, ldw, kmode);
       MS_LAUNCH_CHECK();
       return MS_OK;
     }
@@ -979,7 +1030,7 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
       return MS_ERR_UNSUPPORTED;
     }
     hipLaunchKernelGGL(MS_BY_PREC(gemm_nt_bf16x3_kernel2), dim3(nwg2), dim3(512), SPLIT2_LDS, stream, ah, al, wh, wl, bias, y, M, K, N,
-                       act, lo, hi);
+                       act, lo, hi, lda, ldw);
     MS_LAUNCH_CHECK();
     return MS_OK;
   }
@@ -996,9 +1047,9 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
   }
   const int nwg = cdiv(M, SB_M) * cdiv(N, SB_N);
   if (prec == PREC_F16X3)
-    hipLaunchKernelGGL(gemm_nt_bf16x3_kernel<true>, dim3(nwg), dim3(256), SPLIT_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);
+    hipLaunchKernelGGL(gemm_nt_bf16x3_kernel<true>, dim3(nwg), dim3(256), SPLIT_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi, lda, ldw);
   else
-    hipLaunchKernelGGL(gemm_nt_bf16x3_kernel<false>, dim3(nwg), dim3(256), SPLIT_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi);
+    hipLaunchKernelGGL(gemm_nt_bf16x3_kernel<false>, dim3(nwg), dim3(256), SPLIT_LDS, stream, ah, al, wh, wl, bias, y, M, K, N, act, lo, hi, lda, ldw);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }
@@ -1053,7 +1104,10 @@ extern "C" int ms_linear_split_forward_packed(const float* x, const void* packed
   const unsigned short* wh = (const unsigned short*)packed_w;
   const unsigned short* wl = wh + (size_t)N * K;
   const int prec = ms::split_mode();
-  int rc = ms::split_planes_launch(x, xh, xl, (size_t)M * K, prec, stream);
+  // (MS_TIMING_SKIP_SPLIT=1, read per call: timing experiments that stand in for a GEMM whose operand planes already exist --
+  // tools/overlap_emulation.py; the planes are then whatever the workspace holds)
+  const char* skip = getenv("MS_TIMING_SKIP_SPLIT");
+  int rc = (skip && skip[0] == '1') ? MS_OK : ms::split_planes_launch(x, xh, xl, (size_t)M * K, prec, stream);
   if (rc == MS_OK) rc = ms::gemm_bf16x3_launch(xh, xl, wh, wl, bias, y, M, K, N, act, act_lo, act_hi, prec, stream);
   return rc;
 }

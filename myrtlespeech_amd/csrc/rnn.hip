@@ -39,6 +39,10 @@ int gemm_bf16x3_launch_rows(const unsigned short* ah, const unsigned short* al, 
 int gemm_bf16x3_launch(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
                        const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
                        float hi, int prec, hipStream_t stream);
+int gemm_bf16x3_launch_ld(const unsigned short* ah, const unsigned short* al, const unsigned short* wh,
+                          const unsigned short* wl, const float* bias, float* y, int M, int K, int N, int act, float lo,
+                          float hi, int prec, hipStream_t stream, const int* m_eff, int lda, int ldw, int kmode);
+bool gemm_k_halves_ok(int M, int N);
 int linear_launch(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int act, float lo,
                   float hi, hipStream_t stream);
 }
@@ -165,8 +169,16 @@ PackLayout pack_layout(int cell, int In, int H, int ndir) {
 }
 
 struct WsLayout {
-  size_t status, flags, xproj, hx, hx_bytes, state_h, state_c, dbg, row_off, xsplit, total;
+  size_t status, flags, xproj, xproj_bytes, hx, hx_bytes, state_h, state_c, dbg, row_off, xsplit, total;
+  int xproj_slots;
+  // projection buffer of a layer: slot = layer parity where there are two (the overlapped schedule fills the next layer's
+  // while this layer's is being read)
+  size_t xslot(int parity) const { return xproj + (size_t)(parity % xproj_slots) * xproj_bytes; }
 };
+// Stacks whose layers may run on ms_rnn_stack_forward's overlapped schedule: bidirectional wide-workgroup LSTM layers.
+bool overlap_shape(int cell, int H, int ndir) {
+  return (cell == MS_CELL_LSTM || cell == MS_CELL_HARD_LSTM) && H == 1024 && ndir == 2 && ms::precision_mode() != ms::PREC_F32;
+}
 WsLayout ws_layout(int cell, int T, int N, int H, int ndir, int In) {
   const size_t GH = (size_t)gates_of(cell) * H;
   const int npad = ms::cdiv(N, 32) * 32;
@@ -175,7 +187,9 @@ WsLayout ws_layout(int cell, int T, int N, int H, int ndir, int In) {
   o += STATUS_BYTES;              // [0]: sticky time-out word (set by the kernels, read and cleared by ms_rnn_status)
   L.status = o; o += STATUS_BYTES;  // per-call word, zeroed by every layer call
   L.flags = o; o += ms::align_up((size_t)ndir * std::max(H / 8, 1) * sizeof(unsigned), 256);
-  L.xproj = o; o += ms::align_up((size_t)T * N * ndir * GH * sizeof(float), 256);
+  L.xproj_slots = overlap_shape(cell, H, ndir) ? 2 : 1;
+  L.xproj_bytes = ms::align_up((size_t)T * N * ndir * GH * sizeof(float), 256);
+  L.xproj = o; o += L.xproj_bytes * L.xproj_slots;
   // two slots per (stream, plane) by default; the two-stream kernel may use a ring of 2^lstm_ring_shift() slots
   // (the float32 two-stream kernel: ndir * 2 streams * 2 slots * 16 rows * H floats = the same ndir * 256 * H bytes)
   L.hx = o;
@@ -540,6 +554,11 @@ struct LstmP {
   // wide kernel, packed rows: row_off[t] = first row of frame t in `xproj` and in the planes, which then hold only the
   // rows (t, n) with t < lens[n] (lens sorted in decreasing order), frame after frame; null = every frame has N_total rows
   const int32_t* row_off;
+  // wide kernel, time segments: this launch runs steps [s_begin, s_end) of the layer's `steps` (the step clock: forward t = s,
+  // backward t = steps - 1 - s).  A launch with s_begin > 0 continues the previous one: h0 / c0 are then the state that one
+  // left in hn / cn, and the exchange buffer still holds the h it published last -- in the slot and with the tag the first
+  // step here expects, because the epoch clock is the sequence time, not the launch's step count.
+  int s_begin, s_end;
 };
 
 __device__ __forceinline__ f32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
@@ -1454,8 +1473,11 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
       h[sg] = (valid && p.h0) ? p.h0[sidx] : 0.f;
       c[sg] = (valid && p.c0) ? p.c0[sidx] : 0.f;
       len_n[sg] = valid ? (p.lens ? p.lens[n_base + n] : p.steps) : 0;
-      const int off = sg * STREAM + epoch_par0(d, p.steps, rs) * KG * 256 + jb * 256 + nl * 16;  // slot read by the first step
-      publish_split<P>(h[sg], epoch_tag0(d, p.steps, rs), hx_rsrc, off, PLANE + off, lane, valid);
+      // slot and tag the first step of this launch reads (s_begin = 0: epoch_par0 / epoch_tag0; a continuing segment re-publishes
+      // what its predecessor's last step published there -- the same float32 h, the same bits)
+      const EpochClock ec0 = epoch_clock(d, p.s_begin, p.steps, rs);
+      const int off = sg * STREAM + ec0.par * KG * 256 + jb * 256 + nl * 16;
+      publish_split<P>(h[sg], ec0.em & 1u, hx_rsrc, off, PLANE + off, lane, valid);
     }
   }
   __syncthreads();
@@ -1476,8 +1498,8 @@ __device__ __forceinline__ void wide2_wave(const LstmP& p, float* red, const int
   // PACKED: first row of the step's frame in xproj / the planes; the next step's is fetched a step ahead
   // (a kernel argument of its own, const and restrict: the compiler may then fetch it with scalar loads, outside the vector
   // memory queue whose order the tag checks count on)
-  int roff_next = (PACKED && CELL) ? row_off[d ? p.steps - 1 : 0] : 0;
-  for (int s = 0; s < p.steps; ++s) {
+  int roff_next = (PACKED && CELL) ? row_off[d ? p.steps - 1 - p.s_begin : p.s_begin] : 0;
+  for (int s = p.s_begin; s < p.s_end; ++s) {
     const int t = d ? (p.steps - 1 - s) : s;
     const int roff = roff_next;
     if (PACKED && CELL) roff_next = row_off[s + 1 < p.steps ? (d ? t - 1 : t + 1) : t];
@@ -2631,9 +2653,11 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
                           stream));
 
   // (i) input projection for every frame of every direction: [steps*N, In] x [ndir*GH, In]^T
-  float* xproj = (float*)(ws + W.xproj);
+  float* xproj = (float*)(ws + W.xslot(0));
   int rc;
-  {
+  if (flags & MS_RNN_TIMING_SKIP_PROJECTION) {
+    rc = MS_OK;       // timing experiments: the recurrence runs on whatever the projection region holds
+  } else {
     ProfScope prof(MS_PROF_PROJECTION, stream);
     if (use_split_gemm(cell, H, ndir, In)) {
       unsigned short* xh = (unsigned short*)(ws + W.xsplit);
@@ -2690,6 +2714,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       p.status = (unsigned*)(ws + W.status);
       p.steps = steps; p.N = ng; p.n_base = n0; p.N_total = N; p.H = H; p.ndir = ndir; p.J = H / 8;
       p.d_base = 0;
+      p.s_begin = 0; p.s_end = steps;
       p.NPAD = ms::cdiv(ng, 32) * 32;
       {
         static const int ps = getenv("MS_LSTM_POLL_SLEEP") ? atoi(getenv("MS_LSTM_POLL_SLEEP")) : 1;
@@ -2863,6 +2888,196 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
     }
   }
   MS_LAUNCH_CHECK();
+  return MS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ overlapped stack (round 6)
+//
+// The literal batch-32 step ran its layers strictly one after the other: projection (whole chip, 1.2 ms), recurrence (128 of
+// the 256 CUs, 1.75 ms), ... -- half of the chip idle for 9 of 15 ms.  Here layer l's recurrence runs as S launches over
+// consecutive time segments (state in place in hn / cn, exchange tags carried by the sequence-time clock) while a second
+// stream, behind events, computes layer l+1's projection on the idle CUs IN TWO K HALVES: W_ih(l+1) = [W_f | W_b] along K, the
+// forward half needs only layer l's forward outputs and the backward half only its backward outputs.
+//   after segment k (forward direction has produced times < F_k, backward direction times >= B_k = steps - F_k):
+//     GEMM_K_FIRST   rows of times [F_{k-1}, F_k):  acc = h_fwd . W_f^T                       -> projection buffer (raw accumulators)
+//     GEMM_K_SECOND  rows of times [B_k, F_k) not done yet (the range grows outward from the middle of the utterance):
+//                                                   acc += h_bwd . W_b^T, + bias               -> projection buffer
+// A row's accumulators pass through memory as exact float32 copies between the two launches, so every gate pre-activation is
+// the k-ordered chain of the ONE K = 2H GEMM of the layer-by-layer path: the results are its bits (tests/test_gpu_pipeline.py),
+// in every mode and for every batch -- which is why the halves are not two buffers summed afterwards (measured: two K = H
+// GEMMs writing two buffers cost every mode 0.29 ms per layer, profiles/r06f_overlap_ab.txt) and why the order is forward half
+// first for EVERY row (a per-row choice would depend on the batch's longest utterance).  The price of the fixed order: the
+// backward half of the early rows and the forward half of the late rows arrive last, so the second launches bunch up in the
+// second half of the layer (1.5 of 2 GEMM halves per segment there) and finish ~0.3 ms after the recurrence.
+// Stream events only: the failure mode of this schedule is a slow run, never a hung GPU.  Timing emulation before it was
+// built: tools/overlap_emulation.py, profiles/r06e_overlap_emulation.txt.
+namespace {
+struct OverlapCtx {
+  std::mutex mu;
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> ev;
+};
+OverlapCtx g_overlap[64];
+
+// Steps per time segment of a layer, about steps / want: a segment's GEMM pieces have L * N rows, and the side stream's GEMM
+// gets the CUs the recurrence leaves (128 of 256), one 256 x 256 tile per CU -- so L * N is made a multiple of 1 024 rows
+// (4 row tiles x 32 column tiles = whole rounds of 128 tiles; measured at N = 32: 62-step segments 13.3 ms per stack, 71-step
+// segments 14.6, profiles/r06h_overlap_ab.txt) and large enough for the kernels that can take a contraction cut along K
+// (ms::gemm_k_halves_ok).  0 = no segmentation that qualifies.
+int overlap_segment_steps(int steps, int N, int NG, int want) {
+  want = std::max(2, want);
+  const long rows = (long)steps * N;
+  long j = std::max(1L, (rows + (long)want * 512) / ((long)want * 1024));      // round(rows / (want * 1024))
+  for (; j >= 1; --j) {
+    const int L = (int)((1024 * j) / N);
+    if (L >= 1 && L < steps && ms::gemm_k_halves_ok(L * N, NG)) return L;
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" int ms_rnn_stack_overlap_ok(int cell, int T, int N, int In, int H, int ndir, int nl) {
+  static const bool off = getenv("MS_RNN_OVERLAP") && getenv("MS_RNN_OVERLAP")[0] == '0';
+  if (off || cell < 0 || cell > MS_CELL_HARD_LSTM || T <= 0 || N <= 0 || In <= 0 || nl < 2 || nl > HX_REGIONS) return 0;
+  if (!overlap_shape(cell, H, ndir) || !use_fast(cell, H, ndir) || !use_wide(cell, H, ndir, N) || N > 32) return 0;
+  if (!use_split_gemm(cell, H, ndir, In) || !use_split_gemm(cell, H, ndir, ndir * H)) return 0;
+  if (!ms_rnn_layer_chains_planes(cell, H, ndir) || !hx_preinit_ok(cell, N, H, ndir)) return 0;
+  return overlap_segment_steps(T, N, ndir * 4 * H, 8) > 0 ? 1 : 0;      // (T: the steps the call will run, max_len)
+}
+
+extern "C" int ms_rnn_stack_forward(int cell, const void* const* packed_host, const float* x, const int32_t* lens, int max_len,
+                                    const float* h0, const float* c0, float* out, float* hn, float* cn, int T, int N, int In, int H,
+                                    int ndir, int nl, int segments, void* workspace, size_t workspace_bytes, void* stream_) {
+  MS_REQUIRE(max_len >= 1 && max_len <= T, "max_len must be in [1, T]");
+  MS_REQUIRE(ms_rnn_stack_overlap_ok(cell, max_len, N, In, H, ndir, nl), "this stack does not run on the overlapped schedule (ask ms_rnn_stack_overlap_ok)");
+  MS_REQUIRE(packed_host && x && out && hn && cn && workspace, "null pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int steps = max_len;
+  const size_t GH = (size_t)4 * H;
+  const int NG = (int)(ndir * GH);                       // projection columns (both directions' gates)
+  const int SL = overlap_segment_steps(steps, N, NG, segments);      // steps per segment
+  MS_REQUIRE(SL > 0, "no time segmentation of this stack qualifies (ask ms_rnn_stack_overlap_ok with T = max_len)");
+  const int S = std::max(1, steps / SL);                 // the last segment takes the remainder (SL <= its length < 2 SL)
+  const WsLayout W = ws_layout(cell, T, N, H, ndir, std::max(In, ndir * H));
+  if (workspace_bytes < W.total) {
+    ms::set_error("ms_rnn_stack_forward: workspace too small");
+    return MS_ERR_WORKSPACE;
+  }
+  int dev = 0;
+  MS_HIP(hipGetDevice(&dev));
+  OverlapCtx& oc = g_overlap[dev & 63];
+  std::lock_guard<std::mutex> lock(oc.mu);
+  if (oc.side == nullptr) MS_HIP(hipStreamCreateWithFlags(&oc.side, hipStreamNonBlocking));
+  while ((int)oc.ev.size() < 2 * S) {
+    hipEvent_t e;
+    MS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    oc.ev.push_back(e);
+  }
+  char* ws = (char*)workspace;
+  const bool hard = cell == MS_CELL_HARD_LSTM;
+  const int prec = layer_prec(cell, H, ndir);
+  int rc = ms_rnn_hx_preinit(cell, T, N, std::max(In, ndir * H), H, ndir, max_len, nl, workspace, workspace_bytes, stream_);
+  if (rc != MS_OK) return rc;
+  if (steps < T) MS_HIP(hipMemsetAsync(out + (size_t)steps * N * ndir * H, 0, (size_t)(T - steps) * N * ndir * H * sizeof(float), stream));
+  unsigned short* xh = (unsigned short*)(ws + W.xsplit);
+  // ---- layer 0's projection: it depends on the caller's x (the convolutions), nothing runs beside it
+  {
+    const PackLayout L0 = pack_layout(cell, In, H, ndir);
+    const char* pk = (const char*)packed_host[0];
+    ProfScope prof(MS_PROF_PROJECTION, stream);
+    unsigned short* xl = xh + (size_t)steps * N * In;
+    rc = ms::split_planes_launch(x, xh, xl, (size_t)steps * N * In, prec, stream);
+    if (rc != MS_OK) return rc;
+    ProfScope gemm_only(In >= 1024 ? MS_PROF_GEMM_K_LARGE : MS_PROF_GEMM_K_SMALL, stream);
+    const unsigned short* wh = (const unsigned short*)(pk + L0.wih);
+    rc = ms::gemm_bf16x3_launch_rows(xh, xl, wh, wh + (size_t)ndir * GH * In, (const float*)(pk + L0.bias_x), (float*)(ws + W.xslot(0)),
+                                     steps * N, In, NG, MS_ACT_NONE, 0.f, 0.f, prec, stream, nullptr);
+    if (rc != MS_OK) return rc;
+  }
+  const int Kc = ndir * H;                               // width of a chained layer's input planes
+  unsigned short* ph = xh;                               // planes [steps * N][Kc]: hi, then lo
+  unsigned short* pl = ph + (size_t)steps * N * Kc;
+  const size_t st = (size_t)ndir * N * H;                // one layer's (h, c) state
+  for (int l = 0; l < nl; ++l) {
+    const int in_l = l == 0 ? In : Kc;
+    const PackLayout L = pack_layout(cell, in_l, H, ndir);
+    const char* pk = (const char*)packed_host[l];
+    const bool last_layer = l + 1 == nl;
+    LstmP p;
+    p.xproj = (const float*)(ws + W.xslot(l & 1));
+    p.whh = (const float*)(pk + L.whh);
+    p.lens = lens;
+    p.out = last_layer ? out : nullptr;
+    p.hn = hn + l * st; p.cn = cn + l * st;
+    p.out_hi = last_layer ? nullptr : ph;
+    p.out_lo = last_layer ? nullptr : pl;
+    p.row_off = nullptr;
+    p.hx = (float*)(ws + W.hx + (size_t)l * W.hx_bytes);
+    p.flags = (unsigned*)(ws + W.flags);
+    p.status = (unsigned*)(ws + W.status);
+    p.steps = steps; p.N = N; p.n_base = 0; p.N_total = N; p.H = H; p.ndir = ndir; p.J = H / 8;
+    p.d_base = 0; p.NPAD = 32; p.xcd_map = 0; p.ring_shift = 1;
+    p.dbg = (unsigned long long*)(ws + W.dbg);
+    {
+      static const int ps = getenv("MS_LSTM_POLL_SLEEP") ? atoi(getenv("MS_LSTM_POLL_SLEEP")) : 1;
+      p.poll_sleep = ps > 0 ? ps : 1;
+    }
+    const PackLayout Ln = pack_layout(cell, Kc, H, ndir);
+    const char* pkn = last_layer ? nullptr : (const char*)packed_host[l + 1];
+    float* xnext = (float*)(ws + W.xslot((l + 1) & 1));
+    hipEvent_t last_side = nullptr;
+    int done_lo = 0, done_hi = 0;                        // times [done_lo, done_hi) have both halves (empty at first)
+    for (int k = 0; k < S; ++k) {
+      const int s0 = k * SL, s1 = k + 1 == S ? steps : (k + 1) * SL;
+      p.s_begin = s0; p.s_end = s1;
+      p.h0 = s0 == 0 ? (h0 ? h0 + l * st : nullptr) : p.hn;     // a continuing segment starts from the state its predecessor left
+      p.c0 = s0 == 0 ? (c0 ? c0 + l * st : nullptr) : p.cn;
+      {
+        PersistentTurn turn(stream);
+        if (turn.rc != MS_OK) { ms::set_error("ms_rnn_stack_forward: cross-stream hand-over of the persistent launch failed"); return turn.rc; }
+        ProfScope prof_rec(MS_PROF_RECURRENCE, stream);
+        rc = launch_wide2(p, hard, 1, prec, stream);
+        if (rc != MS_OK) return rc;
+      }
+      if (last_layer) continue;
+      // ---- the next layer's projection of what this segment made available, on the idle CUs
+      hipEvent_t seg_done = oc.ev[2 * k], gemms_done = oc.ev[2 * k + 1];
+      MS_HIP(hipEventRecord(seg_done, stream));
+      MS_HIP(hipStreamWaitEvent(oc.side, seg_done, 0));
+      {
+        ProfScope prof(MS_PROF_PROJECTION, oc.side);
+        ProfScope gemm_only(MS_PROF_GEMM_K_LARGE, oc.side);
+        const unsigned short* wh = (const unsigned short*)(pkn + Ln.wih);
+        const unsigned short* wl = wh + (size_t)ndir * GH * Kc;
+        const float* bias = (const float*)(pkn + Ln.bias_x);
+        auto half = [&](int t0, int t1, int kmode) {       // rows of times [t0, t1), forward (first) or backward (second) half of K
+          if (t1 <= t0) return (int)MS_OK;
+          const size_t r0 = (size_t)t0 * N;
+          const int koff = kmode == ms::GEMM_K_FIRST ? 0 : H;
+          return ms::gemm_bf16x3_launch_ld(ph + r0 * Kc + koff, pl + r0 * Kc + koff, wh + koff, wl + koff, bias, xnext + r0 * NG,
+                                           (t1 - t0) * N, H, NG, MS_ACT_NONE, 0.f, 0.f, prec, oc.side, nullptr, Kc, Kc, kmode);
+        };
+        rc = half(s0, s1, ms::GEMM_K_FIRST);               // the forward direction just produced times [s0, s1)
+        const int f_k = s1, b_k = steps - s1;              // forward done below f_k, backward done from b_k on
+        if (rc == MS_OK && b_k < f_k) {
+          if (done_hi <= done_lo) {                        // first overlap of the two fronts (a sliver waits for the next segment)
+            if (k + 1 == S || ms::gemm_k_halves_ok((f_k - b_k) * N, NG)) {
+              rc = half(b_k, f_k, ms::GEMM_K_SECOND);
+              done_lo = b_k; done_hi = f_k;
+            }
+          } else {
+            rc = half(b_k, done_lo, ms::GEMM_K_SECOND);
+            if (rc == MS_OK) rc = half(done_hi, f_k, ms::GEMM_K_SECOND);
+            done_lo = b_k; done_hi = f_k;
+          }
+        }
+        if (rc != MS_OK) return rc;
+      }
+      MS_HIP(hipEventRecord(gemms_done, oc.side));
+      last_side = gemms_done;
+    }
+    if (last_side != nullptr) MS_HIP(hipStreamWaitEvent(stream, last_side, 0));   // the next layer reads all of its rows
+  }
   return MS_OK;
 }
 

@@ -30,6 +30,8 @@ RNNState = TypeVar("RNNState", torch.Tensor, Tuple[torch.Tensor, torch.Tensor])
 RNNData = TypeVar("RNNData", bound=torch.Tensor)
 Lengths = TypeVar("Lengths", bound=torch.Tensor)
 
+_OVERLAP = os.environ.get("MS_RNN_OVERLAP") != "0"              # A/B switch: 0 = the layer-by-layer schedule everywhere
+_OVERLAP_SEGMENTS = int(os.environ.get("MS_RNN_OVERLAP_SEGMENTS", "8"))   # time segments per layer (tools/overlap_emulation.py)
 _HX_PREINIT = os.environ.get("MS_RNN_HX_PREINIT") != "0"      # A/B switch (tests): 0 = every layer call initialises its exchange
 
 _CELL = {RNNType.LSTM: _lib.CELL_LSTM, RNNType.GRU: _lib.CELL_GRU, RNNType.BASIC_RNN: _lib.CELL_RNN_TANH}
@@ -138,6 +140,24 @@ def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max
                                                         for k in in_sizes)
     # one exchange initialisation for the whole stack where the layer kind allows it (ms_rnn_hx_preinit): the layers then use
     # exchange regions 0 .. nl - 1 of the workspace instead of re-initialising region 0 before every layer
+    # ---- the overlapped schedule (round 6): the whole stack in ONE call, layer l+1's K-half projections computed on a second
+    # stream beside layer l's recurrence (ms_rnn_stack_forward: a bidirectional wide-workgroup LSTM stack of <= 32 sequences
+    # uses half of the CUs per recurrence).  Same bits as the layer loop below.  Not while two batches are in flight (the other
+    # batch already fills the idle CUs, and its issue points are per layer), not inside a stream capture, not for packed rows.
+    state_ok = all(s_ is None or (s_.is_contiguous() and tuple(s_.shape) == (nl * ndir, n, hidden)) for s_ in (h0, c0))
+    if (nl > 1 and chain and not padded and not pack_rows and _OVERLAP and _lib.issue_point is None and state_ok
+            and not torch.cuda.is_current_stream_capturing()
+            and lib.ms_rnn_stack_overlap_ok(cell, t, n, x.shape[2], hidden, ndir, nl)):
+        pks = [packed[layer].get(cell, in_sizes[layer], hidden, layer_params[layer], None) for layer in range(nl)]
+        arr = (ctypes.c_void_p * nl)(*[pk.data_ptr() for pk in pks])
+        out = torch.empty((t, n, ndir * hidden), dtype=torch.float32, device="cuda")
+        _lib.check(lib.ms_rnn_stack_forward(cell, ctypes.cast(arr, ctypes.c_void_p), _lib.ptr(x), _lib.ptr(lens_dev), max_len,
+                                            _lib.ptr(h0), _lib.ptr(c0), _lib.ptr(out), _lib.ptr(hn), _lib.ptr(cn), t, n, x.shape[2],
+                                            hidden, ndir, nl, _OVERLAP_SEGMENTS, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                   "ms_rnn_stack_forward")
+        if check:
+            _lib.check(lib.ms_rnn_status(_lib.ptr(ws), _lib.stream_ptr()), "ms_rnn_stack_forward")
+        return out, hn, cn
     preinit = 0
     if 1 < nl <= 8 and _HX_PREINIT:
         rc = lib.ms_rnn_hx_preinit(cell, t, n, max(in_sizes), hidden, ndir, max_len, nl, _lib.ptr(ws), ws.numel(), _lib.stream_ptr())

@@ -257,3 +257,54 @@ def test_paired_batches_full_size_network_uses_the_wide_kernel_and_matches_the_r
     import cfg_checks
     err = cfg_checks.paired_full(atol=1e-3)
     assert err < 1e-5
+
+
+# ----------------------------------------------------------------------------- the overlapped stack schedule (round 6)
+@pytest.mark.parametrize("kind,N,T_,In,nl,segs,with_hx,ragged", [
+    ("LSTM", 32, 501, 640, 5, 8, False, False),      # the config-2 recurrent stack
+    ("LSTM", 32, 257, 96, 2, 4, True, False),        # initial state given, two layers, a last segment of one step
+    ("LSTM", 5, 300, 64, 3, 8, False, True),         # few sequences (256 x 128 GEMM tiles), lengths that differ
+    ("HardLSTM", 17, 200, 32, 2, 3, False, False),
+    ("LSTM", 32, 130, 640, 3, 16, True, True)])
+def test_overlapped_stack_gives_the_layer_by_layer_bits(kind, N, T_, In, nl, segs, with_hx, ragged):
+    """``ms_rnn_stack_forward``: layer l's recurrence as launches over time segments, layer l+1's projection
+    beside it on a second stream as two K-half launches that share their accumulators through memory -- against the layer loop
+    (``MS_RNN_OVERLAP=0``'s path) on the same inputs: outputs and final states ``torch.equal``, whatever the segmentation."""
+    from myrtlespeech_amd import _lib
+    from myrtlespeech_amd.model import rnn as R
+    cell = _lib.CELL_LSTM if kind == "LSTM" else _lib.CELL_HARD_LSTM
+    H, ndir = 1024, 2
+    torch.manual_seed(N * 1000 + T_)
+    m = R.RNN(R.RNNType.LSTM, In, H, num_layers=nl, bidirectional=True, forget_gate_bias=1.0).eval()
+    with torch.no_grad():
+        for k, v in m.state_dict().items():      # saturate some gates: a rounding difference would not stay hidden
+            if "weight_ih" in k:
+                v.mul_(8.0)
+    x = torch.randn(T_, N, In, device="cuda")
+    lens = torch.full((N,), T_, dtype=torch.int64)
+    if ragged:
+        lens = torch.sort(torch.randint(T_ // 3, T_ + 1, (N,)), descending=True).values
+        lens[0] = T_
+    h0 = c0 = None
+    if with_hx:
+        h0 = (torch.randn(nl * ndir, N, H, device="cuda") * 0.5).contiguous()
+        c0 = (torch.randn(nl * ndir, N, H, device="cuda") * 0.5).contiguous()
+    lib = _lib.load()
+    assert lib.ms_rnn_stack_overlap_ok(cell, T_, N, In, H, ndir, nl) == 1
+
+    def run(overlap):
+        prev = (R._OVERLAP, R._OVERLAP_SEGMENTS)
+        R._OVERLAP, R._OVERLAP_SEGMENTS = overlap, segs
+        try:
+            # (ragged=False: every row is computed, the lengths act through the recurrence's per-frame predicate -- the path a
+            # batch takes when its rows are not packed; the packed-rows path never overlaps)
+            return R.run_layers(cell, x, _lib.lens_i32(lens), T_, m._layer_params(), [R.PackedLayer() for _ in range(nl)], H,
+                                h0, c0, _lib.Workspace(), ragged=False)
+        finally:
+            R._OVERLAP, R._OVERLAP_SEGMENTS = prev
+    want, got = run(False), run(True)
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    assert float(want[0].abs().max()) > 0.5          # (a live network: outputs are not all tiny)
+    again = run(True)                                 # a second call re-uses the library's side stream and events
+    assert all(torch.equal(a, b) for a, b in zip(want, again))
