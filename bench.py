@@ -454,6 +454,19 @@ def main(argv=None, runtime=None, json_fd=None):
     def step(lens, ev=None):
         return step_launch(lens, ev).result()
 
+    def set_overlap(on):
+        """Switch the recurrent stack between its two schedules (same bits): layer by layer, and the overlapped one the library
+        uses by default for one batch of <= 32 utterances (myrtlespeech_amd/model/rnn.py, ms_rnn_stack_forward).  Returns whether
+        the overlapped schedule exists for this model in this mode."""
+        try:
+            from myrtlespeech_amd.model import rnn as _R
+        except Exception:  # noqa: BLE001
+            return False
+        if os.environ.get("MS_RNN_OVERLAP") == "0" or precision_mode() == "f32":
+            return False
+        _R._OVERLAP = bool(on)
+        return True
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -488,7 +501,7 @@ def main(argv=None, runtime=None, json_fd=None):
 
     STAGES = ("projection", "recurrence", "gemm_k_large", "gemm_k_small", "conv", "layout", "linear", "greedy", "other")
 
-    def timed(lens, steps, two, run_ahead=True):
+    def timed(lens, steps, two, run_ahead=True, prof=True):
         """`steps` passes bracketed by barrier + synchronize on both sides; MAX over ranks; in-library HIP-event spans of every
         kernel family.  One batch at a time (`two` False): the host enqueues step k+1 BEFORE it collects step k's transcripts
         (`run_ahead`; one stream, so the device still runs one batch after the other and never idles while the host builds
@@ -496,7 +509,9 @@ def main(argv=None, runtime=None, json_fd=None):
         ev = []
         ms = (ctypes.c_float * len(STAGES))()
         cnt = (ctypes.c_int * len(STAGES))()
-        lib.ms_prof_enable(0 if (two and os.environ.get('BENCH_PROF_TWO') == '0') else 1)
+        # (prof=False: no in-library event spans in this region -- a span is two event records on the stream, and the overlapped
+        # one-batch schedule has ~75 of them per step where the layer-by-layer one has ~30)
+        lib.ms_prof_enable(0 if (not prof or (two and os.environ.get('BENCH_PROF_TWO') == '0')) else 1)
         lib.ms_prof_read(ms, cnt)       # drop spans recorded so far
         barrier()
         t0 = time.perf_counter()
@@ -560,9 +575,24 @@ def main(argv=None, runtime=None, json_fd=None):
     x_ragged = x.clone()
     for _ in range(args.warmup):
         step(lens_full)
-    # leg 1: one batch at a time (kernel durations, rooflines, the encoder / decode split)
+    # leg 1: one batch at a time, LAYER BY LAYER (projection, then recurrence: every kernel alone on the device -- kernel
+    # durations, rooflines, the stage table, the encoder / decode split)
+    overlap_available = set_overlap(False)
     one = timed(lens_full, args.steps, False)
-    one_elapsed, enc_ms, dec_ms = one["elapsed"], one["enc"], one["dec"]
+    one_serial_elapsed, enc_ms, dec_ms = one["elapsed"], one["enc"], one["dec"]
+    set_overlap(True)
+    # leg 1a: the literal batch-32 step as the library runs it by default: the overlapped stack schedule (round 6:
+    # ms_rnn_stack_forward -- layer l+1's projection beside layer l's recurrence; same bits), spans off
+    one_ov = None
+    if overlap_available:
+        try:
+            for _ in range(2):
+                step(lens_full)
+            one_ov = timed(lens_full, args.steps, False, prof=False)
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"bench: overlapped one-batch leg failed: {type(e).__name__}: {e}\n")
+            rt.synchronize()
+    one_elapsed = one_ov["elapsed"] if one_ov is not None else one_serial_elapsed
     # leg 1b (short): the same with the host collecting every step's transcripts before it issues the next step -- the
     # difference to leg 1 is the device time the host's read-back and list building would otherwise expose
     sync_each = timed(lens_full, max(5, args.steps // 4), False, run_ahead=False)
@@ -632,7 +662,7 @@ def main(argv=None, runtime=None, json_fd=None):
         out = []
         for _ in range(reps):
             try:
-                out.append(timed(lens_full, args.steps, runner)["elapsed"] / args.steps * 1e3)
+                out.append(timed(lens_full, args.steps, runner, prof=bool(runner))["elapsed"] / args.steps * 1e3)
             except Exception as e:  # noqa: BLE001
                 spread["error"] = f"{type(e).__name__}: {e}"[:200]
                 rt.synchronize()
@@ -827,6 +857,10 @@ def main(argv=None, runtime=None, json_fd=None):
                        # region is kept beside it; `value` (the headline) stays its first region, as the contract says
                        "one_batch_ms_per_step": spread["one_batch_ms_per_step"]["median"],
                        "one_batch_first_region_ms_per_step": round(one_ms, 3),
+                       # the literal step's two schedules: layer by layer (every kernel alone on the device: what `stages`,
+                       # `roofline` and `projection_gemm` are measured on) and overlapped (the default: one_batch_ms_per_step)
+                       "one_batch_layer_by_layer_ms_per_step": round(one_serial_elapsed / args.steps * 1e3, 3),
+                       "one_batch_schedule": "overlapped_stack" if one_ov is not None else "layer_by_layer",
                        "one_batch_value": round(world * BATCH_PER_GPU * CLIP_SECONDS / (spread["one_batch_ms_per_step"]["median"] * 1e-3), 1),
                        "f32_value": (f32 or {}).get("value"), "f32_ms_per_step": (f32 or {}).get("ms_per_step"),
                        "f32_one_batch_ms_per_step": ((f32 or {}).get("one_batch_in_flight") or {}).get("ms_per_step"),
