@@ -930,7 +930,7 @@ def main(argv=None, runtime=None, json_fd=None):
             from tools import bench_configs
             del pipe, paired
             torch.cuda.empty_cache() if torch.cuda.is_available() else None
-            detail = bench_configs.run_legs(["ctc", "ctcgrad", "beam", "ds1", "rnnt", "stream", "streamctx"], cpu=not args.no_cpu_baseline)
+            detail = bench_configs.run_legs(["ctc", "ctcgrad", "beam", "beamlm", "ds1", "rnnt", "stream", "streamctx"], cpu=not args.no_cpu_baseline)
             if stream_fp16 is not None:
                 detail["cfg5_streaming_fp16"] = stream_fp16
             if gather1 is not None:
@@ -938,7 +938,7 @@ def main(argv=None, runtime=None, json_fd=None):
             out["legs_detail"] = detail
             num = ("ms", "ms_min", "ms_few_rows", "ms_per_chunk", "ms_per_chunk_wall", "floor_ms", "frac_of_floor", "chain_floor_ms", "frac_of_chain_floor", "audio_sec_per_s", "utterances_per_s",
                    "encoder_ms", "beam8_decode_ms", "greedy_decode_ms", "us_per_frame", "realtime_factor", "dtype", "latency_frames",
-                   "transcripts_equal_oracle_fixture", "error", "value", "one_batch_ms", "headline_mode", "steps")
+                   "transcripts_equal_oracle_fixture", "error", "value", "one_batch_ms", "headline_mode", "steps", "lm_calls", "lm_frames")
             legs = {"calibration": detail.get("calibration")}
             for name, rec in detail.items():
                 if name == "calibration" or not isinstance(rec, dict):

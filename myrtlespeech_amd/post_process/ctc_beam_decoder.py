@@ -81,20 +81,54 @@ class CTCBeamDecoder(torch.nn.Module):
             call(0, seq_len, None, 1)
             return ragged_to_lists(out_idx, out_len)
 
-        # host language model: one frame per launch, beam prefixes read back in between
+        # host language model.  The reference consults it for beam entry l at frame t only when the separator extension of l
+        # survives the pruning test -- float32 p[t, n, sep] > prune_threshold, ctc_beam_decoder.py:198 -- and multiplies the
+        # separator extension by float32(lm(l + (sep,)) ** lm_weight) (:214-230).  So the host reads the separator's column of
+        # the posteriors ONCE, advances the kernel over every run of frames in which no utterance's separator survives in one
+        # launch (no factor is read there), and stops only at the frames that need the model: there it reads back the live
+        # beam -- prefix lengths first, then only the first max(prefix length) columns of the prefix table instead of all T
+        # (round 5 copied [batch, width, T] int32 every frame: 513 KB at T = 501, batch 32, width 8) -- and calls the model for
+        # the entries of the utterances whose separator survives, as the reference does.
         beam_len = torch.empty(batch, dtype=torch.int32, device="cuda")
         beam_idx = torch.empty((batch, w, seq_len), dtype=torch.int32, device="cuda")
         beam_plen = torch.empty((batch, w), dtype=torch.int32, device="cuda")
-        max_len = int(lengths.max())
+        lens_h = _lib.host_lens(lengths)
+        max_len = int(lens_h.max())
+        thr = torch.tensor(float(self.prune_threshold), dtype=torch.float32)
+        # [T, N] bool: the separator extension of utterance n is visited at frame t (float32 compare, as in the reference)
+        # (the reference SKIPS when p <= thr: a NaN probability is visited, so the test is "not (p <= thr)")
+        need = ~(xd[:max_len, :, sep].cpu() <= thr) & (torch.arange(max_len)[:, None] < lens_h[None, :].to(torch.int64))
+        need_t = need.any(dim=1).tolist()
+        self.lm_calls = self.lm_frames = 0
         call(0, 0, None, 0, beam_len, beam_idx, beam_plen)  # initialise: beam = [()]
-        for t in range(max_len):
-            bl, bi, bp = beam_len.cpu().tolist(), beam_idx.cpu(), beam_plen.cpu().tolist()
+        t = 0
+        while t < max_len:
+            if not need_t[t]:
+                t1 = t + 1
+                while t1 < max_len and not need_t[t1]:
+                    t1 += 1
+                call(t, t1, None, 1 if t1 == max_len else 0, beam_len, beam_idx, beam_plen)
+                t = t1
+                continue
+            bl, bp = beam_len.cpu().tolist(), beam_plen.cpu()
+            longest = int(bp.max()) if bp.numel() else 0
+            bi = beam_idx[:, :, :max(longest, 1)].cpu() if longest else None
+            bp = bp.tolist()
             fac = torch.ones((batch, w), dtype=torch.float32)
+            row = need[t].tolist()
             for n in range(batch):
+                if not row[n]:
+                    continue
                 for k in range(bl[n]):
-                    prefix = tuple(bi[n, k, :bp[n][k]].tolist()) + (sep,)
+                    pre = tuple(bi[n, k, :bp[n][k]].tolist()) if bp[n][k] else ()
+                    if pre and pre[-1] == sep:
+                        continue        # a repeated separator takes the repeat-character branch (:210-213): no model there
+                    prefix = pre + (sep,)
                     fac[n, k] = float(self.language_model(prefix) ** self.lm_weight)
+                    self.lm_calls += 1
+            self.lm_frames += 1
             call(t, t + 1, fac.cuda(), 1 if t == max_len - 1 else 0, beam_len, beam_idx, beam_plen)
+            t += 1
         if max_len == 0:
             call(0, 0, None, 1)
         return ragged_to_lists(out_idx, out_len)

@@ -996,6 +996,31 @@ def test_beam_reference_kats():
         assert dec(x, ln) == [[al[c] for c in target + " "]]
 
 
+def test_beam_with_host_language_model_config_size_vs_oracle_and_the_reference_call_pattern():
+    """The host-LM path at T = 501: 4 ragged utterances of peaky posteriors, beam 8, separator 0 with a
+    language model and a word weight -- transcripts equal the oracle's (ctc_beam_decoder.py:175-258 restated), and the model is
+    called exactly for the (frame, utterance, beam entry) triples the reference calls it for: those whose separator extension
+    passes the float32 pruning test (ctc_beam_decoder.py:198, 214-230) -- counted by running the oracle with a counting model."""
+    from myrtlespeech_amd.post_process.ctc_beam_decoder import CTCBeamDecoder
+    torch.manual_seed(5)
+    probs = torch.softmax(torch.randn(501, 4, 29) * 12, dim=2)
+    lens = torch.tensor([501, 300, 120, 40], dtype=torch.int64)
+    calls = {"n": 0}
+
+    def lm(prefix):
+        calls["n"] += 1
+        return O.toy_language_model(prefix)
+    dec = CTCBeamDecoder(28, 8, 0.001, language_model=lm, lm_weight=0.8, separator_index=0, word_weight=1.2)
+    got = dec(T(probs.numpy()), lens)
+    gpu_calls = calls["n"]
+    calls["n"] = 0
+    want = O.ctc_beam_decode(probs.numpy(), lens.numpy(), 28, 8, 0.001, language_model=lm, lm_weight=0.8, separator_index=0,
+                             word_weight=1.2)
+    assert got == want
+    assert gpu_calls == calls["n"] == dec.lm_calls, (gpu_calls, calls["n"], dec.lm_calls)
+    assert 0 < dec.lm_frames < 501            # the frames in between ran as runs, one launch each
+
+
 def test_beam_golden_random():
     from myrtlespeech_amd.post_process.ctc_beam_decoder import CTCBeamDecoder
     g = Golden("beam_random")

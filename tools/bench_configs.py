@@ -299,6 +299,45 @@ def leg_ctc_beam(ctx):
     return out
 
 
+def leg_ctc_beam_lm(ctx):
+    """The prefix beam search WITH a host language model (ctc_beam_decoder.py:214-230: the model is a Python callable consulted
+    for the separator extension of every beam entry that survives pruning): T = 501, 4 utterances, beam 8, separator 0, a
+    deterministic stand-in model.  The kernel advances over the runs of frames in which no utterance's separator survives in one
+    launch and stops where the model is needed."""
+    from myrtlespeech_amd.post_process.ctc_beam_decoder import CTCBeamDecoder
+    g = torch.Generator().manual_seed(1)
+    probs = torch.softmax(torch.randn(501, 4, 29, generator=g) * 12, dim=2)
+    probs_d = probs.cuda()
+    lens = torch.tensor([501, 433, 250, 77], dtype=torch.int64)
+
+    def lm(prefix):          # a pure function of the prefix in [0.05, 0.85] (the shape of oracle.ds_oracle.toy_language_model)
+        h = 0
+        for s_ in prefix:
+            h = (h * 31 + int(s_) + 1) % 1009
+        return 0.05 + (h % 17) / 20.0
+    dec = CTCBeamDecoder(blank_index=28, beam_width=8, language_model=lm, lm_weight=0.7, separator_index=0, word_weight=1.3)
+    ms, ms_min = ev_timed(lambda: dec(probs_d, lens), 1, 4)
+    plain = CTCBeamDecoder(blank_index=28, beam_width=8, separator_index=0, word_weight=1.3)
+    ms_plain, _ = ev_timed(lambda: plain(probs_d, lens), 1, 4)
+    out = {"workload": "CTC beam decode with a host language model: softmax(randn(501,4,29)*12), beam 8, separator 0, lm_weight 0.7",
+           "ms": round(ms, 3), "ms_min": round(ms_min, 3), "utterances_per_s": round(4 / ms * 1e3, 1),
+           "lm_calls": dec.lm_calls, "lm_frames": dec.lm_frames, "frames": 501,
+           "ms_same_search_without_the_model": round(ms_plain, 3),
+           "note": "host-bound by construction: every frame whose separator survives pruning costs a read-back of the live beam, "
+                   "the model's Python calls and a launch; the frames in between run as one launch per run"}
+    if ctx.get("cpu"):
+        from oracle import ds_oracle as O
+        t0 = time.perf_counter()
+        want = O.ctc_beam_decode(probs[:, 3:4].numpy(), np.array([77]), 28, 8, 0.001, language_model=lm, lm_weight=0.7,
+                                 separator_index=0, word_weight=1.3)
+        dt = time.perf_counter() - t0
+        got = dec(probs_d[:, 3:4].contiguous(), lens[3:4])
+        out["cpu_baseline"] = {"value": round(77.0 / 501 / dt, 3), "unit": "utterances/s (a 501-frame utterance, from 77 frames)",
+                               "cores": 1, "kind": "port", "sample": "utterance 3 (77 frames) through the numpy restatement",
+                               "same_transcript_as_gpu": bool(got == want)}
+    return out
+
+
 def leg_rnnt(ctx):
     """BASELINE configs[3] (own specification, parity unpinned): DS2 encoder at batch 16 + 2 x LSTM-1024 predictor + joint 512,
     beam 8, on the inputs and weights of tests/golden/gen_rnnt_cfg4.py (transcripts checked against its stored answers)."""
@@ -531,7 +570,7 @@ def leg_frontend(ctx):
 
 
 LEGS = {"ds1": ("cfg1_ds1", leg_ds1), "ctc": ("ctc_loss", leg_ctc_loss), "ctcgrad": ("ctc_loss_backward", leg_ctc_grad),
-        "beam": ("ctc_beam_decode", leg_ctc_beam),
+        "beam": ("ctc_beam_decode", leg_ctc_beam), "beamlm": ("ctc_beam_decode_lm", leg_ctc_beam_lm),
         "rnnt": ("cfg4_rnnt", leg_rnnt), "stream": ("cfg5_streaming", leg_stream), "streamctx": ("stream_carried_context", leg_stream_context),
         "frontend": ("frontend", leg_frontend)}
 
