@@ -296,6 +296,25 @@ def test_bench_line_stays_parseable_whatever_the_detail_grows_to():
     assert line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
 
 
+def test_the_driver_record_carries_the_box_calibration_as_flat_config_scalars():
+    """a reader of BENCH_rNN.json must be able to tell a slow box from a regression.  The round's own record
+    (profiles/r06_bench_detail_20steps.json, the full output of `python bench.py --steps 20 --warmup 5`) goes through
+    `bench_line`: the calibration figures, the second kernel's launch time / fraction and the literal step's two schedules are
+    flat scalars of `config` (the driver keeps those), and the line stays under the limit."""
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r06_bench_detail_20steps.json")) as f:
+        rec = json.loads(f.read())
+    line = _check_line(bench.bench_line(rec, "bench_detail.json"))
+    cfg = line["config"]
+    for key in ("calib_lstm_step_us_n1", "calib_lstm_step_us_n64", "calib_barrier_step_us", "projection_gemm_launch_ms",
+                "projection_gemm_frac", "recurrence_launch_ms", "one_batch_ms_per_step", "one_batch_layer_by_layer_ms_per_step"):
+        assert isinstance(cfg.get(key), (int, float)) and cfg[key] > 0, key
+    assert cfg["one_batch_schedule"] == "overlapped_stack"
+    assert all(not isinstance(v, (dict, list)) for v in cfg.values())
+    assert line["dtype"].startswith("f16x3") and line["roofline"]["traffic"] > 0
+
+
 def test_bench_spawns_its_own_ranks_without_torchrun(tmp_path):
     """`python bench.py --gpus 2` with no RANK in the environment: the parent starts the ranks under
     torch.distributed.run before it touches a device, relays rank 0's ONE line and the exit code."""

@@ -580,6 +580,7 @@ def shader_clock_under_projection_ghz():
     by one wave on a stream of its own (ms_clock_probe: {100 MHz wall ticks, shader cycles} every 20 us; tools/clock_probe.py):
     the mean over 0.5 .. 4.5 ms of ~6 ms of back-to-back launches.  A box calibration figure: the GEMM is clock-capped, so a
     slow box shows here (and in lstm_step_us_*) while a regression of the kernels does not."""
+    from myrtlespeech_amd import _lib
     lib = _lib.load()
     M, K, NN = 501 * 32, 2048, 8192
     xa = torch.randn(M, K, device="cuda")
@@ -616,8 +617,8 @@ def context(cpu=True, which=None):
     ctx["barrier_step_us"] = barrier_step_us()
     try:
         ctx["shader_clock_under_gemm_ghz_us_"] = shader_clock_under_projection_ghz()     # ("_us_": kept by run_legs' calibration filter)
-    except Exception:  # noqa: BLE001 -- a calibration figure, never a reason to lose the legs
-        pass
+    except Exception as e:  # noqa: BLE001 -- a calibration figure, never a reason to lose the legs
+        sys.stderr.write(f"bench_configs: shader clock calibration failed: {type(e).__name__}: {e}\n")
     which = which or set(LEGS)
     if "ds1" in which:
         ctx["lstm_step_us_n1"] = lstm_step_us(1, 201)

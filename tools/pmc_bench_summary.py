@@ -14,7 +14,7 @@ import re
 import sys
 from collections import defaultdict
 
-root, precision = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "bf16x3")
+root, precision = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "f16x3")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
