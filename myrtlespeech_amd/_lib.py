@@ -144,8 +144,9 @@ def stream_ptr():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def ptr(t):
-    """DEVICE pointer of a tensor (None -> NULL) for a C-ABI argument.  Every pointer of include/ms_hotpath.h is a device
+def ptr(t, strided=False):
+    """DEVICE pointer of a tensor (None -> NULL) for a C-ABI argument (``strided=True``: only for the entry points that take the
+    tensor's element strides as arguments -- ms_lookahead_* -- and so may be handed a view).  Every pointer of include/ms_hotpath.h is a device
     pointer unless its name ends in ``_host`` and every kernel assumes dense storage, so anything else is refused HERE with an
     exception: a host tensor's ``data_ptr()`` handed to a kernel is a GPU page fault that takes the whole process down (round
     5: a test passed CPU tensors to ``run_layers``; the runtime aborted inside ``ms_rnn_status``), and a strided view would be
@@ -157,7 +158,7 @@ def ptr(t):
     if not t.is_cuda:
         raise ValueError(f"_lib.ptr: a {t.device.type} tensor (shape {tuple(t.shape)}) cannot be a device-pointer argument; "
                          "move it to the GPU first (host buffers go through _lib.host_ptr)")
-    if not t.is_contiguous():
+    if not strided and not t.is_contiguous():
         raise ValueError(f"_lib.ptr: tensor of shape {tuple(t.shape)} and strides {tuple(t.stride())} is not contiguous; the "
                          "kernels read dense storage (call .contiguous())")
     return c_void_p(t.data_ptr())

@@ -25,7 +25,8 @@ def lookahead_apply(x: torch.Tensor, weight: torch.Tensor, x_strides, n: int, f:
         y = torch.empty((n, t, f), dtype=torch.float32, device="cuda")
         ys = (t * f, 1, f)
     a, lo, hi = (_lib.ACT_NONE, 0.0, 0.0) if clamp is None else (_lib.ACT_CLAMP, clamp[0], clamp[1])
-    _lib.check(lib.ms_lookahead_window_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), n, f, t_in, t, ctx, x_strides[0],
+    # (x may be a view: this entry point takes its element strides)
+    _lib.check(lib.ms_lookahead_window_forward(_lib.ptr(x, strided=True), _lib.ptr(w), _lib.ptr(y), n, f, t_in, t, ctx, x_strides[0],
                                                x_strides[1], x_strides[2], ys[0], ys[1], ys[2], a, lo, hi, _lib.stream_ptr()),
                "ms_lookahead_forward")
     return y
