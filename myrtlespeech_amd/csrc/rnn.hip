@@ -2914,7 +2914,8 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
 namespace {
 struct OverlapCtx {
   std::mutex mu;
-  hipStream_t side = nullptr;
+  hipStream_t side = nullptr;      // the projection pieces of a layer's segments, in segment order
+  hipStream_t urgent = nullptr;    // ... except those of its LAST segment(s): the rows the next layer needs first
   std::vector<hipEvent_t> ev;
 };
 OverlapCtx g_overlap[64];
@@ -2968,7 +2969,12 @@ extern "C" int ms_rnn_stack_forward(int cell, const void* const* packed_host, co
   OverlapCtx& oc = g_overlap[dev & 63];
   std::lock_guard<std::mutex> lock(oc.mu);
   if (oc.side == nullptr) MS_HIP(hipStreamCreateWithFlags(&oc.side, hipStreamNonBlocking));
-  while ((int)oc.ev.size() < 2 * S) {
+  if (oc.urgent == nullptr) {
+    int lo_pri = 0, hi_pri = 0;
+    MS_HIP(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
+    MS_HIP(hipStreamCreateWithPriority(&oc.urgent, hipStreamNonBlocking, hi_pri));
+  }
+  while ((int)oc.ev.size() < 4 * S) {
     hipEvent_t e;
     MS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     oc.ev.push_back(e);
@@ -2998,11 +3004,20 @@ extern "C" int ms_rnn_stack_forward(int cell, const void* const* packed_host, co
   unsigned short* ph = xh;                               // planes [steps * N][Kc]: hi, then lo
   unsigned short* pl = ph + (size_t)steps * N * Kc;
   const size_t st = (size_t)ndir * N * H;                // one layer's (h, c) state
+  // What the side stream has finished, for the layer that consumes it: after `ev`, the projection rows of times [a0, a1) and
+  // [b0, b1) are complete (a batch = the pieces issued after one segment).  The rows at the two ends of the utterance, which the
+  // next layer needs FIRST, are made LAST, behind the backlog of the layer's second half (the side stream's GEMM is longer than
+  // the recurrence beside it).  Two experiments live behind switches here (both measured worse than waiting for everything):
+  // per-batch waits, and the last batch on a second, high-priority stream (MS_RNN_OVERLAP_URGENT=<segments>).
+  struct Batch { int a0, a1, b0, b1; hipEvent_t ev; bool waited; };
+  std::vector<Batch> made_prev, made;
+  static const int urgent_segments = getenv("MS_RNN_OVERLAP_URGENT") ? atoi(getenv("MS_RNN_OVERLAP_URGENT")) : 0;   // (experiment, see below)
   for (int l = 0; l < nl; ++l) {
     const int in_l = l == 0 ? In : Kc;
     const PackLayout L = pack_layout(cell, in_l, H, ndir);
     const char* pk = (const char*)packed_host[l];
     const bool last_layer = l + 1 == nl;
+    hipEvent_t* evl = oc.ev.data() + (size_t)(l & 1) * 2 * S;      // this layer's events: [2 k] segment done, [2 k + 1] its pieces done
     LstmP p;
     p.xproj = (const float*)(ws + W.xslot(l & 1));
     p.whh = (const float*)(pk + L.whh);
@@ -3025,15 +3040,31 @@ extern "C" int ms_rnn_stack_forward(int cell, const void* const* packed_host, co
     const PackLayout Ln = pack_layout(cell, Kc, H, ndir);
     const char* pkn = last_layer ? nullptr : (const char*)packed_host[l + 1];
     float* xnext = (float*)(ws + W.xslot((l + 1) & 1));
-    hipEvent_t last_side = nullptr;
+    made_prev.swap(made);
+    made.clear();
     int done_lo = 0, done_hi = 0;                        // times [done_lo, done_hi) have both halves (empty at first)
-    // (profiling spans: ONE around the layer's segment launches -- nothing else is enqueued on this stream between them -- and
-    // one per segment around the side stream's GEMMs; a span is two event records, and an event per launch cost this schedule
-    // 0.6 ms per step of its 0.9 ms gain when the spans were on)
+    int part_hi = 0;                                     // times [0, part_hi) hold at least the forward half's accumulators
+    hipEvent_t first_half_ev = nullptr;                  // after it, every forward-half piece issued so far (side stream) is done
+    // (profiling spans: ONE around the layer's segment launches and one per segment around its pieces; a span is two event
+    // records, and an event per launch cost this schedule 0.6 ms per step of its gain when the spans were on)
     {
     ProfScope prof_rec(MS_PROF_RECURRENCE, stream);
     for (int k = 0; k < S; ++k) {
       const int s0 = k * SL, s1 = k + 1 == S ? steps : (k + 1) * SL;
+      // ---- this segment reads the projection rows of times [s0, s1) (forward) and [steps - s1, steps - s0) (backward)
+      // A layer starts when ALL of its rows exist (default).  MS_RNN_OVERLAP_WAIT_ALL=0: a segment waits only for the batches
+      // that made its rows, so the side stream's backlog runs beside the next layer's first segments -- measured WORSE (13.2
+      // against 12.6 ms per stack, same box; with the end rows' batch on a high-priority stream 13.1): a persistent launch that
+      // starts while GEMM tiles still hold CUs has part of its workgroups spinning on peers that are not resident yet
+      // (profiles/r06_overlap_schedule_ab.txt)
+      static const bool wait_all = !(getenv("MS_RNN_OVERLAP_WAIT_ALL") && getenv("MS_RNN_OVERLAP_WAIT_ALL")[0] == '0');
+      for (Batch& m : made_prev) {
+        auto hits = [&](int q0, int q1) { return (q0 < m.a1 && m.a0 < q1) || (q0 < m.b1 && m.b0 < q1); };
+        if (!m.waited && (wait_all || hits(s0, s1) || hits(steps - s1, steps - s0))) {
+          MS_HIP(hipStreamWaitEvent(stream, m.ev, 0));
+          m.waited = true;
+        }
+      }
       p.s_begin = s0; p.s_end = s1;
       p.h0 = s0 == 0 ? (h0 ? h0 + l * st : nullptr) : p.hn;     // a continuing segment starts from the state its predecessor left
       p.c0 = s0 == 0 ? (c0 ? c0 + l * st : nullptr) : p.cn;
@@ -3045,43 +3076,82 @@ extern "C" int ms_rnn_stack_forward(int cell, const void* const* packed_host, co
       }
       if (last_layer) continue;
       // ---- the next layer's projection of what this segment made available, on the idle CUs
-      hipEvent_t seg_done = oc.ev[2 * k], gemms_done = oc.ev[2 * k + 1];
+      // (the urgent stream never gets a forward-half piece: second launches on the side stream find their accumulators in order)
+      hipStream_t ss = (k + urgent_segments >= S && steps - s1 < s1 && part_hi >= steps - s1) ? oc.urgent : oc.side;
+      hipEvent_t seg_done = evl[2 * k], pieces_done = evl[2 * k + 1];
       MS_HIP(hipEventRecord(seg_done, stream));
-      MS_HIP(hipStreamWaitEvent(oc.side, seg_done, 0));
+      MS_HIP(hipStreamWaitEvent(ss, seg_done, 0));
+      Batch made_now{0, 0, 0, 0, pieces_done, false};
       {
-        ProfScope prof(MS_PROF_PROJECTION, oc.side);
+        ProfScope prof(MS_PROF_PROJECTION, ss);
         const unsigned short* wh = (const unsigned short*)(pkn + Ln.wih);
         const unsigned short* wl = wh + (size_t)ndir * GH * Kc;
         const float* bias = (const float*)(pkn + Ln.bias_x);
-        auto half = [&](int t0, int t1, int kmode) {       // rows of times [t0, t1), forward (first) or backward (second) half of K
+        // rows of times [t0, t1): GEMM_K_FIRST = the forward half of K (accumulators out), GEMM_K_SECOND = the backward half on top
+        // of them (+ bias), GEMM_K_WHOLE = both in one launch -- the same k-ordered chain either way
+        auto piece = [&](int t0, int t1, int kmode) -> int {
           if (t1 <= t0) return (int)MS_OK;
+          if (kmode == ms::GEMM_K_SECOND && ss != oc.side && first_half_ev != nullptr)
+            MS_HIP(hipStreamWaitEvent(ss, first_half_ev, 0));      // its accumulators were written on the other stream
           const size_t r0 = (size_t)t0 * N;
-          const int koff = kmode == ms::GEMM_K_FIRST ? 0 : H;
+          const int koff = kmode == ms::GEMM_K_SECOND ? H : 0;
           return ms::gemm_bf16x3_launch_ld(ph + r0 * Kc + koff, pl + r0 * Kc + koff, wh + koff, wl + koff, bias, xnext + r0 * NG,
-                                           (t1 - t0) * N, H, NG, MS_ACT_NONE, 0.f, 0.f, prec, oc.side, nullptr, Kc, Kc, kmode);
+                                           (t1 - t0) * N, kmode == ms::GEMM_K_WHOLE ? Kc : H, NG, MS_ACT_NONE, 0.f, 0.f, prec, ss,
+                                           nullptr, Kc, Kc, kmode);
         };
-        rc = half(s0, s1, ms::GEMM_K_FIRST);               // the forward direction just produced times [s0, s1)
-        const int f_k = s1, b_k = steps - s1;              // forward done below f_k, backward done from b_k on
-        if (rc == MS_OK && b_k < f_k) {
-          if (done_hi <= done_lo) {                        // first overlap of the two fronts (a sliver waits for the next segment)
-            if (k + 1 == S || ms::gemm_k_halves_ok((f_k - b_k) * N, NG)) {
-              rc = half(b_k, f_k, ms::GEMM_K_SECOND);
-              done_lo = b_k; done_hi = f_k;
-            }
+        auto cut_ok = [&](int t0, int t1) { return t1 > t0 && ms::gemm_k_halves_ok((t1 - t0) * N, NG); };
+        // rows [t0, t1) become complete: those below part_hi hold the forward half's accumulators already (second launch), the
+        // others get the whole contraction at once -- no accumulator round trip for them; a second-launch piece too small for
+        // the kernels that take one is simply recomputed whole (the same bits)
+        auto complete = [&](int t0, int t1) {
+          int rc2 = MS_OK;
+          const int mid = std::min(std::max(part_hi, t0), t1);
+          if (mid > t0 && cut_ok(t0, mid)) {
+            rc2 = piece(t0, mid, ms::GEMM_K_SECOND);
+            if (rc2 == MS_OK) rc2 = piece(mid, t1, ms::GEMM_K_WHOLE);
           } else {
-            rc = half(b_k, done_lo, ms::GEMM_K_SECOND);
-            if (rc == MS_OK) rc = half(done_hi, f_k, ms::GEMM_K_SECOND);
-            done_lo = b_k; done_hi = f_k;
+            rc2 = piece(t0, t1, ms::GEMM_K_WHOLE);
           }
+          return rc2;
+        };
+        const int f_k = s1, b_k = steps - s1;              // forward done below f_k, backward done from b_k on
+        bool first_half_piece = false;
+        if (b_k >= f_k) {                                  // nothing the backward direction has produced is among the forward's rows yet
+          if (cut_ok(part_hi, f_k)) {                      // (a sliver waits for the next segment)
+            rc = piece(part_hi, f_k, ms::GEMM_K_FIRST);
+            part_hi = f_k;
+            first_half_piece = true;
+          }
+        } else {
+          // rows the forward direction has produced that the backward direction has not reached yet and that hold nothing so
+          // far: the forward half now (a sliver stays untouched and is computed whole when its time comes: `complete`
+          // decides by part_hi, which is not raised past rows without accumulators)
+          if (part_hi < b_k && cut_ok(part_hi, b_k)) {
+            rc = piece(part_hi, b_k, ms::GEMM_K_FIRST);
+            part_hi = b_k;
+            first_half_piece = true;
+          }
+          if (rc == MS_OK) {
+            if (done_hi <= done_lo) {                      // first meeting of the two fronts
+              rc = complete(b_k, f_k);
+              made_now.a0 = b_k; made_now.a1 = f_k;
+            } else {
+              rc = complete(b_k, done_lo);
+              if (rc == MS_OK) rc = complete(done_hi, f_k);
+              made_now.a0 = b_k; made_now.a1 = done_lo; made_now.b0 = done_hi; made_now.b1 = f_k;
+            }
+          }
+          done_lo = b_k; done_hi = f_k;
         }
         if (rc != MS_OK) return rc;
+        if (first_half_piece) first_half_ev = pieces_done;
       }
-      MS_HIP(hipEventRecord(gemms_done, oc.side));
-      last_side = gemms_done;
+      MS_HIP(hipEventRecord(pieces_done, ss));
+      if (made_now.a1 > made_now.a0 || made_now.b1 > made_now.b0) made.push_back(made_now);
     }
-    }   // (the recurrence span ends here, before the wait for the side stream)
-    if (last_side != nullptr) MS_HIP(hipStreamWaitEvent(stream, last_side, 0));   // the next layer reads all of its rows
+    }   // (the recurrence span ends here)
   }
+  // (the last layer's segments have waited for every batch of the layer below it; nothing is outstanding on the side streams)
   return MS_OK;
 }
 
