@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol(lib):
     import re
     with open(_lib.HEADER_PATH) as f:
         header_version = int(re.search(r"#define MS_ABI_VERSION (\d+)", f.read()).group(1))
-    assert lib.ms_abi_version() == header_version == _lib.ABI_VERSION == 3
+    assert lib.ms_abi_version() == header_version == _lib.ABI_VERSION == 4
 
 
 def test_size_queries_without_gpu(lib):
