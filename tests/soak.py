@@ -152,6 +152,59 @@ def packed_rows_case(seed):
     np.testing.assert_allclose(cn.cpu().numpy(), wc, rtol=1e-4, atol=1e-4)
 
 
+_overlap_rnn = {}
+
+
+def overlap_case(seed):
+    """The overlapped stack schedule (ms_rnn_stack_forward: time-segment launches of the recurrence, the next layer's projection as
+    K-cut / whole GEMM pieces on a second stream) against the layer-by-layer schedule: `torch.equal` outputs and states for random
+    step counts, batch sizes <= 32, 2 .. 4 layers, segment counts, lengths that differ (rows not packed) and given initial states
+    -- every combination of sliver deferrals, remainders and piece kinds the segment arithmetic can produce."""
+    from myrtlespeech_amd import _lib
+    from myrtlespeech_amd.model import rnn as R
+    rng = np.random.default_rng(seed)
+    nl = int(rng.integers(2, 5))
+    In = int(rng.choice([32, 64, 96]))
+    key = (nl, In)
+    if key not in _overlap_rnn:
+        torch.manual_seed(700 + nl * 10 + In)
+        m = R.RNN(R.RNNType.LSTM, In, 1024, num_layers=nl, bidirectional=True, forget_gate_bias=1.0).eval()
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                if "weight_ih" in k:
+                    v.mul_(6.0)
+        _overlap_rnn[key] = m
+    m = _overlap_rnn[key]
+    N = int(rng.integers(1, 33))
+    T_ = int(rng.integers(max(2, -(-300 // N)), 420))
+    segs = int(rng.integers(2, 17))
+    lib = _lib.load()
+    if not lib.ms_rnn_stack_overlap_ok(_lib.CELL_LSTM, T_, N, In, 1024, 2, nl):
+        return
+    x = torch.from_numpy(rng.normal(size=(T_, N, In)).astype(np.float32)).cuda()
+    lens = np.full(N, T_)
+    if seed % 3 == 0:
+        lens = np.sort(rng.integers(1, T_ + 1, size=N))[::-1].copy()
+        lens[0] = T_
+    lens_t = torch.from_numpy(lens)
+    h0 = c0 = None
+    if seed % 4 == 1:
+        h0 = torch.from_numpy(rng.normal(size=(nl * 2, N, 1024)).astype(np.float32) * 0.5).cuda()
+        c0 = torch.from_numpy(rng.normal(size=(nl * 2, N, 1024)).astype(np.float32) * 0.5).cuda()
+
+    def run(overlap):
+        prev = (R._OVERLAP, R._OVERLAP_SEGMENTS)
+        R._OVERLAP, R._OVERLAP_SEGMENTS = overlap, segs
+        try:
+            return R.run_layers(_lib.CELL_LSTM, x, _lib.lens_i32(lens_t), T_, m._layer_params(), m._packed, 1024, h0, c0,
+                                m._workspace, ragged=False)
+        finally:
+            R._OVERLAP, R._OVERLAP_SEGMENTS = prev
+    want, got = run(False), run(True)
+    for a, b in zip(want, got):
+        assert torch.equal(a, b), (seed, nl, In, N, T_, segs, float((a - b).abs().max()))
+
+
 def ctc_case(seed):
     from myrtlespeech_amd.loss.ctc_loss import CTCLoss
     rng = np.random.default_rng(seed)
@@ -551,6 +604,7 @@ if _ties:
     print(f"  rnn-t beam: {len(_ties)} case(s) decided by a <= 4 ulp score difference (summation order): seeds {_ties[:8]}", flush=True)
 family("lstm/gru/rnn vs oracle", rnn_case)
 family("ragged LSTM-1024, packed rows", packed_rows_case)
+family("overlapped stack == layer by layer", overlap_case)
 family("mask-conv2d vs oracle", conv_case)
 family("mask-conv1d vs oracle", conv1d_case)
 family("linear kernels vs float64", linear_case)
