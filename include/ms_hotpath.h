@@ -238,9 +238,12 @@ int ms_rnn_layer_forward(int cell, const void* packed, const float* x, const int
  *                            same T, N, max_len and workspace); `x` may be NULL.
  * Same arithmetic as splitting the float32 output afterwards, one pass over the activations less per layer. */
 enum { MS_RNN_X_PLANES_IN_WS = 1, MS_RNN_OUT_PLANES_TO_WS = 2, MS_RNN_PACKED_ROWS = 4, MS_RNN_HX_PREINIT = 4096,
-       /* TIMING EXPERIMENTS ONLY (tools/overlap_emulation.py): the call launches its recurrence on whatever the workspace's
-        * projection region holds and skips the input-projection GEMM; the outputs are meaningless. */
-       MS_RNN_TIMING_SKIP_PROJECTION = 8192 };
+       /* A layer call in two halves, for callers that interleave two batches' layers on two streams (model/rnn.py: the
+        * half-batch pipeline of short sequences): MS_RNN_PROJECTION_ONLY = the input projection into the workspace, nothing
+        * else; MS_RNN_RECURRENCE_ONLY = the recurrence on the projection an earlier MS_RNN_PROJECTION_ONLY call with the same
+        * arguments left in the SAME workspace (stream-ordered behind it).  Together they do what the plain call does. */
+       MS_RNN_RECURRENCE_ONLY = 8192, MS_RNN_TIMING_SKIP_PROJECTION = 8192 /* (tools/overlap_emulation.py's name for it) */,
+       MS_RNN_PROJECTION_ONLY = 16384 };
 int ms_rnn_layer_chains_planes(int cell, int H, int ndir);
 /* One initialisation of the cross-workgroup exchange for a whole stack (rnn.py:112-120 num_layers > 1): every layer call
  * of the persistent kernels starts with a small launch that sets its exchange buffer's epoch tags and zeroes the per-call

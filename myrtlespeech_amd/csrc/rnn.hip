@@ -2644,19 +2644,21 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
   // status + epoch flags are re-zeroed on every call (cdna_hip_programming.md G16): by hx_init_kernel on the paths that
   // launch it anyway, by a memset otherwise
   const bool hx_path = use_split(cell, H, ndir) || use_f32x2(cell, H, ndir) || use_gru_persistent(cell, H, ndir);
-  if (!hx_path) MS_HIP(hipMemsetAsync(ws + W.status, 0, W.xproj - W.status, stream));
+  const bool projection_only = (flags & MS_RNN_PROJECTION_ONLY) != 0;
+  MS_REQUIRE(!(projection_only && (flags & MS_RNN_RECURRENCE_ONLY)), "MS_RNN_PROJECTION_ONLY and MS_RNN_RECURRENCE_ONLY exclude each other");
+  if (!hx_path && !projection_only) MS_HIP(hipMemsetAsync(ws + W.status, 0, W.xproj - W.status, stream));
   auto zero_base = [&](int n0) { return (unsigned*)(ws + (n0 == 0 ? W.status : W.flags)); };
   auto zero_words = [&](int n0) { return (int)((W.xproj - (n0 == 0 ? W.status : W.flags)) / sizeof(unsigned)); };
   // frames t >= max_len are all padding (the planes of a chained layer are only read up to max_len)
-  if (steps < T && out)
+  if (steps < T && out && !projection_only)
     MS_HIP(hipMemsetAsync(out + (size_t)steps * N * ndir * H, 0, (size_t)(T - steps) * N * ndir * H * sizeof(float),
                           stream));
 
   // (i) input projection for every frame of every direction: [steps*N, In] x [ndir*GH, In]^T
   float* xproj = (float*)(ws + W.xslot(0));
   int rc;
-  if (flags & MS_RNN_TIMING_SKIP_PROJECTION) {
-    rc = MS_OK;       // timing experiments: the recurrence runs on whatever the projection region holds
+  if (flags & MS_RNN_RECURRENCE_ONLY) {
+    rc = MS_OK;       // the projection region holds what an MS_RNN_PROJECTION_ONLY call left there
   } else {
     ProfScope prof(MS_PROF_PROJECTION, stream);
     if (use_split_gemm(cell, H, ndir, In)) {
@@ -2686,6 +2688,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
     }
   }
   if (rc != MS_OK) return rc;
+  if (projection_only) return MS_OK;
 
   if (fast) {
     PersistentTurn turn(stream);   // never resident together with another stream's persistent launch

@@ -32,6 +32,12 @@ Lengths = TypeVar("Lengths", bound=torch.Tensor)
 
 _OVERLAP = os.environ.get("MS_RNN_OVERLAP") != "0"              # A/B switch: 0 = the layer-by-layer schedule everywhere
 _OVERLAP_SEGMENTS = int(os.environ.get("MS_RNN_OVERLAP_SEGMENTS", "8"))   # time segments per layer (tools/overlap_emulation.py)
+# The half-batch pipeline (below) is OFF unless MS_RNN_HALVES=1: measured slower than the one-batch form it was meant to beat --
+# 1.107 against 0.957 ms per streaming chunk of 64 streams x 16 steps, same box, inside the replayed HIP graph
+# (profiles/r06_stream_half_batch_pipeline_ab.txt): ten cross-stream dependencies per chunk (7 .. 25 us of idle each on this
+# chip, EXPERIMENTS.md round 5), the slicing / concatenation kernels and 512-row GEMMs cost more than the overlap returns.
+_HALVES = os.environ.get("MS_RNN_HALVES") == "1"
+_HALVES_MAX_ROWS = int(os.environ.get("MS_RNN_HALVES_MAX_ROWS", "4096"))   # steps x sequences up to which the half-batch pipeline is used
 _HX_PREINIT = os.environ.get("MS_RNN_HX_PREINIT") != "0"      # A/B switch (tests): 0 = every layer call initialises its exchange
 
 _CELL = {RNNType.LSTM: _lib.CELL_LSTM, RNNType.GRU: _lib.CELL_GRU, RNNType.BASIC_RNN: _lib.CELL_RNN_TANH}
@@ -158,6 +164,16 @@ def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max
         if check:
             _lib.check(lib.ms_rnn_status(_lib.ptr(ws), _lib.stream_ptr()), "ms_rnn_stack_forward")
         return out, hn, cn
+    # ---- two half-batches in a pipeline (round 6; an experiment that did not pay, see _HALVES): 33 .. 64 SHORT sequences (a streaming chunk: 64 streams x 16 steps) ran as
+    # one batch whose recurrence holds every CU for a launch that is latency-bound anyway, its projections in between.  As
+    # two halves on two streams -- half A's recurrence (128 CUs) beside half B's projection, then the roles swapped -- a layer
+    # takes two phases of max(recurrence, projection) instead of recurrence + projection.  Every utterance goes through the
+    # same arithmetic whichever group or batch it is in (section 5 of DESIGN.md), so the outputs are the same bits.
+    if (_HALVES and 32 < n <= 64 and t * n <= _HALVES_MAX_ROWS and chain and not padded and not pack_rows and nl <= 8
+            and _lib.issue_point is None and bool(lib.ms_rnn_layer_is_wide(cell, hidden, ndir, n))
+            and all(s_ is None or tuple(s_.shape) == (nl * ndir, n, hidden) for s_ in (h0, c0))):
+        return _run_layers_halves(lib, cell, x, lens_dev, max_len, layer_params, packed, hidden, h0, c0, hn, cn, workspace, check,
+                                  in_sizes, lstm_like)
     preinit = 0
     if 1 < nl <= 8 and _HX_PREINIT:
         rc = lib.ms_rnn_hx_preinit(cell, t, n, max(in_sizes), hidden, ndir, max_len, nl, _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
@@ -192,6 +208,80 @@ def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max
         hn = hn[..., :true_hidden].contiguous()
         cn = None if cn is None else cn[..., :true_hidden].contiguous()
     return inp, hn, cn
+
+
+def _run_layers_halves(lib, cell, x, lens_dev, max_len, layer_params, packed, hidden, h0, c0, hn, cn, workspace, check, in_sizes,
+                       lstm_like):
+    """``run_layers`` for 33 .. 64 short sequences as two half-batches ([0, 32) and [32, n)) interleaved on two streams: a layer
+    call is issued in its two parts (MS_RNN_PROJECTION_ONLY, MS_RNN_RECURRENCE_ONLY); a half's recurrence waits for the other
+    half's previous one (two persistent launches are never resident together), its next projection follows on its own stream
+    and runs beside the other half's recurrence.  Works inside a stream capture (the second stream is forked from and joined
+    to the current one)."""
+    t, n, _ = x.shape
+    ndir, nl = len(layer_params[0]), len(layer_params)
+    cur = torch.cuda.current_stream()
+    extra = getattr(workspace, "_halves", None)
+    if extra is None:
+        extra = workspace._halves = (_lib.Workspace(), _lib.Workspace(), torch.cuda.Stream())
+    streams = (cur, extra[2])
+    cuts = ((0, 32), (32, n))
+    xs = [x[:, a:b].contiguous() for a, b in cuts]
+    lens_h = [None if lens_dev is None else lens_dev[a:b].contiguous() for a, b in cuts]
+    # a half's longest sequence (lengths are sorted in decreasing order: the second half's is not the batch's)
+    outs = [torch.empty((t, b - a, ndir * hidden), dtype=torch.float32, device="cuda") for a, b in cuts]
+    hns = [torch.empty((nl * ndir, b - a, hidden), dtype=torch.float32, device="cuda") for a, b in cuts]
+    cns = [torch.empty_like(h_) if lstm_like else None for h_ in hns]
+    h0s = [None if h0 is None else h0[:, a:b].contiguous() for a, b in cuts]
+    c0s = [None if (c0 is None or not lstm_like) else c0[:, a:b].contiguous() for a, b in cuts]
+    wss = [extra[i].get(max(lib.ms_rnn_workspace_bytes(cell, t, b - a, k, hidden, ndir) for k in in_sizes)) for i, (a, b) in enumerate(cuts)]
+    pks = [packed[layer].get(cell, in_sizes[layer], hidden, layer_params[layer], None) for layer in range(nl)]
+    PROJ, REC = 16384, 8192          # MS_RNN_PROJECTION_ONLY, MS_RNN_RECURRENCE_ONLY
+    streams[1].wait_stream(cur)
+    pre = [0, 0]
+    for i in (0, 1):
+        with torch.cuda.stream(streams[i]):
+            if 1 < nl and _HX_PREINIT:
+                rc = lib.ms_rnn_hx_preinit(cell, t, cuts[i][1] - cuts[i][0], max(in_sizes), hidden, ndir, max_len, nl, _lib.ptr(wss[i]),
+                                           wss[i].numel(), _lib.stream_ptr())
+                if rc == 0:
+                    pre[i] = 4096
+                elif rc != 5:
+                    _lib.check(rc, "ms_rnn_hx_preinit")
+
+    def part(i, layer, which):
+        nh = cuts[i][1] - cuts[i][0]
+        flags = (1 if layer > 0 else 0) | (2 if layer < nl - 1 else 0) | pre[i] | ((layer << 8) if pre[i] else 0) | which
+        sl = slice(layer * ndir, (layer + 1) * ndir)
+        h0l = None if h0s[i] is None else h0s[i][sl].contiguous()
+        c0l = None if c0s[i] is None else c0s[i][sl].contiguous()
+        out = outs[i] if layer == nl - 1 else None
+        _lib.check(lib.ms_rnn_layer_forward_ex(cell, _lib.ptr(pks[layer]), _lib.ptr(xs[i] if layer == 0 else None), _lib.ptr(lens_h[i]),
+                                               max_len, _lib.ptr(h0l), _lib.ptr(c0l), _lib.ptr(out), _lib.ptr(hns[i][sl]),
+                                               _lib.ptr(cns[i][sl] if lstm_like else None), t, nh, in_sizes[layer], hidden, ndir, flags,
+                                               _lib.ptr(wss[i]), wss[i].numel(), _lib.stream_ptr()), "ms_rnn_layer_forward")
+    for i in (0, 1):
+        with torch.cuda.stream(streams[i]):
+            part(i, 0, PROJ)
+    rec_done = [None, None]
+    for layer in range(nl):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                if rec_done[1 - i] is not None:
+                    streams[i].wait_event(rec_done[1 - i])
+                part(i, layer, REC)
+                rec_done[i] = torch.cuda.Event()
+                rec_done[i].record(streams[i])
+                if layer + 1 < nl:
+                    part(i, layer + 1, PROJ)
+    cur.wait_stream(streams[1])
+    if check:
+        for w_ in wss:
+            _lib.check(lib.ms_rnn_status(_lib.ptr(w_), _lib.stream_ptr()), "ms_rnn_layer_forward")
+    out = torch.cat(outs, dim=1)
+    hn.copy_(torch.cat(hns, dim=1))
+    if lstm_like:
+        cn.copy_(torch.cat(cns, dim=1))
+    return out, hn, cn
 
 
 class RNN(torch.nn.Module):

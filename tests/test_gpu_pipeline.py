@@ -308,3 +308,42 @@ def test_overlapped_stack_gives_the_layer_by_layer_bits(kind, N, T_, In, nl, seg
     assert float(want[0].abs().max()) > 0.5          # (a live network: outputs are not all tiny)
     again = run(True)                                 # a second call re-uses the library's side stream and events
     assert all(torch.equal(a, b) for a, b in zip(want, again))
+
+
+@pytest.mark.parametrize("N,T_,In,nl,with_hx,ragged", [(64, 16, 640, 5, True, False), (48, 16, 96, 2, False, False),
+                                                       (33, 40, 64, 3, True, True), (64, 7, 32, 1, False, True)])
+def test_half_batch_pipeline_gives_the_one_batch_bits(N, T_, In, nl, with_hx, ragged):
+    """33 .. 64 short sequences (a streaming chunk) as two half-batches interleaved on two streams -- a half's recurrence beside
+    the other half's projection, layer calls issued as MS_RNN_PROJECTION_ONLY + MS_RNN_RECURRENCE_ONLY -- against the same batch
+    as one call per layer (two batch groups per recurrence launch): outputs and final states ``torch.equal``."""
+    from myrtlespeech_amd import _lib
+    from myrtlespeech_amd.model import rnn as R
+    H, ndir = 1024, 2
+    torch.manual_seed(N + T_)
+    m = R.RNN(R.RNNType.LSTM, In, H, num_layers=nl, bidirectional=True, forget_gate_bias=1.0).eval()
+    with torch.no_grad():
+        for k, v in m.state_dict().items():
+            if "weight_ih" in k:
+                v.mul_(8.0)
+    x = torch.randn(T_, N, In, device="cuda")
+    lens = torch.full((N,), T_, dtype=torch.int64)
+    if ragged:
+        lens = torch.sort(torch.randint(1, T_ + 1, (N,)), descending=True).values
+        lens[0] = T_
+    h0 = c0 = None
+    if with_hx:
+        h0 = (torch.randn(nl * ndir, N, H, device="cuda") * 0.5).contiguous()
+        c0 = (torch.randn(nl * ndir, N, H, device="cuda") * 0.5).contiguous()
+
+    def run(halves):
+        prev = R._HALVES
+        R._HALVES = halves
+        try:
+            return R.run_layers(_lib.CELL_LSTM, x, _lib.lens_i32(lens), T_, m._layer_params(), [R.PackedLayer() for _ in range(nl)], H,
+                                h0, c0, _lib.Workspace(), ragged=False)
+        finally:
+            R._HALVES = prev
+    want, got = run(False), run(True)
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    assert float(want[0].abs().max()) > 0.3
