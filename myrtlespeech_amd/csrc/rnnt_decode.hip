@@ -1194,6 +1194,17 @@ __device__ __forceinline__ void pred_gemm3_body(const Beam2P& p, const unsigned 
   store_split3(p.hpl + (size_t)l * 3 * p.hplane, p.hplane, frag_off(r, u, H), h_new);
 }
 
+// Round 6: layer l's cell GEMM (W_ih(l) . h'_{l-1}) and G of layer l - 1 (W_hh(l-1) . h'_{l-1}) contract the SAME rows -- the
+// new h of layer l - 1 -- so they are one launch, blockIdx.z = 0 / 1: 2 x H / 8 workgroups fill the chip where the cell GEMM
+// alone used half of it, and the joint's launch carries only the top layer's G (27.7 -> ~19 us).  Same bodies, same sums.
+template <int RG>
+__global__ __launch_bounds__(512) void pred_gemm3_cell_g_kernel(Beam2P p, const unsigned short* __restrict__ wih, const unsigned short* __restrict__ whh,
+                                                                 int l_cell) {
+  __shared__ float red[8][32][33];
+  if (blockIdx.z == 0) pred_gemm3_body<true, RG>(p, wih, l_cell, blockIdx.x, blockIdx.y, red);
+  else pred_gemm3_body<false, RG>(p, whh, l_cell - 1, blockIdx.x, blockIdx.y, red);
+}
+
 template <bool CELL, int RG>
 __global__ __launch_bounds__(512) void pred_gemm3_kernel(Beam2P p, const unsigned short* __restrict__ wp_base, int l_cell) {
   __shared__ float red[8][32][33];
@@ -1315,7 +1326,8 @@ __global__ __launch_bounds__(512) void beam2_joint_kernel(Beam2P p, const unsign
 template <int RGJ, int RGG>
 __global__ __launch_bounds__(512) void beam2_joint_g_kernel(Beam2P p, const unsigned short* __restrict__ wpred, const float* __restrict__ enc_p,
                                                             const float* __restrict__ w_out, float* __restrict__ plog, int t,
-                                                            const unsigned short* __restrict__ whh, int jx, int jy, int gx, int gy) {
+                                                            const unsigned short* __restrict__ whh, int jx, int jy, int gx, int gy,
+                                                            int g_layer0) {
   __shared__ float red[8][32][33];
   __shared__ float zs[32 * RGJ][33];
   extern __shared__ __attribute__((aligned(16))) float wo[];
@@ -1325,7 +1337,7 @@ __global__ __launch_bounds__(512) void beam2_joint_g_kernel(Beam2P p, const unsi
     return;
   }
   id -= jx * jy;
-  const int b = id % gx, rb = (id / gx) % gy, l = id / (gx * gy);
+  const int b = id % gx, rb = (id / gx) % gy, l = g_layer0 + id / (gx * gy);      // (the lower layers' G rode with the cell GEMMs)
   pred_gemm3_body<false, RGG>(p, whh, l, b, rb, red);
 }
 
@@ -1790,19 +1802,30 @@ int beam2_decode(const BeamP& bp, const DecLayout& W, char* ws, const float* emb
   const dim3 ggrid(H / 8, (R + 32 * rgg - 1) / (32 * rgg));
   const dim3 jgrid(J / 32, (R + 32 * rgj - 1) / (32 * rgj));
   const size_t cand_lds = (size_t)w * V1 * 4, wo_lds = (size_t)V1 * 32 * 4;
+  // (MS_RNNT_FUSE_G=0, read per call: the lower layers' G in the joint's launch as in round 5 -- A/B runs)
+  const char* fg = getenv("MS_RNNT_FUSE_G");
+  const bool fuse_g = !(fg && fg[0] == '0') && L > 1;
   auto predictor_step2 = [&]() {       // cell 0 of the request rows, then cells 1 .. L - 1; G rides with the step's joint launch
     hipLaunchKernelGGL(beam2_cell0_kernel, dim3(R), dim3(256), 0, s, q);
     for (int l = 1; l < L; ++l) {
-      if (rgg == 1) hipLaunchKernelGGL((pred_gemm3_kernel<true, 1>), ggrid, dim3(512), 0, s, q, (const unsigned short*)wih, l);
-      else hipLaunchKernelGGL((pred_gemm3_kernel<true, 2>), ggrid, dim3(512), 0, s, q, (const unsigned short*)wih, l);
+      if (fuse_g) {
+        const dim3 cg(ggrid.x, ggrid.y, 2);
+        if (rgg == 1) hipLaunchKernelGGL((pred_gemm3_cell_g_kernel<1>), cg, dim3(512), 0, s, q, (const unsigned short*)wih, (const unsigned short*)whh, l);
+        else hipLaunchKernelGGL((pred_gemm3_cell_g_kernel<2>), cg, dim3(512), 0, s, q, (const unsigned short*)wih, (const unsigned short*)whh, l);
+      } else if (rgg == 1) {
+        hipLaunchKernelGGL((pred_gemm3_kernel<true, 1>), ggrid, dim3(512), 0, s, q, (const unsigned short*)wih, l);
+      } else {
+        hipLaunchKernelGGL((pred_gemm3_kernel<true, 2>), ggrid, dim3(512), 0, s, q, (const unsigned short*)wih, l);
+      }
     }
   };
   auto joint = [&](int t, bool after_step) {
-    const int nj = jgrid.x * jgrid.y, ng = ggrid.x * ggrid.y * L;
+    const int g_layer0 = fuse_g ? L - 1 : 0;
+    const int nj = jgrid.x * jgrid.y, ng = ggrid.x * ggrid.y * (L - g_layer0);
     if (after_step) {
       // the step's new states: their projected predictor output (joint) and their G (beside it)
 #define MS_JG(RJ, RGm) hipLaunchKernelGGL((beam2_joint_g_kernel<RJ, RGm>), dim3(nj + ng), dim3(512), wo_lds, s, q, (const unsigned short*)wpred, \
-                                          enc_p, w_out, plog, t, (const unsigned short*)whh, (int)jgrid.x, (int)jgrid.y, (int)ggrid.x, (int)ggrid.y)
+                                          enc_p, w_out, plog, t, (const unsigned short*)whh, (int)jgrid.x, (int)jgrid.y, (int)ggrid.x, (int)ggrid.y, g_layer0)
       if (rgj == 1 && rgg == 1) MS_JG(1, 1);
       else if (rgj == 1) MS_JG(1, 2);
       else if (rgg == 1) MS_JG(2, 1);
