@@ -182,7 +182,19 @@ __device__ __forceinline__ void store_split3(unsigned short* planes, size_t plan
   planes[2 * plane_stride + off] = (unsigned short)l;
 }
 typedef __bf16 bf16x8r __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8r __attribute__((ext_vector_type(8)));
 typedef float f32x16r __attribute__((ext_vector_type(16)));
+// Round 6 (the re-cut beam sequence only): `two` != 0 = TWO fp16 planes hi + lo (22 mantissa bits; the encoder's f16x3 split)
+// in planes 0 and 1 instead of the exact three-bf16 decomposition -- a launch of these GEMMs is a per-CU operand pull (590 KB
+// at ~50 GB/s: EXPERIMENTS.md round 5), two planes are two thirds of it and half of the MFMAs.  MS_RNNT_PLANES=3 keeps the
+// exact form.
+__device__ __forceinline__ void store_split(unsigned short* planes, size_t plane_stride, size_t off, float x, int two) {
+  if (!two) { store_split3(planes, plane_stride, off, x); return; }
+  unsigned hi, lo;
+  ms::plane_split<true>(x, hi, lo);
+  planes[off] = (unsigned short)hi;
+  planes[plane_stride + off] = (unsigned short)lo;
+}
 
 __device__ __forceinline__ unsigned bf16_rne(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
 
@@ -1009,7 +1021,7 @@ GreedyPoll* greedy_poll() {
 // Shapes: H % 64 == 0, J % 32 == 0; anything else takes the round-4 sequence.  MS_RNNT_V2=0 (read per call) selects it too.
 
 // rows [rows][K] float32 -> three fragment-major bf16 planes; unit_major: gate row g H + u -> row (u / 8) 32 + g 8 + u % 8
-__global__ void pack_rows3_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes, int rows, int K, int H_units) {
+__global__ void pack_rows3_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes, int rows, int K, int H_units, int two) {
   const int src_row = blockIdx.x;
   int row = src_row;
   if (H_units > 0) {
@@ -1018,7 +1030,7 @@ __global__ void pack_rows3_kernel(const float* __restrict__ w, unsigned short* _
   }
   const size_t plane = (size_t)rows * K;
   for (int k = threadIdx.x; k < K; k += blockDim.x)
-    store_split3(planes, plane, frag_off(row, k, K), w[(size_t)src_row * K + k]);
+    store_split(planes, plane, frag_off(row, k, K), w[(size_t)src_row * K + k], two);
 }
 
 // out[unit-major row] = a[row] + b[row] (+ tab[v][row] for a table of nv rows)
@@ -1048,6 +1060,7 @@ struct Beam2P {
   unsigned short* hpl;          // [L][3][rpad * H] planes of the rows' new h of every layer
   size_t hplane;                // rpad * H
   int N, w, V, bcap, maxn, R, H, L, J, NS;
+  int two;                      // operand planes of the step's GEMMs: 0 = three bf16 (exact), 1 = two fp16 (store_split)
 };
 
 __device__ __forceinline__ void lstm_cell(const float pre[4], float c_old, float& h_new, float& c_new) {
@@ -1094,7 +1107,7 @@ __global__ __launch_bounds__(256) void beam2_cell0_kernel(Beam2P p) {
       lstm_cell(pre, cv[m], h_new, c_new);
       p.st_h[((size_t)dst * L + 0) * H + u] = h_new;
       p.st_c[((size_t)dst * L + 0) * H + u] = c_new;
-      store_split3(p.hpl, p.hplane, frag_off(r, u, H), h_new);
+      store_split(p.hpl, p.hplane, frag_off(r, u, H), h_new, p.two);
     }
   }
 }
@@ -1104,7 +1117,7 @@ __global__ __launch_bounds__(256) void beam2_cell0_kernel(Beam2P p) {
 // CELL: weight rows = W_ih of layer l (unit-major), x = the rows' new h of layer l - 1; pre = sum + bias + G_l[src] -> cell
 //       -> state of the destination slot, the rows' new h of layer l as planes.
 // !CELL: blockIdx.z = layer; weight rows = W_hh of that layer, x = the rows' new h of that layer; G_l[dst] = sum.
-template <bool CELL, int RG>
+template <bool CELL, int RG, bool TWO>
 __device__ __forceinline__ void pred_gemm3_body(const Beam2P& p, const unsigned short* __restrict__ wp_base, int l, int b, int rb,
                                                 float (*red)[32][33]) {
   constexpr int KQ = 8 / RG;
@@ -1125,15 +1138,25 @@ __device__ __forceinline__ void pred_gemm3_body(const Beam2P& p, const unsigned 
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   constexpr int PF = 4;
-  u32x4r xf[PF][3], wf[PF][3];
+  u32x4r xf[PF][TWO ? 2 : 3], wf[PF][TWO ? 2 : 3];
+  constexpr int two = TWO ? 1 : 0;                                   // two fp16 planes instead of three bf16 (a template parameter: as a
+                                                                     // uniform run-time flag it cost the three-plane form 10 %)
   auto load = [&](int slot, int ks) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
+      if (pl >= (TWO ? 2 : 3)) continue;
       xf[slot][pl] = *reinterpret_cast<const u32x4r*>(xp + (size_t)pl * p.hplane + (size_t)ks * 512);
       wf[slot][pl] = *reinterpret_cast<const u32x4r*>(w0 + (size_t)pl * wplane + (size_t)ks * 512);
     }
   };
   auto step = [&](int slot) {
+    if constexpr (TWO) {     // hi.hi + lo.hi + hi.lo in fp16 (smallest terms first)
+      const f16x8r wh_ = __builtin_bit_cast(f16x8r, wf[slot][0]), wl_ = __builtin_bit_cast(f16x8r, wf[slot][1]);
+      const f16x8r xh_ = __builtin_bit_cast(f16x8r, xf[slot][0]), xl_ = __builtin_bit_cast(f16x8r, xf[slot][1]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl_, wh_, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh_, wl_, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh_, wh_, acc, 0, 0, 0);
+    } else {
     const bf16x8r bh = __builtin_bit_cast(bf16x8r, wf[slot][0]), bm = __builtin_bit_cast(bf16x8r, wf[slot][1]);
     const bf16x8r bl = __builtin_bit_cast(bf16x8r, wf[slot][2]);
     const bf16x8r xh = __builtin_bit_cast(bf16x8r, xf[slot][0]), xm = __builtin_bit_cast(bf16x8r, xf[slot][1]);
@@ -1144,6 +1167,7 @@ __device__ __forceinline__ void pred_gemm3_body(const Beam2P& p, const unsigned 
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc, 0, 0, 0);
+    }
   };
   const int nks = kslice / 16;
 #pragma unroll
@@ -1191,30 +1215,30 @@ __device__ __forceinline__ void pred_gemm3_body(const Beam2P& p, const unsigned 
   lstm_cell(pre, c_old, h_new, c_new);
   p.st_h[((size_t)dst * L + l) * H + u] = h_new;
   p.st_c[((size_t)dst * L + l) * H + u] = c_new;
-  store_split3(p.hpl + (size_t)l * 3 * p.hplane, p.hplane, frag_off(r, u, H), h_new);
+  store_split(p.hpl + (size_t)l * 3 * p.hplane, p.hplane, frag_off(r, u, H), h_new, p.two);
 }
 
 // Round 6: layer l's cell GEMM (W_ih(l) . h'_{l-1}) and G of layer l - 1 (W_hh(l-1) . h'_{l-1}) contract the SAME rows -- the
 // new h of layer l - 1 -- so they are one launch, blockIdx.z = 0 / 1: 2 x H / 8 workgroups fill the chip where the cell GEMM
 // alone used half of it, and the joint's launch carries only the top layer's G (27.7 -> ~19 us).  Same bodies, same sums.
-template <int RG>
+template <int RG, bool TWO>
 __global__ __launch_bounds__(512) void pred_gemm3_cell_g_kernel(Beam2P p, const unsigned short* __restrict__ wih, const unsigned short* __restrict__ whh,
                                                                  int l_cell) {
   __shared__ float red[8][32][33];
-  if (blockIdx.z == 0) pred_gemm3_body<true, RG>(p, wih, l_cell, blockIdx.x, blockIdx.y, red);
-  else pred_gemm3_body<false, RG>(p, whh, l_cell - 1, blockIdx.x, blockIdx.y, red);
+  if (blockIdx.z == 0) pred_gemm3_body<true, RG, TWO>(p, wih, l_cell, blockIdx.x, blockIdx.y, red);
+  else pred_gemm3_body<false, RG, TWO>(p, whh, l_cell - 1, blockIdx.x, blockIdx.y, red);
 }
 
-template <bool CELL, int RG>
+template <bool CELL, int RG, bool TWO>
 __global__ __launch_bounds__(512) void pred_gemm3_kernel(Beam2P p, const unsigned short* __restrict__ wp_base, int l_cell) {
   __shared__ float red[8][32][33];
-  pred_gemm3_body<CELL, RG>(p, wp_base, CELL ? l_cell : (int)blockIdx.z, blockIdx.x, blockIdx.y, red);
+  pred_gemm3_body<CELL, RG, TWO>(p, wp_base, CELL ? l_cell : (int)blockIdx.z, blockIdx.x, blockIdx.y, red);
 }
 
 // pred_proj + joint: grid (J / 32, cdiv(R, 32 RG)), 512 threads (RG row groups of 32 x 8 / RG K slices).  pp[slot][j] = W_pred[j] . h_top of a row whose state is new
 // (`gemm` != 0 and ext_dst[r] >= 0: committed to the pool), else the pool's; z = tanh(enc_p[t, i, j] + pp); the output
 // layer's partial sums over this workgroup's 32 joint units go to plog[slice][r][v].
-template <int RG>
+template <int RG, bool TWO>
 __device__ __forceinline__ void beam2_joint_body(const Beam2P& p, const unsigned short* __restrict__ wpred, const float* __restrict__ enc_p,
                                                  const float* __restrict__ w_out, float* __restrict__ plog, int t, int gemm, int js, int rb,
                                                  float (*red)[32][33], float (*zs)[33], float* wo) {
@@ -1238,15 +1262,23 @@ __device__ __forceinline__ void beam2_joint_body(const Beam2P& p, const unsigned
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     constexpr int PF = 4;
-    u32x4r xf[PF][3], wf[PF][3];
+    u32x4r xf[PF][TWO ? 2 : 3], wf[PF][TWO ? 2 : 3];
     auto load = [&](int slot, int ks) {
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
+        if (pl >= (TWO ? 2 : 3)) continue;
         xf[slot][pl] = *reinterpret_cast<const u32x4r*>(xp + (size_t)pl * p.hplane + (size_t)ks * 512);
         wf[slot][pl] = *reinterpret_cast<const u32x4r*>(w0 + (size_t)pl * wplane + (size_t)ks * 512);
       }
     };
     auto step = [&](int slot) {
+      if constexpr (TWO) {     // hi.hi + lo.hi + hi.lo in fp16 (smallest terms first)
+        const f16x8r wh_ = __builtin_bit_cast(f16x8r, wf[slot][0]), wl_ = __builtin_bit_cast(f16x8r, wf[slot][1]);
+        const f16x8r xh_ = __builtin_bit_cast(f16x8r, xf[slot][0]), xl_ = __builtin_bit_cast(f16x8r, xf[slot][1]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl_, wh_, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh_, wl_, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh_, wh_, acc, 0, 0, 0);
+      } else {
       const bf16x8r bh = __builtin_bit_cast(bf16x8r, wf[slot][0]), bm = __builtin_bit_cast(bf16x8r, wf[slot][1]);
       const bf16x8r bl = __builtin_bit_cast(bf16x8r, wf[slot][2]);
       const bf16x8r xh = __builtin_bit_cast(bf16x8r, xf[slot][0]), xm = __builtin_bit_cast(bf16x8r, xf[slot][1]);
@@ -1257,6 +1289,7 @@ __device__ __forceinline__ void beam2_joint_body(const Beam2P& p, const unsigned
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc, 0, 0, 0);
+      }
     };
     const int nks = kslice / 16;
 #pragma unroll
@@ -1310,20 +1343,20 @@ __device__ __forceinline__ void beam2_joint_body(const Beam2P& p, const unsigned
   }
 }
 
-template <int RG>
+template <int RG, bool TWO>
 __global__ __launch_bounds__(512) void beam2_joint_kernel(Beam2P p, const unsigned short* __restrict__ wpred, const float* __restrict__ enc_p,
                                                           const float* __restrict__ w_out, float* __restrict__ plog, int t, int gemm) {
   __shared__ float red[8][32][33];
   __shared__ float zs[32 * RG][33];
   extern __shared__ __attribute__((aligned(16))) float wo[];           // [V1][32] this slice's columns of W_out
-  beam2_joint_body<RG>(p, wpred, enc_p, w_out, plog, t, gemm, blockIdx.x, blockIdx.y, red, zs, wo);
+  beam2_joint_body<RG, TWO>(p, wpred, enc_p, w_out, plog, t, gemm, blockIdx.x, blockIdx.y, red, zs, wo);
 }
 
 // The joint of a predictor step and G of the step's new states in ONE launch: G is not on the step's chain (a state's G is first
 // read a round later), the joint is and uses a quarter of the CUs -- so the G workgroups (block ids behind the joint's) fill
 // the rest of the chip beside it instead of a launch of their own (19 us per step).  A second stream was measured for this: the
 // event hand-overs between two streams cost 7 .. 25 us of idle each on this chip (profiles/r05k_*), more than G itself.
-template <int RGJ, int RGG>
+template <int RGJ, int RGG, bool TWO>
 __global__ __launch_bounds__(512) void beam2_joint_g_kernel(Beam2P p, const unsigned short* __restrict__ wpred, const float* __restrict__ enc_p,
                                                             const float* __restrict__ w_out, float* __restrict__ plog, int t,
                                                             const unsigned short* __restrict__ whh, int jx, int jy, int gx, int gy,
@@ -1333,12 +1366,12 @@ __global__ __launch_bounds__(512) void beam2_joint_g_kernel(Beam2P p, const unsi
   extern __shared__ __attribute__((aligned(16))) float wo[];
   int id = blockIdx.x;
   if (id < jx * jy) {
-    beam2_joint_body<RGJ>(p, wpred, enc_p, w_out, plog, t, 1, id % jx, id / jx, red, zs, wo);
+    beam2_joint_body<RGJ, TWO>(p, wpred, enc_p, w_out, plog, t, 1, id % jx, id / jx, red, zs, wo);
     return;
   }
   id -= jx * jy;
   const int b = id % gx, rb = (id / gx) % gy, l = g_layer0 + id / (gx * gy);      // (the lower layers' G rode with the cell GEMMs)
-  pred_gemm3_body<false, RGG>(p, whh, l, b, rb, red);
+  pred_gemm3_body<false, RGG, TWO>(p, whh, l, b, rb, red);
 }
 
 // cand[j * V1 + v] = log_softmax_v(b_out[v] + sum over the J / 32 slices, in slice order, of plog[slice][i w + j][v]) for the
@@ -1754,6 +1787,10 @@ int beam2_decode(const BeamP& bp, const DecLayout& W, char* ws, const float* emb
   const int R = W.R, V1 = V + 1;
   const size_t rpad = (size_t)((R + 63) / 64 * 64);
   Beam2P q{};
+  {
+    const char* e = getenv("MS_RNNT_PLANES");      // 3 = the exact three-bf16 operands of round 5 (A/B runs); default: two fp16 planes
+    q.two = (e && e[0] == '3') ? 0 : 1;
+  }
   q.lens = bp.lens;
   int32_t* a2 = (int32_t*)(ws + W.v2_A2);
   int32_t* Acnt[2] = {bp.A_cnt, a2};
@@ -1780,14 +1817,14 @@ int beam2_decode(const BeamP& bp, const DecLayout& W, char* ws, const float* emb
   // ---- once per call: the operand planes, the embedding table, the biases
   const size_t wplane3 = (size_t)3 * 4 * H * H;
   for (int l = 0; l < L; ++l) {
-    hipLaunchKernelGGL(pack_rows3_kernel, dim3(4 * H), dim3(256), 0, s, w_hh[l], whh + (size_t)l * wplane3, 4 * H, H, H);
+    hipLaunchKernelGGL(pack_rows3_kernel, dim3(4 * H), dim3(256), 0, s, w_hh[l], whh + (size_t)l * wplane3, 4 * H, H, H, q.two);
     if (l > 0) {
-      hipLaunchKernelGGL(pack_rows3_kernel, dim3(4 * H), dim3(256), 0, s, w_ih[l], wih + (size_t)(l - 1) * wplane3, 4 * H, H, H);
+      hipLaunchKernelGGL(pack_rows3_kernel, dim3(4 * H), dim3(256), 0, s, w_ih[l], wih + (size_t)(l - 1) * wplane3, 4 * H, H, H, q.two);
       hipLaunchKernelGGL(unit_major_add_kernel, dim3(ms::cdiv(4 * H, 256)), dim3(256), 0, s, (const float*)nullptr, b_ih[l], b_hh[l],
                          (float*)(ws + W.v2_bias) + (size_t)l * 4 * H, H, 0);
     }
   }
-  hipLaunchKernelGGL(pack_rows3_kernel, dim3(J), dim3(256), 0, s, w_pred, wpred, J, H, 0);
+  hipLaunchKernelGGL(pack_rows3_kernel, dim3(J), dim3(256), 0, s, w_pred, wpred, J, H, 0, q.two);
   MS_LAUNCH_CHECK();
   int rc = ms::linear_launch(embedding, w_ih[0], nullptr, (float*)(ws + W.v2_Etmp), V1, D, 4 * H, MS_ACT_NONE, 0.f, 0.f, s);
   if (rc != MS_OK) return rc;
@@ -1810,12 +1847,17 @@ int beam2_decode(const BeamP& bp, const DecLayout& W, char* ws, const float* emb
     for (int l = 1; l < L; ++l) {
       if (fuse_g) {
         const dim3 cg(ggrid.x, ggrid.y, 2);
-        if (rgg == 1) hipLaunchKernelGGL((pred_gemm3_cell_g_kernel<1>), cg, dim3(512), 0, s, q, (const unsigned short*)wih, (const unsigned short*)whh, l);
-        else hipLaunchKernelGGL((pred_gemm3_cell_g_kernel<2>), cg, dim3(512), 0, s, q, (const unsigned short*)wih, (const unsigned short*)whh, l);
+#define MS_CG(RG_) \
+        if (q.two) hipLaunchKernelGGL((pred_gemm3_cell_g_kernel<RG_, true>), cg, dim3(512), 0, s, q, (const unsigned short*)wih, (const unsigned short*)whh, l); \
+        else hipLaunchKernelGGL((pred_gemm3_cell_g_kernel<RG_, false>), cg, dim3(512), 0, s, q, (const unsigned short*)wih, (const unsigned short*)whh, l)
+        if (rgg == 1) { MS_CG(1); } else { MS_CG(2); }
+#undef MS_CG
       } else if (rgg == 1) {
-        hipLaunchKernelGGL((pred_gemm3_kernel<true, 1>), ggrid, dim3(512), 0, s, q, (const unsigned short*)wih, l);
+        if (q.two) hipLaunchKernelGGL((pred_gemm3_kernel<true, 1, true>), ggrid, dim3(512), 0, s, q, (const unsigned short*)wih, l);
+        else hipLaunchKernelGGL((pred_gemm3_kernel<true, 1, false>), ggrid, dim3(512), 0, s, q, (const unsigned short*)wih, l);
       } else {
-        hipLaunchKernelGGL((pred_gemm3_kernel<true, 2>), ggrid, dim3(512), 0, s, q, (const unsigned short*)wih, l);
+        if (q.two) hipLaunchKernelGGL((pred_gemm3_kernel<true, 2, true>), ggrid, dim3(512), 0, s, q, (const unsigned short*)wih, l);
+        else hipLaunchKernelGGL((pred_gemm3_kernel<true, 2, false>), ggrid, dim3(512), 0, s, q, (const unsigned short*)wih, l);
       }
     }
   };
@@ -1824,17 +1866,21 @@ int beam2_decode(const BeamP& bp, const DecLayout& W, char* ws, const float* emb
     const int nj = jgrid.x * jgrid.y, ng = ggrid.x * ggrid.y * (L - g_layer0);
     if (after_step) {
       // the step's new states: their projected predictor output (joint) and their G (beside it)
-#define MS_JG(RJ, RGm) hipLaunchKernelGGL((beam2_joint_g_kernel<RJ, RGm>), dim3(nj + ng), dim3(512), wo_lds, s, q, (const unsigned short*)wpred, \
+#define MS_JG(RJ, RGm) do { if (q.two) MS_JG2(RJ, RGm, true); else MS_JG2(RJ, RGm, false); } while (0)
+#define MS_JG2(RJ, RGm, TW) hipLaunchKernelGGL((beam2_joint_g_kernel<RJ, RGm, TW>), dim3(nj + ng), dim3(512), wo_lds, s, q, (const unsigned short*)wpred, \
                                           enc_p, w_out, plog, t, (const unsigned short*)whh, (int)jgrid.x, (int)jgrid.y, (int)ggrid.x, (int)ggrid.y, g_layer0)
       if (rgj == 1 && rgg == 1) MS_JG(1, 1);
       else if (rgj == 1) MS_JG(1, 2);
       else if (rgg == 1) MS_JG(2, 1);
       else MS_JG(2, 2);
 #undef MS_JG
+#undef MS_JG2
     } else if (rgj == 1) {
-      hipLaunchKernelGGL(beam2_joint_kernel<1>, jgrid, dim3(512), wo_lds, s, q, (const unsigned short*)wpred, enc_p, w_out, plog, t, 0);
+      if (q.two) hipLaunchKernelGGL((beam2_joint_kernel<1, true>), jgrid, dim3(512), wo_lds, s, q, (const unsigned short*)wpred, enc_p, w_out, plog, t, 0);
+      else hipLaunchKernelGGL((beam2_joint_kernel<1, false>), jgrid, dim3(512), wo_lds, s, q, (const unsigned short*)wpred, enc_p, w_out, plog, t, 0);
     } else {
-      hipLaunchKernelGGL(beam2_joint_kernel<2>, jgrid, dim3(512), wo_lds, s, q, (const unsigned short*)wpred, enc_p, w_out, plog, t, 0);
+      if (q.two) hipLaunchKernelGGL((beam2_joint_kernel<2, true>), jgrid, dim3(512), wo_lds, s, q, (const unsigned short*)wpred, enc_p, w_out, plog, t, 0);
+      else hipLaunchKernelGGL((beam2_joint_kernel<2, false>), jgrid, dim3(512), wo_lds, s, q, (const unsigned short*)wpred, enc_p, w_out, plog, t, 0);
     }
   };
   // ---- the root hypotheses' predictor state (blank on the zero state)
