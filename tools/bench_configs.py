@@ -390,11 +390,12 @@ def leg_rnnt(ctx):
         pass
     frames = int(lens.sum())
     rows = G.N * G.W
-    # floor of the round-5 sequence (csrc/rnnt_decode.hip, beam2_*): per predictor step the three-plane operand planes of
-    # W_hh0, W_ih1, W_hh1 (4H x H x 6 B each) and W_pred (J x H x 6 B) are streamed once; a frame is 10 dependent launches
+    # floor of the round-5 sequence (csrc/rnnt_decode.hip, beam2_*): per predictor step the operand planes of W_hh0, W_ih1,
+    # W_hh1 (4H x H) and W_pred (J x H) -- two fp16 planes per weight since round 6, three bf16 before -- are streamed once; a frame is 10 dependent launches
     # (joint, round, cell 0, layer 1 | joint + G, round, cell 0, layer 1 | joint + G, frame end) at the chip's dependent-launch
     # boundary (MI355X_MICROARCH.md price list, "boundary": 1.45 us)
-    plane_bytes = (3 * 4 * G.P * G.P + G.J * G.P) * 6
+    planes = 3 if os.environ.get("MS_RNNT_PLANES") == "3" else 2          # round 6: two fp16 planes (4 B per weight) by default
+    plane_bytes = (3 * 4 * G.P * G.P + G.J * G.P) * 2 * planes
     launches = 3 * G.MS + 2 * (G.MS - 1) - 1 + 2 * (G.MS - 1) * (G.L - 2)      # 10 at MS = 3, L = 2
     per_frame_us = (G.MS - 1) * plane_bytes / (HBM_GBS * 1e3) + launches * 1.45
     floor = G.T * per_frame_us * 1e-3
@@ -407,7 +408,7 @@ def leg_rnnt(ctx):
            "launches_per_frame": launches,
            "transcripts_equal_oracle_fixture": gold,
            "floor_ms": round(floor, 2), "frac_of_floor": round(floor / ms_b, 3),
-           "floor": f"decode only: 501 frames x ({G.MS - 1} predictor steps x {plane_bytes / 1e6:.0f} MB of three-plane operand planes "
+           "floor": f"decode only: 501 frames x ({G.MS - 1} predictor steps x {plane_bytes / 1e6:.0f} MB of operand planes ({planes} x 16 bit per weight) "
                     f"(W_hh0, W_ih1, W_hh1, W_pred) at 8 TB/s + {launches} dependent launches x 1.45 us); the kernels' own latency "
                     "chains (2 .. 4 dependent L2 round trips each) are not in the floor"}
     if ctx.get("cpu"):
