@@ -123,11 +123,16 @@ __device__ __forceinline__ int find_in_beam(const int* bmn, int W8, int node) {
 #define MS_BEAM_STAMP_BEGIN() do { if (stamping) st_prev = wall_clock64(); } while (0)
 #define MS_BEAM_STAMP(k) do { if (stamping) { const unsigned long long now_ = wall_clock64(); st_acc[k] += (unsigned)(now_ - st_prev); st_prev = now_; } } while (0)
 
-template <bool BIG, int NT>
+// VC / WC (round 6): the alphabet size and the beam width as COMPILE-TIME constants (0 = taken from the arguments).  Every
+// working array is at an offset from the LDS base that depends on V and W only; with both known the ~40 array pointers the
+// frame loop keeps live (106 SGPRs, part of them spilled to VGPR lanes and fetched with v_readlane: DESIGN 9.3 of round 5)
+// become immediate offsets of the LDS instructions, and the divisions by V constant multiplications.  Instantiated for the
+// reference's decode size -- 29 symbols (configs/deep_speech_2_en.config), width 8; the arithmetic is untouched.
+template <bool BIG, int NT, int VC = 0, int WC = 0>
 __global__ __launch_bounds__(NT) void beam_kernel(BeamP p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, n = blockIdx.x;
-  const int V = p.V, W = p.W, M = p.L.M, WV = W * V;
+  const int V = VC ? VC : p.V, W = WC ? WC : p.W, M = (VC && WC) ? WC * (VC + 1) : p.L.M, WV = W * V;
   char* u = p.ws + (size_t)n * p.L.per_utt;
   // ---- working arrays
   char* arr = BIG ? (u + p.L.scratch) : smem_raw;
@@ -575,6 +580,8 @@ extern "C" int ms_ctc_beam_decode(const float* probs, const int32_t* lens, int32
   const bool one_wave = nt_env == 64;
   if (L.big) hipLaunchKernelGGL((beam_kernel<true, 256>), dim3(N), dim3(256), 0, (hipStream_t)stream, p);
   else if (one_wave && lds <= 64 * 1024) hipLaunchKernelGGL((beam_kernel<false, 64>), dim3(N), dim3(64), lds, (hipStream_t)stream, p);
+  else if (V == 29 && beam_width == 8 && !(getenv("MS_BEAM_CONST") && getenv("MS_BEAM_CONST")[0] == '0'))
+    hipLaunchKernelGGL((beam_kernel<false, 256, 29, 8>), dim3(N), dim3(256), lds, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((beam_kernel<false, 256>), dim3(N), dim3(256), lds, (hipStream_t)stream, p);
   MS_LAUNCH_CHECK();
   return MS_OK;
