@@ -1657,24 +1657,24 @@ __global__ __launch_bounds__(256) void beam2_frame_end_kernel(Beam2P p, int t, i
   if (src != dst) {
     // h, c (L H each), G (4 L H), pp (J): ~50 KB at two layers of 1024.  Up to that size every load of the move is issued
     // before the first store (13 float4 per thread); larger states go array by array.
-    const float4* sh4 = reinterpret_cast<const float4*>(p.st_h + src * LH);
-    const float4* sc4 = reinterpret_cast<const float4*>(p.st_c + src * LH);
-    const float4* sg4 = reinterpret_cast<const float4*>(p.G + src * 4 * LH);
-    const float4* sp4 = reinterpret_cast<const float4*>(p.pp + src * J);
-    float4* dh4 = reinterpret_cast<float4*>(p.st_h + dst * LH);
-    float4* dc4 = reinterpret_cast<float4*>(p.st_c + dst * LH);
-    float4* dg4 = reinterpret_cast<float4*>(p.G + dst * 4 * LH);
-    float4* dp4 = reinterpret_cast<float4*>(p.pp + dst * J);
+    const u32x4r* sh4 = reinterpret_cast<const u32x4r*>(p.st_h + src * LH);
+    const u32x4r* sc4 = reinterpret_cast<const u32x4r*>(p.st_c + src * LH);
+    const u32x4r* sg4 = reinterpret_cast<const u32x4r*>(p.G + src * 4 * LH);
+    const u32x4r* sp4 = reinterpret_cast<const u32x4r*>(p.pp + src * J);
+    u32x4r* dh4 = reinterpret_cast<u32x4r*>(p.st_h + dst * LH);
+    u32x4r* dc4 = reinterpret_cast<u32x4r*>(p.st_c + dst * LH);
+    u32x4r* dg4 = reinterpret_cast<u32x4r*>(p.G + dst * 4 * LH);
+    u32x4r* dp4 = reinterpret_cast<u32x4r*>(p.pp + dst * J);
     const int nh = LH / 4, ng = LH, np4 = J / 4;
     if (LH % 4 == 0 && J % 4 == 0 && nh <= 512 && np4 <= 256) {
-      float4 vh[2], vc[2], vg[8], vp;
+      // (the loads are unconditional at clamped indices: behind `if (index < n)` hipcc kept the thirteen values in scratch
+      // memory and waited for every load before the next one -- the move was a chain of thirteen round trips)
+      u32x4r vh[2], vc[2], vg[8], vp;
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-        if (tid + 256 * m < nh) { vh[m] = sh4[tid + 256 * m]; vc[m] = sc4[tid + 256 * m]; }
+      for (int m = 0; m < 2; ++m) { vh[m] = sh4[min(tid + 256 * m, nh - 1)]; vc[m] = sc4[min(tid + 256 * m, nh - 1)]; }
 #pragma unroll
-      for (int m = 0; m < 8; ++m)
-        if (tid + 256 * m < ng) vg[m] = sg4[tid + 256 * m];
-      if (tid < np4) vp = sp4[tid];
+      for (int m = 0; m < 8; ++m) vg[m] = sg4[min(tid + 256 * m, ng - 1)];
+      vp = sp4[min(tid, np4 - 1)];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
         if (tid + 256 * m < nh) { dh4[tid + 256 * m] = vh[m]; dc4[tid + 256 * m] = vc[m]; }
