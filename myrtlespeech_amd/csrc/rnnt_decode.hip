@@ -1374,27 +1374,34 @@ __global__ __launch_bounds__(512) void beam2_joint_g_kernel(Beam2P p, const unsi
   pred_gemm3_body<false, RGG, TWO>(p, whh, l, b, rb, red);
 }
 
-// cand[j * V1 + v] = log_softmax_v(b_out[v] + sum over the J / 32 slices, in slice order, of plog[slice][i w + j][v]) for the
-// rows j < rows of utterance i; `cand` in LDS, all 256 threads, ends with a barrier
-__device__ __forceinline__ void beam2_logp_rows(const Beam2P& p, float* cand, int i, int rows, int tid) {
-  const int V1 = p.V + 1, w = p.w, lane = tid & 63, wave = tid >> 6;
-  for (int c = tid; c < rows * V1; c += 256) {
-    const int j = c / V1, v = c - j * V1;
-    const float* src = p.plog + ((size_t)i * w + j) * V1 + v;
-    const size_t stride = (size_t)p.R * V1;
-    float a = 0.f;
-    // the slices' partial sums in batches of 16 independent loads (a load at a time waited for an L2 round trip per slice:
-    // 7 us of the round kernel), added in slice order
-    for (int s0 = 0; s0 < p.NS; s0 += 16) {
-      float part[16];
+// The logit of candidate c (row c / V1 of utterance i's w rows, label c % V1): b_out[v] + the J / 32 slices' partial sums, loaded
+// in batches of 16 independent loads (a load at a time waited for an L2 round trip per slice: 7 us of the round kernel) and
+// added in slice order.  Needs nothing but the launch arguments, so a kernel calls it for c = tid BEFORE it waits for its first
+// loaded word (the live count, the length): the logits' round trip then runs beside that one instead of after it.  Rows past
+// the live count hold stale sums; they are loaded and never used.
+__device__ __forceinline__ float beam2_logit(const Beam2P& p, int i, int c) {
+  const int V1 = p.V + 1;
+  const int j = c / V1, v = c - j * V1;
+  const float* src = p.plog + ((size_t)i * p.w + j) * V1 + v;
+  const size_t stride = (size_t)p.R * V1;
+  float a = 0.f;
+  for (int s0 = 0; s0 < p.NS; s0 += 16) {
+    float part[16];
 #pragma unroll
-      for (int m = 0; m < 16; ++m) part[m] = s0 + m < p.NS ? src[(size_t)(s0 + m) * stride] : 0.f;
+    for (int m = 0; m < 16; ++m) part[m] = s0 + m < p.NS ? src[(size_t)(s0 + m) * stride] : 0.f;
 #pragma unroll
-      for (int m = 0; m < 16; ++m)
-        if (s0 + m < p.NS) a = (s0 + m == 0) ? part[m] : a + part[m];
-    }
-    cand[c] = a + (p.b_out ? p.b_out[v] : 0.f);
+    for (int m = 0; m < 16; ++m)
+      if (s0 + m < p.NS) a = (s0 + m == 0) ? part[m] : a + part[m];
   }
+  return a + (p.b_out ? p.b_out[v] : 0.f);
+}
+
+// cand[j * V1 + v] = log_softmax_v(logit of (j, v)) for the rows j < rows of utterance i; `cand` in LDS, all 256 threads, ends
+// with a barrier.  `first` = beam2_logit(p, i, tid), loaded by the caller at its top (any value when tid >= w * V1).
+__device__ __forceinline__ void beam2_logp_rows(const Beam2P& p, float* cand, int i, int rows, int tid, float first) {
+  const int V1 = p.V + 1, lane = tid & 63, wave = tid >> 6;
+  if (tid < rows * V1) cand[tid] = first;
+  for (int c = tid + 256; c < rows * V1; c += 256) cand[c] = beam2_logit(p, i, c);
   __syncthreads();
   for (int j = wave; j < rows; j += 4) {
     float m = -INFINITY;
@@ -1484,21 +1491,28 @@ __global__ __launch_bounds__(256) void beam2_round_kernel(Beam2P p, int t, int r
   __shared__ int match_at[32];
   const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = p.w, V1 = p.V + 1, blank = p.V;
+  // every load of the kernel's top is issued before the first loaded word is used: the sets' entries into registers, then the
+  // logits, and only then the LDS copies (which wait)
   const int len_i = p.lens[i], cnt = p.A_cnt[i], bc0 = first ? 0 : p.B_cnt[i], nodes0 = p.node_cnt[i];
+  const int ia = i * w + min(tid, w - 1);
+  const size_t ib = (size_t)i * p.bcap + min(tid, p.bcap - 1);
+  const int a_node = p.A_node[ia], a_slot = p.A_slot[ia], bb_node = p.B_node[ib], bb_slot = p.B_slot[ib];
+  const float a_score = p.A_score[ia], bb_score = p.B_score[ib];
+  const float logit0 = beam2_logit(p, i, min(tid, w * V1 - 1));
   if (tid < w) {
-    old_node[tid] = p.A_node[i * w + tid];
-    old_slot[tid] = p.A_slot[i * w + tid];
-    old_score[tid] = p.A_score[i * w + tid];
+    old_node[tid] = a_node;
+    old_slot[tid] = a_slot;
+    old_score[tid] = a_score;
     p.ext_dst[i * w + tid] = -1;  // requests default to "none" (also for utterances that have ended)
   }
   if (tid < p.bcap) {
-    b_node[tid] = p.B_node[(size_t)i * p.bcap + tid];
-    b_score[tid] = p.B_score[(size_t)i * p.bcap + tid];
-    b_slot[tid] = p.B_slot[(size_t)i * p.bcap + tid];
+    b_node[tid] = bb_node;
+    b_score[tid] = bb_score;
+    b_slot[tid] = bb_slot;
   }
   if (t >= len_i) return;
   if (tid == 0) { n_pick = 0; next_node = nodes0; }
-  beam2_logp_rows(p, cand, i, cnt, tid);
+  beam2_logp_rows(p, cand, i, cnt, tid, logit0);
   beam2_blank_merge(cnt, bc0, p.bcap, V1, blank, cand, old_node, old_slot, old_score, b_node, b_slot, b_score, match_at, wi, tid);
   {
     const int bc = wi[0];
@@ -1593,16 +1607,22 @@ __global__ __launch_bounds__(256) void beam2_frame_end_kernel(Beam2P p, int t, i
   __shared__ int n_sel;
   const int q = blockIdx.x, i = blockIdx.y, tid = threadIdx.x;
   const int w = p.w, V1 = p.V + 1, blank = p.V;
+  // (the loads of the top all issued before the first use, as in the round kernel)
   const int len_i = p.lens[i], cnt = p.A_cnt[i], bc0 = first ? 0 : p.B_cnt[i];
+  const int ia = i * w + min(tid, w - 1);
+  const size_t ib = (size_t)i * p.bcap + min(tid, p.bcap - 1);
+  const int a_node = p.A_node[ia], a_slot = p.A_slot[ia], bb_node = p.B_node[ib], bb_slot = p.B_slot[ib];
+  const float a_score = p.A_score[ia], bb_score = p.B_score[ib];
+  const float logit0 = beam2_logit(p, i, min(tid, w * V1 - 1));
   if (tid < w) {
-    old_node[tid] = p.A_node[i * w + tid];
-    old_slot[tid] = p.A_slot[i * w + tid];
-    old_score[tid] = p.A_score[i * w + tid];
+    old_node[tid] = a_node;
+    old_slot[tid] = a_slot;
+    old_score[tid] = a_score;
   }
   if (tid < p.bcap) {
-    b_node[tid] = p.B_node[(size_t)i * p.bcap + tid];
-    b_score[tid] = p.B_score[(size_t)i * p.bcap + tid];
-    b_slot[tid] = p.B_slot[(size_t)i * p.bcap + tid];
+    b_node[tid] = bb_node;
+    b_score[tid] = bb_score;
+    b_slot[tid] = bb_slot;
   }
   if (t >= len_i) {      // the utterance has ended: its final set moves along unchanged, so that it ends in the last frame's buffer
     if (q == 0) {
@@ -1613,7 +1633,7 @@ __global__ __launch_bounds__(256) void beam2_frame_end_kernel(Beam2P p, int t, i
     }
     return;
   }
-  beam2_logp_rows(p, cand, i, cnt, tid);
+  beam2_logp_rows(p, cand, i, cnt, tid, logit0);
   beam2_blank_merge(cnt, bc0, p.bcap, V1, blank, cand, old_node, old_slot, old_score, b_node, b_slot, b_score, match_at, wi, tid);
   const int bc = wi[0];
   // the beam_width best of B, one after the other (first maximum = earliest arrival among equals), by ONE wave
