@@ -1134,6 +1134,14 @@ __device__ __forceinline__ void pred_gemm3_body(const Beam2P& p, const unsigned 
   const unsigned short* xp = x + frag_off(m, k0 + half * 8, K);
   const unsigned short* w0 = wp + frag_off(b * 32 + l31, k0 + half * 8, K);
 
+  // the epilogue's row (its eight threads per row own a unit each): which request it serves is asked for HERE, before the
+  // operands -- after the K loop the answer has long arrived, where asking then cost the epilogue a round trip of its own
+  const int t = threadIdx.x;
+  const int rowl = t >> 3, u8 = t & 7, rgi = (rowl >> 5) % RG, rr = rowl & 31;
+  const int r = rb * 32 * RG + rowl, u = b * 8 + u8;
+  const bool epi = t < 256 * RG && r < R;
+  const int src = p.ext_src[min(r, R - 1)], dst = p.ext_dst[min(r, R - 1)];
+
   f32x16r acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1181,16 +1189,24 @@ __device__ __forceinline__ void pred_gemm3_body(const Beam2P& p, const unsigned 
         if (ks + j + PF < nks) load(j, ks + j + PF);
       }
   }
+  // the cell's other inputs (bias, G of the source state, its c) are on their way while the partial sums meet in LDS
+  const bool serve = epi && dst >= 0;                                 // a request in this row
+  float bias_v[4] = {0.f, 0.f, 0.f, 0.f}, g_v[4] = {0.f, 0.f, 0.f, 0.f}, c_old = 0.f;
+  if (CELL && serve) {
+    const float* bias = p.bias + (size_t)l * 4 * H + b * 32 + u8;
+#pragma unroll
+    for (int gate = 0; gate < 4; ++gate) bias_v[gate] = bias[gate * 8];
+    if (src >= 0) {
+      const float* g = p.G + ((size_t)src * L + l) * 4 * H + b * 32 + u8;
+#pragma unroll
+      for (int gate = 0; gate < 4; ++gate) g_v[gate] = g[gate * 8];
+      c_old = p.st_c[((size_t)src * L + l) * H + u];
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
   __syncthreads();
-  const int t = threadIdx.x;
-  if (t >= 256 * RG) return;
-  const int rowl = t >> 3, u8 = t & 7, rgi = rowl >> 5, rr = rowl & 31;
-  const int r = rb * 32 * RG + rowl, u = b * 8 + u8;
-  if (r >= R) return;
-  const int src = p.ext_src[r], dst = p.ext_dst[r];
-  if (dst < 0) return;                                                // no request in this row
+  if (!serve) return;
   float sum[4];
 #pragma unroll
   for (int gate = 0; gate < 4; ++gate) {
@@ -1205,12 +1221,9 @@ __device__ __forceinline__ void pred_gemm3_body(const Beam2P& p, const unsigned 
     for (int gate = 0; gate < 4; ++gate) g[gate * 8] = sum[gate];
     return;
   }
-  const float* bias = p.bias + (size_t)l * 4 * H + b * 32 + u8;
-  const float* g = src >= 0 ? p.G + ((size_t)src * L + l) * 4 * H + b * 32 + u8 : nullptr;
   float pre[4];
 #pragma unroll
-  for (int gate = 0; gate < 4; ++gate) pre[gate] = (sum[gate] + bias[gate * 8]) + (g ? g[gate * 8] : 0.f);
-  const float c_old = src >= 0 ? p.st_c[((size_t)src * L + l) * H + u] : 0.f;
+  for (int gate = 0; gate < 4; ++gate) pre[gate] = (sum[gate] + bias_v[gate]) + g_v[gate];
   float h_new, c_new;
   lstm_cell(pre, c_old, h_new, c_new);
   p.st_h[((size_t)dst * L + l) * H + u] = h_new;
@@ -1247,6 +1260,24 @@ __device__ __forceinline__ void beam2_joint_body(const Beam2P& p, const unsigned
   const int l31 = lane & 31, half = lane >> 5;
   const int rg = wave % RG, kq = wave / RG;
   const int H = p.H, J = p.J, V1 = p.V + 1, R = p.R, w = p.w, K = H;
+  // What the z phase needs from memory -- is the row live, its slot, is its state new, the encoder's term -- is asked for HERE,
+  // before the operands: asked after the GEMM it was a chain of three round trips (length and count -> slot -> pp) behind the
+  // barrier.  A thread's ZI (row, unit) pairs are those of its z loop below.
+  constexpr int ZI = ROWS * 32 / 512;
+  bool z_live[ZI];
+  int z_slot[ZI], z_dst[ZI];
+  float z_enc[ZI];
+#pragma unroll
+  for (int k = 0; k < ZI; ++k) {
+    const int idx = threadIdx.x + 512 * k, rowl = idx >> 5, c = idx & 31;
+    const int r = rb * ROWS + rowl, rc = min(r, R - 1);
+    const int i = rc / w, j = rc - i * w;
+    const int len_i = p.lens[i], cnt_i = p.A_cnt[i];
+    z_slot[k] = p.A_slot[rc];
+    z_dst[k] = p.ext_dst[rc];
+    z_enc[k] = enc_p[((size_t)t * p.N + i) * J + js * 32 + c];
+    z_live[k] = r < R && t < len_i && j < cnt_i;
+  }
   for (int idx = threadIdx.x; idx < V1 * 32; idx += 512) {
     const int v = idx >> 5, c = idx & 31;
     wo[idx] = w_out[(size_t)v * J + js * 32 + c];
@@ -1308,26 +1339,23 @@ __device__ __forceinline__ void beam2_joint_body(const Beam2P& p, const unsigned
   }
   __syncthreads();
   // z of this workgroup's 64 rows x 32 joint units
-  for (int idx = threadIdx.x; idx < ROWS * 32; idx += 512) {
-    const int rowl = idx >> 5, c = idx & 31, rgi = rowl >> 5, rr = rowl & 31;
-    const int r = rb * ROWS + rowl;
-    float z = 0.f;
-    if (r < R) {
-      const int i = r / w, j = r - i * w;
-      if (t < p.lens[i] && j < p.A_cnt[i]) {
-        const int slot = p.A_slot[r];
-        float* ppv = p.pp + (size_t)slot * J + js * 32 + c;
-        float pv;
-        if (gemm && p.ext_dst[r] >= 0) {
-          pv = red[rgi][rr][c];
 #pragma unroll
-          for (int q = 1; q < KQ; ++q) pv += red[q * RG + rgi][rr][c];
-          *ppv = pv;
-        } else {
-          pv = *ppv;
-        }
-        z = tanhf(enc_p[((size_t)t * p.N + i) * J + js * 32 + c] + pv);
+  for (int k = 0; k < ZI; ++k) {
+    const int idx = threadIdx.x + 512 * k;
+    const int rowl = idx >> 5, c = idx & 31, rgi = rowl >> 5, rr = rowl & 31;
+    float z = 0.f;
+    if (z_live[k]) {
+      float* ppv = p.pp + (size_t)z_slot[k] * J + js * 32 + c;
+      float pv;
+      if (gemm && z_dst[k] >= 0) {
+        pv = red[rgi][rr][c];
+#pragma unroll
+        for (int q = 1; q < KQ; ++q) pv += red[q * RG + rgi][rr][c];
+        *ppv = pv;
+      } else {
+        pv = *ppv;
       }
+      z = tanhf(z_enc[k] + pv);
     }
     zs[rowl][c] = z;
   }
