@@ -39,6 +39,10 @@ int linear_splitk_launch(const float* x, const float* w, const float* bias, floa
 }
 
 constexpr int KSPLIT = 8;  // K slices of the gate GEMMs (partials added in slice order by lstm_cell_kernel)
+#ifndef MS_RNNT_PF2
+#define MS_RNNT_PF2 4      // k-steps of operands in flight in the two-plane beam GEMMs (8 measured: 163 VGPRs, one workgroup
+                          // per CU instead of two, cell GEMM 12.9 -> 14.7 us)
+#endif
 constexpr int GREEDY_CHUNK = 32;  // greedy decode: frames evaluated per utterance and iteration
 
 namespace {
@@ -1145,7 +1149,7 @@ __device__ __forceinline__ void pred_gemm3_body(const Beam2P& p, const unsigned 
   f32x16r acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  constexpr int PF = 4;
+  constexpr int PF = TWO ? MS_RNNT_PF2 : 4;                         // k-steps of operands in flight (two-plane form: registers for eight)
   u32x4r xf[PF][TWO ? 2 : 3], wf[PF][TWO ? 2 : 3];
   constexpr int two = TWO ? 1 : 0;                                   // two fp16 planes instead of three bf16 (a template parameter: as a
                                                                      // uniform run-time flag it cost the three-plane form 10 %)
@@ -1292,7 +1296,7 @@ __device__ __forceinline__ void beam2_joint_body(const Beam2P& p, const unsigned
     f32x16r acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    constexpr int PF = 4;
+    constexpr int PF = TWO ? MS_RNNT_PF2 : 4;
     u32x4r xf[PF][TWO ? 2 : 3], wf[PF][TWO ? 2 : 3];
     auto load = [&](int slot, int ks) {
 #pragma unroll
