@@ -1,7 +1,8 @@
 #!/bin/bash
 # Counter passes over one python script (GPU box): tools/pmc_script.sh <tag> <script.py> [args]
 # Each pass is its own rocprofv3 run (PMC only, no tracing flags); the program after `--` is python3 itself.
-# Writes gpurun_out/<tag>_pmc_summary.txt: per kernel name the mean of every counter over its dispatches.
+# Writes gpurun_out/<tag>_pmc_summary.txt: per kernel name the mean of every counter over its dispatches (kernels whose name
+# holds one of the comma-separated PMC_KERNELS substrings).
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 SCRIPT=$ROOT/$1; shift
@@ -16,7 +17,8 @@ ARGS="$@"
 pass p1 FETCH_SIZE || exit 1
 pass p2 WRITE_SIZE || exit 1
 pass p3 SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_INSTS_LDS || exit 1
-python3 - "$OUT" > $ROOT/gpurun_out/${TAG}_pmc_summary.txt <<'PY'
+pass p4 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum || exit 1
+python3 - "$OUT" "${PMC_KERNELS:-ctc,pred_layer,gemm_nt_bf16x3_tile64,lookahead,gru_persistent,lstm_persistent_split2}" > $ROOT/gpurun_out/${TAG}_pmc_summary.txt <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -24,7 +26,7 @@ for f in glob.glob(out + "/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in sorted(acc.items()):
-    if not any(s in k for s in ("ctc", "pred_layer", "gemm_nt_bf16x3_tile64", "lookahead", "gru_persistent", "lstm_persistent_split2")):
+    if not any(s in k for s in sys.argv[2].split(",")):
         continue
     print(k)
     for c, v in sorted(cs.items()):
