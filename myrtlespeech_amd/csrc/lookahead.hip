@@ -66,13 +66,14 @@ __global__ __launch_bounds__(256) void lookahead_strided_kernel(const float* __r
 #pragma unroll
     for (int k = 0; k < LA_KC; ++k) wk[k] = (k0 + k < ctx) ? wk[k] : 0.f;
 #pragma unroll
-    for (int j = 0; j < TT + LA_KC - 1; ++j) {
-      const float v = (t0 + k0 + j < T) ? xv[j] : 0.f;
+    for (int j = 0; j < TT + LA_KC - 1; ++j) xv[j] = (t0 + k0 + j < T) ? xv[j] : 0.f;
+    // (round 6) output-major: two loops of constant trip count, every index static.  The input-major form (for j: for i:
+    // k = j - i, guarded) left hipcc's unroller with a 47 x 32 body at TT = 32 that it did not flatten: xv[] was indexed at
+    // run time and lived in scratch memory (192 bytes per lane).  Per output the products still arrive in tap order.
 #pragma unroll
-      for (int i = 0; i < TT; ++i) {
-        const int k = j - i;  // static after unrolling
-        if (k >= 0 && k < LA_KC) acc[i] += wk[k] * v;
-      }
+    for (int i = 0; i < TT; ++i) {
+#pragma unroll
+      for (int k = 0; k < LA_KC; ++k) acc[i] += wk[k] * xv[i + k];
     }
   }
 #pragma unroll
