@@ -2697,7 +2697,11 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
     // batch groups of <= 64 sequences, one persistent launch each (stream-ordered; the epoch
     // flags are re-zeroed in between, the status word is kept so any time-out is reported)
     const bool f32x2 = use_f32x2(cell, H, ndir);
-    const int group = ((use_split(cell, H, ndir) && two_stream_shape(H)) || f32x2) ? 32 : 64;
+    // (round 6) batches of more than 64 sequences on a wide-workgroup shape: launches of 64 rows (two groups of 32 side by
+    // side), not of 32 on the 8-unit kernel -- [501, 128, 2048] 12.8 -> 9.5 ms per layer, and an utterance then gets the bits
+    // it gets in a batch of 32 (tools/batch_sweep.py)
+    const bool wide_rows = use_wide(cell, H, ndir, std::min(N, 64));
+    const int group = wide_rows ? 64 : ((use_split(cell, H, ndir) && two_stream_shape(H)) || f32x2) ? 32 : 64;
     for (int n0 = 0; n0 < N; n0 += group) {
       const int ng = std::min(group, N - n0);
       if (n0 > 0 && !hx_path) MS_HIP(hipMemsetAsync(ws + W.flags, 0, W.xproj - W.flags, stream));
@@ -2727,13 +2731,13 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       p.dbg = (unsigned long long*)(ws + W.dbg);
       const bool pipe = (H % 256 == 0);
       static const bool stamps = getenv("MS_LSTM_STAMPS") && getenv("MS_LSTM_STAMPS")[0] == '1';
-      if (n0 == 0 && use_wide(cell, H, ndir, N)) {
-        // all batch groups (one or two of <= 32 rows) in ONE launch of the wide-workgroup kernel
-        const int groups = ms::cdiv(N, 32);
+      if (wide_rows) {
+        // this launch's batch groups (one or two of <= 32 rows) in ONE launch of the wide-workgroup kernel
+        const int groups = ms::cdiv(ng, 32);
         const int rs = 1;
         const size_t words_per_dir = (size_t)32 * H << rs;
         p.ring_shift = rs;
-        p.N = N;                       // the kernel cuts it into groups of 32 rows
+        p.N = ng;                      // the kernel cuts it into groups of 32 rows
         {
           // measured SLOWER (2.2 against 1.9 .. 2.06 ms per layer, profiles/r03y_*): with one h vector per XCD all 32 CUs of
           // the XCD ask the same L2 channels for the same lines at the same time; four vectors per XCD spread the requests
@@ -2743,15 +2747,15 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
         // one launch for all batch groups: a group's exchange region is `ndir` directions long, so group g's direction d is
         // "direction" g * ndir + d of a region with groups * ndir of them, and the tag a slot starts with depends on the
         // direction's parity only (hx_init_kernel: d & 1 -- forward / backward -- when ndir == 2, forward when ndir == 1)
-        if (!hx_preinit) {
+        if (!hx_preinit || n0 > 0) {
           hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir * groups)), dim3(256), 0, stream,
-                             (unsigned*)hx_ptr, words_per_dir, (size_t)8 * H, ndir * groups, steps, rs, zero_base(0), zero_words(0), ndir);
+                             (unsigned*)hx_ptr, words_per_dir, (size_t)8 * H, ndir * groups, steps, rs, zero_base(n0), zero_words(n0), ndir);
           MS_LAUNCH_CHECK();
         }
         if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.row_off - W.dbg, stream));   // the stamp area only: row_off (packed rows) follows it
         rc = launch_wide2(p, cell == MS_CELL_HARD_LSTM, groups, layer_prec(cell, H, ndir), stream);
         if (rc != MS_OK) return rc;
-        break;
+        continue;
       }
       if (use_split(cell, H, ndir)) {
         const bool hard_ = (cell == MS_CELL_HARD_LSTM);

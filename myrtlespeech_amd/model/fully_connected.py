@@ -38,6 +38,7 @@ def linear_stack_plan(module: Union[torch.nn.Linear, torch.nn.Sequential], train
 
 
 _SPLIT_MIN_FLOPS = 2e9  # below this the two plane-split passes cost more than they save
+_OUTPUT_LAYER_MAX_COLUMNS = 64   # csrc/gemm.hip linear_splitk_slices: layers this narrow take K slices of the exact-f32 kernel
 _SPLITK = os.environ.get("MS_LINEAR_SPLITK") != "0"   # K slices for exact-f32 layers with few output tiles (A/B runs: 0)
 # Operand-plane scratch of the split GEMM, one per HIP stream: work on one stream is ordered, so successive layers may share
 # a buffer, but two streams (pipeline.BatchesInFlight) must not -- one stream's planes would be overwritten under the other's GEMM.
@@ -122,7 +123,9 @@ def run_linear_stack(x2d: torch.Tensor, plan, few_rows: bool = False) -> torch.T
         a, lo, hi = (_lib.ACT_NONE, 0.0, 0.0) if clamp is None else (_lib.ACT_CLAMP, clamp[0], clamp[1])
         w = _lib.f32c(lin.weight.detach())
         b = None if lin.bias is None else _lib.f32c(lin.bias.detach())
-        if _lib.split_precision() and k % 32 == 0 and 2.0 * m * k * n >= _SPLIT_MIN_FLOPS:
+        # (an output layer -- <= 64 columns -- is exact float32 at EVERY row count: with the flop threshold alone the 29-column
+        # layer of a batch of >= 68 ten-second utterances crossed it and an utterance's logits depended on its batch: round 6)
+        if _lib.split_precision() and k % 32 == 0 and n > _OUTPUT_LAYER_MAX_COLUMNS and 2.0 * m * k * n >= _SPLIT_MIN_FLOPS:
             # the weight planes are made once per (weight, version) and kept with the layer; the scratch holds the x planes
             pw = _packed_planes(lin, w, k, n)
             ws = _stream_workspace().get((m * k * 4 + 255) // 256 * 256, zero=False)

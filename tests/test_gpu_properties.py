@@ -42,6 +42,23 @@ def test_shards_reproduce_the_whole_batch_bit_for_bit(setup):
         assert hyps == whole
 
 
+def test_a_batch_of_96_gives_every_utterance_the_bits_of_its_batch_of_32(setup):
+    """Batches beyond the 64 rows of one wide-workgroup recurrence launch run as launches of 64 rows of the SAME kernel
+    (round 6; they used to fall to the 8-unit kernel in groups of 32, whose K shares add up in another order): an
+    utterance's logits do not depend on how many others share its batch -- here three interleaved copies of the ragged
+    batch, sorted by length as the reference requires (rnn.py:170-183)."""
+    model, dec, x, lens, y, ol = setup
+    lens3 = torch.cat([lens, lens, lens])
+    order = torch.sort(lens3, descending=True, stable=True).indices
+    x3 = torch.cat([x, x, x])[order]
+    (y3, ol3), _ = model((x3.clone(), lens3[order]))
+    src = (order % 32).to(y.device)
+    assert y3.shape == (y.shape[0], 96, y.shape[2])
+    assert torch.equal(y3, y.index_select(1, src))
+    assert torch.equal(ol3.cpu(), ol.cpu()[order % 32])
+    assert dec(y3, ol3) == [dec(y, ol)[k] for k in (order % 32).tolist()]
+
+
 def test_padding_content_is_ignored(setup):
     """Whatever lies in the padded frames of the input (t >= len) cannot reach the output: MaskConv zeroes it
     (cnn.py:425-443) and the packed recurrence never reads it."""
