@@ -2589,7 +2589,8 @@ static bool layer_packs_rows(int cell, int steps, int N, int In, int H, int ndir
   static const bool off = getenv("MS_RNN_PACKED") && getenv("MS_RNN_PACKED")[0] == '0';
   if (off || !(cell == MS_CELL_LSTM || cell == MS_CELL_HARD_LSTM)) return false;
   const int GH4 = 4 * H;
-  return use_fast(cell, H, ndir) && use_wide(cell, H, ndir, N) && use_split_gemm(cell, H, ndir, In) && !use_f16(cell, H, ndir) &&
+  // (batches beyond 64 rows run as wide launches of 64: the kernel's packed-row index is roff[t] + n_base + n in every launch)
+  return use_fast(cell, H, ndir) && use_wide(cell, H, ndir, std::min(N, 64)) && use_split_gemm(cell, H, ndir, In) && !use_f16(cell, H, ndir) &&
          ms::gemm_rows_from_device_ok(steps * N, 32, ndir * GH4) && (size_t)steps * N * std::max(In, ndir * H) * 2 < ((size_t)1 << 31);
 }
 

@@ -24,11 +24,16 @@ def main():
                 ms = timed(lambda: m((x, lens)))
                 print(f"RNN {kind.name} H={H} bi={bi} [{T},{N},{inp}]: {ms:8.3f} ms  {ms / N * 1e3:8.1f} us per utterance", flush=True)
         model = bench.build_model()
-        for N in sizes:
-            x = torch.randn(N, 1, 80, 1001, device="cuda")
-            lens = torch.full((N,), 1001, dtype=torch.int64)
-            ms = timed(lambda: model((x, lens)))
-            print(f"config-2 network, batch {N}: {ms:8.3f} ms  {ms / N:8.3f} ms per utterance = {N * 10.0 / (ms * 1e-3):9.0f} audio-s/s", flush=True)
+        for ragged in (False, True):
+            for N in sizes:
+                x = torch.randn(N, 1, 80, 1001, device="cuda")
+                lens = torch.full((N,), 1001, dtype=torch.int64)
+                if ragged:      # 5 .. 10 s, sorted, the longest a full clip
+                    lens = torch.sort(torch.randint(501, 1002, (N,), generator=torch.Generator().manual_seed(N)), descending=True).values
+                    lens[0] = 1001
+                ms = timed(lambda: model((x, lens)))
+                secs = float(lens.sum()) / 100.0
+                print(f"config-2 network, batch {N}{' ragged' if ragged else ''}: {ms:8.3f} ms  {ms / N:8.3f} ms per utterance = {secs / (ms * 1e-3):9.0f} audio-s/s", flush=True)
 
 
 if __name__ == "__main__":
