@@ -135,7 +135,10 @@ bool use_gru_persistent(int cell, int H, int ndir) {
   const int U = gru_units(H);
   if (U == 0) return false;
   const int cus = ms::num_cus();
-  return cus > 0 && ndir * (H / U) <= cus * std::min(1, persistent_blocks_per_cu(true));
+  // (round 6) ONE direction's workgroups must fit the CUs; when both do not, the directions run as two launches (GruP::d_base),
+  // as the two-stream LSTM's do -- a bidirectional GRU-1536 / -2048 had fallen to one launch per step (14.0 / 17.7 ms per layer)
+  (void)ndir;
+  return cus > 0 && (H / U) <= cus * std::min(1, persistent_blocks_per_cu(true));
 }
 
 // MS_LSTM_RING=<slots> (power of two, 2..128; default 2): exchange slots per (stream, plane) of the two-stream LSTM kernel
@@ -1889,6 +1892,7 @@ struct GruP {
   float* hx;                   // exchange buffer, per direction [stream][plane][parity][H/8][16][8 bf16]
   unsigned* status;
   int steps, N, n_base, N_total, ndir, J, poll_sleep, ring_shift;
+  int d_base;                  // direction of workgroup 0 (a bidirectional layer whose directions run as two launches)
   unsigned short* out_hi;      // when set: the next layer's GEMM operand planes instead of float32 `out` (see LstmP)
   unsigned short* out_lo;
 };
@@ -1911,7 +1915,7 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
-  const int d = blockIdx.x / p.J, j = blockIdx.x % p.J;
+  const int d = p.d_base + blockIdx.x / p.J, j = blockIdx.x % p.J;
   const bool cell_thread = tid < 16 * U;
   const int nl = cell_thread ? tid / U : 0, u = cell_thread ? tid % U : 0;
   const int unit = U * j + u;
@@ -2847,18 +2851,23 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
         g.poll_sleep = ps > 0 ? ps : 1;
       }
       const size_t lds = (size_t)RED_FLOATS * sizeof(float);
-      switch (H) {
+      // every workgroup of a launch has to be resident: directions that do not fit the CUs together run one after the other
+      const int launches = ndir * g.J > ms::num_cus() ? ndir : 1, dirs = ndir / launches;
+      for (int l = 0; l < launches; ++l) {
+        g.d_base = l;
+        switch (H) {
 #define MS_GRU_CASE(HH, KS_, U_) \
-        case HH:                                                                                                         \
-          if (two_plane_mode() == ms::PREC_F16X3) hipLaunchKernelGGL((gru_persistent_kernel<KS_, U_, true>), dim3(ndir * g.J), dim3(256), lds, stream, g); \
-          else hipLaunchKernelGGL((gru_persistent_kernel<KS_, U_, false>), dim3(ndir * g.J), dim3(256), lds, stream, g);  \
-          break;
-        MS_GRU_CASE(2560, 20, 10) MS_GRU_CASE(1280, 10, 10) MS_GRU_CASE(2048, 16, 8) MS_GRU_CASE(1536, 12, 8)
-        MS_GRU_CASE(1024, 8, 8) MS_GRU_CASE(768, 6, 8) MS_GRU_CASE(512, 4, 8)
+          case HH:                                                                                                         \
+            if (two_plane_mode() == ms::PREC_F16X3) hipLaunchKernelGGL((gru_persistent_kernel<KS_, U_, true>), dim3(dirs * g.J), dim3(256), lds, stream, g); \
+            else hipLaunchKernelGGL((gru_persistent_kernel<KS_, U_, false>), dim3(dirs * g.J), dim3(256), lds, stream, g);  \
+            break;
+          MS_GRU_CASE(2560, 20, 10) MS_GRU_CASE(1280, 10, 10) MS_GRU_CASE(2048, 16, 8) MS_GRU_CASE(1536, 12, 8)
+          MS_GRU_CASE(1024, 8, 8) MS_GRU_CASE(768, 6, 8) MS_GRU_CASE(512, 4, 8)
 #undef MS_GRU_CASE
-        default: ms::set_error("persistent GRU: unsupported hidden size"); return MS_ERR_UNSUPPORTED;
+          default: ms::set_error("persistent GRU: unsupported hidden size"); return MS_ERR_UNSUPPORTED;
+        }
+        MS_LAUNCH_CHECK();
       }
-      MS_LAUNCH_CHECK();
     }
     return MS_OK;
   }

@@ -109,6 +109,9 @@ def test_lstm_persistent_vs_oracle(H, N, T_, bidir):
                                                   ("GRU", 512, 32, 7, True, 48), ("GRU", 768, 20, 5, True, 64),
                                                   ("GRU", 1536, 33, 4, False, 32), ("GRU", 2048, 32, 3, False, 64),
                                                   ("GRU", 2048, 9, 3, True, 32),
+                                                  # round 6: bidirectional layers whose two directions do not fit the CUs together
+                                                  # (persistent, one launch per direction; they used to take a launch per step)
+                                                  ("GRU", 1536, 40, 4, True, 32), ("GRU", 2560, 33, 3, True, 64),
                                                   # ... and the two-stream LSTM beyond 1024 (a bidirectional layer's directions in two launches)
                                                   ("LSTM", 1280, 32, 5, True, 64), ("LSTM", 1536, 20, 4, False, 32),
                                                   ("LSTM", 2048, 32, 4, True, 64), ("LSTM", 2048, 40, 3, False, 32),
