@@ -776,6 +776,12 @@ __global__ void ctc_reduce_kernel(float* __restrict__ nll, const int32_t* __rest
 // 256: argmax per frame (first maximum wins, NaN counts as maximum like torch.argmax),
 // keep = sym != blank && (t == 0 || sym != sym[t-1]); kept symbols are compacted with a
 // wave ballot + popcount prefix and a 4-entry cross-wave scan.
+// PRE (round 6; alphabets beyond 64 symbols): the arg max of frame t already lies in out_idx[n * T + t]
+// (ctc_argmax_wave_kernel) and is compacted in place -- a kept symbol's place is never behind its frame, a chunk's threads
+// have all read their frames before the first of them writes, and a chunk writes in front of the next chunk's frames.
+// Without it a THREAD walks its frame's row alone: 29 loads for the reference's alphabet, 5 000 dependent ones for a
+// 5 000-symbol alphabet (2.0 ms at [501, 32, 5000]; tools/ctc_sweep.py).
+template <bool PRE>
 __global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict__ x, const int32_t* __restrict__ lens,
                                                          int32_t* __restrict__ out_idx, int32_t* __restrict__ out_len,
                                                          int T, int N, int V, int blank) {
@@ -791,12 +797,16 @@ __global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict
     const int t = t0 + tid;
     int sym = -1;
     if (t < len) {
-      const float* row = x + ((size_t)t * N + n) * V;
-      float best = row[0];
-      sym = 0;
-      for (int v = 1; v < V; ++v) {
-        const float c = row[v];
-        if (c > best || (c != c && best == best)) { best = c; sym = v; }
+      if (PRE) {
+        sym = out_idx[(size_t)n * T + t];
+      } else {
+        const float* row = x + ((size_t)t * N + n) * V;
+        float best = row[0];
+        sym = 0;
+        for (int v = 1; v < V; ++v) {
+          const float c = row[v];
+          if (c > best || (c != c && best == best)) { best = c; sym = v; }
+        }
       }
     }
     int prev = __shfl_up(sym, 1, 64);
@@ -818,6 +828,38 @@ __global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict
     __syncthreads();
   }
   if (tid == 0) out_len[n] = base;
+}
+
+// One wave per (frame, utterance): lanes stride the row (coalesced), every lane keeps the first maximum of its columns
+// (NaN counts as the maximum, the first NaN wins: torch.argmax), the lanes' candidates meet in a butterfly under the same
+// order -- NaN before numbers, then the larger value, then the lower index.  Result into out_idx[n * T + t].
+__global__ __launch_bounds__(256) void ctc_argmax_wave_kernel(const float* __restrict__ x, const int32_t* __restrict__ lens,
+                                                              int32_t* __restrict__ out_idx, int T, int N, int V) {
+  const int lane = threadIdx.x & 63;
+  const long f = (long)blockIdx.x * 4 + (threadIdx.x >> 6);     // frame-major pair index t * N + n
+  if (f >= (long)T * N) return;
+  const int t = (int)(f / N), n = (int)(f - (long)t * N);
+  if (t >= min(max(lens[n], 0), T)) return;
+  const float* row = x + (size_t)f * V;
+  float best = 0.f;
+  int sym = 0x7fffffff;                                          // a lane without a column never wins
+  for (int v = lane; v < V; v += 64) {
+    const float c = row[v];
+    if (sym == 0x7fffffff || c > best || (c != c && best == best)) { best = c; sym = v; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int os = __shfl_xor(sym, o, 64);
+    const bool mine_nan = best != best, other_nan = ob != ob;
+    bool take;
+    if (os == 0x7fffffff) take = false;
+    else if (sym == 0x7fffffff) take = true;
+    else if (mine_nan || other_nan) take = other_nan && (!mine_nan || os < sym);
+    else take = ob > best || (ob == best && os < sym);
+    if (take) { best = ob; sym = os; }
+  }
+  if (lane == 0) out_idx[(size_t)n * T + t] = sym;
 }
 
 }  // namespace
@@ -964,8 +1006,18 @@ extern "C" int ms_ctc_greedy_decode(const float* x, const int32_t* lens, int32_t
   ms::ProfScope prof_span(MS_PROF_GREEDY, (hipStream_t)stream);
   MS_REQUIRE(x && lens && out_idx && out_len, "null pointer");
   MS_REQUIRE(T > 0 && N > 0 && V > 0, "bad shape");
-  hipLaunchKernelGGL(ctc_greedy_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, lens, out_idx, out_len, T, N, V,
-                     blank);
+  if (V > 64) {
+    const long pairs = (long)T * N;
+    MS_REQUIRE((pairs + 3) / 4 <= 0x7fffffffL, "T * N exceeds the grid limit");
+    hipLaunchKernelGGL(ctc_argmax_wave_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, lens, out_idx,
+                       T, N, V);
+    MS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ctc_greedy_kernel<true>, dim3(N), dim3(256), 0, (hipStream_t)stream, x, lens, out_idx, out_len, T, N, V,
+                       blank);
+  } else {
+    hipLaunchKernelGGL(ctc_greedy_kernel<false>, dim3(N), dim3(256), 0, (hipStream_t)stream, x, lens, out_idx, out_len, T, N, V,
+                       blank);
+  }
   MS_LAUNCH_CHECK();
   return MS_OK;
 }

@@ -740,7 +740,9 @@ def test_greedy_golden():
         assert got == unragged(g[f"out/flat_b{b}"], g[f"out/lens_b{b}"])
 
 
-@pytest.mark.parametrize("Tn,N,V", [(501, 32, 29), (1000, 3, 5), (257, 5, 64), (1, 1, 2)])
+@pytest.mark.parametrize("Tn,N,V", [(501, 32, 29), (1000, 3, 5), (257, 5, 64), (1, 1, 2),
+                                    # alphabets beyond 64 symbols: a wave per frame finds the arg max (round 6)
+                                    (300, 7, 65), (257, 5, 200), (130, 3, 5000)])
 def test_greedy_vs_oracle(Tn, N, V):
     from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
     rng = np.random.default_rng(Tn + N + V)
@@ -749,6 +751,21 @@ def test_greedy_vs_oracle(Tn, N, V):
     lens[0] = Tn
     got = CTCGreedyDecoder(V - 1)(T(x), T(lens))
     assert got == O.ctc_greedy_decode(x, lens, V - 1)
+
+
+@pytest.mark.parametrize("V", [29, 100])
+def test_greedy_counts_nan_as_the_maximum_like_torch_argmax(V):
+    """A NaN logit is the frame's arg max, the first one if there are several (torch.argmax, which the reference calls:
+    ctc_greedy_decoder.py:73) -- on the thread-per-frame path and on the wave-per-frame one (V > 64)."""
+    from myrtlespeech_amd.post_process.ctc_greedy_decoder import CTCGreedyDecoder
+    rng = np.random.default_rng(V)
+    x = rng.normal(size=(90, 4, V)).astype(np.float32)
+    for t, n, v in [(3, 0, V - 2), (3, 0, 5), (10, 1, 0), (40, 2, V - 1), (41, 2, 70 % V), (41, 2, 7), (89, 3, 1)]:
+        x[t, n, v] = np.nan
+    lens = np.array([90, 80, 90, 90], dtype=np.int64)
+    want = [torch.unique_consecutive(torch.from_numpy(x[:l, n]).argmax(-1)).tolist() for n, l in enumerate(lens)]
+    want = [[v for v in w if v != V - 1] for w in want]
+    assert CTCGreedyDecoder(V - 1)(T(x), T(lens)) == want
 
 
 # ----------------------------------------------------------------------------- config-2, full size
