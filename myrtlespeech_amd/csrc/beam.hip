@@ -564,6 +564,7 @@ extern "C" int ms_ctc_beam_decode(const float* probs, const int32_t* lens, int32
   static ms::DeviceOnce attr_once;
   if (attr_once.need()) {
     MS_HIP(hipFuncSetAttribute((const void*)beam_kernel<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MS_HIP(hipFuncSetAttribute((const void*)beam_kernel<false, 256, 29, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_once.done();
   }
   BeamP p;
@@ -582,6 +583,14 @@ extern "C" int ms_ctc_beam_decode(const float* probs, const int32_t* lens, int32
   else if (one_wave && lds <= 64 * 1024) hipLaunchKernelGGL((beam_kernel<false, 64>), dim3(N), dim3(64), lds, (hipStream_t)stream, p);
   else if (V == 29 && beam_width == 8 && !(getenv("MS_BEAM_CONST") && getenv("MS_BEAM_CONST")[0] == '0'))
     hipLaunchKernelGGL((beam_kernel<false, 256, 29, 8>), dim3(N), dim3(256), lds, (hipStream_t)stream, p);
+  // (the reference's alphabet at the other usual widths: the generic instantiation costs 4.4 us per frame at width 4 and
+  // 6.3 at width 16 where 29 x 8 costs 3.5 -- tools/ctc_sweep.py)
+  else if (V == 29 && beam_width == 4 && !(getenv("MS_BEAM_CONST") && getenv("MS_BEAM_CONST")[0] == '0'))
+    hipLaunchKernelGGL((beam_kernel<false, 256, 29, 4>), dim3(N), dim3(256), lds, (hipStream_t)stream, p);
+  else if (V == 29 && beam_width == 16 && !(getenv("MS_BEAM_CONST") && getenv("MS_BEAM_CONST")[0] == '0'))
+    hipLaunchKernelGGL((beam_kernel<false, 256, 29, 16>), dim3(N), dim3(256), lds, (hipStream_t)stream, p);
+  else if (V == 29 && beam_width == 32 && !(getenv("MS_BEAM_CONST") && getenv("MS_BEAM_CONST")[0] == '0'))
+    hipLaunchKernelGGL((beam_kernel<false, 256, 29, 32>), dim3(N), dim3(256), lds, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((beam_kernel<false, 256>), dim3(N), dim3(256), lds, (hipStream_t)stream, p);
   MS_LAUNCH_CHECK();
   return MS_OK;

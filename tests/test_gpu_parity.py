@@ -1063,7 +1063,10 @@ def test_beam_golden_random():
                                                     # layout refused beam_width >= 84 at V = 29): 76 is the last LDS width, 100
                                                     # and 128 run with the working arrays in the workspace
                                                     (24, 3, 29, 76, 0.0, None, 1.5), (24, 3, 29, 100, 0.0, None, 1.5),
-                                                    (20, 2, 29, 128, 0.0005, 7, 1.0), (12, 2, 8, 256, 0.0, None, 0.8)])
+                                                    (20, 2, 29, 128, 0.0005, 7, 1.0), (12, 2, 8, 256, 0.0, None, 0.8),
+                                                    # round 6: the constant-shape instantiations at 29 symbols x widths 4 / 16 / 32
+                                                    (60, 4, 29, 4, 0.001, None, 6.0), (50, 3, 29, 16, 0.0, 5, 3.0),
+                                                    (40, 3, 29, 32, 0.0005, None, 2.0), (70, 2, 29, 32, 0.0, 28 - 3, 0.6)])
 def test_beam_vs_oracle(Tn, N, V, W, thr, sep, temp):
     from myrtlespeech_amd.post_process.ctc_beam_decoder import CTCBeamDecoder
     rng = np.random.default_rng(Tn * 31 + V)
