@@ -547,6 +547,7 @@ struct LstmP {
   unsigned long long* dbg;  // [ndir*J][8] stamp sums (diagnostic build only; the wide kernel: [workgroup][16])
   int steps, N, n_base, N_total, H, ndir, J, NPAD;
   int d_base;      // two-stream kernel: direction of workgroup 0 (a bidirectional layer whose directions run as two launches)
+  int grp_wgs;     // two-stream kernel: workgroups per batch group of <= 32 rows when one launch holds two groups side by side (0: one group)
   int poll_sleep;  // s_sleep(1) repetitions between polls of the exchange buffer
   int xcd_map;     // wide kernel: (group, direction) -> XCD pair (two groups, two directions, J / 2 = 64)
   int ring_shift;  // two-stream kernel: log2 of the number of exchange slots per (stream, plane) (1 = two slots)
@@ -1190,10 +1191,16 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
-  const int d = p.d_base + blockIdx.x / p.J, j = blockIdx.x % p.J;
+  // (round 6) batch groups side by side: where two groups' workgroups fit the CUs together (H <= 512 bidirectional, H <= 1024
+  // unidirectional) a launch of 33 .. 64 rows runs them at the same time instead of one after the other -- the wide
+  // kernel's group index, here for the 8-unit kernel.  Group g: rows n_base + 32 g .., exchange region g (of ndir directions).
+  const int grp = p.grp_wgs ? (int)blockIdx.x / p.grp_wgs : 0;
+  const int bx = p.grp_wgs ? (int)blockIdx.x % p.grp_wgs : (int)blockIdx.x;
+  const int d = p.d_base + bx / p.J, j = bx % p.J;
   const int nl = (tid >> 3) & 15, u = tid & 7;  // cell threads are waves 0 and 1
   const int unit = 8 * j + u;
-  const int N = p.N;
+  const int n_base = p.n_base + 32 * grp;
+  const int N = min(32, p.N - 32 * grp);
 
   // this wave's share of W_hh (its K-quarter x 32 gate rows, hi and lo planes) stays in 128 VGPRs
   // per lane for the whole sequence: the MFMA B operand never touches LDS or HBM again
@@ -1216,7 +1223,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
   const int rs = p.ring_shift;
   const int PLANE = (KG * 256) << rs;       // bytes: [slot][kg][16][8 bf16]
   const int STREAM = 2 * PLANE;
-  char* hx_d = reinterpret_cast<char*>(p.hx) + (size_t)d * 2 * STREAM;
+  char* hx_d = reinterpret_cast<char*>(p.hx) + ((size_t)grp * p.ndir + d) * 2 * STREAM;
   const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx_d, 0, 2 * STREAM, 0x00020000);
 
   float c[2] = {0.f, 0.f}, h[2] = {0.f, 0.f};
@@ -1226,10 +1233,10 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
     for (int sg = 0; sg < 2; ++sg) {
       const int n = sg * 16 + nl;
       const bool valid = n < N;
-      const size_t sidx = ((size_t)d * p.N_total + p.n_base + n) * H + unit;
+      const size_t sidx = ((size_t)d * p.N_total + n_base + n) * H + unit;
       h[sg] = (valid && p.h0) ? p.h0[sidx] : 0.f;
       c[sg] = (valid && p.c0) ? p.c0[sidx] : 0.f;
-      len_n[sg] = valid ? (p.lens ? p.lens[p.n_base + n] : p.steps) : 0;
+      len_n[sg] = valid ? (p.lens ? p.lens[n_base + n] : p.steps) : 0;
       const int off = sg * STREAM + epoch_par0(d, p.steps, rs) * KG * 256 + j * 256 + nl * 16;  // slot read by the first step
       publish_split<P>(h[sg], epoch_tag0(d, p.steps, rs), hx_rsrc, off, PLANE + off, lane);
     }
@@ -1253,7 +1260,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
       float xg[4] = {0.f, 0.f, 0.f, 0.f};
       const int n = sg * 16 + nl;
       if (wave < 2 && n < N) {
-        const float* xp = p.xproj + ((size_t)t * p.N_total + p.n_base + n) * xcols + d * 4 * H + j * 32 + u;
+        const float* xp = p.xproj + ((size_t)t * p.N_total + n_base + n) * xcols + d * 4 * H + j * 32 + u;
 #pragma unroll
         for (int g = 0; g < 4; ++g) xg[g] = xp[g * 8];
       }
@@ -1359,7 +1366,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
         const int off = sg * STREAM + ec.wpar * KG * 256 + j * 256 + nl * 16;
         publish_split<P>(h[sg], wtag, hx_rsrc, off, PLANE + off, lane);
         if (n < N) {
-          const size_t oidx = ((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit;
+          const size_t oidx = ((size_t)t * p.N_total + n_base + n) * (p.ndir * H) + d * H + unit;
           const float ov = active ? hnew : 0.f;
           if (p.out_hi) {   // exactly split_planes_kernel's arithmetic
             if (F16) {
@@ -1387,7 +1394,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
     for (int sg = 0; sg < 2; ++sg) {
       const int n = sg * 16 + nl;
       if (n < N) {
-        const size_t sidx = ((size_t)d * p.N_total + p.n_base + n) * H + unit;
+        const size_t sidx = ((size_t)d * p.N_total + n_base + n) * H + unit;
         p.hn[sidx] = h[sg];
         p.cn[sidx] = c[sg];
       }
@@ -1893,6 +1900,7 @@ struct GruP {
   unsigned* status;
   int steps, N, n_base, N_total, ndir, J, poll_sleep, ring_shift;
   int d_base;                  // direction of workgroup 0 (a bidirectional layer whose directions run as two launches)
+  int grp_wgs;                 // workgroups per batch group of <= 32 rows when one launch holds two groups side by side (0: one group)
   unsigned short* out_hi;      // when set: the next layer's GEMM operand planes instead of float32 `out` (see LstmP)
   unsigned short* out_lo;
 };
@@ -1915,11 +1923,15 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
-  const int d = p.d_base + blockIdx.x / p.J, j = blockIdx.x % p.J;
+  // (batch groups side by side: see lstm_persistent_split2_kernel)
+  const int grp = p.grp_wgs ? (int)blockIdx.x / p.grp_wgs : 0;
+  const int bx = p.grp_wgs ? (int)blockIdx.x % p.grp_wgs : (int)blockIdx.x;
+  const int d = p.d_base + bx / p.J, j = bx % p.J;
+  const int n_base = p.n_base + 32 * grp;
   const bool cell_thread = tid < 16 * U;
   const int nl = cell_thread ? tid / U : 0, u = cell_thread ? tid % U : 0;
   const int unit = U * j + u;
-  const int N = p.N;
+  const int N = min(32, p.N - 32 * grp);
 
   // this wave's K-quarter of the workgroup's 32 packed gate rows (hi and lo planes): 16*KS VGPRs per lane
   u32x4 wh0[KS], wh1[KS], wl0[KS], wl1[KS];
@@ -1939,7 +1951,7 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
   const int rs = p.ring_shift;
   const int PLANE = (KG * 256) << rs;       // bytes: [slot][kg][16][8 bf16]
   const int STREAM = 2 * PLANE;
-  char* hx_d = reinterpret_cast<char*>(p.hx) + (size_t)d * 2 * STREAM;
+  char* hx_d = reinterpret_cast<char*>(p.hx) + ((size_t)grp * p.ndir + d) * 2 * STREAM;
   const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(hx_d, 0, 2 * STREAM, 0x00020000);
   const int elem_off = ((unit >> 3) * 16 + nl) * 16 + (unit & 7) * 2;   // this thread's element inside a parity slab
 
@@ -1953,9 +1965,9 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
     for (int sg = 0; sg < 2; ++sg) {
       const int n = sg * 16 + nl;
       const bool valid = n < N;
-      const size_t sidx = ((size_t)d * p.N_total + p.n_base + n) * H + unit;
+      const size_t sidx = ((size_t)d * p.N_total + n_base + n) * H + unit;
       h[sg] = (valid && p.h0) ? p.h0[sidx] : 0.f;
-      len_n[sg] = valid ? (p.lens ? p.lens[p.n_base + n] : p.steps) : 0;
+      len_n[sg] = valid ? (p.lens ? p.lens[n_base + n] : p.steps) : 0;
       const int off = sg * STREAM + epoch_par0(d, p.steps, rs) * KG * 256 + elem_off;  // slot read by the first step
       publish_elem<HM>(h[sg], epoch_tag0(d, p.steps, rs), hx_rsrc, off, PLANE + off);
     }
@@ -1977,7 +1989,7 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
       float xg[3] = {0.f, 0.f, 0.f};
       const int n = sg * 16 + nl;
       if (cell_thread && n < N) {
-        const float* xp = p.xproj + ((size_t)t * p.N_total + p.n_base + n) * xcols + d * 3 * H + unit;
+        const float* xp = p.xproj + ((size_t)t * p.N_total + n_base + n) * xcols + d * 3 * H + unit;
 #pragma unroll
         for (int g = 0; g < 3; ++g) xg[g] = xp[g * H];
       }
@@ -2058,7 +2070,7 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
         const int off = sg * STREAM + ec.wpar * KG * 256 + elem_off;
         publish_elem<HM>(h[sg], wtag, hx_rsrc, off, PLANE + off);
         if (n < N) {
-          const size_t oidx = ((size_t)t * p.N_total + p.n_base + n) * (p.ndir * H) + d * H + unit;
+          const size_t oidx = ((size_t)t * p.N_total + n_base + n) * (p.ndir * H) + d * H + unit;
           const float ov = active ? hnew : 0.f;
           if (p.out_hi) {   // exactly split_planes_kernel's arithmetic
             unsigned hb, lb;
@@ -2076,7 +2088,7 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruP p) {
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg) {
       const int n = sg * 16 + nl;
-      if (n < N) p.hn[((size_t)d * p.N_total + p.n_base + n) * H + unit] = h[sg];
+      if (n < N) p.hn[((size_t)d * p.N_total + n_base + n) * H + unit] = h[sg];
     }
   }
 }
@@ -2427,7 +2439,8 @@ static int launch_split2(const LstmP& p, hipStream_t stream) {
     }
     return MS_OK;
   }
-  hipLaunchKernelGGL((lstm_persistent_split2_kernel<KS, HARD, STAMP, P>), dim3(p.ndir * p.J), dim3(256), lds, stream, p);
+  const int groups = p.grp_wgs ? ms::cdiv(p.N, 32) : 1;
+  hipLaunchKernelGGL((lstm_persistent_split2_kernel<KS, HARD, STAMP, P>), dim3(groups * p.ndir * p.J), dim3(256), lds, stream, p);
   MS_LAUNCH_CHECK();
   return MS_OK;
 }
@@ -2587,6 +2600,17 @@ extern "C" int ms_rnn_layer_forward(int cell, const void* packed, const float* x
                                  workspace_bytes, stream_);
 }
 
+// Two batch groups of the 8-unit two-stream LSTM kernel in one launch (LstmP::grp_wgs): both groups' workgroups must be resident
+// together (they spin on their own group's peers only, but a launch is dispatched as a whole), the exchange region holds
+// exactly two groups (ws_layout: min(npad, 64) rows).  MS_LSTM_PAIR_GROUPS=0 keeps one group per launch (A/B runs).
+static bool two_stream_pairs_groups(int cell, int H, int ndir) {
+  static const bool off = getenv("MS_LSTM_PAIR_GROUPS") && getenv("MS_LSTM_PAIR_GROUPS")[0] == '0';
+  static const bool one_stream = getenv("MS_LSTM_ONE_STREAM") && getenv("MS_LSTM_ONE_STREAM")[0] == '1';
+  if (off || !use_fast(cell, H, ndir) || !use_split(cell, H, ndir) || !two_stream_shape(H)) return false;
+  if (one_stream && !use_f16(cell, H, ndir) && H <= 1024) return false;
+  return 2 * ndir * (H / 8) <= ms::num_cus();
+}
+
 // Packed rows need the wide-workgroup recurrence (the only kernel that reads them) and the LDS-DMA GEMM (the only one that
 // takes its row count from device memory); the answer must not depend on In, since a stack's layers chain their planes.
 static bool layer_packs_rows(int cell, int steps, int N, int In, int H, int ndir) {
@@ -2706,7 +2730,10 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
     // side), not of 32 on the 8-unit kernel -- [501, 128, 2048] 12.8 -> 9.5 ms per layer, and an utterance then gets the bits
     // it gets in a batch of 32 (tools/batch_sweep.py)
     const bool wide_rows = use_wide(cell, H, ndir, std::min(N, 64));
-    const int group = wide_rows ? 64 : ((use_split(cell, H, ndir) && two_stream_shape(H)) || f32x2) ? 32 : 64;
+    // ... and two groups of 32 rows side by side in one launch of the 8-unit two-stream kernel where their workgroups fit
+    // the CUs together (LstmP::grp_wgs): H <= 512 bidirectional, H <= 1024 unidirectional
+    const bool pair_groups = !wide_rows && two_stream_pairs_groups(cell, H, ndir);
+    const int group = (wide_rows || pair_groups) ? 64 : ((use_split(cell, H, ndir) && two_stream_shape(H)) || f32x2) ? 32 : 64;
     for (int n0 = 0; n0 < N; n0 += group) {
       const int ng = std::min(group, N - n0);
       if (n0 > 0 && !hx_path) MS_HIP(hipMemsetAsync(ws + W.flags, 0, W.xproj - W.flags, stream));
@@ -2726,6 +2753,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       p.status = (unsigned*)(ws + W.status);
       p.steps = steps; p.N = ng; p.n_base = n0; p.N_total = N; p.H = H; p.ndir = ndir; p.J = H / 8;
       p.d_base = 0;
+      p.grp_wgs = 0;
       p.s_begin = 0; p.s_end = steps;
       p.NPAD = ms::cdiv(ng, 32) * 32;
       {
@@ -2766,16 +2794,20 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
         const bool hard_ = (cell == MS_CELL_HARD_LSTM);
         if (stamps) MS_HIP(hipMemsetAsync(ws + W.dbg, 0, W.row_off - W.dbg, stream));
         static const bool one_stream = getenv("MS_LSTM_ONE_STREAM") && getenv("MS_LSTM_ONE_STREAM")[0] == '1';
-        const bool two_stream = p.NPAD == 32 && two_stream_shape(H) && (!one_stream || use_f16(cell, H, ndir) || H > 1024);
+        const bool two_stream = (p.NPAD == 32 || pair_groups) && two_stream_shape(H) && (!one_stream || use_f16(cell, H, ndir) || H > 1024);
+        const int groups = (two_stream && pair_groups) ? ms::cdiv(ng, 32) : 1;     // batch groups side by side in this launch
+        p.grp_wgs = groups > 1 ? ndir * p.J : 0;
         {
           // every word of every slot starts with the tag that is NOT the first one expected there
           const int rs = two_stream ? lstm_ring_shift() : 1;
           const size_t slab_words = two_stream ? (size_t)8 * H : (size_t)H * p.NPAD / 2;
           const size_t words_per_dir = two_stream ? ((size_t)32 * H << rs) : (size_t)2 * H * p.NPAD;
           p.ring_shift = rs;
-          if (!(hx_preinit && two_stream)) {
-            hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir)), dim3(256), 0, stream,
-                               (unsigned*)hx_ptr, words_per_dir, slab_words, ndir, steps, rs, zero_base(n0), zero_words(n0), ndir);
+          MS_REQUIRE(words_per_dir * ndir * groups * sizeof(unsigned) <= W.hx_bytes, "exchange region smaller than the launch's batch groups");
+          if (!(hx_preinit && two_stream) || groups > 1) {
+            // (group g's direction d is region g * ndir + d; a region's first tags depend on its direction only)
+            hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(words_per_dir * ndir * groups)), dim3(256), 0, stream,
+                               (unsigned*)hx_ptr, words_per_dir, slab_words, ndir * groups, steps, rs, zero_base(n0), zero_words(n0), ndir);
             MS_LAUNCH_CHECK();
           }
         }
@@ -2823,12 +2855,18 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
     PersistentTurn turn(stream);
     if (turn.rc != MS_OK) { ms::set_error("ms_rnn_layer_forward: cross-stream hand-over of the persistent launch failed"); return turn.rc; }
     ProfScope prof_rec(MS_PROF_RECURRENCE, stream);
-    // one persistent launch per group of 32 sequences (two interleaved streams of 16)
-    for (int n0 = 0; n0 < N; n0 += 32) {
+    // one persistent launch per group of 32 sequences (two interleaved streams of 16) -- or (round 6) per TWO groups side by
+    // side where both groups' workgroups fit the CUs together (GruP::grp_wgs; MS_LSTM_PAIR_GROUPS=0: one group per launch)
+    static const bool pair_off = getenv("MS_LSTM_PAIR_GROUPS") && getenv("MS_LSTM_PAIR_GROUPS")[0] == '0';
+    const bool pair_groups = !pair_off && 2 * ndir * (H / gru_units(H)) <= ms::num_cus();
+    const int rows_per_launch = pair_groups ? 64 : 32;
+    for (int n0 = 0; n0 < N; n0 += rows_per_launch) {
       const int rs = lstm_ring_shift();
-      if (!hx_preinit) {
-        hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(((size_t)32 * H << rs) * ndir)), dim3(256), 0, stream,
-                           (unsigned*)hx_ptr, (size_t)32 * H << rs, (size_t)8 * H, ndir, steps, rs, zero_base(n0), zero_words(n0), ndir);
+      const int ng = std::min(rows_per_launch, N - n0), groups = ms::cdiv(ng, 32);
+      MS_REQUIRE(((size_t)32 * H << rs) * ndir * groups * sizeof(unsigned) <= W.hx_bytes, "exchange region smaller than the launch's batch groups");
+      if (!hx_preinit || groups > 1) {
+        hipLaunchKernelGGL(hx_init_kernel, dim3(blocks_for(((size_t)32 * H << rs) * ndir * groups)), dim3(256), 0, stream,
+                           (unsigned*)hx_ptr, (size_t)32 * H << rs, (size_t)8 * H, ndir * groups, steps, rs, zero_base(n0), zero_words(n0), ndir);
         MS_LAUNCH_CHECK();
       }
       GruP g;
@@ -2844,7 +2882,8 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       }
       g.hx = (float*)hx_ptr;
       g.status = (unsigned*)(ws + W.status);
-      g.steps = steps; g.N = std::min(32, N - n0); g.n_base = n0; g.N_total = N; g.ndir = ndir; g.J = H / gru_units(H);
+      g.steps = steps; g.N = ng; g.n_base = n0; g.N_total = N; g.ndir = ndir; g.J = H / gru_units(H);
+      g.grp_wgs = groups > 1 ? ndir * g.J : 0;
       g.ring_shift = rs;
       {
         static const int ps = getenv("MS_LSTM_POLL_SLEEP") ? atoi(getenv("MS_LSTM_POLL_SLEEP")) : 1;
@@ -2852,7 +2891,7 @@ extern "C" int ms_rnn_layer_forward_ex(int cell, const void* packed, const float
       }
       const size_t lds = (size_t)RED_FLOATS * sizeof(float);
       // every workgroup of a launch has to be resident: directions that do not fit the CUs together run one after the other
-      const int launches = ndir * g.J > ms::num_cus() ? ndir : 1, dirs = ndir / launches;
+      const int launches = ndir * g.J > ms::num_cus() ? ndir : 1, dirs = (ndir / launches) * groups;     // (groups > 1 only where launches == 1)
       for (int l = 0; l < launches; ++l) {
         g.d_base = l;
         switch (H) {
@@ -3044,6 +3083,7 @@ extern "C" int ms_rnn_stack_forward(int cell, const void* const* packed_host, co
     p.out_hi = last_layer ? nullptr : ph;
     p.out_lo = last_layer ? nullptr : pl;
     p.row_off = nullptr;
+    p.grp_wgs = 0;
     p.hx = (float*)(ws + W.hx + (size_t)l * W.hx_bytes);
     p.flags = (unsigned*)(ws + W.flags);
     p.status = (unsigned*)(ws + W.status);

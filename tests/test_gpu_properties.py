@@ -113,3 +113,37 @@ def test_recurrent_layers_do_not_mix_utterances(kind, H, bidir):
             hs = hs[0] if isinstance(hs, tuple) else hs
             assert torch.equal(ys, yw[:, sl]), (kind, H, world, r, float((ys - yw[:, sl]).abs().max()))
             assert torch.equal(hs, hw[:, sl])
+
+
+@pytest.mark.parametrize("kind,H,bidir,N", [("LSTM", 512, True, 64), ("LSTM", 256, True, 50), ("LSTM", 768, False, 64),
+                                            ("LSTM", 512, False, 45), ("LSTM", 768, True, 64), ("LSTM", 512, True, 100),
+                                            ("GRU", 512, True, 64), ("GRU", 1024, False, 40), ("GRU", 1280, False, 64),
+                                            ("GRU", 768, True, 64), ("GRU", 1280, True, 50)])
+def test_two_batch_groups_in_one_launch_give_the_bits_of_their_own_launches(kind, H, bidir, N):
+    """Round 6: where two batch groups' workgroups of the 8-unit two-stream LSTM kernel fit the CUs together (H <= 512
+    bidirectional, H <= 1024 unidirectional) a batch of 33 .. 64 rows runs both groups in ONE launch (and 100 rows as 64 + 36);
+    768 bidirectional does not fit and keeps one group per launch.  Either way every row gets the bits it gets when its group
+    of 32 runs alone, initial state and ragged lengths included."""
+    from myrtlespeech_amd.model.rnn import RNN, RNNType
+    torch.manual_seed(H + N)
+    m = RNN(getattr(RNNType, kind), 96, H, num_layers=2, bidirectional=bidir, forget_gate_bias=1.0 if kind == "LSTM" else None).eval()
+    g = torch.Generator().manual_seed(H + N + 1)
+    T_ = 37
+    D = 2 if bidir else 1
+    x = torch.randn(T_, N, 96, generator=g)
+    lens = torch.sort(torch.randint(3, T_ + 1, (N,), generator=g), descending=True).values
+    lens[0] = T_
+    h0, c0 = torch.randn(2 * D, N, H, generator=g) * 0.3, torch.randn(2 * D, N, H, generator=g) * 0.3
+    lstm = kind == "LSTM"
+    (yw, _), hid = m((x, lens), (h0, c0) if lstm else h0)
+    hw, cw = hid if lstm else (hid, None)
+    for a in range(0, N, 32):
+        sl = slice(a, min(a + 32, N))
+        # (a slice's longest sequence may be shorter than the batch's: the module returns max(lens) frames' worth of time)
+        hx = (h0[:, sl].contiguous(), c0[:, sl].contiguous()) if lstm else h0[:, sl].contiguous()
+        (ys, _), hid = m((x[:, sl].contiguous(), lens[sl]), hx)
+        hs, cs = hid if lstm else (hid, None)
+        t = ys.shape[0]
+        assert torch.equal(ys, yw[:t, sl]), (kind, H, N, a, float((ys - yw[:t, sl]).abs().max()))
+        assert float(yw[t:, sl].abs().max()) == 0.0 if t < yw.shape[0] else True
+        assert torch.equal(hs, hw[:, sl]) and (not lstm or torch.equal(cs, cw[:, sl]))
