@@ -385,6 +385,85 @@ __device__ __forceinline__ bool alpha_wave_normalise(const float* __restrict__ l
   return bad != 0;
 }
 
+// One frame of phase 1 for a wide alphabet, by ONE WAVE (lanes across the symbols): the row's normaliser, the per-state copy
+// lps_row[s] of the normalised log2-domain log-probabilities the recursion reads and (ROWS) every symbol's value lpn_row[v] for
+// the gradient kernel.  Returns 1 when the normaliser is not finite.  Called by the pipeline kernel's own four waves (phase 1
+// inside the launch) and by ctc_normalise_wide_kernel (phase 1 as a chip-wide launch of its own).
+template <bool ROWS>
+__device__ __forceinline__ int ctc_normalise_wide_frame(const float* __restrict__ row, float* __restrict__ lpn_row,
+                                                        float* __restrict__ lps_row, const int32_t* __restrict__ tg, int S, int V,
+                                                        int blank, int log_probs_in, int lane) {
+  constexpr int NV = 16;
+  int bad = 0;
+  float lz = 0.f;
+  float r[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) r[i] = (lane + 64 * i < V) ? row[lane + 64 * i] : neg_inf();
+  if (!log_probs_in) {
+    float m = neg_inf();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) m = fmaxf(m, r[i]);
+    for (int v0 = 64 * NV; v0 < V; v0 += 64 * NV) {
+      float q[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) q[i] = (v0 + lane + 64 * i < V) ? row[v0 + lane + 64 * i] : neg_inf();
+#pragma unroll
+      for (int i = 0; i < NV; ++i) m = fmaxf(m, q[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sum += expf(r[i] - m);
+    for (int v0 = 64 * NV; v0 < V; v0 += 64 * NV) {
+      float q[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) q[i] = (v0 + lane + 64 * i < V) ? row[v0 + lane + 64 * i] : neg_inf();
+#pragma unroll
+      for (int i = 0; i < NV; ++i) sum += expf(q[i] - m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    lz = logf(sum) + m;
+    bad |= (fabsf(lz) < INFINITY) ? 0 : 1;
+  }
+  if (ROWS) {                                   // every symbol's value: only the gradient kernel reads these
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < V) lpn_row[lane + 64 * i] = fminf(fmaxf((r[i] - lz) * 1.4426950408889634f, CTC_NEG), -CTC_NEG);
+    for (int v = 64 * NV + lane; v < V; v += 64)
+      lpn_row[v] = fminf(fmaxf((row[v] - lz) * 1.4426950408889634f, CTC_NEG), -CTC_NEG);
+  }
+  for (int s2 = lane; s2 < S; s2 += 64) {
+    const int lab = (s2 & 1) ? tg[s2 >> 1] : blank;
+    lps_row[s2] = fminf(fmaxf((row[lab] - lz) * 1.4426950408889634f, CTC_NEG), -CTC_NEG);
+  }
+  return bad;
+}
+
+// Phase 1 of a wide-alphabet loss as its own launch (round 6): a wave per (frame, utterance) over the whole chip.  Inside the
+// pipeline kernel the utterance's four waves walked its T frames of V symbols alone -- 10 MB per workgroup at [501, 32, 5000],
+// 1.4 ms for the forward, 3.8 .. 4.9 with the backward (tools/ctc_sweep.py).  bad[n] |= 1 where a frame's normaliser is not
+// finite (the pipeline kernel reads it in place of its own phase-1 flag: mode bit 1).
+template <bool ROWS>
+__global__ __launch_bounds__(256) void ctc_normalise_wide_kernel(const float* __restrict__ logits, const int32_t* __restrict__ in_lens,
+                                                                 const int32_t* __restrict__ targets,
+                                                                 const int32_t* __restrict__ tgt_offsets,
+                                                                 const int32_t* __restrict__ tgt_lens, float* __restrict__ lpn_ws,
+                                                                 float* __restrict__ lps_ws, int* __restrict__ bad, int T, int N,
+                                                                 int V, int S_max, int blank, int log_probs_in) {
+  const int lane = threadIdx.x & 63;
+  const long f = (long)blockIdx.x * 4 + (threadIdx.x >> 6);      // frame-major: consecutive waves read consecutive rows
+  if (f >= (long)T * N) return;
+  const int t = (int)(f / N), n = (int)(f - (long)t * N);
+  if (t >= min(max(in_lens[n], 0), T)) return;
+  const int S = 2 * max(tgt_lens[n], 0) + 1;
+  const int b = ctc_normalise_wide_frame<ROWS>(logits + (size_t)f * V, ROWS ? lpn_ws + ((size_t)n * T + t) * V : nullptr,
+                                               lps_ws + ((size_t)n * T + t) * S_max, targets + tgt_offsets[n], S, V, blank,
+                                               log_probs_in, lane);
+  if (b && lane == 0) atomicOr(&bad[n], 1);
+}
+
 // mode: bit 0 = the reversed recursion (beta), bit 1 = the workspace already holds this call's normalised log-probabilities
 // (a second launch of the same backward).  ROWS: rows_ws [N][T][S_max] receives every frame's values; ll2_out [N] the
 // log2-domain log-likelihood (CTC_NEG or below: no path).
@@ -400,7 +479,8 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
                                                                      int mode = 0, float* __restrict__ ll2_out = nullptr,
                                                                      float* __restrict__ rows_ws_rev = nullptr,
                                                                      float* __restrict__ lps_ws = nullptr,
-                                                                     unsigned* __restrict__ status = nullptr) {
+                                                                     unsigned* __restrict__ status = nullptr,
+                                                                     const int* __restrict__ bad_in = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
   int bad_row = 0;        // a frame whose normaliser is not finite (a NaN / +inf logit, a row of -inf): the loss is NaN (torch); an int
@@ -421,6 +501,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
   float* lps = wide_v ? lps_ws + (size_t)n * T * S_max : nullptr;
 
   if (mode & 2) {
+    if (bad_in != nullptr) bad_row = bad_in[n];        // phase 1 ran as its own launch (ctc_normalise_wide_kernel)
   } else if (V <= 32) bad_row = (int)alpha_wave_normalise<32>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
   else if (V <= 64) bad_row = (int)alpha_wave_normalise<64>(logits, lpn, n, Tn, N, V, log_probs_in, tid);
   else {
@@ -430,53 +511,9 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alpha_wave_kernel(const float
     // 64 x 16 symbols are walked in slabs of that size, the later passes re-reading them.  The recursion then reads a
     // per-STATE copy of the row (lps: a wave's load is 256 contiguous bytes, not 64 cache lines of a 4 KB row)
     const int lane = tid & 63;
-    constexpr int NV = 16;
-    for (int t = w; t < Tn; t += CTC_THREADS / 64) {
-      const float* row = logits + ((size_t)t * N + n) * V;
-      float lz = 0.f;
-      float r[NV];
-#pragma unroll
-      for (int i = 0; i < NV; ++i) r[i] = (lane + 64 * i < V) ? row[lane + 64 * i] : neg_inf();
-      if (!log_probs_in) {
-        float m = neg_inf();
-#pragma unroll
-        for (int i = 0; i < NV; ++i) m = fmaxf(m, r[i]);
-        for (int v0 = 64 * NV; v0 < V; v0 += 64 * NV) {
-          float q[NV];
-#pragma unroll
-          for (int i = 0; i < NV; ++i) q[i] = (v0 + lane + 64 * i < V) ? row[v0 + lane + 64 * i] : neg_inf();
-#pragma unroll
-          for (int i = 0; i < NV; ++i) m = fmaxf(m, q[i]);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) sum += expf(r[i] - m);
-        for (int v0 = 64 * NV; v0 < V; v0 += 64 * NV) {
-          float q[NV];
-#pragma unroll
-          for (int i = 0; i < NV; ++i) q[i] = (v0 + lane + 64 * i < V) ? row[v0 + lane + 64 * i] : neg_inf();
-#pragma unroll
-          for (int i = 0; i < NV; ++i) sum += expf(q[i] - m);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        lz = logf(sum) + m;
-        bad_row |= (fabsf(lz) < INFINITY) ? 0 : 1;
-      }
-      if (ROWS) {                                   // every symbol's value: only the gradient kernel reads these
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-          if (lane + 64 * i < V) lpn[(size_t)t * V + lane + 64 * i] = fminf(fmaxf((r[i] - lz) * 1.4426950408889634f, CTC_NEG), -CTC_NEG);
-        for (int v = 64 * NV + lane; v < V; v += 64)
-          lpn[(size_t)t * V + v] = fminf(fmaxf((row[v] - lz) * 1.4426950408889634f, CTC_NEG), -CTC_NEG);
-      }
-      for (int s2 = lane; s2 < S; s2 += 64) {
-        const int lab = (s2 & 1) ? tg[s2 >> 1] : blank;
-        lps[(size_t)t * S_max + s2] = fminf(fmaxf((row[lab] - lz) * 1.4426950408889634f, CTC_NEG), -CTC_NEG);
-      }
-    }
+    for (int t = w; t < Tn; t += CTC_THREADS / 64)
+      bad_row |= ctc_normalise_wide_frame<ROWS>(logits + ((size_t)t * N + n) * V, ROWS ? lpn + (size_t)t * V : nullptr,
+                                                lps + (size_t)t * S_max, tg, S, V, blank, log_probs_in, lane);
   }
   for (int i = tid; i < 3 * T; i += CTC_THREADS) mb[i] = MbEntry{__uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu)};
   if (tid < 2) fin[tid] = CTC_NEG;
@@ -921,18 +958,33 @@ extern "C" int ms_ctc_loss_forward(const float* logits, const int32_t* in_lens, 
   float* lpn_ws = (float*)((char*)workspace + ms::align_up((size_t)T * N * sizeof(float), 256));
   if (wave_ok) {
     const size_t wl = alpha_wave_lds(T);
+    // wide alphabets: phase 1 (every frame's log-softmax and the per-state copy of it) as a chip-wide launch of its own; the
+    // per-utterance "a normaliser was not finite" words live where ctc_alpha_kernel keeps its normalisers (unused on this path).
+    // MS_CTC_WIDE_PHASE1=0 (read per call) keeps phase 1 inside the pipeline kernel (A/B runs)
+    int mode = 0;
+    int* bad = nullptr;
+    const char* pe = getenv("MS_CTC_WIDE_PHASE1");
+    if (V > 64 && !(pe && pe[0] == '0')) {
+      bad = (int*)workspace;
+      MS_HIP(hipMemsetAsync(bad, 0, (size_t)N * sizeof(int), (hipStream_t)stream));
+      const long pairs = (long)T * N;
+      hipLaunchKernelGGL((ctc_normalise_wide_kernel<false>), dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits,
+                         in_lens, targets, tgt_offsets, tgt_lens, (float*)nullptr, lpn_ws, bad, T, N, V, S_max, blank, lpi);
+      MS_LAUNCH_CHECK();
+      mode = 2;
+    }
     if (S_max <= 256)
       hipLaunchKernelGGL((ctc_alpha_wave_kernel<1, 16>), dim3(N), dim3(CTC_THREADS), wl, (hipStream_t)stream, logits, in_lens,
-                         targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi, (float*)nullptr, S_max, 0, (float*)nullptr,
-                         (float*)nullptr, lpn_ws, status);
+                         targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi, (float*)nullptr, S_max, mode, (float*)nullptr,
+                         (float*)nullptr, lpn_ws, status, (const int*)bad);
     else if (S_max <= 512)
       hipLaunchKernelGGL((ctc_alpha_wave_kernel<2, 16>), dim3(N), dim3(CTC_THREADS), wl, (hipStream_t)stream, logits, in_lens,
-                         targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi, (float*)nullptr, S_max, 0, (float*)nullptr,
-                         (float*)nullptr, lpn_ws, status);
+                         targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi, (float*)nullptr, S_max, mode, (float*)nullptr,
+                         (float*)nullptr, lpn_ws, status, (const int*)bad);
     else
       hipLaunchKernelGGL((ctc_alpha_wave_kernel<4, 8>), dim3(N), dim3(CTC_THREADS), wl, (hipStream_t)stream, logits, in_lens,
-                         targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi, (float*)nullptr, S_max, 0, (float*)nullptr,
-                         (float*)nullptr, lpn_ws, status);
+                         targets, tgt_offsets, tgt_lens, nll, lpn_ws, T, N, V, blank, lpi, (float*)nullptr, S_max, mode, (float*)nullptr,
+                         (float*)nullptr, lpn_ws, status, (const int*)bad);
   } else {
     hipLaunchKernelGGL(ctc_alpha_kernel, dim3(N), dim3(CTC_THREADS), lds, (hipStream_t)stream, logits, in_lens, targets,
                        tgt_offsets, tgt_lens, nll, (float*)workspace, T, N, V, S_max, blank, lpi);
@@ -1069,16 +1121,29 @@ extern "C" int ms_ctc_loss_backward(const float* logits, const int32_t* in_lens,
       const int lpi = (zero_infinity & MS_CTC_LOG_PROBS_IN) ? 1 : 0;
       const size_t wl = alpha_wave_lds(T);
       hipStream_t st = (hipStream_t)stream;
+      // wide alphabets: phase 1 as a chip-wide launch (see ms_ctc_loss_forward); here it also writes every symbol's value
+      int mode = 0;
+      int* bad = nullptr;
+      const char* pe = getenv("MS_CTC_WIDE_PHASE1");
+      if (V > 64 && !(pe && pe[0] == '0')) {
+        bad = (int*)wsb;
+        MS_HIP(hipMemsetAsync(bad, 0, (size_t)N * sizeof(int), st));
+        const long pairs = (long)T * N;
+        hipLaunchKernelGGL((ctc_normalise_wide_kernel<true>), dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, st, logits, in_lens,
+                           targets, tgt_offsets, tgt_lens, lpn, lps, bad, T, N, V, S_max, blank, lpi);
+        MS_LAUNCH_CHECK();
+        mode = 2;
+      }
       // alpha and beta (= the reversed recursion) side by side: grid (N, 2)
       if (S_max <= 256)
         hipLaunchKernelGGL((ctc_alpha_wave_kernel<1, 16, true>), dim3(N, 2), dim3(CTC_THREADS), wl, st, logits, in_lens, targets,
-                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows, lps, status);
+                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, mode, ll2, beta_rows, lps, status, (const int*)bad);
       else if (S_max <= 512)
         hipLaunchKernelGGL((ctc_alpha_wave_kernel<2, 16, true>), dim3(N, 2), dim3(CTC_THREADS), wl, st, logits, in_lens, targets,
-                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows, lps, status);
+                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, mode, ll2, beta_rows, lps, status, (const int*)bad);
       else
         hipLaunchKernelGGL((ctc_alpha_wave_kernel<4, 8, true>), dim3(N, 2), dim3(CTC_THREADS), wl, st, logits, in_lens, targets,
-                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, 0, ll2, beta_rows, lps, status);
+                           tgt_offsets, tgt_lens, (float*)nullptr, lpn, T, N, V, blank, lpi, alpha_rows, S_max, mode, ll2, beta_rows, lps, status, (const int*)bad);
       MS_LAUNCH_CHECK();
       hipLaunchKernelGGL(ctc_grad_rows_kernel, dim3(ms::cdiv(T, 4 * GR_FRAMES), N), dim3(CTC_THREADS), rows_lds, st, lpn, alpha_rows,
                          beta_rows, ll2, in_lens, targets, tgt_offsets, tgt_lens, grad_nll, grad_logits, T, N, V, S_max, blank,

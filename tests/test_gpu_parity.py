@@ -539,40 +539,41 @@ def test_ctc_loss_golden():
         np.testing.assert_allclose(cpu(got), g[f"out/{red}_0"], rtol=1e-4, atol=1e-3)
 
 
-def test_ctc_loss_nan_logits_give_nan_like_torch_and_no_timeout_status():
+@pytest.mark.parametrize("V", [29, 200])      # 200: phase 1 as the chip-wide launch, its flags handed to the pipeline kernel
+def test_ctc_loss_nan_logits_give_nan_like_torch_and_no_timeout_status(V):
     """the four-wave pipeline clamps normalised log-probabilities to a finite "log zero"; a NaN logit row used to
     come out as nll = +inf, which ``zero_infinity`` silently turned into 0 (loss AND gradient) where torch.nn.CTCLoss gives
     NaN.  A non-finite normaliser now poisons that utterance's loss -- and only that one's -- and is NOT a time-out."""
     from myrtlespeech_amd import _lib
     from myrtlespeech_amd.loss.ctc_loss import CTCLoss
     rng = np.random.default_rng(11)
-    x = rng.normal(size=(60, 4, 29)).astype(np.float32)
+    x = rng.normal(size=(60, 4, V)).astype(np.float32)
     xl = np.array([60, 55, 50, 40], dtype=np.int32)
-    y = rng.integers(0, 28, size=(4, 12)).astype(np.int32)
+    y = rng.integers(0, V - 1, size=(4, 12)).astype(np.int32)
     yl = np.array([12, 10, 8, 5], dtype=np.int32)
     bad = x.copy()
     bad[17, 1, 3] = np.nan           # utterance 1, inside its length
     bad[45, 3, :] = 7.0              # utterance 3, past its length (40): ignored
     bad[45, 3, 2] = np.nan
     bad[20, 2, 5] = np.inf           # utterance 2: log_softmax gives NaN at that symbol
-    want = torch.nn.CTCLoss(blank=28, reduction="none", zero_infinity=True)(
+    want = torch.nn.CTCLoss(blank=V - 1, reduction="none", zero_infinity=True)(
         torch.log_softmax(torch.from_numpy(bad), -1), torch.from_numpy(y).long(), torch.from_numpy(xl).long(), torch.from_numpy(yl).long()).numpy()
     assert np.isnan(want[1]) and np.isfinite(want[0]) and np.isfinite(want[3])
     for zi in (False, True):
-        loss = CTCLoss(blank=28, reduction="none", zero_infinity=zi)      # check_status on: a time-out would raise here
+        loss = CTCLoss(blank=V - 1, reduction="none", zero_infinity=zi)      # check_status on: a time-out would raise here
         got = cpu(loss((T(bad), T(xl)), (T(y), T(yl))))
         assert np.isnan(got[1]) and np.isnan(got[2])
         np.testing.assert_allclose(got[[0, 3]], want[[0, 3]], rtol=1e-4, atol=1e-4)
         loss.status()                                                      # nothing sticky was left behind
     # the same through autograd: the poisoned utterances' gradients are NaN, the others' match torch
     xt = T(bad).requires_grad_(True)
-    loss = CTCLoss(blank=28, reduction="sum", zero_infinity=True)
+    loss = CTCLoss(blank=V - 1, reduction="sum", zero_infinity=True)
     loss((xt, T(xl)), (T(y), T(yl))).backward()
     g = cpu(xt.grad)
     assert np.isnan(g[:, 1]).any() and np.isfinite(g[:, 0]).all() and np.isfinite(g[:, 3]).all()
     # C ABI: ms_ctc_status on a clean workspace is MS_OK; a set word is reported once as MS_ERR_TIMEOUT and cleared
     lib = _lib.load()
-    ws = torch.zeros(lib.ms_ctc_loss_workspace_bytes(60, 4, 29, 25), dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(lib.ms_ctc_loss_workspace_bytes(60, 4, V, 25), dtype=torch.uint8, device="cuda")
     assert lib.ms_ctc_status(_lib.ptr(ws), _lib.stream_ptr()) == 0
     ws[0] = 1
     assert lib.ms_ctc_status(_lib.ptr(ws), _lib.stream_ptr()) == 4          # MS_ERR_TIMEOUT
@@ -645,7 +646,8 @@ def test_ctc_loss_full_size_vs_oracle():
 @pytest.mark.parametrize("Tn,N,V,L", [(501, 32, 29, 120), (64, 9, 29, 20), (17, 4, 5, 3), (16, 3, 7, 8), (15, 3, 7, 7),
                                       (33, 5, 29, 16), (2, 3, 4, 1), (1, 2, 4, 1), (700, 6, 40, 255), (300, 5, 29, 128),
                                       (400, 4, 29, 200), (900, 3, 33, 400), (1200, 2, 29, 511), (1300, 2, 29, 600),
-                                      (120, 3, 100, 30), (90, 2, 300, 25), (60, 2, 65, 12)])     # wide alphabets: a wave per frame
+                                      (120, 3, 100, 30), (90, 2, 300, 25), (60, 2, 65, 12),      # wide alphabets: a wave per frame
+                                      (70, 3, 1500, 20), (40, 2, 5000, 9)])                       # ... rows beyond one 1 024-symbol slab
 def test_ctc_alpha_wave_pipeline_vs_the_lds_row_kernel_and_the_oracle(Tn, N, V, L, monkeypatch):
     """The four-wave pipeline (alphas in registers, DPP + a per-frame LDS mailbox; csrc/ctc.hip) against the LDS-row kernel it
     replaced (MS_CTC_WAVE=0, read per call) and against the oracle.  (Its first form shared lse3 with that kernel and was
@@ -686,7 +688,7 @@ def test_ctc_alpha_wave_pipeline_vs_the_lds_row_kernel_and_the_oracle(Tn, N, V, 
 @pytest.mark.parametrize("Tn,N,V,L,zi", [(501, 8, 29, 120, False), (64, 9, 29, 20, True), (17, 4, 5, 3, False), (16, 3, 7, 8, True),
                                          (33, 5, 29, 16, False), (2, 3, 4, 1, True), (1, 2, 4, 1, False), (300, 5, 29, 128, False),
                                          (400, 4, 29, 200, True), (700, 3, 33, 400, False), (100, 3, 130, 20, False),
-                                         (80, 2, 70, 15, True)])
+                                         (80, 2, 70, 15, True), (50, 2, 1200, 10, False), (30, 2, 5000, 6, True)])
 def test_ctc_gradient_pipeline_vs_the_lds_row_kernel_and_the_oracle(Tn, N, V, L, zi, monkeypatch):
     """The backward of the loss on the pipeline path (alpha rows, beta rows = the same kernel on the reversed utterance,
     then one wave per frame for the gradient row; csrc/ctc.hip) against ``ctc_grad_kernel`` (MS_CTC_WAVE=0, read per call) and
