@@ -49,6 +49,17 @@ class PackedLayer:
     def __init__(self):
         self.key = None
         self.buf = None
+        self._gru_key = None
+        self._gru_params = None
+
+    def tanh_as_gru(self, params: List[Tuple[Optional[torch.Tensor], ...]]):
+        """A tanh-RNN layer's parameters as those of the GRU that computes it (``tanh_rnn_as_gru``), rebuilt when a parameter
+        changes (the packed copy is keyed on THESE tensors, so it survives from call to call)."""
+        key = tuple((p.data_ptr(), _lib.version_of(p)) if p is not None else None for d in params for p in d)
+        if key != self._gru_key:
+            self._gru_params = tanh_rnn_as_gru(params)
+            self._gru_key = key
+        return self._gru_params
 
     def get(self, cell: int, in_size: int, hidden: int, params: List[Tuple[Optional[torch.Tensor], ...]],
             pad: Optional[Tuple[int, bool, int]] = None):
@@ -75,6 +86,30 @@ class PackedLayer:
                                        _lib.stream_ptr()), "ms_rnn_pack")
             self.key = key
         return self.buf
+
+
+_GATE_SATURATED = 1.0e4     # sigmoid(+-1e4) is exactly 1 / 0 in float32 (exp2 underflows to 0 / overflows to inf; csrc/rnn.hip fast_sigmoid)
+_TANH_AS_GRU = os.environ.get("MS_RNN_TANH_AS_GRU") != "0"
+
+
+def tanh_rnn_as_gru(params):
+    """A tanh-RNN layer (rnn.py:112-127, ``RNNType.BASIC_RNN``: h' = tanh(W_ih x + b_ih + W_hh h + b_hh)) written as a GRU:
+    with the reset gate held at exactly 1 and the update gate at exactly 0 -- zero weight rows, input biases of +-1e4 --
+    torch's GRU cell  n = tanh(W_in x + b_in + r (W_hn h + b_hn)),  h' = (1 - z) n + z h  IS that layer (1 * a = a,
+    0 * h = 0 and n + 0 = n are exact; only the association of the sum inside the tanh differs).  The persistent GRU kernel
+    then serves it (round 6: one launch per layer instead of one per step, 6.9 -> ~2.5 ms at [501, 32, 1024] bidirectional)
+    at three times the gate rows -- registers and MFMA issue it has to spare.  Per direction (w_ih, w_hh, b_ih, b_hh)."""
+    out = []
+    for w_ih, w_hh, b_ih, b_hh in params:
+        h, dev = w_hh.shape[0], w_hh.device
+        f32 = lambda t_: t_.detach().float()      # noqa: E731
+        wi = torch.cat([torch.zeros(2 * h, w_ih.shape[1], device=dev), f32(w_ih)]).contiguous()
+        wh = torch.cat([torch.zeros(2 * h, h, device=dev), f32(w_hh)]).contiguous()
+        bi = torch.cat([torch.full((h,), _GATE_SATURATED, device=dev), torch.full((h,), -_GATE_SATURATED, device=dev),
+                        torch.zeros(h, device=dev) if b_ih is None else f32(b_ih)]).contiguous()
+        bh = torch.cat([torch.zeros(2 * h, device=dev), torch.zeros(h, device=dev) if b_hh is None else f32(b_hh)]).contiguous()
+        out.append((wi, wh, bi, bh))
+    return out
 
 
 def pad_layer_params(cell: int, params, hp: int, padded_input: bool, in_pad: int = 0):
@@ -113,6 +148,13 @@ def run_layers(cell: int, x: torch.Tensor, lens_dev: Optional[torch.Tensor], max
     t, n, _ = x.shape
     ndir = len(layer_params[0])
     nl = len(layer_params)
+    if cell == _lib.CELL_RNN_TANH and _TANH_AS_GRU and _lib.split_precision():
+        # a tanh-RNN stack on the persistent GRU kernel where that width has one (tanh_rnn_as_gru); else a launch per step
+        hp = int(lib.ms_rnn_padded_hidden(_lib.CELL_GRU, hidden, ndir))
+        if lib.ms_rnn_layer_chains_planes(_lib.CELL_GRU, hp, ndir):
+            gru_params = [packed[layer].tanh_as_gru(layer_params[layer]) for layer in range(nl)]
+            return run_layers(_lib.CELL_GRU, x, lens_dev, max_len, gru_params, packed, hidden, h0, None, workspace, check, ragged,
+                              keep_padding, state_inplace)
     lstm_like = cell in (_lib.CELL_LSTM, _lib.CELL_HARD_LSTM)
     # a hidden size without a persistent kernel runs at the next width that has one, its extra units held at exactly 0 by zero
     # weights (ms_rnn_padded_hidden; rnn.py:112-120 accepts any hidden_size)

@@ -112,6 +112,10 @@ def test_lstm_persistent_vs_oracle(H, N, T_, bidir):
                                                   # round 6: bidirectional layers whose two directions do not fit the CUs together
                                                   # (persistent, one launch per direction; they used to take a launch per step)
                                                   ("GRU", 1536, 40, 4, True, 32), ("GRU", 2560, 33, 3, True, 64),
+                                                  # ... and tanh-RNN layers on the persistent GRU kernel (reset gate held at 1,
+                                                  # update gate at 0: model/rnn.py tanh_rnn_as_gru), also padded widths and 2 layers
+                                                  ("BASIC_RNN", 1024, 32, 6, True, 64), ("BASIC_RNN", 700, 40, 4, False, 48),
+                                                  ("BASIC_RNN", 256, 20, 9, True, 32),
                                                   # ... and the two-stream LSTM beyond 1024 (a bidirectional layer's directions in two launches)
                                                   ("LSTM", 1280, 32, 5, True, 64), ("LSTM", 1536, 20, 4, False, 32),
                                                   ("LSTM", 2048, 32, 4, True, 64), ("LSTM", 2048, 40, 3, False, 32),

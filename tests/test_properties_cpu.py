@@ -206,3 +206,35 @@ def test_zero_padded_recurrent_weights_keep_the_padded_units_at_zero_and_the_rea
         for g_, w_ in zip(got_h if isinstance(got_h, tuple) else (got_h,), want_h if isinstance(want_h, tuple) else (want_h,)):
             assert float(g_[..., h:].abs().max()) == 0.0
             assert torch.allclose(g_[..., :h], w_, atol=1e-6)
+
+
+def test_a_tanh_rnn_written_as_a_gru_is_that_tanh_rnn():
+    """``model.rnn.tanh_rnn_as_gru`` (round 6: ``RNNType.BASIC_RNN`` stacks run on the persistent GRU kernel) on the CPU, through
+    stock torch cells: a two-layer bidirectional tanh RNN and the GRU built from its parameters -- reset gate held at exactly 1,
+    update gate at exactly 0 -- give the same outputs and final states, with and without biases and an initial state."""
+    import torch
+    from myrtlespeech_amd.model.rnn import tanh_rnn_as_gru
+
+    for bias in (True, False):
+        torch.manual_seed(3 + bias)
+        In, h, T_, N = 7, 6, 11, 4
+        ref = torch.nn.RNN(In, h, num_layers=2, bidirectional=True, nonlinearity="tanh", bias=bias)
+        gru = torch.nn.GRU(In, h, num_layers=2, bidirectional=True, bias=True)
+        with torch.no_grad():
+            for p in ref.parameters():
+                p.mul_(3.0)                      # pre-activations well into the tanh's curved part
+            for layer in range(2):
+                names = ("weight_ih", "weight_hh") + (("bias_ih", "bias_hh") if bias else ())
+                params = [tuple(getattr(ref, f"{n}_l{layer}{sfx}") for n in names) + (() if bias else (None, None))
+                          for sfx in ("", "_reverse")]
+                for sfx, tensors in zip(("", "_reverse"), tanh_rnn_as_gru(params)):
+                    for n, v in zip(("weight_ih", "weight_hh", "bias_ih", "bias_hh"), tensors):
+                        dst = getattr(gru, f"{n}_l{layer}{sfx}")
+                        assert dst.shape == v.shape
+                        dst.copy_(v)
+            x = torch.randn(T_, N, In)
+            h0 = torch.randn(4, N, h) * 0.5
+            for hx in (None, h0):
+                want, want_h = ref(x, hx)
+                got, got_h = gru(x, hx)
+                assert torch.allclose(got, want, atol=2e-6) and torch.allclose(got_h, want_h, atol=2e-6)
