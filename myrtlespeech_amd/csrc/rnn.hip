@@ -1188,6 +1188,12 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
   constexpr int RED2 = 4 * 16 * RED_STRIDE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* red = smem;  // [stream][4 waves][16 rows][RED_STRIDE]
+  // (round 6) H = 2048: a wave's share of W_hh is 256 registers per lane, with the operand chunks beside it the kernel took
+  // all 512 and still spilled 26 words that every stream-step re-loaded (8.3 us per step where H = 1536 takes 4.6).  The lo
+  // plane of the share now lives in LDS (128 KB: [wave][k-step][tile][lane] x 16 bytes, a lane reads back what it wrote --
+  // consecutive lanes, consecutive 16-byte words: conflict-free), the hi plane stays in registers.
+  constexpr bool WL_LDS = KS == 16 && !F16;
+  u32x4* wlds = reinterpret_cast<u32x4*>(smem + RED_FLOATS);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
@@ -1214,8 +1220,13 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
       wh0[ks] = *reinterpret_cast<const u32x4*>(wp);
       wh1[ks] = *reinterpret_cast<const u32x4*>(wp + 256);
       if (!F16) {
-        wl0[ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512);
-        wl1[ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512 + 256);
+        if (WL_LDS) {
+          wlds[((wave * KS + ks) * 2 + 0) * 64 + lane] = *reinterpret_cast<const u32x4*>(wp + KG * 512);
+          wlds[((wave * KS + ks) * 2 + 1) * 64 + lane] = *reinterpret_cast<const u32x4*>(wp + KG * 512 + 256);
+        } else {
+          wl0[ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512);
+          wl1[ks] = *reinterpret_cast<const u32x4*>(wp + KG * 512 + 256);
+        }
       }
     }
   }
@@ -1320,7 +1331,9 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_split2_kernel(LstmP p)
           acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, __builtin_bit_cast(f16x8v, wh0[ks]), acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, __builtin_bit_cast(f16x8v, wh1[ks]), acc1, 0, 0, 0);
         } else {
-          const u32x4 bh0 = wh0[ks], bh1 = wh1[ks], bl0 = wl0[ks], bl1 = wl1[ks];
+          const u32x4 bh0 = wh0[ks], bh1 = wh1[ks];
+          const u32x4 bl0 = WL_LDS ? wlds[((wave * KS + ks) * 2 + 0) * 64 + lane] : wl0[ks];
+          const u32x4 bl1 = WL_LDS ? wlds[((wave * KS + ks) * 2 + 1) * 64 + lane] : wl1[ks];
           const u32x4 xh = ah[ks], xl = al[ks];
           acc0 = ms::mfma_16x16x32<HM>(xh, bh0, acc0);
           acc1 = ms::mfma_16x16x32<HM>(xh, bh1, acc1);
@@ -2165,11 +2178,11 @@ int persistent_blocks_per_cu(bool gru) {
           {(const void*)lstm_persistent_split_kernel<1, 4, false>, big},
           {(const void*)lstm_persistent_split_kernel<2, 0, false>, big},
           {(const void*)lstm_persistent_split2_kernel<8, false>, red},
-          {(const void*)lstm_persistent_split2_kernel<16, false>, red},
+          {(const void*)lstm_persistent_split2_kernel<16, false>, red + (size_t)4 * 16 * 2 * 64 * 16},
           {(const void*)lstm_persistent_split2_kernel<8, true>, red},
           {(const void*)lstm_persistent_split2_kernel<8, false, false, ms::PREC_F16>, red},
           {(const void*)lstm_persistent_split2_kernel<8, false, false, ms::PREC_F16X3>, red},
-          {(const void*)lstm_persistent_split2_kernel<16, false, false, ms::PREC_F16X3>, red},
+          {(const void*)lstm_persistent_split2_kernel<16, false, false, ms::PREC_F16X3>, red + (size_t)4 * 16 * 2 * 64 * 16},
           {(const void*)lstm_persistent_split_kernel<1, 4, false, false, true>, big},
           {(const void*)lstm_persistent_f32x2_kernel<16, false>, red},
           {(const void*)lstm_persistent_f32x2_kernel<16, true>, red}};
@@ -2426,9 +2439,17 @@ static int launch_split(const LstmP& p, hipStream_t stream) {
                                             : launch_split_hm<NB, NCH, HARD, STAMP, false>(p, stream);
 }
 
+constexpr size_t SPLIT2_WL_LDS_BYTES = (size_t)4 * 16 * 2 * 64 * 16;       // H = 2048, two-plane modes: the lo plane of W_hh (128 KB)
 template <int KS, bool HARD, bool STAMP = false, int P = ms::PREC_BF16X3>
 static int launch_split2(const LstmP& p, hipStream_t stream) {
-  const size_t lds = (size_t)RED_FLOATS * sizeof(float);
+  const size_t lds = (size_t)RED_FLOATS * sizeof(float) + ((KS == 16 && P != ms::PREC_F16) ? SPLIT2_WL_LDS_BYTES : 0);
+  if (lds > 64 * 1024) {
+    static ms::DeviceOnce attr_once;
+    if (attr_once.need()) {
+      MS_HIP(hipFuncSetAttribute((const void*)lstm_persistent_split2_kernel<KS, HARD, STAMP, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_once.done();
+    }
+  }
   if (p.ndir * p.J > ms::num_cus()) {
     // every workgroup of a launch has to be resident: the directions of a wide bidirectional layer run one after the other
     for (int d = 0; d < p.ndir; ++d) {
