@@ -500,7 +500,11 @@ __device__ __forceinline__ void lds_dma_16(__amdgpu_buffer_rsrc_t rsrc, char* ds
 // waves of 64 x 64 (round 4): twice the workgroups of the 256 x 256 form for outputs that would otherwise leave CUs idle
 // (a streaming chunk's projection is 1 024 x 8 192: 128 tiles of 256 x 256 on 256 CUs), every output still the same
 // k-ordered sum (bit-identical), 8 fragment reads per 12 MFMAs instead of 12 per 24.
-template <int P, int WN, int PER_STEP_ = 3, bool SPACED = false, int NJ = 4>
+// TM = tile rows: 256 (the forms above) or, with WN = 2 and NJ = 2, 128 -- a 128 x 128 tile on FOUR waves of 64 x 64 (round 6):
+// outputs of ~500 rows (one utterance's projection, a 32-stream chunk's) get 120 .. 128 workgroups of 256 x 128, half of the
+// chip; 128-row tiles give them 240 .. 256.  A wave's work per K-block is the 256 x 128 form's (same loop, same k-ordered sums:
+// bit-identical); its DMA share is 4 x-pieces + 4 W-pieces (F16: 2 + 2).
+template <int P, int WN, int PER_STEP_ = 3, bool SPACED = false, int NJ = 4, int TM = 256>
 __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah, const unsigned short* __restrict__ Al,
                                            const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl,
                                            const float* __restrict__ bias, float* __restrict__ Y, int M, int K, int N, int act,
@@ -513,14 +517,15 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int TN = 32 * NJ * WN;
   static_assert(NJ == 4 || (NJ == 2 && WN == 2), "the narrow form is the 8-wave kernel");
+  static_assert(TM == 256 || (TM == 128 && NJ == 2 && WN == 2), "128-row tiles: the four-wave 128 x 128 form");
   // m_eff (optional): the number of rows that exist is a word in device memory (<= the M the grid was sized for): the
   // recurrent layers' packed projection, whose row count is the sum of the batch's lengths (rnn.hip).  Workgroups past
   // the tiles of that many rows leave at once.
   if (m_eff != nullptr) {
     M = __builtin_amdgcn_readfirstlane(*m_eff);
-    if ((int)blockIdx.x >= ((N + TN - 1) / TN) * ((M + S2_M - 1) / S2_M)) return;
+    if ((int)blockIdx.x >= ((N + TN - 1) / TN) * ((M + TM - 1) / TM)) return;
   }
-  const int nbn = (N + TN - 1) / TN, nbm = (M + S2_M - 1) / S2_M;
+  const int nbn = (N + TN - 1) / TN, nbm = (M + TM - 1) / TM;
   const int nwg = nbn * nbm;
   int bid = blockIdx.x;
   {
@@ -533,7 +538,7 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
   const int gm = min(GM, nbm - first_m);
   const int bm = first_m + (bid % per_group) % gm;
   const int bn = (bid % per_group) / gm;
-  const int m0 = bm * S2_M, n0 = bn * TN;
+  const int m0 = bm * TM, n0 = bn * TN;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -544,10 +549,14 @@ __device__ __forceinline__ void gemm4_body(const unsigned short* __restrict__ Ah
   // WN = 2: 8 waves x 8 pieces of ONE plane (F16: 4); WN = 1: 4 waves x (8 of an x plane + 4 of a W plane) (F16: 4 + 2).
   // NJ = 2 (8 waves, 256 x 128): 32 x-pieces + 16 W-pieces per K-block = 4 + 2 per wave (F16: 2 + 1)
   constexpr int NPA = NJ == 2 ? (F16 ? 2 : 4) : WN == 2 ? (F16 ? 4 : 8) : (F16 ? 4 : 8);
-  constexpr int NPB = NJ == 2 ? (F16 ? 1 : 2) : WN == 2 ? 0 : (F16 ? 2 : 4);
+  constexpr int NPB = TM == 128 ? NPA : NJ == 2 ? (F16 ? 1 : 2) : WN == 2 ? 0 : (F16 ? 2 : 4);
   constexpr int NP = NPA + NPB;
   int PA, RA, PB = 2, RB = 0;
-  if (NJ == 2) {
+  if (TM == 128) {
+    // four waves, 128 x-rows and 128 W-rows per plane: a wave takes 4 (F16: 2) pieces of 16 rows from each
+    if (F16) { PA = 0; RA = wave * 32; PB = 2; RB = wave * 32; }
+    else { PA = wave >> 1; RA = (wave & 1) * 64; PB = 2 + (wave >> 1); RB = (wave & 1) * 64; }
+  } else if (NJ == 2) {
     if (F16) { PA = 0; RA = wave * 32; PB = 2; RB = wave * 16; }
     else { PA = wave >> 2; RA = (wave & 3) * 64; PB = 2 + (wave >> 2); RB = (wave & 3) * 32; }
   } else if (WN == 2) {
@@ -857,6 +866,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x3_kernel4h(const unsigned
   gemm4_body<P, 2, 3, false, 2>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff, lda, ldw, kmode);
 }
 
+// 128 x 128 tiles on four waves (NJ = 2, TM = 128): outputs whose 256 x 128 tiles would fill at most half of the CUs
+template <int P>
+__global__ __launch_bounds__(256, 1) void gemm_nt_bf16x3_kernel4q(const unsigned short* __restrict__ Ah,
+                                                                  const unsigned short* __restrict__ Al,
+                                                                  const unsigned short* __restrict__ Wh,
+                                                                  const unsigned short* __restrict__ Wl,
+                                                                  const float* __restrict__ bias, float* __restrict__ Y,
+                                                                  int M, int K, int N, int act, float lo, float hi,
+                                                                  const int* __restrict__ m_eff, int lda, int ldw, int kmode) {
+  gemm4_body<P, 2, 3, false, 2, 128>(Ah, Al, Wh, Wl, bias, Y, M, K, N, act, lo, hi, m_eff, lda, ldw, kmode);
+}
+
 // the 4-wave form, capped at 208 VGPRs (the two-stream LSTM kernel allocates 304 of a SIMD's 512): experiment only
 template <int P, int PER_STEP = 3, bool SPACED = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel4n(
@@ -958,6 +979,7 @@ int gemm_bf16x3_launch_ld(const unsigned short* ah, const unsigned short* al, co
     MS_ATTR3(gemm_nt_bf16x3_kernel4, G4_LDS)
     MS_ATTR3(gemm_nt_bf16x3_kernel4n, G4_LDS)
     MS_ATTR3(gemm_nt_bf16x3_kernel4h, G4_LDS)
+    MS_ATTR3(gemm_nt_bf16x3_kernel4q, G4_LDS)
 #undef MS_ATTR3
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<PREC_BF16X3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
     MS_HIP(hipFuncSetAttribute((const void*)gemm_nt_bf16x3_kernel4n<PREC_BF16X3, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
@@ -993,6 +1015,16 @@ int gemm_bf16x3_launch_ld(const unsigned short* ah, const unsigned short* al, co
   }
   if (!half_off && !small_tile && starved && m_eff == nullptr && (long)M * N >= 1024L * 1024 &&
       g_gemm_variant.load(std::memory_order_relaxed) == 0 && std::max((size_t)M * lda, (size_t)N * ldw) * 2 < ((size_t)1 << 31)) {
+    // ... and 128 x 128 tiles on four waves where those 256 x 128 tiles would fill at most half of the CUs (round 6: a
+    // 32-stream chunk's projection, 512 x 7 680: 120 -> 240 workgroups; one utterance's, 501 x 8 192: 128 -> 256).  The same
+    // k-ordered sums (bit-identical).  MS_GEMM_QUARTER_TILE=0 (read per call) keeps the 256 x 128 form (A/B runs).
+    const char* qe = getenv("MS_GEMM_QUARTER_TILE");
+    if (!(qe && qe[0] == '0') && (long)cdiv(M, S2_M) * cdiv(N, 128) * 2 <= (long)num_cus() && cdiv(M, 128) > cdiv(M, S2_M)) {
+      hipLaunchKernelGGL(MS_BY_PREC(gemm_nt_bf16x3_kernel4q), dim3(cdiv(M, 128) * cdiv(N, 128)), dim3(256), G4_LDS, stream, ah, al, wh, wl,
+                         bias, y, M, K, N, act, lo, hi, m_eff, lda, ldw, kmode);
+      MS_LAUNCH_CHECK();
+      return MS_OK;
+    }
     hipLaunchKernelGGL(MS_BY_PREC(gemm_nt_bf16x3_kernel4h), dim3(cdiv(M, S2_M) * cdiv(N, 128)), dim3(512), G4_LDS, stream, ah, al, wh, wl,
                        bias, y, M, K, N, act, lo, hi, m_eff, lda, ldw, kmode);
     MS_LAUNCH_CHECK();
