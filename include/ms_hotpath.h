@@ -381,7 +381,8 @@ int ms_ctc_loss_backward(const float* logits, const int32_t* in_lens, const int3
 
 /* CTCGreedyDecoder.forward (ctc_greedy_decoder.py:74-92): argmax over symbols
  * (ties -> lowest index), drop repeats and blanks.  x [T,N,V] (any real scores);
- * out_idx [N, T] int32, out_len [N]. */
+ * out_idx [N, T] int32, out_len [N]; row n's entries past out_len[n] are unspecified (alphabets beyond 64 symbols keep
+ * the frames' arg maxes there before the in-place compaction). */
 int ms_ctc_greedy_decode(const float* x, const int32_t* lens, int32_t* out_idx, int32_t* out_len, int T, int N,
                          int V, int blank, void* stream);
 
