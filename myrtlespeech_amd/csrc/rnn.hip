@@ -84,7 +84,8 @@ bool use_fast(int cell, int H, int ndir) {
   if (!(cell == MS_CELL_LSTM || cell == MS_CELL_HARD_LSTM)) return false;
   const int cus = ms::num_cus();
   if (H > 1024) {
-    if (!wide_lstm_h(H) || cell != MS_CELL_LSTM || !(ms::precision_mode() == ms::PREC_BF16X3 || ms::precision_mode() == ms::PREC_F16X3)) return false;
+    // (round 6: HardLSTM too -- the reference's ONNX-exportable cell, hard_lstm.py; a DeepSpeech1 of the paper's width, 2 048, used it)
+    if (!wide_lstm_h(H) || !(ms::precision_mode() == ms::PREC_BF16X3 || ms::precision_mode() == ms::PREC_F16X3)) return false;
     return cus > 0 && (H / 8) <= cus * std::min(1, persistent_blocks_per_cu(false));
   }
   if (H % 32 != 0) return false;
@@ -2584,9 +2585,9 @@ static int launch_split2_prec(const LstmP& p, bool hard, bool stamps, hipStream_
   }
   if constexpr (P != ms::PREC_F16) {
     switch (p.H) {
-      case 1280: return launch_split2<10, false, false, P>(p, stream);      // (use_fast admits the wide shapes for the plain LSTM cell only)
-      case 1536: return launch_split2<12, false, false, P>(p, stream);
-      case 2048: return launch_split2<16, false, false, P>(p, stream);
+      case 1280: return hard ? launch_split2<10, true, false, P>(p, stream) : launch_split2<10, false, false, P>(p, stream);
+      case 1536: return hard ? launch_split2<12, true, false, P>(p, stream) : launch_split2<12, false, false, P>(p, stream);
+      case 2048: return hard ? launch_split2<16, true, false, P>(p, stream) : launch_split2<16, false, false, P>(p, stream);
       default: break;
     }
     if (stamps && !hard) return launch_split2<8, false, true, P>(p, stream);

@@ -264,6 +264,24 @@ def test_hard_lstm_persistent_vs_oracle():
     np.testing.assert_allclose(cpu(cn), wcn, **TOL)
 
 
+@pytest.mark.parametrize("H,bidir,N", [(1280, True, 9), (2048, False, 32), (1536, True, 40)])
+def test_hard_lstm_beyond_1024_runs_on_the_two_stream_kernel_vs_oracle(H, bidir, N):
+    """Round 6: HardLSTM (hard_lstm.py: the ONNX-exportable cell) at H = 1280 / 1536 / 2048 on the persistent two-stream kernel
+    (it took a launch per step there; the plain LSTM has had these widths since round 4): against the oracle, with more than
+    one batch group and -- bidirectional -- one launch per direction."""
+    from myrtlespeech_amd.model.hard_lstm import HardLSTM
+    torch.manual_seed(H + N)
+    m = HardLSTM(24, H, num_layers=1, bidirectional=bidir, forget_gate_bias=1.0).eval()
+    rng = np.random.default_rng(H + N)
+    x = (rng.normal(size=(5, N, 24)) * 2).astype(np.float32)
+    (out, _), (hn, cn) = m((T(x), torch.tensor([5] * N)))
+    sd = {k[len("rnn."):]: cpu(v) for k, v in m.state_dict().items()}
+    want, (whn, wcn) = O.hard_lstm_forward(x, sd, H, 1, bidir)
+    np.testing.assert_allclose(cpu(out), want, **TOL)
+    np.testing.assert_allclose(cpu(hn), whn, **TOL)
+    np.testing.assert_allclose(cpu(cn), wcn, **TOL)
+
+
 @pytest.mark.parametrize("hard,bidir,N", [(False, True, 40), (False, False, 64), (True, True, 37), (False, True, 33)])
 def test_wide_workgroup_lstm_two_groups_vs_oracle(hard, bidir, N):
     """``lstm_persistent_wide2_kernel`` (round 3; H = 1024, 33 .. 64 sequences = two batch groups side by side in one launch):
