@@ -2313,19 +2313,28 @@ extern "C" int ms_rnn_padded_hidden(int cell, int H, int ndir) {
   if (off || cell < 0 || cell > MS_CELL_HARD_LSTM || H <= 0 || ndir < 1 || ndir > 2 || force_generic()) return H;
   if (cell == MS_CELL_LSTM || cell == MS_CELL_HARD_LSTM) {
     auto ok = [&](int h) { return use_fast(cell, h, ndir) && (!want_split() || use_split(cell, h, ndir)); };
+    // (round 6) in the two-plane modes a width of 129 .. 1 024 units that is not one of the two-stream kernel's (256, 512, 768,
+    // 1 024) runs at the NEXT of those: the one-stream kernel that serves the other multiples of 64 takes 1.8 .. 4.9 ms per
+    // bidirectional layer at [501, 32, H] for H = 320 .. 960 where its two-stream neighbours take 1.6 / 1.9 / 2.4 (tools/
+    // width_sweep.py) -- LSTM-640 3.19 -> 1.93 ms, LSTM-832 (what 800 was padded to) 4.23 -> 2.44.  64 and 128 stay (0.8 / 1.0 ms).
+    static const bool two_stream_pad_off = getenv("MS_RNN_PAD_TWO_STREAM") && getenv("MS_RNN_PAD_TWO_STREAM")[0] == '0';
+    if (want_split() && !two_stream_pad_off && H > 128 && H <= 1024 && !two_stream_shape(H)) {
+      for (int h : {256, 512, 768, 1024})
+        if (h >= H && ok(h)) return h;
+    }
     if (ok(H)) return H;
     for (int h = ms::cdiv(H, 64) * 64; h <= 1024; h += 64)
       if (ok(h)) return h;
     for (int h : {1280, 1536, 2048})
       if (h >= H && ok(h)) return h;
-    return H;
-  }
-  if (cell == MS_CELL_GRU) {
+  } else if (cell == MS_CELL_GRU) {
     if (use_gru_persistent(cell, H, ndir)) return H;
     for (int h : {512, 768, 1024, 1280, 1536, 2048, 2560})
       if (h >= H && use_gru_persistent(cell, h, ndir)) return h;
   }
-  return H;
+  // no persistent kernel at or above this width: at least the MFMA step kernel (H % 64 == 0) instead of the scalar one, which
+  // takes 0.5 .. 1.5 ms PER STEP at H = 3 000 (tools/fallback_audit.py)
+  return (H % 64 != 0) ? ms::cdiv(H, 64) * 64 : H;
 }
 
 extern "C" size_t ms_rnn_packed_bytes(int cell, int In, int H, int ndir) {
