@@ -106,7 +106,8 @@ def rnn_case(seed):
     kind, H, bidir = [("LSTM", 64, True), ("LSTM", 256, False), ("GRU", 64, True), ("GRU", 128, False), ("BASIC_RNN", 64, True),
                       ("LSTM", 96, True), ("LSTM", 512, True), ("LSTM", 1024, False), ("LSTM", 768, True),
                       ("LSTM", 1024, True), ("GRU", 512, True), ("GRU", 1024, False), ("GRU", 1536, True),
-                      ("BASIC_RNN", 512, True), ("BASIC_RNN", 600, False), ("LSTM", 768, False)][seed % 16]
+                      ("BASIC_RNN", 512, True), ("BASIC_RNN", 600, False), ("LSTM", 768, False),
+                      ("LSTM", 320, True), ("LSTM", 832, False), ("GRU", 2112, False)][seed % 19]     # (padded to 512 / 1 024 / 2 560)
     key = (kind, H, bidir)
     if key not in _rnn:
         torch.manual_seed(seed)
