@@ -210,7 +210,10 @@ int ms_lookahead_window_forward(const float* x, const float* w, float* y, int N,
  * caller should PAD a layer of hidden size H to (zero weight rows / columns, zero biases, zero initial state for the padded
  * units: they stay exactly 0, so out[..., :H], h_n[..., :H], c_n[..., :H] are the unpadded layer's values with exact zeros
  * added to their sums) so that it runs on a persistent kernel instead of one launch per step; H itself when no padding is
- * needed or none helps.  MS_RNN_PAD_HIDDEN=0 always returns H. */
+ * needed or none helps.  Round 6: in the two-plane modes an LSTM width of 129 .. 1024 that is not 256 / 512 / 768 / 1024 is sent
+ * to the NEXT of those (the two-stream kernel is about twice as fast as the one that serves the other multiples of 64), and a
+ * width beyond every persistent kernel to the next multiple of 64 (the MFMA step kernel instead of the scalar one).
+ * MS_RNN_PAD_HIDDEN=0 always returns H. */
 int ms_rnn_padded_hidden(int cell, int H, int ndir);
 size_t ms_rnn_packed_bytes(int cell, int In, int H, int ndir);
 int ms_rnn_pack(int cell, int In, int H, int ndir, const float* const* w_ih_host, const float* const* w_hh_host,
